@@ -1,0 +1,74 @@
+"""ctypes binding of libbist_hip.so (C ABI: include/bist_hip.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises, and no
+operator in bist_amd has a CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbist_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+
+
+class BistGemm(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("a_rs", C.c_int64), ("a_ks", C.c_int64), ("b_rs", C.c_int64), ("b_ks", C.c_int64),
+        ("ldc", C.c_int64), ("ldr", C.c_int64),
+        ("batch1", C.c_int32), ("batch2", C.c_int32),
+        ("a_bs1", C.c_int64), ("a_bs2", C.c_int64), ("b_bs1", C.c_int64), ("b_bs2", C.c_int64),
+        ("c_bs1", C.c_int64), ("c_bs2", C.c_int64), ("r_bs1", C.c_int64), ("r_bs2", C.c_int64),
+        ("bias_bs2", C.c_int64),
+        ("alpha", C.c_float), ("act", C.c_int32), ("res_outer", C.c_int32), ("res_inner", C.c_int32),
+        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+    ]
+
+
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); exactly the declarations of include/bist_hip.h
+SIGNATURES = {
+    "bist_version": (C.c_int, []),
+    "bist_last_error": (C.c_char_p, []),
+    "bist_device_ok": (C.c_int, []),
+    "bist_gemm": (C.c_int, [C.POINTER(BistGemm), _P]),
+    "bist_gemm_is_fast": (C.c_int, [C.POINTER(BistGemm)]),
+    "bist_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I64, _I64, _F, _I32, _P]),
+    "bist_mha_core_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32,
+                                    _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
+    "bist_st_stage1_pv_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _P]),
+    "bist_st_stage2_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "bist_embed_pe_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
+    "bist_temporal_mask": (C.c_int, [_P, _P, _I64, _I64, _I32, _P]),
+    "bist_fuse_modalities": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _I64, _I32, _I32, _I32, _P]),
+    "bist_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"bist_amd: {LIB_PATH} is missing -- build it with `make -C bist_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+class BistError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise BistError(f"{what} failed (rc={rc}): {lib.bist_last_error().decode()}")

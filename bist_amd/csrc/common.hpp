@@ -1,0 +1,63 @@
+// Shared device/host helpers for libbist_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/bist_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---- host-side error plumbing (defined in api.hip) -------------------------------------------
+void bist_set_error(const char* fmt, ...);
+#define BIST_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      bist_set_error(__VA_ARGS__);         \
+      return BIST_EINVAL;                  \
+    }                                      \
+  } while (0)
+#define BIST_LAUNCH_CHECK(name)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      bist_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return BIST_ELAUNCH;                                                   \
+    }                                                                        \
+  } while (0)
+
+// ---- element conversion ----------------------------------------------------------------------
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }  // v_cvt_pk_bf16_f32, RNE
+
+// ---- wave-level reductions (64 lanes) ---------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based dropout mask ----------------------------------------------------------------
+// keep(idx) is a pure function of (seed, idx), so the backward pass regenerates the same mask.
+__device__ __forceinline__ uint32_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
+  const uint32_t u = mix64(seed + idx * 0x9E3779B97F4A7C15ULL);
+  return (float)(u >> 8) * (1.0f / 16777216.0f) >= p;
+}

@@ -1,0 +1,150 @@
+// Row-wise and elementwise kernels of the BiST hot path (memory-bound; one wave per row).
+#include "common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Reference LayerNorm (model/modules.py:28-31): a*(x-mean)/(std_unbiased+eps)+b.
+// One 64-lane wave per row; the row is read three times (mean, centred sum of squares, output):
+// the second and third reads hit L1/L2.  Two-pass variance, like torch.std.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ b,
+                                                        T* __restrict__ y, long rows, int d, long ldx, long ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += to_f(xr[c]);
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int c = lane; c < d; c += 64) { const float t = to_f(xr[c]) - mean; q += t * t; }
+  const float stdv = sqrtf(wave_sum(q) / (float)(d - 1));
+  const float inv = 1.f / (stdv + eps);
+  T* yr = y + row * ldy;
+  for (int c = lane; c < d; c += 64) yr[c] = from_f<T>(to_f(a[c]) * (to_f(xr[c]) - mean) * inv + to_f(b[c]));
+}
+
+// Embeddings*sqrt(d) + PositionalEncoding (modules.py:121-123, 141-144); pe is the f32 table.
+template <typename T>
+__global__ void embed_pe_kernel(const long* __restrict__ ids, const T* __restrict__ lut, const float* __restrict__ pe,
+                                T* __restrict__ y, long rows, int L, int d, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * d) return;
+  const long row = idx / d; const int c = (int)(idx % d);
+  const long id = ids[row];
+  y[idx] = from_f<T>(to_f(lut[id * d + c]) * scale + pe[(row % L) * (long)d + c]);
+}
+
+// temporal_mask[row] = (sum of the row's S*C features != 0)  (data/dataset.py:79)
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_mask_kernel(const T* __restrict__ f, unsigned char* __restrict__ m, long rows, long n) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* p = f + row * n;
+  float s = 0.f;
+  for (long c = lane; c < n; c += 64) s += to_f(p[c]);
+  s = wave_sum(s);
+  if (lane == 0) m[row] = s != 0.f ? 1 : 0;
+}
+
+// Dynamic modality fusion (decoder.py:155-159): out = sum_j softmax(score[row,:n])_j * x_j[row,:]
+struct FusePtrs { const void* x[4]; };
+template <typename T>
+__global__ void fuse_kernel(const T* __restrict__ score, FusePtrs xs, T* __restrict__ out, long rows, int n, int d) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * d) return;
+  const long row = idx / d;
+  float sc[4], mx = -INFINITY, den = 0.f;
+  for (int j = 0; j < n; ++j) { sc[j] = to_f(score[row * n + j]); mx = fmaxf(mx, sc[j]); }
+  for (int j = 0; j < n; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+  float acc = 0.f;
+  for (int j = 0; j < n; ++j) acc += (sc[j] / den) * to_f(reinterpret_cast<const T*>(xs.x[j])[idx]);
+  out[idx] = from_f<T>(acc);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = from_f<TD>(to_f(s[i]));
+}
+
+inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int bist_layernorm_fwd(const void* x, const void* a, const void* b, void* y, int64_t rows, int32_t d,
+                                  int64_t ldx, int64_t ldy, float eps, int32_t dtype, void* stream) {
+  BIST_REQUIRE(x && a && b && y, "bist_layernorm_fwd: null pointer");
+  BIST_REQUIRE(rows > 0 && d > 1 && ldx >= d && ldy >= d, "bist_layernorm_fwd: bad shape rows=%ld d=%d", (long)rows, d);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = blocks_for(rows, 4);
+  if (dtype == BIST_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, d, ldx, ldy, eps);
+  else if (dtype == BIST_F32)
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)b, (float*)y, rows, d, ldx, ldy, eps);
+  else { bist_set_error("bist_layernorm_fwd: bad dtype %d", dtype); return BIST_EINVAL; }
+  BIST_LAUNCH_CHECK("bist_layernorm_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_embed_pe_fwd(const int64_t* ids, const void* lut, const float* pe, void* y, int64_t rows, int32_t L,
+                                 int32_t d, int32_t dtype, void* stream) {
+  BIST_REQUIRE(ids && lut && pe && y, "bist_embed_pe_fwd: null pointer");
+  BIST_REQUIRE(rows > 0 && L > 0 && d > 0, "bist_embed_pe_fwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = sqrtf((float)d);
+  const unsigned g = blocks_for(rows * d, 256);
+  if (dtype == BIST_BF16)
+    hipLaunchKernelGGL(embed_pe_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const long*)ids, (const bf16_t*)lut, pe, (bf16_t*)y, rows, L, d, scale);
+  else if (dtype == BIST_F32)
+    hipLaunchKernelGGL(embed_pe_kernel<float>, dim3(g), dim3(256), 0, st, (const long*)ids, (const float*)lut, pe, (float*)y, rows, L, d, scale);
+  else { bist_set_error("bist_embed_pe_fwd: bad dtype %d", dtype); return BIST_EINVAL; }
+  BIST_LAUNCH_CHECK("bist_embed_pe_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_temporal_mask(const void* fts, uint8_t* mask, int64_t BT, int64_t row_elems, int32_t dtype, void* stream) {
+  BIST_REQUIRE(fts && mask && BT > 0 && row_elems > 0, "bist_temporal_mask: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = blocks_for(BT, 4);
+  if (dtype == BIST_BF16)
+    hipLaunchKernelGGL(temporal_mask_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)fts, mask, BT, row_elems);
+  else if (dtype == BIST_F32)
+    hipLaunchKernelGGL(temporal_mask_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)fts, mask, BT, row_elems);
+  else { bist_set_error("bist_temporal_mask: bad dtype %d", dtype); return BIST_EINVAL; }
+  BIST_LAUNCH_CHECK("bist_temporal_mask");
+  return BIST_OK;
+}
+
+extern "C" int bist_fuse_modalities(const void* score, const void* const* xs, void* out, int64_t rows, int32_t n, int32_t d,
+                                    int32_t dtype, void* stream) {
+  BIST_REQUIRE(score && xs && out && rows > 0 && d > 0 && n >= 1 && n <= 4, "bist_fuse_modalities: bad argument");
+  FusePtrs p;
+  for (int j = 0; j < 4; ++j) p.x[j] = j < n ? xs[j] : nullptr;
+  for (int j = 0; j < n; ++j) BIST_REQUIRE(p.x[j], "bist_fuse_modalities: null input %d", j);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = blocks_for(rows * d, 256);
+  if (dtype == BIST_BF16)
+    hipLaunchKernelGGL(fuse_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)score, p, (bf16_t*)out, rows, n, d);
+  else if (dtype == BIST_F32)
+    hipLaunchKernelGGL(fuse_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)score, p, (float*)out, rows, n, d);
+  else { bist_set_error("bist_fuse_modalities: bad dtype %d", dtype); return BIST_EINVAL; }
+  BIST_LAUNCH_CHECK("bist_fuse_modalities");
+  return BIST_OK;
+}
+
+extern "C" int bist_cast(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, void* stream) {
+  BIST_REQUIRE(src && dst && n > 0, "bist_cast: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = blocks_for(n, 256);
+  if (sd == BIST_F32 && dd == BIST_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (sd == BIST_BF16 && dd == BIST_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+  else { bist_set_error("bist_cast: unsupported dtype pair %d -> %d", sd, dd); return BIST_EINVAL; }
+  BIST_LAUNCH_CHECK("bist_cast");
+  return BIST_OK;
+}

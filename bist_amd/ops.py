@@ -1,0 +1,250 @@
+"""Tensor-level wrappers over the C ABI of libbist_hip.so.
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every arithmetic
+step of the hot path is a kernel of libbist_hip.so launched on that stream.  No wrapper has a
+PyTorch/CPU fallback: a CPU tensor, a missing library or an unsupported dtype raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, BF16, F32, BistGemm, check, lib
+
+Tensor = torch.Tensor
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dtype_code(t: torch.dtype) -> int:
+    try:
+        return _DT[t]
+    except KeyError:
+        raise TypeError(f"bist_amd: unsupported dtype {t} (float32 or bfloat16 only)") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts: Optional[Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("bist_amd: operands must live on the MI355X (got a CPU tensor); there is no CPU path")
+
+
+def _ptr(t: Optional[Tensor], off_elems: int = 0) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() + off_elems * t.element_size()
+
+
+def gemm_desc(a: Tensor, b: Tensor, c: Tensor, *, M: int, N: int, K: int, a_rs: int, b_rs: int, ldc: int,
+              a_ks: int = 1, b_ks: int = 1, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
+              alpha: float = 1.0, act: int = ACT_NONE, batch: Tuple[int, int] = (1, 1),
+              a_bs: Tuple[int, int] = (0, 0), b_bs: Tuple[int, int] = (0, 0), c_bs: Tuple[int, int] = (0, 0),
+              r_bs: Tuple[int, int] = (0, 0), bias_bs2: int = 0, res_map: Tuple[int, int] = (0, 0),
+              a_off: int = 0, b_off: int = 0, c_off: int = 0, bias_off: int = 0, r_off: int = 0,
+              drop_p: float = 0.0, drop_seed: int = 0) -> BistGemm:
+    _dev(a, b, c, bias, residual)
+    if a.dtype != b.dtype:
+        raise TypeError("bist_amd.gemm: A and B dtypes differ")
+    if bias is not None and bias.dtype != a.dtype:
+        raise TypeError("bist_amd.gemm: bias dtype must equal the operand dtype")
+    if residual is not None and residual.dtype != c.dtype:
+        raise TypeError("bist_amd.gemm: residual dtype must equal the output dtype")
+    g = BistGemm()
+    g.A, g.B, g.C = _ptr(a, a_off), _ptr(b, b_off), _ptr(c, c_off)
+    g.bias, g.residual = _ptr(bias, bias_off), _ptr(residual, r_off)
+    g.M, g.N, g.K = M, N, K
+    g.a_rs, g.a_ks, g.b_rs, g.b_ks, g.ldc, g.ldr = a_rs, a_ks, b_rs, b_ks, ldc, ldr
+    g.batch1, g.batch2 = batch
+    g.a_bs1, g.a_bs2 = a_bs
+    g.b_bs1, g.b_bs2 = b_bs
+    g.c_bs1, g.c_bs2 = c_bs
+    g.r_bs1, g.r_bs2 = r_bs
+    g.bias_bs2 = bias_bs2
+    g.alpha, g.act = alpha, act
+    g.res_outer, g.res_inner = res_map
+    g.in_dtype, g.out_dtype = dtype_code(a.dtype), dtype_code(c.dtype)
+    g.drop_p, g.drop_seed = drop_p, drop_seed
+    return g
+
+
+def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
+    """C = epilogue(alpha * A.B^T) with explicit element strides (see include/bist_hip.h)."""
+    g = gemm_desc(a, b, c, **kw)
+    check(lib.bist_gemm(C.byref(g), _stream()), "bist_gemm")
+    return c
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE, residual: Optional[Tensor] = None,
+           res_map: Tuple[int, int] = (0, 0), alpha: float = 1.0, out: Optional[Tensor] = None,
+           out_dtype: Optional[torch.dtype] = None, accumulate: bool = False, drop_p: float = 0.0, drop_seed: int = 0) -> Tensor:
+    """y = act(alpha * x.W^T + bias) (+ residual): nn.Linear on the MFMA GEMM.
+
+    x [..., K] with a contiguous last dim and uniform row stride; W [N, K] (rows may be strided).
+    ``accumulate`` adds into ``out`` (residual = out).  ``res_map=(outer, inner)`` reads residual
+    row (m // outer) * inner + m % inner.
+    """
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    M, N = x2.shape[0], w.shape[0]
+    if x2.stride(1) != 1 or w.stride(1) != 1:
+        raise ValueError("bist_amd.linear: last dims must be contiguous")
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=out_dtype or x.dtype)
+    o2 = out.reshape(-1, N) if out.dim() != 2 else out
+    if accumulate:
+        residual = o2
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, N) if residual.dim() != 2 else residual
+    gemm(x2, w, o2, M=M, N=N, K=K, a_rs=x2.stride(0), b_rs=w.stride(0), ldc=o2.stride(0), bias=bias,
+         residual=r2, ldr=r2.stride(0) if r2 is not None else 0, alpha=alpha, act=act, res_map=res_map,
+         drop_p=drop_p, drop_seed=drop_seed)
+    return out
+
+
+def layernorm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6, out: Optional[Tensor] = None) -> Tensor:
+    """The reference's LayerNorm (modules.py:28-31): unbiased std, eps outside the sqrt."""
+    _dev(x, a, b)
+    d = x.shape[-1]
+    x2 = x.reshape(-1, d)
+    if x2.stride(1) != 1:
+        raise ValueError("bist_amd.layernorm: last dim must be contiguous")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    o2 = out.reshape(-1, d)
+    check(lib.bist_layernorm_fwd(x2.data_ptr(), a.data_ptr(), b.data_ptr(), o2.data_ptr(), x2.shape[0], d,
+                                 x2.stride(0), o2.stride(0), eps, dtype_code(x.dtype), _stream()), "bist_layernorm_fwd")
+    return out
+
+
+def mha_core(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], h: int, *, want_p: bool = False,
+             out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """softmax(QK^T/sqrt(dk), masked -1e9) V per head; q [N,Lq,d], k/v [N,Lk,d] (row-strided views ok).
+
+    mask: bool/uint8 [N,1,Lk], [N,Lq,Lk], [1,Lq,Lk] or None (modules.py:59-60 semantics).
+    """
+    _dev(q, k, v, mask)
+    N, Lq, d = q.shape
+    Lk = k.shape[1]
+    dk = d // h
+    for t in (q, k, v):
+        if t.stride(2) != 1:
+            raise ValueError("bist_amd.mha_core: last dim must be contiguous")
+    if out is None:
+        out = torch.empty((N, Lq, d), device=q.device, dtype=q.dtype)
+    p = torch.empty((N, h, Lq, Lk), device=q.device, dtype=torch.float32) if want_p else None
+    mptr, mbs, mqs = None, 0, 0
+    if mask is not None:
+        m = mask if mask.dtype == torch.uint8 else mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        if m.stride(-1) != 1:
+            m = m.contiguous()
+        mbs = m.stride(0) if m.shape[0] > 1 else 0
+        mqs = m.stride(1) if m.shape[1] > 1 else 0
+        mptr = m.data_ptr()
+        mask = m  # keep alive
+    check(lib.bist_mha_core_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), mptr, out.data_ptr(), _ptr(p),
+                                N, Lq, Lk, h, dk, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                q.stride(0), k.stride(0), v.stride(0), out.stride(0), mbs, mqs,
+                                1.0 / math.sqrt(dk), dtype_code(q.dtype), _stream()), "bist_mha_core_fwd")
+    return out, p
+
+
+def st_stage1_pv(scores: Tensor, v: Tensor, tmask: Optional[Tensor], *, B: int, T: int, S: int, Lq: int, h: int,
+                 dk: int, direction: int, out: Optional[Tensor] = None) -> Tensor:
+    """Stage-1 softmax + P.V of t2s (direction 0) / s2t (direction 1); see include/bist_hip.h."""
+    _dev(scores, v, tmask)
+    d = h * dk
+    G = S if direction == 0 else T
+    if not scores.is_contiguous() or scores.numel() != B * Lq * h * T * S:
+        raise ValueError("bist_amd.st_stage1_pv: scores must be contiguous [B, Lq*h, T*S]")
+    if v.stride(-1) != 1:
+        raise ValueError("bist_amd.st_stage1_pv: V last dim must be contiguous")
+    ldv = v.stride(-2)
+    if out is None:
+        out = torch.empty((B, G, Lq, d), device=v.device, dtype=v.dtype)
+    mptr = None
+    if tmask is not None:
+        tmask = tmask.reshape(B, T)
+        tmask = (tmask.view(torch.uint8) if tmask.dtype == torch.bool else tmask.to(torch.uint8)).contiguous()
+        mptr = tmask.data_ptr()
+    check(lib.bist_st_stage1_pv_fwd(scores.data_ptr(), v.data_ptr(), mptr, out.data_ptr(), B, T, S, Lq, h, dk, ldv,
+                                    direction, dtype_code(scores.dtype), dtype_code(v.dtype), _stream()),
+          "bist_st_stage1_pv_fwd")
+    return out
+
+
+def st_stage2(q2f: Tensor, y: Tensor, gmask: Optional[Tensor], *, h: int, out: Optional[Tensor] = None) -> Tensor:
+    """Stage-2 attention over the stage-1 outputs with K/V folded out; q2f [B,Lq,h,d], y [B,G,Lq,d]."""
+    _dev(q2f, y, gmask)
+    B, G, Lq, d = y.shape
+    if not (q2f.is_contiguous() and y.is_contiguous()):
+        raise ValueError("bist_amd.st_stage2: q2f and Y must be contiguous")
+    if out is None:
+        out = torch.empty((B, Lq, h, d), device=y.device, dtype=y.dtype)
+    mptr = None
+    if gmask is not None:
+        gmask = gmask.reshape(B, G)
+        gmask = (gmask.view(torch.uint8) if gmask.dtype == torch.bool else gmask.to(torch.uint8)).contiguous()
+        mptr = gmask.data_ptr()
+    check(lib.bist_st_stage2_fwd(q2f.data_ptr(), y.data_ptr(), mptr, out.data_ptr(), B, G, Lq, h, d,
+                                 dtype_code(y.dtype), _stream()), "bist_st_stage2_fwd")
+    return out
+
+
+def embed_pe(ids: Tensor, lut: Tensor, pe: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """lut[ids]*sqrt(d) + pe[:L]  (modules.py:121-123,141-144); ids int64 [B,L], pe f32 [>=L,d]."""
+    _dev(ids, lut, pe)
+    B, L = ids.shape
+    d = lut.shape[1]
+    if ids.dtype != torch.int64 or pe.dtype != torch.float32 or pe.shape[0] < L or pe.shape[1] != d:
+        raise ValueError("bist_amd.embed_pe: bad ids/pe")
+    ids = ids.contiguous()
+    if out is None:
+        out = torch.empty((B, L, d), device=lut.device, dtype=lut.dtype)
+    check(lib.bist_embed_pe_fwd(ids.data_ptr(), lut.data_ptr(), pe.data_ptr(), out.data_ptr(), B * L, L, d,
+                                dtype_code(lut.dtype), _stream()), "bist_embed_pe_fwd")
+    return out
+
+
+def temporal_mask(fts: Tensor) -> Tensor:
+    """(fts.sum(2).sum(-1) != 0).unsqueeze(-2) of data/dataset.py:79, computed on the device."""
+    _dev(fts)
+    B, T = fts.shape[0], fts.shape[1]
+    f = fts.contiguous()
+    m = torch.empty((B, 1, T), device=fts.device, dtype=torch.uint8)
+    check(lib.bist_temporal_mask(f.data_ptr(), m.data_ptr(), B * T, f.numel() // (B * T), dtype_code(f.dtype), _stream()),
+          "bist_temporal_mask")
+    return m.view(torch.bool)
+
+
+def fuse_modalities(score: Tensor, xs: Sequence[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    """sum_j softmax(score)[..., j] * xs[j]   (decoder.py:155-159); score [..., n], xs[j] [..., d]."""
+    _dev(score, *xs)
+    n, d = score.shape[-1], xs[0].shape[-1]
+    xs = [x.contiguous() for x in xs]
+    score = score.contiguous()
+    rows = xs[0].numel() // d
+    if out is None:
+        out = torch.empty_like(xs[0])
+    arr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    check(lib.bist_fuse_modalities(score.data_ptr(), arr, out.data_ptr(), rows, n, d, dtype_code(score.dtype), _stream()),
+          "bist_fuse_modalities")
+    return out
+
+
+def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
+    _dev(x)
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(lib.bist_cast(x.data_ptr(), out.data_ptr(), x.numel(), dtype_code(x.dtype), dtype_code(dtype), _stream()), "bist_cast")
+    return out

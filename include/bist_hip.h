@@ -1,0 +1,169 @@
+/*
+ * bist_hip.h -- C ABI of libbist_hip.so, the MI355X (gfx950) kernels behind the BiST
+ * bi-directional spatio-temporal attention hot path.
+ *
+ * The reference (salesforce/BiST) has no native/FFI layer at all: its hot path is a chain of
+ * stock PyTorch ops issued from Python.  Each entry point below therefore
+ * cites the reference *Python* call site whose arithmetic it replaces; the Python host code in
+ * bist_amd/ binds these with ctypes (see INTEGRATION.md for the binding a maintainer adds).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted;
+ *   - the caller owns every buffer; the library never allocates or frees device memory;
+ *   - every launcher is asynchronous on the hipStream_t passed as the last argument (opaque
+ *     `void*` here so the header needs no HIP include) and never synchronises;
+ *   - return value: 0 on success, a negative BIST_E* code otherwise; nothing throws or exits;
+ *     bist_last_error() returns a thread-local message for the last failure;
+ *   - dtype codes: BIST_F32 = 0 (exact fp32 path, parity gate), BIST_BF16 = 1 (bf16 storage,
+ *     fp32 accumulate -- throughput path).
+ */
+#ifndef BIST_HIP_H
+#define BIST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BIST_OK 0
+#define BIST_EINVAL (-1)   /* bad argument (shape/stride/alignment/dtype)            */
+#define BIST_ELAUNCH (-2)  /* hipLaunchKernel reported an error                       */
+#define BIST_ENODEV (-3)   /* no gfx950 device visible                                */
+
+#define BIST_F32 0
+#define BIST_BF16 1
+
+#define BIST_ACT_NONE 0
+#define BIST_ACT_RELU 1
+
+int bist_version(void);
+const char* bist_last_error(void);
+/* 1 when a HIP device is visible and is gfx950, else 0 (host-side probe, no kernel launch). */
+int bist_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  C[z] = epilogue( alpha * A[z] . B[z]^T )            (fp32 accumulate on the MFMA units)
+ *
+ * Replaces every nn.Linear / torch.matmul on the path: the Q/K/V/out projections of
+ * MultiHeadedAttention.forward (model/modules.py:89-91,100), PositionwiseFeedForward
+ * (modules.py:112-113), the video input projection VidEncoder8 (model/encoder.py:75) and the
+ * vocabulary projection (model/generator.py:86).  Operands are addressed by element strides,
+ *     A(m,k) = A[m*a_rs + k*a_ks],  B(n,k) = B[n*b_rs + k*b_ks],  C(m,n) = C[m*ldc + n]
+ * so x.W^T (nn.Linear), x.W and x^T.y (the backward products) are all the same call.
+ * Batch index z = z1*batch2 + z2 advances each operand by z1*?_bs1 + z2*?_bs2 elements.
+ * Epilogue, in order: *alpha, +bias[n], activation, +residual, store as out_dtype.
+ * The residual row of output row m is (m / res_outer)*res_inner + (m % res_inner): with
+ * res_outer = G*Lq, res_inner = Lq this adds the un-expanded query row to each of G groups,
+ * which is the "x + sublayer(x)" of SublayerConnection (modules.py:44) applied to the
+ * expanded query of temporal2spatial/spatial2temporal (encoder.py:114-121,145-148) without
+ * materialising the expansion.  res_outer = res_inner = 0 means the plain row m.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct BistGemm {
+  const void* A;
+  const void* B;
+  void* C;
+  const void* bias;      /* [N] in in_dtype precision class (f32 for F32, bf16 for BF16) or NULL */
+  const void* residual;  /* out_dtype elements, leading dimension ldr, or NULL                 */
+  int32_t M, N, K;
+  int64_t a_rs, a_ks, b_rs, b_ks, ldc, ldr;
+  int32_t batch1, batch2;
+  int64_t a_bs1, a_bs2, b_bs1, b_bs2, c_bs1, c_bs2, r_bs1, r_bs2, bias_bs2;
+  float alpha;
+  int32_t act;
+  int32_t res_outer, res_inner;
+  int32_t in_dtype, out_dtype;
+  /* inverted dropout applied after the activation and before the residual add
+   * (SublayerConnection's dropout, modules.py:44): keep-probability 1-drop_p, counter-based
+   * mask keyed by (drop_seed, element index) so backward can regenerate it. 0 disables.      */
+  float drop_p;
+  uint64_t drop_seed;
+} BistGemm;
+
+int bist_gemm(const BistGemm* g, void* stream);
+/* Which kernel bist_gemm would pick for this problem: 1 = LDS-DMA MFMA tile kernel,
+ * 0 = generic strided kernel (host-side query, used by tests and the bench report).          */
+int bist_gemm_is_fast(const BistGemm* g);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm of the reference:  y = a * (x - mean) / (std_unbiased + eps) + b   per row
+ * (model/modules.py:28-31 -- N-1 variance, eps added OUTSIDE the square root).
+ * x,y [rows, d] with row strides ldx/ldy; a,b [d] in the same dtype as x.
+ * ------------------------------------------------------------------------------------------ */
+int bist_layernorm_fwd(const void* x, const void* a, const void* b, void* y, int64_t rows, int32_t d,
+                       int64_t ldx, int64_t ldy, float eps, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small multi-head attention core (after the projections):
+ *     O[n,i,hh*dk+c] = sum_j softmax_j( Q[n,i,hh,:].K[n,j,hh,:] * scale  masked -1e9 ) V[n,j,hh,c]
+ * = attention() model/modules.py:54-64 for every head of MultiHeadedAttention (modules.py:94).
+ * Q [N,Lq,*] K,V [N,Lk,*] with row strides ldq/ldk/ldv (elements) and per-n strides
+ * q_bs/k_bs/v_bs, heads side by side in the last dim (h*dk columns).  mask is uint8 (torch.bool)
+ * with strides (mask_bs per n, mask_qs per query row; 0 broadcasts) or NULL; masked scores are
+ * REPLACED by -1e9 (not -inf) exactly as the reference does, so a fully masked row is uniform.
+ * p_attn (nullable) receives the probabilities as f32 [N,h,Lq,Lk] -- the `.attn` side channel
+ * the pointer generator reads (model/generator.py:109-110).
+ * Used for the query self-attentions A0/A3 (encoder.py:176,184), CapEncoderLayer
+ * (encoder.py:214-215), MultimodalDecoderLayer12 (decoder.py:21-58) and the pointer attentions.
+ * ------------------------------------------------------------------------------------------ */
+int bist_mha_core_fwd(const void* Q, const void* K, const void* V, const uint8_t* mask, void* O, float* p_attn,
+                      int32_t N, int32_t Lq, int32_t Lk, int32_t h, int32_t dk,
+                      int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                      int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                      int64_t mask_bs, int64_t mask_qs, float scale, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 1 of temporal->spatial (direction 0, encoder.py:110-123) and spatial->temporal
+ * (direction 1, encoder.py:142-150), after the score GEMM.
+ *
+ * scores [B, Lq*h, T*S] (f32 or bf16 = sc_dtype) hold  Qf[b,(i,hh),:] . vft[b,t,s,:]  where Qf is
+ * the query folded through W_k and pre-scaled by 1/sqrt(dk) (the key bias cancels in the
+ * softmax), row order r = i*h + hh.  V [B,T,S,*] is the value projection (row stride ldv).
+ *   direction 0: softmax over t for every (b,s), masked by tmask[b,t] (uint8, nullable);
+ *                O[b,s,i,hh*dk+c] = sum_t P[b,i,hh,t,s] V[b,t,s,hh*dk+c]        O: [B,S,Lq,d]
+ *   direction 1: softmax over s for every (b,t), no mask;
+ *                O[b,t,i,hh*dk+c] = sum_s P[b,i,hh,t,s] V[b,t,s,hh*dk+c]        O: [B,T,Lq,d]
+ * which is attention() (modules.py:54-64) of every (b,s) / (b,t) group without materialising
+ * K, the permuted video tensor or the expanded query.
+ * ------------------------------------------------------------------------------------------ */
+int bist_st_stage1_pv_fwd(const void* scores, const void* V, const uint8_t* tmask, void* O,
+                          int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk,
+                          int64_t ldv, int32_t direction, int32_t sc_dtype, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 2 of both directions (encoder.py:125-134 / 152-165): query position (b,i) attends,
+ * alone, over the G stage-1 outputs Y[b,g,i,:] of its own position (G = S for t2s, T for s2t).
+ * With the query folded through W_k (q2f [B,Lq,h,d], pre-scaled) and the value projection
+ * applied after the weighted sum, the kernel needs only Y:
+ *     sc[hh,g] = q2f[b,i,hh,:] . Y[b,g,i,:]   (masked -1e9 by gmask[b,g] if given)
+ *     PY[b,i,hh,:] = sum_g softmax_g(sc)[hh,g] * Y[b,g,i,:]                    PY: [B,Lq,h,d]
+ * ------------------------------------------------------------------------------------------ */
+int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t* gmask, void* PY,
+                       int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise helpers on the path.
+ * ------------------------------------------------------------------------------------------ */
+/* y[b,l,:] = lut[ids[b,l],:]*sqrt(d) + pe[l,:]   Embeddings + PositionalEncoding
+ * (modules.py:121-123,141-144); y and lut in dtype, ids int64 [rows = B*L], pe the f32
+ * sinusoid table [>=L, d] (the reference's registered buffer `pe`, modules.py:131-139).       */
+int bist_embed_pe_fwd(const int64_t* ids, const void* lut, const float* pe, void* y, int64_t rows, int32_t L,
+                      int32_t d, int32_t dtype, void* stream);
+
+/* temporal_mask[b,t] = any(fts[b,t,:,:] != 0) computed as sum != 0 exactly like
+ * data/dataset.py:79 ((fts.sum(2).sum(-1) != 0)); fts [B,T,S*C] in dtype, out uint8 [B,T].     */
+int bist_temporal_mask(const void* fts, uint8_t* mask, int64_t BT, int64_t row_elems, int32_t dtype, void* stream);
+
+/* out = sum_j softmax_j(score[row,:n])[perm] * x_j[row,:]  -- the dynamic modality fusion of
+ * MultimodalDecoder8.forward (decoder.py:155-159): score [rows,n] f32/bf16, xs = n pointers
+ * (host array of device pointers, n <= 4) each [rows,d]; out [rows,d].                         */
+int bist_fuse_modalities(const void* score, const void* const* xs, void* out, int64_t rows, int32_t n, int32_t d,
+                         int32_t dtype, void* stream);
+
+/* dst = cast(src) between f32 and bf16 (n elements). */
+int bist_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIST_HIP_H */

@@ -1,0 +1,259 @@
+"""Operator-level parity of the HIP kernels (through the C ABI) against plain fp32/fp64 PyTorch
+on the CPU.  fp32 kernels: 2e-5 relative to the output scale (fp32 MFMA is an exact fmaf chain);
+bf16 kernels: inputs are rounded to bf16 first, the reference is computed from those rounded
+values in fp64, and the tolerance is bf16's output rounding (2^-8 relative) plus accumulation."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-5
+BF16_TOL = 1.2e-2
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    from bist_amd import _lib, ops as o
+    assert _lib.lib.bist_device_ok() == 1, _lib.lib.bist_last_error()
+    return o
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _cmp(got, ref, tol, what):
+    got = got.detach().float().cpu().double()
+    ref = ref.double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert math.isfinite(err) and err <= tol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e}, tol {tol})"
+
+
+def _q(x, dtype):
+    """value as the kernel sees it (rounded to the storage dtype), in fp64 on the CPU"""
+    return x.to(dtype).double()
+
+
+CASES = [  # (M, N, K) -- K multiples of 64 take the LDS-DMA kernel for both dtypes
+    (128, 128, 64), (300, 200, 128), (77, 513, 192), (1, 5, 64), (257, 129, 512),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("M,N,K", CASES)
+def test_gemm_fast_linear(ops, dtype, tol, M, N, K):
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    r = _rand(M, N, seed=4)
+    xd, wd, bd, rd = (t.to(dtype).cuda() for t in (x, w, b, r))
+    from bist_amd import _lib
+    g = ops.gemm_desc(xd, wd, torch.empty(M, N, device="cuda", dtype=dtype), M=M, N=N, K=K, a_rs=K, b_rs=K, ldc=N)
+    assert _lib.lib.bist_gemm_is_fast(g) == 1
+    ref = _q(x, dtype) @ _q(w, dtype).t() + _q(b, dtype)
+    _cmp(ops.linear(xd, wd, bd), ref, tol, "linear")
+    _cmp(ops.linear(xd, wd, bd, act=ops.ACT_RELU), ref.clamp_min(0), tol, "linear+relu")
+    _cmp(ops.linear(xd, wd, bd, residual=rd, alpha=0.5),
+         0.5 * (_q(x, dtype) @ _q(w, dtype).t()) + _q(b, dtype) + _q(r, dtype), tol, "linear+residual")
+    _cmp(ops.linear(xd, wd, None, out_dtype=torch.float32), _q(x, dtype) @ _q(w, dtype).t(),
+         F32_TOL if dtype == torch.float32 else 2e-3, "linear f32 out")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+def test_gemm_generic_strides(ops, dtype, tol):
+    # K tail (50), unaligned leading dims, transposed operands: all take the generic kernel
+    M, N, K = 150, 70, 50
+    a, b = _rand(M, K, seed=5), _rand(N, K, seed=6)
+    ref = _q(a, dtype) @ _q(b, dtype).t()
+    ad, bd = a.to(dtype).cuda(), b.to(dtype).cuda()
+    _cmp(ops.linear(ad, bd), ref, tol, "K tail")
+    at = a.t().contiguous().to(dtype).cuda()      # A stored [K, M]: a_rs = 1, a_ks = M
+    bt = b.t().contiguous().to(dtype).cuda()      # B stored [K, N]
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(at, bd, out, M=M, N=N, K=K, a_rs=1, a_ks=M, b_rs=K, b_ks=1, ldc=N)
+    _cmp(out, ref, tol, "A transposed (TN)")
+    ops.gemm(ad, bt, out, M=M, N=N, K=K, a_rs=K, a_ks=1, b_rs=1, b_ks=N, ldc=N)
+    _cmp(out, ref, tol, "B transposed (NN)")
+    ops.gemm(at, bt, out, M=M, N=N, K=K, a_rs=1, a_ks=M, b_rs=1, b_ks=N, ldc=N)
+    _cmp(out, ref, tol, "both transposed")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+def test_gemm_batched_head_fold(ops, dtype, tol):
+    # the K-fold: Qf[(b,i), hh*d + n] = sum_c Q[(b,i), hh*dk + c] * Wk[hh*dk + c, n]   (batch over heads)
+    Bq, h, dk = 37, 4, 16
+    d = h * dk
+    q, wk = _rand(Bq, d, seed=7), _rand(d, d, seed=8, scale=d ** -0.5)
+    qd, wd = q.to(dtype).cuda(), wk.to(dtype).cuda()
+    out = torch.empty(Bq, h * d, device="cuda", dtype=dtype)
+    ops.gemm(qd, wd, out, M=Bq, N=d, K=dk, a_rs=d, a_ks=1, b_rs=1, b_ks=d, ldc=h * d, batch=(1, h),
+             a_bs=(0, dk), b_bs=(0, dk * d), c_bs=(0, d), alpha=0.25)
+    ref = torch.einsum("mhc,hcn->mhn", _q(q, dtype).view(Bq, h, dk), _q(wk, dtype).view(h, dk, d)).reshape(Bq, h * d) * 0.25
+    _cmp(out, ref, tol, "head fold")
+
+
+def test_gemm_residual_row_map_and_accumulate(ops):
+    B, G, Lq, d = 3, 5, 7, 64
+    o, w, bias, x = _rand(B * G * Lq, d, seed=9), _rand(d, d, seed=10, scale=d ** -0.5), _rand(d, seed=11), _rand(B * Lq, d, seed=12)
+    y = ops.linear(o.cuda(), w.cuda(), bias.cuda(), residual=x.cuda(), res_map=(G * Lq, Lq))
+    ref = (o.double() @ w.double().t() + bias.double()).view(B, G, Lq, d) + x.double().view(B, 1, Lq, d)
+    _cmp(y, ref.reshape(-1, d), F32_TOL, "expanded-query residual")
+    acc = ops.linear(o.cuda(), w.cuda(), bias.cuda())
+    ops.linear(o.cuda(), w.cuda(), None, out=acc, accumulate=True)
+    _cmp(acc, 2 * (o.double() @ w.double().t()) + bias.double(), F32_TOL, "accumulate")
+
+
+def test_gemm_dropout_mask_statistics(ops):
+    M = N = 256
+    x, w = torch.ones(M, 64), torch.zeros(N, 64)
+    w[:, 0] = 1.0
+    y = ops.linear(x.cuda(), w.cuda(), None, drop_p=0.25, drop_seed=1234).cpu()
+    kept = (y != 0)
+    assert abs(kept.float().mean().item() - 0.75) < 0.01
+    assert torch.allclose(y[kept], torch.full_like(y[kept], 1 / 0.75), atol=1e-6)
+    y2 = ops.linear(x.cuda(), w.cuda(), None, drop_p=0.25, drop_seed=1234).cpu()
+    assert torch.equal(y, y2)                                   # same seed -> same mask
+    y3 = ops.linear(x.cuda(), w.cuda(), None, drop_p=0.25, drop_seed=99).cpu()
+    assert not torch.equal(y, y3)
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from bist_amd._lib import BistError
+    x = torch.zeros(4, 64, device="cuda")
+    with pytest.raises(BistError):
+        ops.gemm(x, x, x, M=0, N=4, K=64, a_rs=64, b_rs=64, ldc=4)
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(4, 64), torch.zeros(4, 64))       # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("d", [64, 512, 100])
+def test_layernorm(ops, dtype, tol, d):
+    x, a, b = _rand(37, d, seed=13, scale=3.0) + 0.5, 1 + 0.1 * _rand(d, seed=14), 0.1 * _rand(d, seed=15)
+    xq, aq, bq = _q(x, dtype), _q(a, dtype), _q(b, dtype)
+    mean = xq.mean(-1, keepdim=True)
+    ref = aq * (xq - mean) / (xq.std(-1, keepdim=True) + 1e-6) + bq          # torch.std is unbiased
+    _cmp(ops.layernorm(x.to(dtype).cuda(), a.to(dtype).cuda(), b.to(dtype).cuda()), ref, tol, "layernorm")
+    # the reference LayerNorm is NOT F.layer_norm: the two differ by > 1e-3 on this data
+    assert (torch.nn.functional.layer_norm(xq, (d,), aq, bq, 1e-6) - ref).abs().max() > 1e-3
+
+
+def _ref_attn(q, k, v, mask, h):
+    N, Lq, d = q.shape
+    dk = d // h
+    qs, ks, vs = (t.view(N, -1, h, dk).transpose(1, 2) for t in (q, k, v))
+    sc = qs @ ks.transpose(-1, -2) / math.sqrt(dk)
+    if mask is not None:
+        sc = sc.masked_fill(mask.unsqueeze(1) == 0, -1e9)
+    p = torch.softmax(sc, -1)
+    return (p @ vs).transpose(1, 2).reshape(N, Lq, d), p
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("N,Lq,Lk,h,dk,mk", [
+    (3, 5, 7, 4, 16, "key"), (2, 20, 20, 8, 64, "key"), (2, 9, 9, 8, 8, "causal"),
+    (2, 6, 130, 1, 64, "key"), (2, 4, 11, 2, 32, None)])
+def test_mha_core(ops, dtype, tol, N, Lq, Lk, h, dk, mk):
+    d = h * dk
+    q, k, v = _rand(N, Lq, d, seed=16), _rand(N, Lk, d, seed=17), _rand(N, Lk, d, seed=18)
+    mask = None
+    if mk == "key":
+        mask = torch.ones(N, 1, Lk, dtype=torch.bool)
+        mask[0, 0, Lk // 2:] = False
+        mask[N - 1, 0, :] = False                  # fully masked -> uniform, not NaN
+    elif mk == "causal":
+        mask = torch.tril(torch.ones(1, Lq, Lk, dtype=torch.bool)).expand(N, Lq, Lk).clone()
+        mask[1, :, 0] = False
+    ref, pref = _ref_attn(_q(q, dtype), _q(k, dtype), _q(v, dtype), mask, h)
+    out, p = ops.mha_core(q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda(),
+                          None if mask is None else mask.cuda(), h, want_p=True)
+    _cmp(out, ref, tol, "mha_core out")
+    _cmp(p, pref, 1e-5 if dtype == torch.float32 else 1e-2, "mha_core p_attn")
+    if mk == "key":
+        assert torch.allclose(p[N - 1].cpu(), torch.full_like(p[N - 1].cpu(), 1.0 / Lk), atol=1e-6)
+    # strided views: q/k/v as column slices of one packed projection
+    packed = torch.cat([q, q, q], -1).to(dtype).cuda()
+    if Lq == Lk:
+        kk = torch.cat([q, k, v], -1).to(dtype).cuda()
+        out2, _ = ops.mha_core(kk[..., :d], kk[..., d:2 * d], kk[..., 2 * d:], None if mask is None else mask.cuda(), h)
+        _cmp(out2, ref, tol, "mha_core strided views")
+    del packed
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("B,T,S,Lq,h,dk", [(2, 6, 9, 7, 4, 16), (2, 8, 49, 20, 8, 8), (1, 32, 49, 20, 8, 64)])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_st_stage1_pv(ops, dtype, tol, B, T, S, Lq, h, dk, direction):
+    d = h * dk
+    sc = _rand(B, Lq * h, T * S, seed=19, scale=2.0)
+    v = _rand(B, T, S, 2 * d, seed=20)                      # V is a column slice of a wider buffer
+    tm = torch.ones(B, 1, T, dtype=torch.bool)
+    tm[0, 0, T // 2:] = False
+    if B > 1:
+        tm[B - 1, 0, :] = False                              # one fully masked clip -> uniform over t
+    scq = _q(sc, torch.float32).view(B, Lq, h, T, S)
+    vq = _q(v[..., d:], dtype).view(B, T, S, h, dk)
+    if direction == 0:
+        s_ = scq.masked_fill(tm.view(B, 1, 1, T, 1) == 0, -1e9)
+        p = torch.softmax(s_, dim=3)
+        ref = torch.einsum("bihts,btshc->bsihc", p, vq).reshape(B, S, Lq, d)
+    else:
+        p = torch.softmax(scq, dim=4)
+        ref = torch.einsum("bihts,btshc->btihc", p, vq).reshape(B, T, Lq, d)
+    vd = v.to(dtype).cuda()
+    out = ops.st_stage1_pv(sc.cuda(), vd[..., d:], tm.cuda() if direction == 0 else None, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk,
+                           direction=direction)
+    _cmp(out, ref, tol, f"st_stage1_pv dir{direction}")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("B,G,Lq,h,d,masked", [(2, 9, 7, 4, 64, False), (2, 49, 20, 8, 64, False), (2, 32, 20, 8, 512, True),
+                                               (1, 128, 5, 8, 512, True)])
+def test_st_stage2(ops, dtype, tol, B, G, Lq, h, d, masked):
+    q2f, y = _rand(B, Lq, h, d, seed=21, scale=d ** -0.5), _rand(B, G, Lq, d, seed=22)
+    gm = None
+    if masked:
+        gm = torch.ones(B, 1, G, dtype=torch.bool)
+        gm[0, 0, G // 3:] = False
+        if B > 1:
+            gm[B - 1, 0, :] = False
+    qq, yq = _q(q2f, dtype), _q(y, dtype)
+    sc = torch.einsum("bihe,bgie->bihg", qq, yq)
+    if gm is not None:
+        sc = sc.masked_fill(gm.view(B, 1, 1, G) == 0, -1e9)
+    ref = torch.einsum("bihg,bgie->bihe", torch.softmax(sc, -1), yq)
+    out = ops.st_stage2(q2f.to(dtype).cuda(), y.to(dtype).cuda(), None if gm is None else gm.cuda(), h=h)
+    _cmp(out, ref, tol, "st_stage2")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, BF16_TOL)])
+def test_embed_temporal_mask_fuse_cast(ops, dtype, tol):
+    V, d, B, L = 50, 64, 3, 9
+    lut = _rand(V, d, seed=23)
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(24))
+    pos = torch.arange(0.0, 20).unsqueeze(1)
+    div = torch.exp(torch.arange(0.0, d, 2) * -(math.log(10000.0) / d))
+    pe = torch.zeros(20, d); pe[:, 0::2] = torch.sin(pos * div); pe[:, 1::2] = torch.cos(pos * div)
+    ref = _q(lut, dtype)[ids] * math.sqrt(d) + pe[:L].double()
+    _cmp(ops.embed_pe(ids.cuda(), lut.to(dtype).cuda(), pe.cuda()), ref, tol, "embed_pe")
+
+    fts = _rand(B, 6, 5, 16, seed=25)
+    fts[0, 4:] = 0; fts[2] = 0
+    m = ops.temporal_mask(fts.to(dtype).cuda()).cpu()
+    assert torch.equal(m, (fts.sum(2).sum(-1) != 0).unsqueeze(-2))
+
+    xs = [_rand(B, L, d, seed=30 + j) for j in range(3)]
+    score = _rand(B, L, 3, seed=26)
+    w = torch.softmax(_q(score, dtype), -1)
+    ref = sum(w[..., j:j + 1] * _q(xs[j], dtype) for j in range(3))
+    _cmp(ops.fuse_modalities(score.to(dtype).cuda(), [x.to(dtype).cuda() for x in xs]), ref, tol, "fuse")
+
+    x = _rand(1000, seed=27)
+    assert torch.equal(ops.cast(x.cuda(), torch.bfloat16).cpu(), x.to(torch.bfloat16))
+    assert torch.equal(ops.cast(x.to(torch.bfloat16).cuda(), torch.float32).cpu(), x.to(torch.bfloat16).float())
