@@ -46,6 +46,12 @@ SIGNATURES = {
     "bist_embed_pe_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "bist_temporal_mask": (C.c_int, [_P, _P, _I64, _I64, _I32, _P]),
     "bist_fuse_modalities": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _I64, _I32, _I32, _I32, _P]),
+    "bist_add_bcast": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _P]),
+    "bist_pointer_mix_fwd": (C.c_int, [_P, _P, _I32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                       _P, _I64, _I32, _I32, _I32, _P]),
+    "bist_log_softmax_fwd": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "bist_label_smoothing_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _I32, _P]),
+    "bist_sum_div": (C.c_int, [_P, _I64, _P, _P, _I32, _P]),
     "bist_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _P]),
 }
 

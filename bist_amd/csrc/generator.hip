@@ -1,0 +1,153 @@
+// Output heads of the path: pointer-generator mixture, log-softmax, label-smoothed KL loss.
+// One 256-thread workgroup per output row (a target position); V-wide rows stay in L2/HBM.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();                       // red[] may still be read from a previous reduction
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+  return r;
+}
+
+struct PtrSrc { const float* p; const long* text; int L; };
+struct PtrArgs { PtrSrc s[3]; int n; };
+
+// MultiPointerGenerator / PointerGenerator (model/generator.py:36-75, 84-127):
+//   out[row, v] = log( sw[n] * softmax(logits[row])[v] + sum_j sw[j] * sum_{t: text_j[b,t]==v} p_j[row, t] )
+// with sw = softmax(switch[row, :n+1]) (n > 1) or sw = (1-sigmoid, sigmoid) (single pointer).
+__global__ __launch_bounds__(256) void pointer_mix_kernel(const float* __restrict__ logits, const float* __restrict__ sw_logits,
+                                                          PtrArgs a, float* __restrict__ out, int V, int Lt, int sigmoid_switch) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const int b = (int)(row / Lt);
+  const float* lg = logits + row * V;
+  float* o = out + row * V;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, lg[v]);
+  mx = block_reduce(mx, red, true);
+  float den = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) den += expf(lg[v] - mx);
+  den = block_reduce(den, red, false);
+  float sw[4];
+  const int ns = a.n + 1;
+  if (sigmoid_switch) {                   // generator.py:72-73: switch = sigmoid(W x); ptr gets (1 - switch)
+    const float s = 1.f / (1.f + expf(-sw_logits[row]));
+    sw[0] = 1.f - s; sw[1] = s;
+  } else {
+    float m2 = -INFINITY, d2 = 0.f;
+    for (int j = 0; j < ns; ++j) m2 = fmaxf(m2, sw_logits[row * ns + j]);
+    for (int j = 0; j < ns; ++j) { sw[j] = expf(sw_logits[row * ns + j] - m2); d2 += sw[j]; }
+    for (int j = 0; j < ns; ++j) sw[j] /= d2;
+  }
+  const float vs = sw[a.n] / den;
+  for (int v = threadIdx.x; v < V; v += 256) o[v] = vs * expf(lg[v] - mx);
+  __syncthreads();
+  if (threadIdx.x == 0) {                 // scatter_add of the copy distributions: serial, so repeated ids are exact
+    for (int j = 0; j < a.n; ++j) {
+      const float* p = a.s[j].p + row * a.s[j].L;
+      const long* text = a.s[j].text + (long)b * a.s[j].L;
+      for (int t = 0; t < a.s[j].L; ++t) o[text[t]] += sw[j] * p[t];
+    }
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < V; v += 256) o[v] = logf(o[v]);
+}
+
+// Generator.forward (generator.py:21-27): log_softmax over the vocabulary.
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int V) {
+  __shared__ float red[4];
+  const float* xr = x + (long)blockIdx.x * V;
+  float* yr = y + (long)blockIdx.x * V;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, xr[v]);
+  mx = block_reduce(mx, red, true);
+  float den = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) den += expf(xr[v] - mx);
+  den = block_reduce(den, red, false);
+  const float lse = mx + logf(den);
+  for (int v = threadIdx.x; v < V; v += 256) yr[v] = xr[v] - lse;
+}
+
+// LabelSmoothing.forward (label_smoothing.py:20-30): KLDiv(sum) of the row against the smoothed
+// one-hot: confidence on the target, smoothing/(V-2) elsewhere, 0 on the pad column, whole row 0
+// when the target is pad.  row_loss[row] = sum_v td[v] * (log td[v] - logp[v]).
+__global__ __launch_bounds__(256) void label_smoothing_kernel(const float* __restrict__ logp, const long* __restrict__ target,
+                                                              float* __restrict__ row_loss, int V, float smoothing, int pad) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const long t = target[row];
+  if (t == pad) { if (threadIdx.x == 0) row_loss[row] = 0.f; return; }
+  const float* lp = logp + row * V;
+  const float s = smoothing / (float)(V - 2), conf = 1.f - smoothing;
+  const float ls = s > 0.f ? logf(s) : 0.f;
+  float acc = 0.f;
+  if (s > 0.f)
+    for (int v = threadIdx.x; v < V; v += 256)
+      if (v != t && v != pad) acc += s * (ls - lp[v]);
+  acc = block_reduce(acc, red, false);
+  if (threadIdx.x == 0) row_loss[row] = acc + (conf > 0.f ? conf * (logf(conf) - lp[t]) : 0.f);
+}
+
+// out[0] (+)= sum(x[0..n)) / denom[0]   -- single workgroup, fixed order: bitwise reproducible
+__global__ __launch_bounds__(256) void sum_div_kernel(const float* __restrict__ x, long n, const long* __restrict__ denom,
+                                                      float* __restrict__ out, int accumulate) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) acc += x[i];
+  acc = block_reduce(acc, red, false);
+  if (threadIdx.x == 0) {
+    const float v = acc / (denom ? (float)denom[0] : 1.f);
+    out[0] = accumulate ? out[0] + v : v;
+  }
+}
+
+}  // namespace
+
+extern "C" int bist_pointer_mix_fwd(const float* logits, const float* switch_logits, int32_t n_ptr, const float* const* ptr_p,
+                                    const int64_t* const* ptr_text, const int32_t* ptr_len, float* out, int64_t rows, int32_t Lt,
+                                    int32_t V, int32_t sigmoid_switch, void* stream) {
+  BIST_REQUIRE(logits && switch_logits && out && rows > 0 && Lt > 0 && V > 2, "bist_pointer_mix_fwd: bad argument");
+  BIST_REQUIRE(n_ptr >= 1 && n_ptr <= 3, "bist_pointer_mix_fwd: 1..3 pointer sources");
+  BIST_REQUIRE(!sigmoid_switch || n_ptr == 1, "bist_pointer_mix_fwd: sigmoid switch needs exactly one pointer source");
+  PtrArgs a;
+  a.n = n_ptr;
+  for (int j = 0; j < 3; ++j) a.s[j] = PtrSrc{nullptr, nullptr, 0};
+  for (int j = 0; j < n_ptr; ++j) {
+    BIST_REQUIRE(ptr_p[j] && ptr_text[j] && ptr_len[j] > 0, "bist_pointer_mix_fwd: bad pointer source %d", j);
+    a.s[j] = PtrSrc{ptr_p[j], (const long*)ptr_text[j], ptr_len[j]};
+  }
+  hipLaunchKernelGGL(pointer_mix_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, switch_logits, a, out, V, Lt,
+                     sigmoid_switch);
+  BIST_LAUNCH_CHECK("bist_pointer_mix_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_log_softmax_fwd(const float* x, float* y, int64_t rows, int32_t V, void* stream) {
+  BIST_REQUIRE(x && y && rows > 0 && V > 0, "bist_log_softmax_fwd: bad argument");
+  hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, y, V);
+  BIST_LAUNCH_CHECK("bist_log_softmax_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_label_smoothing_fwd(const float* logp, const int64_t* target, float* row_loss, int64_t rows, int32_t V,
+                                        float smoothing, int32_t pad, void* stream) {
+  BIST_REQUIRE(logp && target && row_loss && rows > 0 && V > 2, "bist_label_smoothing_fwd: bad argument");
+  BIST_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "bist_label_smoothing_fwd: smoothing out of range");
+  hipLaunchKernelGGL(label_smoothing_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logp, (const long*)target,
+                     row_loss, V, smoothing, pad);
+  BIST_LAUNCH_CHECK("bist_label_smoothing_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_sum_div(const float* x, int64_t n, const int64_t* denom, float* out, int32_t accumulate, void* stream) {
+  BIST_REQUIRE(x && out && n > 0, "bist_sum_div: bad argument");
+  hipLaunchKernelGGL(sum_div_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, (long)n, (const long*)denom, out, accumulate);
+  BIST_LAUNCH_CHECK("bist_sum_div");
+  return BIST_OK;
+}

@@ -71,6 +71,13 @@ __global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long n
   if (i < n) d[i] = from_f<TD>(to_f(s[i]));
 }
 
+// out[i] = a[i] + b[i % nb]  (residual add; nb < n broadcasts b, e.g. the positional table)
+template <typename T>
+__global__ void add_bcast_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long n, long nb) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = from_f<T>(to_f(a[i]) + to_f(b[i % nb]));
+}
+
 inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -146,5 +153,18 @@ extern "C" int bist_cast(const void* src, void* dst, int64_t n, int32_t sd, int3
     hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
   else { bist_set_error("bist_cast: unsupported dtype pair %d -> %d", sd, dd); return BIST_EINVAL; }
   BIST_LAUNCH_CHECK("bist_cast");
+  return BIST_OK;
+}
+
+extern "C" int bist_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t nb, int32_t dtype, void* stream) {
+  BIST_REQUIRE(a && b && out && n > 0 && nb > 0, "bist_add_bcast: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = blocks_for(n, 256);
+  if (dtype == BIST_BF16)
+    hipLaunchKernelGGL(add_bcast_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, nb);
+  else if (dtype == BIST_F32)
+    hipLaunchKernelGGL(add_bcast_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n, nb);
+  else { bist_set_error("bist_add_bcast: bad dtype %d", dtype); return BIST_EINVAL; }
+  BIST_LAUNCH_CHECK("bist_add_bcast");
   return BIST_OK;
 }

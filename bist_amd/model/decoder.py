@@ -1,0 +1,139 @@
+"""Response decoder layer and the layer loop with modality fusion on the HIP kernels
+(reference: model/decoder.py)."""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .encoder import _cross_attention, _feed_forward, _self_attention
+from .modules import LayerNorm, SublayerConnection, clones
+
+Tensor = torch.Tensor
+
+
+class MultimodalDecoderLayer12(nn.Module):
+    """Causal self-attention, attention to history, to the query, to the fused/encoded modalities,
+    FFN (reference: decoder.py:11-60)."""
+
+    def __init__(self, size, attn, nb_attn, ff, dropout, args):
+        super().__init__()
+        self.size = size
+        self.attn = clones(attn, nb_attn)
+        self.ff = ff
+        self.sublayer = clones(SublayerConnection(size, dropout), nb_attn + 1)
+        self.args = args
+
+    def forward(self, b, ft, x):
+        a, s, args = self.attn, self.sublayer, self.args
+        x = _self_attention(s[0], a[0], x, b.trg_mask)                                   # decoder.py:21
+        x = _cross_attention(s[1], a[1], x, ft["encoded_his"], b.his_mask)               # :22
+        x = _cross_attention(s[2], a[2], x, ft["encoded_query"], b.query_mask)           # :23
+        cnt = 3
+        if args.nb_venc_blocks > 0 and args.nb_cenc_blocks > 0 and getattr(args, "enc_vc_combine", "none") != "none":
+            x = _cross_attention(s[cnt], a[cnt], x, ft["encoded_ft"], b.query_mask); cnt += 1            # :27-29
+        else:
+            if args.include_caption != "none":                                                           # :31-36
+                if args.nb_cenc_blocks > 0:
+                    x = _cross_attention(s[cnt], a[cnt], x, ft["cap_ft"], b.query_mask)
+                else:
+                    x = _cross_attention(s[cnt], a[cnt], x, ft["encoded_cap"], b.cap_mask)
+                cnt += 1
+            if args.nb_venc_blocks > 0:                                                                  # :37-54
+                if args.enc_st_combine != "none":
+                    raise NotImplementedError("enc_st_combine != 'none' is outside the hot path (SURVEY.md 8a)")
+                if args.dec_st_combine == "seq":
+                    if args.s2t:
+                        x = _cross_attention(s[cnt], a[cnt], x, ft["temporal_ft"], b.query_mask); cnt += 1
+                    if args.t2s:
+                        x = _cross_attention(s[cnt], a[cnt], x, ft["spatial_ft"], b.query_mask); cnt += 1
+                else:
+                    tx = _cross_attention(s[cnt], a[cnt], x, ft["temporal_ft"], b.query_mask); cnt += 1
+                    sx = _cross_attention(s[cnt], a[cnt], x, ft["spatial_ft"], b.query_mask); cnt += 1
+                    x = Fn.add(tx, sx)
+        return _feed_forward(s[cnt], self.ff, x)                                                         # :58
+
+
+class MultimodalDecoder8(nn.Module):
+    """Layer loop: visual reasoning layer, caption layer, modality fusion, decoder layer
+    (reference: decoder.py:62-186).  Only ``enc_st_combine == 'none'`` is in scope."""
+
+    def __init__(self, v_layer, c_layer, a_layer, layer, venc_N, cenc_N, aenc_N, N, args):
+        super().__init__()
+        self.layers = clones(layer, N)
+        self.N, self.v_N, self.c_N, self.a_N = N, venc_N, cenc_N, aenc_N
+        self.norm = LayerNorm(layer.size)
+        self.args = args
+        if aenc_N > 0:
+            raise NotImplementedError("audio reasoning is outside the hot path (SURVEY.md 8a)")
+        if self.v_N > 0:
+            if args.enc_st_combine != "none":
+                raise NotImplementedError("enc_st_combine=%s is outside the hot path: multi-layer models only run "
+                                          "with 'none' in the reference (SURVEY.md appendix)" % args.enc_st_combine)
+            self.v_layers = clones(v_layer, self.v_N)
+            self.spatial_out_norm = LayerNorm(v_layer.size)
+            self.temporal_out_norm = LayerNorm(v_layer.size)
+        if self.c_N > 0:
+            self.c_layers = clones(c_layer, self.c_N)
+            self.cap_out_norm = LayerNorm(c_layer.size)
+        if self.v_N > 0 and args.enc_vc_combine == "dyn":
+            factor = 1 + (args.include_caption != "none") + bool(args.t2s) + bool(args.s2t)    # decoder.py:95-103
+            self.vc_combine_W = nn.Linear(v_layer.size * factor, factor - 1)
+
+    def _fuse(self, ft: Dict[str, Tensor]) -> None:
+        """ft['encoded_ft'] (decoder.py:137-181).  The concat feeding vc_combine_W is never built:
+        each modality multiplies its own column block of the weight and accumulates in place."""
+        args = self.args
+        mode = getattr(args, "enc_vc_combine", "none")
+        if self.v_N == 0:
+            return
+        if self.c_N > 0 and mode == "sum":
+            ft["encoded_ft"] = Fn.add(Fn.add(ft["temporal_ft"], ft["spatial_ft"]), ft["cap_ft"])
+            return
+        if mode != "dyn":
+            return
+        parts = [ft["encoded_query"]]
+        if self.c_N > 0:
+            parts.append(ft["cap_ft"])
+        if args.t2s:
+            parts.append(ft["spatial_ft"])
+        if args.s2t:
+            parts.append(ft["temporal_ft"])
+        W, bias = self.vc_combine_W.weight, self.vc_combine_W.bias
+        d = parts[0].shape[-1]
+        if W.shape[1] != d * len(parts):
+            raise ValueError("vc_combine_W does not match the enabled modalities")
+        score = None
+        for j, p in enumerate(parts):                      # concat order: query, cap, spatial, temporal
+            score = Fn.linear(p, W[:, j * d:(j + 1) * d], bias if j == 0 else None, out=score, accumulate=j > 0)
+        # score column -> modality (decoder.py:156-165): 0 temporal, 1 spatial, 2 cap (both directions);
+        # one direction: 0 that direction, 1 cap.  Without a caption layer: 0 temporal, 1 spatial.
+        if args.t2s and args.s2t:
+            xs = [ft["temporal_ft"], ft["spatial_ft"]] + ([ft["cap_ft"]] if self.c_N > 0 else [])
+        elif args.s2t:
+            xs = [ft["temporal_ft"], ft["cap_ft"]]
+        else:
+            xs = [ft["spatial_ft"], ft["cap_ft"]]
+        if self.c_N == 0 and not (args.t2s and args.s2t):
+            return                                          # the reference defines no encoded_ft here (decoder.py:168-181)
+        ft["encoded_ft"] = Fn.fuse_modalities(score.view(*parts[0].shape[:-1], -1), xs)
+
+    def forward(self, b, ft: Dict[str, Tensor], x: Tensor) -> Dict[str, Tensor]:
+        q = ft["encoded_query"]
+        in_ft = {"t2s": q, "s2t": q, "audio": q, "cap": q}
+        for l, layer in enumerate(self.layers):
+            if self.v_N > 0:
+                in_ft = self.v_layers[l](in_ft, ft, b)
+                if self.args.s2t:
+                    ft["temporal_ft"] = self.temporal_out_norm(in_ft["s2t"])                 # decoder.py:127
+                if self.args.t2s:
+                    ft["spatial_ft"] = self.spatial_out_norm(in_ft["t2s"])                   # :129
+            if self.c_N > 0:
+                in_ft = self.c_layers[l](in_ft, ft, b)
+                ft["cap_ft"] = self.cap_out_norm(in_ft["cap"])                               # :132
+            self._fuse(ft)
+            x = layer(b, ft, x)                                                              # :182
+        ft["decoded_text"] = self.norm(x)                                                    # :185
+        return ft

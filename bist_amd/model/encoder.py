@@ -1,0 +1,220 @@
+"""Text normalisation, video input projection and the bi-directional spatio-temporal reasoning
+layer on the HIP kernels (reference: model/encoder.py).
+
+``VidEncoderLayer4`` is the hot spot (87.8 % of the reference's forward).  The
+reference materialises, per direction, a permuted copy of the video tensor, an S- or T-fold
+expansion of the query, and K/V projections of both; here
+
+  stage 1  scores = (LN(x) W_q^T + b_q) folded through W_k  x  raw video rows     (one batched GEMM)
+           V      = video rows x [W_v(t2s); W_v(s2t)]^T                            (one GEMM for both directions)
+           O      = softmax(scores, temporal mask) . V  per (clip, region/segment) (st_stage1_pv kernel)
+           Y      = x (un-expanded, added per group in the epilogue) + O W_o^T     (GEMM)
+  stage 2  q2f    = stage-2 query folded through its W_k                           (batched GEMM, tiny)
+           PY     = softmax(q2f . Y) . Y   per (clip, query position)              (st_stage2 kernel, reads Y once)
+           out    = x + (PY W_v^T + b_v) W_o^T                                     (2 tiny GEMMs)
+
+so K is never computed, nothing is permuted or expanded, and the video tensor is read in place.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .modules import LayerNorm, MultiHeadedAttention, PositionwiseFeedForward, SublayerConnection, clones
+
+Tensor = torch.Tensor
+
+
+class Encoder(nn.Module):
+    """One LayerNorm per text stream, applied in argument order (reference: encoder.py:11-41)."""
+
+    def __init__(self, size: int, nb_layers: int):
+        super().__init__()
+        self.norm = nn.ModuleList(LayerNorm(size) for _ in range(nb_layers))
+        self.nb_layers = nb_layers
+
+    def forward(self, *seqs):
+        out, i = [], 0
+        for s in seqs:
+            if isinstance(s, list):
+                grp = []
+                for t in s:
+                    grp.append(self.norm[i](t)); i += 1
+                out.append(grp)
+            elif s is None:
+                out.append(None)
+            else:
+                out.append(self.norm[i](s)); i += 1
+        return out
+
+
+class VidEncoder8(nn.Module):
+    """P0: ft['spatiotemporal_ft'] = LN(ReLU(W fts + b))   (reference: encoder.py:55-93).
+
+    The ReLU is the GEMM epilogue; the features are read in place as a [B*T*S, C] matrix.
+    """
+
+    def __init__(self, W, a_W, vid_position, v_N, a_N, size, args):
+        super().__init__()
+        self.v_N, self.a_N, self.args = v_N, a_N, args
+        if a_N > 0:
+            raise NotImplementedError("audio features are outside the hot path (SURVEY.md 8a; the reference's audio "
+                                      "branch reads the undefined args.noW_venc, encoder.py:84)")
+        if v_N > 0:
+            self.W = W
+            self.vid_position = vid_position
+            self.in_norm = LayerNorm(size)
+            if vid_position is not None:
+                raise NotImplementedError("vid_position is always None in the reference (mtn.py:106)")
+
+    def forward(self, b, ft: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        if self.v_N > 0:
+            fts = b.fts
+            if fts.dtype != self.W.weight.dtype:
+                fts = Fn.ops.cast(fts, self.W.weight.dtype)
+            B, T, S, C = fts.shape
+            act = Fn.linear(fts.reshape(B * T * S, C), self.W.weight, self.W.bias, act=Fn.ACT_RELU)
+            ft["spatiotemporal_ft"] = self.in_norm(act).view(B, T, S, -1)
+        return ft
+
+
+def _self_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """x + MHA(LN(x), LN(x), LN(x), mask): A0/A3 and every other self-attention sublayer."""
+    xn = sub.norm(x)
+    ctx = attn.context(xn, xn, xn, mask)
+    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x).view_as(x)
+
+
+def _cross_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Tensor, mem: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """x + MHA(LN(x), mem, mem, mask) -- only the query stream is normalised (modules.py:44)."""
+    ctx = attn.context(sub.norm(x), mem, mem, mask)
+    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x).view_as(x)
+
+
+def _feed_forward(sub: SublayerConnection, ff: PositionwiseFeedForward, x: Tensor) -> Tensor:
+    """x + FFN(LN(x)); the residual is the second GEMM's epilogue."""
+    return ff(sub.norm(x), residual=x)
+
+
+class VidEncoderLayer4(nn.Module):
+    """Bi-directional spatio-temporal reasoning layer (reference: encoder.py:95-201).
+
+    Index order, fixed by the reference's run-time counters (encoder.py:173): with both
+    directions on, attn 0..5 = A0,A1,A2,A3,A4,A5; sublayer 0..7 = A0,A1,A2,F0,A3,A4,A5,F1; ff 0,1.
+    """
+
+    def __init__(self, size, attn, nb_attn, ff, nb_ff, dropout, args):
+        super().__init__()
+        self.size = size
+        self.attn = clones(attn, nb_attn)
+        self.ff = clones(ff, nb_ff)
+        self.sublayer = clones(SublayerConnection(size, dropout), nb_attn + nb_ff)
+        self.args = args
+        if args.enc_st_combine in ("early_sum", "early_dyn"):
+            raise NotImplementedError("enc_st_combine=%s cannot run for more than one layer in the reference "
+                                      "(decoder.py:123-124 overwrites the video tensor)" % args.enc_st_combine)
+
+    # -- stage 1 ------------------------------------------------------------------------------
+    def _stage1(self, ai: int, si: int, x: Tensor, vft: Tensor, v: Tensor, tmask: Optional[Tensor], direction: int) -> Tensor:
+        """A1 (direction 0, encoder.py:110-123) / A4 (direction 1, encoder.py:142-150) -> [B,G,Lq,d]."""
+        attn, sub = self.attn[ai], self.sublayer[si]
+        B, T, S, d = vft.shape
+        Lq, h, dk = x.shape[1], attn.h, attn.d_k
+        q = Fn.linear(sub.norm(x), attn.linears[0].weight, attn.linears[0].bias)                  # [B*Lq, d]
+        qf = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq * h, d)   # rows (i, hh)
+        scores = Fn.st_scores(qf, vft.view(B, T * S, d))
+        o = Fn.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
+        G = o.shape[1]
+        y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=x, res_map=(G * Lq, Lq))
+        return y.view(B, G, Lq, d)
+
+    # -- stage 2 ------------------------------------------------------------------------------
+    def _stage2(self, ai: int, si: int, x: Tensor, y: Tensor, gmask: Optional[Tensor]) -> Tensor:
+        """A2 (encoder.py:125-134) / A5 (encoder.py:152-165) -> [B,Lq,d]."""
+        attn, sub = self.attn[ai], self.sublayer[si]
+        B, G, Lq, d = y.shape
+        h, dk = attn.h, attn.d_k
+        q = Fn.linear(sub.norm(x), attn.linears[0].weight, attn.linears[0].bias)
+        q2f = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq, h, d)
+        py = Fn.st_stage2(q2f, y, gmask, h=h)
+        ctx = Fn.head_unfold(py.view(B * Lq, h * d), attn.linears[2].weight, attn.linears[2].bias, h)
+        return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x).view(B, Lq, d)
+
+    def value_projection(self, vft: Tensor):
+        """V of A1 and A4 in one GEMM over the video tensor: returns (v_t2s, v_s2t) column views."""
+        both = self.args.t2s and self.args.s2t
+        B, T, S, d = vft.shape
+        if both:
+            a1, a4 = self.attn[1], self.attn[4]
+            if torch.is_grad_enabled():
+                w = Fn.pack_rows(a1.linears[2].weight, a4.linears[2].weight)
+                bb = Fn.pack_rows(a1.linears[2].bias, a4.linears[2].bias)
+            else:
+                key = tuple((p.data_ptr(), p._version) for p in (a1.linears[2].weight, a4.linears[2].weight,
+                                                                 a1.linears[2].bias, a4.linears[2].bias))
+                hit = self.__dict__.get("_vpack")
+                if hit is None or hit[0] != key:
+                    hit = (key, Fn.pack_rows(a1.linears[2].weight, a4.linears[2].weight),
+                           Fn.pack_rows(a1.linears[2].bias, a4.linears[2].bias))
+                    self.__dict__["_vpack"] = hit
+                w, bb = hit[1], hit[2]
+            v = Fn.linear(vft.view(B * T * S, d), w, bb).view(B, T, S, 2 * d)
+            return v[..., :d], v[..., d:]
+        a = self.attn[1]
+        v = Fn.linear(vft.view(B * T * S, d), a.linears[2].weight, a.linears[2].bias).view(B, T, S, d)
+        return (v, None) if self.args.t2s else (None, v)
+
+    def forward(self, in_ft: Dict[str, Tensor], ft: Dict[str, Tensor], b) -> Dict[str, Tensor]:
+        vft = ft["spatiotemporal_ft"]
+        t2s_on = (not hasattr(self.args, "t2s")) or self.args.t2s
+        s2t_on = (not hasattr(self.args, "s2t")) or self.args.s2t
+        v_t2s, v_s2t = self.value_projection(vft)
+        ai = si = fi = 0
+        if t2s_on:
+            x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
+            y = self._stage1(ai + 1, si + 1, x, vft, v_t2s, b.temporal_mask, 0)                   # A1
+            z = self._stage2(ai + 2, si + 2, x, y, None)                                          # A2
+            in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
+            ai, si, fi = ai + 3, si + 4, fi + 1
+        if s2t_on:
+            x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
+            y = self._stage1(ai + 1, si + 1, x, vft, v_s2t, None, 1)                              # A4
+            z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
+            in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
+        return in_ft
+
+
+class CapEncoderLayer(nn.Module):
+    """Self-attention, attention to the encoded caption, FFN (reference: encoder.py:203-218)."""
+
+    def __init__(self, size, attn, nb_attn, ff, dropout):
+        super().__init__()
+        self.size = size
+        self.attn = clones(attn, nb_attn)
+        self.ff = ff
+        self.sublayer = clones(SublayerConnection(size, dropout), nb_attn + 1)
+
+    def forward(self, in_ft, ft, b):
+        c = _self_attention(self.sublayer[0], self.attn[0], in_ft["cap"], b.query_mask)
+        c = _cross_attention(self.sublayer[1], self.attn[1], c, ft["encoded_cap"], b.cap_mask)
+        in_ft["cap"] = _feed_forward(self.sublayer[2], self.ff, c)
+        return in_ft
+
+
+class AudioEncoderLayer(nn.Module):
+    """Parameter container only (the reference builds one even with nb_aenc_blocks == 0, mtn.py:131);
+    its forward is outside the hot path."""
+
+    def __init__(self, size, attn, nb_attn, ff, dropout):
+        super().__init__()
+        self.size = size
+        self.attn = clones(attn, nb_attn)
+        self.ff = ff
+        self.sublayer = clones(SublayerConnection(size, dropout), nb_attn + 1)
+
+    def forward(self, in_ft, ft, b):
+        raise NotImplementedError("audio reasoning is outside the hot path (SURVEY.md 8a)")

@@ -1,0 +1,133 @@
+"""Log-probability heads on the HIP kernels (reference: model/generator.py).
+
+The vocabulary projection is the MFMA GEMM against the shared embedding matrix (f32 output for
+both compute dtypes), the softmax / copy-distribution scatter / mixture / log are one kernel
+(``pointer_mix``).  No hard-coded ``.cuda()`` (the reference has two, generator.py:66,113).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .. import ops
+
+Tensor = torch.Tensor
+UNK = 0
+
+
+class Generator(nn.Module):
+    """log_softmax(x . W^T) with the shared embedding matrix (reference: generator.py:11-27)."""
+
+    def __init__(self, d_model, vocab, W=None):
+        super().__init__()
+        if W is not None:
+            self.proj = W
+            self.shared_W = True
+        else:
+            self.proj = nn.Linear(d_model, vocab)
+            self.shared_W = False
+
+    def forward(self, ft, batch, args, ft_key="decoded_text"):
+        x = ft[ft_key]
+        if self.shared_W:
+            logits = Fn.linear(x, self.proj, None, out_dtype=torch.float32)
+        else:
+            logits = Fn.linear(x, self.proj.weight, self.proj.bias, out_dtype=torch.float32)
+        return ops.log_softmax(logits).view(*x.shape[:-1], -1)
+
+
+def _pointer_source(name: str, ft: Dict[str, Tensor], batch):
+    if name == "query":
+        return batch.query, ft["encoded_query"], batch.query_mask
+    if name == "his":
+        return batch.his, ft["encoded_his"], batch.his_mask
+    if name == "cap":
+        return batch.cap, ft["encoded_cap"], batch.cap_mask
+    raise ValueError("unknown pointer source %r" % name)
+
+
+def _pointer_probs(attn, x: Tensor, enc: Tensor, mask: Tensor) -> Tensor:
+    """The single-head pointer attention's probabilities [B,Lt,L] f32 (generator.py:109-110): only
+    Q and K are projected -- the reference also computes V, P.V and the output projection and
+    throws them away."""
+    B, Lt, d = x.shape
+    q = Fn.linear(x, attn.linears[0].weight, attn.linears[0].bias).view(B, Lt, d)
+    k = Fn.linear(enc, attn.linears[1].weight, attn.linears[1].bias).view(B, enc.shape[1], d)
+    _, p = Fn.mha_core(q, k, k, mask, 1, want_p=True)
+    attn.attn = p
+    return p.view(B, Lt, -1)
+
+
+def _text_vector(p: Tensor, enc: Tensor) -> Tensor:
+    """sum_t p[b,i,t] * enc[b,t,:]  (generator.py:117-118) as a batched GEMM; p f32 [B,Lt,L]."""
+    B, Lt, L = p.shape
+    d = enc.shape[-1]
+    pc = ops.cast(p, enc.dtype)
+    out = torch.empty((B, Lt, d), device=enc.device, dtype=enc.dtype)
+    ops.gemm(pc, enc, out, M=Lt, N=d, K=L, a_rs=L, a_ks=1, b_rs=1, b_ks=enc.stride(1), ldc=d, batch=(B, 1),
+             a_bs=(Lt * L, 0), b_bs=(enc.stride(0), 0), c_bs=(Lt * d, 0))
+    return out
+
+
+def _switch_logits(lin: nn.Linear, parts) -> Tensor:
+    """lin(cat(parts)) without the concat: each part multiplies its own column block."""
+    d = parts[0].shape[-1]
+    out = None
+    for j, p in enumerate(parts):
+        out = Fn.linear(p, lin.weight[:, j * d:(j + 1) * d], lin.bias if j == 0 else None, out=out, accumulate=j > 0,
+                        out_dtype=torch.float32)
+    return out
+
+
+class PointerGenerator(nn.Module):
+    """Single copy source with a sigmoid switch (reference: generator.py:29-75)."""
+
+    def __init__(self, d_model, vocab_gen, pointer_attn):
+        super().__init__()
+        self.vocab_gen = vocab_gen
+        self.pointer_gen_W = nn.Linear(d_model * 3, 1)
+        self.pointer_attn = pointer_attn
+        pointer_attn.keep_attn = True
+
+    def forward(self, ft, batch, args):
+        x = ft["decoded_text"]
+        B, Lt, d = x.shape
+        if args.ptr_ft == "query+cap":
+            raise NotImplementedError("ptr_ft='query+cap' is outside the hot path")
+        text, enc, mask = _pointer_source(args.ptr_ft, ft, batch)
+        if args.mask_unk:
+            mask = mask & (text != UNK).unsqueeze(-2)
+        logits = Fn.linear(x, self.vocab_gen, None, out_dtype=torch.float32)
+        p = _pointer_probs(self.pointer_attn, x, enc, mask)
+        sw = _switch_logits(self.pointer_gen_W, [x, _text_vector(p, enc), ft["encoded_tgt"]])    # generator.py:71
+        return ops.pointer_mix(logits, sw, [p], [text], Lt, sigmoid_switch=True).view(B, Lt, -1)
+
+
+class MultiPointerGenerator(nn.Module):
+    """Several copy sources mixed by a softmax switch (reference: generator.py:77-127)."""
+
+    def __init__(self, d_model, vocab_gen, pointer_attn, nb_pointer_ft):
+        super().__init__()
+        self.vocab_gen = vocab_gen
+        self.pointer_gen_W = nn.Linear(d_model * (nb_pointer_ft + 2), nb_pointer_ft + 1)
+        self.pointer_attn = pointer_attn
+        for a in pointer_attn:
+            a.keep_attn = True
+
+    def forward(self, ft, batch, args):
+        x = ft["decoded_text"]
+        B, Lt, d = x.shape
+        logits = Fn.linear(x, self.vocab_gen, None, out_dtype=torch.float32)
+        ps, texts, vec = [], [], [x, ft["encoded_tgt"]]                                   # generator.py:92
+        for idx, name in enumerate(args.ptr_ft.split(",")):
+            text, enc, mask = _pointer_source(name, ft, batch)
+            if args.mask_unk:
+                mask = mask & (text != UNK).unsqueeze(-2)                                 # generator.py:106-107
+            p = _pointer_probs(self.pointer_attn[idx], x, enc, mask)
+            ps.append(p); texts.append(text)
+            vec.append(_text_vector(p, enc))
+        sw = _switch_logits(self.pointer_gen_W, vec)
+        return ops.pointer_mix(logits, sw, ps, texts, Lt).view(B, Lt, -1)

@@ -1,0 +1,199 @@
+"""Transformer primitives of the hot path on the HIP kernels.
+
+Same class names, constructor signatures, parameter names (``a_2``/``b_2``, ``linears.{0..3}``,
+``w_1``/``w_2``, ``lut``) and ``forward`` signatures as the reference's model/modules.py, so
+``state_dict``s and whole-module pickles are interchangeable; the arithmetic is dispatched to
+libbist_hip.so through ``bist_amd.functional`` (no nn.Linear/F.softmax/torch.matmul call).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+
+Tensor = torch.Tensor
+
+
+def clones(module: nn.Module, n: int) -> nn.ModuleList:
+    """n independent deep copies (reference: modules.py:10-12)."""
+    return nn.ModuleList(copy.deepcopy(module) for _ in range(n))
+
+
+class LayerNorm(nn.Module):
+    """a_2 * (x - mean) / (std_unbiased + eps) + b_2   (reference: modules.py:20-31)."""
+
+    def __init__(self, features: int, eps: float = 1e-6):
+        super().__init__()
+        self.a_2 = nn.Parameter(torch.ones(features))
+        self.b_2 = nn.Parameter(torch.zeros(features))
+        self.eps = eps
+
+    def forward(self, x: Tensor) -> Tensor:
+        return Fn.layernorm(x, self.a_2, self.b_2, self.eps)
+
+
+class SublayerConnection(nn.Module):
+    """x + dropout(sublayer(norm(x)))   (reference: modules.py:33-44).
+
+    The layer classes of encoder.py/decoder.py fuse the residual add (and dropout) into the
+    last GEMM of the sublayer and only borrow ``self.norm``; this generic form stays for callers
+    that pass an arbitrary ``sublayer`` callable.
+    """
+
+    def __init__(self, size: int, dropout: float):
+        super().__init__()
+        self.norm = LayerNorm(size)
+        self.dropout = nn.Dropout(dropout)   # holds p; the mask itself is generated inside the kernels
+        self.p = dropout
+
+    def forward(self, x: Tensor, sublayer) -> Tensor:
+        if self.training and self.p > 0:
+            raise NotImplementedError("generic SublayerConnection.forward has no fused dropout; use the layer classes")
+        return Fn.add(x, sublayer(self.norm(x)))
+
+
+class MultiHeadedAttention(nn.Module):
+    """Multi-head attention with the reference's masking rule (modules.py:54-100).
+
+    ``self.attn`` (the probabilities, [N,h,Lq,Lk] f32) is only materialised when
+    ``self.keep_attn`` is set: the pointer generators are its only readers (generator.py:62-63,
+    109-110) and writing it for every attention on the path would be pure HBM traffic.
+    """
+
+    def __init__(self, h: int, d_model: int, d_in: int = -1, dropout: float = 0.1):
+        super().__init__()
+        assert d_model % h == 0
+        self.d_k = d_model // h
+        self.h = h
+        if d_in < 0:
+            d_in = d_model
+        self.linears = clones(nn.Linear(d_in, d_model), 3)
+        self.linears.append(nn.Linear(d_model, d_in))
+        self.attn: Optional[Tensor] = None
+        self.keep_attn = False
+        self.dropout = nn.Dropout(p=dropout)
+
+    # -- packed projection weights (device-side concatenation, cached while parameters are unchanged)
+    def _packed(self, idx):
+        ws = [self.linears[i].weight for i in idx]
+        bs = [self.linears[i].bias for i in idx]
+        key = (tuple(idx),) + tuple((w.data_ptr(), w._version) for w in ws + bs)
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        hit = cache.get(tuple(idx))
+        if hit is not None and hit[0] == key and not torch.is_grad_enabled():
+            return hit[1], hit[2]
+        w, b = Fn.pack_rows(*ws), Fn.pack_rows(*bs)
+        if not torch.is_grad_enabled():
+            cache[tuple(idx)] = (key, w, b)
+        return w, b
+
+    def project_qkv(self, query: Tensor, key: Tensor, value: Tensor):
+        """Q, K, V projections as column views of as few GEMM outputs as the aliasing allows."""
+        d = self.h * self.d_k
+        n, lq = query.shape[0], query.shape[1]
+        if query is key and key is value:
+            w, b = self._packed((0, 1, 2))
+            qkv = Fn.linear(query, w, b).view(n, lq, 3 * d)
+            return qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        q = Fn.linear(query, self.linears[0].weight, self.linears[0].bias).view(n, lq, d)
+        lk = key.shape[1]
+        if key is value:
+            w, b = self._packed((1, 2))
+            kv = Fn.linear(key, w, b).view(n, lk, 2 * d)
+            return q, kv[..., :d], kv[..., d:]
+        k = Fn.linear(key, self.linears[1].weight, self.linears[1].bias).view(n, lk, d)
+        v = Fn.linear(value, self.linears[2].weight, self.linears[2].bias).view(n, lk, d)
+        return q, k, v
+
+    def context(self, query: Tensor, key: Tensor, value: Tensor, mask: Optional[Tensor]) -> Tensor:
+        """Head-concatenated attention output BEFORE the output projection, [N,Lq,d]."""
+        q, k, v = self.project_qkv(query, key, value)
+        ctx, p = Fn.mha_core(q, k, v, mask, self.h, want_p=self.keep_attn)
+        self.attn = p
+        return ctx
+
+    def forward(self, query: Tensor, key: Tensor, value: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+        ctx = self.context(query, key, value, mask)
+        out = Fn.linear(ctx, self.linears[3].weight, self.linears[3].bias)
+        return out.view(query.shape[0], query.shape[1], -1)
+
+
+class PositionwiseFeedForward(nn.Module):
+    """w_2(relu(w_1 x))   (reference: modules.py:102-113); ReLU is the first GEMM's epilogue."""
+
+    def __init__(self, d_model: int, d_ff: int, dropout: float = 0.1, d_out: int = -1):
+        super().__init__()
+        self.w_1 = nn.Linear(d_model, d_ff)
+        if d_out < 0:
+            d_out = d_model
+        self.w_2 = nn.Linear(d_ff, d_out)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+        hdn = Fn.linear(x, self.w_1.weight, self.w_1.bias, act=Fn.ACT_RELU)
+        out = Fn.linear(hdn, self.w_2.weight, self.w_2.bias, residual=residual)
+        return out.view(*x.shape[:-1], -1)
+
+
+class Embeddings(nn.Module):
+    """lut(x) * sqrt(d_model)   (reference: modules.py:115-123)."""
+
+    def __init__(self, d_model: int, vocab: int):
+        super().__init__()
+        self.lut = nn.Embedding(vocab, d_model)
+        self.d_model = d_model
+
+    def forward(self, x):
+        if x is None:
+            return x
+        zero = torch.zeros((x.shape[1], self.d_model), device=self.lut.weight.device, dtype=torch.float32)
+        return Fn.embed_pe(x, self.lut.weight, zero)
+
+
+class PositionalEncoding(nn.Module):
+    """x + pe[:, :L]   (reference: modules.py:125-144); ``pe`` is the same registered buffer."""
+
+    def __init__(self, d_model: int, dropout: float, max_len: int = 5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0.0, max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0.0, d_model, 2) * -(math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def table(self) -> Tensor:
+        """f32 [max_len, d] table.  If the module was cast to bf16 the buffer lost precision, so the
+        f32 table is rebuilt from the closed form (same expression as __init__) and cached."""
+        pe = self.pe[0]
+        if pe.dtype == torch.float32:
+            return pe
+        cached = self.__dict__.get("_pe_f32")
+        if cached is None or cached.device != pe.device:
+            max_len, d_model = pe.shape
+            t = torch.zeros(max_len, d_model)
+            position = torch.arange(0.0, max_len).unsqueeze(1)
+            div_term = torch.exp(torch.arange(0.0, d_model, 2) * -(math.log(10000.0) / d_model))
+            t[:, 0::2] = torch.sin(position * div_term)
+            t[:, 1::2] = torch.cos(position * div_term)
+            cached = t.to(pe.device)
+            self.__dict__["_pe_f32"] = cached
+        return cached
+
+    def forward(self, x):
+        if x is None:
+            return x
+        L = x.shape[1]
+        return Fn.add(x, self.table()[:L].to(x.dtype))
+
+
+def embed_with_position(seq: nn.Sequential, ids: Tensor) -> Tensor:
+    """Fused ``nn.Sequential(Embeddings, PositionalEncoding)`` (mtn.py:79-82) in one kernel."""
+    emb, pos = seq[0], seq[1]
+    return Fn.embed_pe(ids, emb.lut.weight, pos.table())

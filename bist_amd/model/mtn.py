@@ -1,0 +1,114 @@
+"""``MTN`` container and ``make_model`` factory with the reference's signatures and parameter
+naming (reference: model/mtn.py) so that train.py / generate.py call it unchanged.
+
+``state_dict`` names are identical to the reference's (including its spelling
+``mutlimodal_decoder``), the embedding matrix is one tensor shared by ``query_embed``,
+``tgt_embed``, ``generator.vocab_gen`` and ``ae_generator.proj`` (mtn.py:82,90,101).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .decoder import MultimodalDecoder8, MultimodalDecoderLayer12
+from .encoder import AudioEncoderLayer, CapEncoderLayer, Encoder, VidEncoder8, VidEncoderLayer4
+from .generator import Generator, MultiPointerGenerator, PointerGenerator
+from .modules import (Embeddings, MultiHeadedAttention, PositionalEncoding, PositionwiseFeedForward,
+                      embed_with_position)
+
+Tensor = torch.Tensor
+
+
+class MTN(nn.Module):
+    """forward(b) -> ft dict with the reference's keys (mtn.py:17-61)."""
+
+    def __init__(self, args, text_encoder, vid_encoder, text_decoder, mutlimodal_decoder, query_embed, his_embed,
+                 cap_embed, tgt_embed, generator, ae_generator, ptr_gen=False):
+        super().__init__()
+        self.text_encoder = text_encoder
+        self.vid_encoder = vid_encoder
+        self.text_decoder = text_decoder
+        self.mutlimodal_decoder = mutlimodal_decoder
+        self.query_embed = query_embed
+        self.tgt_embed = tgt_embed
+        self.generator = generator
+        self.ae_generator = ae_generator
+        self.ptr_gen = ptr_gen
+        self.args = args
+
+    def forward(self, b) -> Dict[str, Tensor]:
+        return self.decode(b, self.encode(b))
+
+    def encode(self, b) -> Dict[str, Tensor]:
+        return self.encode_vid(b, self.encode_text(b, {}))
+
+    def encode_text(self, b, ft):
+        e = self.query_embed
+        q, c, h = self.text_encoder(embed_with_position(e, b.query),
+                                    embed_with_position(e, b.cap) if b.cap is not None else None,
+                                    embed_with_position(e, b.his))
+        ft["encoded_query"], ft["encoded_cap"], ft["encoded_his"] = q, c, h
+        return ft
+
+    def encode_vid(self, b, ft):
+        return self.vid_encoder(b, ft)
+
+    def decode(self, b, ft):
+        return self.multimodal_decode_text(b, ft)
+
+    def multimodal_decode_text(self, b, ft):
+        ft["encoded_tgt"] = embed_with_position(self.tgt_embed, b.trg)     # not layer-normed (mtn.py:58-59)
+        return self.mutlimodal_decoder(b, ft, ft["encoded_tgt"])
+
+
+def make_model(src_vocab, tgt_vocab, args, ft_sizes=None, embeddings=None):
+    """Same construction order and sharing as the reference factory (mtn.py:63-167): d_ff is always
+    4*d_model (args.d_ff is ignored there too), every attention/ff is an independent deep copy,
+    xavier-uniform on every parameter with more than one dimension."""
+    N, venc_N, cenc_N, aenc_N = args.nb_blocks, args.nb_venc_blocks, args.nb_cenc_blocks, args.nb_aenc_blocks
+    d_model, h, dropout = args.d_model, args.att_h, args.dropout
+    d_ff = d_model * 4
+    c = copy.deepcopy
+    attn = MultiHeadedAttention(h, d_model)
+    ff = PositionwiseFeedForward(d_model, d_ff, dropout)
+    query_embed = nn.Sequential(Embeddings(d_model, src_vocab), PositionalEncoding(d_model, dropout))
+    tgt_embed = query_embed
+    lut = tgt_embed[0].lut.weight
+    if not args.ptr_gen:
+        raise NotImplementedError("ptr_gen=0 raises NameError in the reference (mtn.py:95); only ptr_gen=1 is in scope")
+    names = args.ptr_ft.split(",")
+    if len(names) > 1:
+        ptr = nn.ModuleList(MultiHeadedAttention(1, d_model, dropout=0) for _ in names)
+        generator = MultiPointerGenerator(d_model, lut, ptr, len(names))
+    else:
+        generator = PointerGenerator(d_model, lut, MultiHeadedAttention(1, d_model, dropout=0))
+    ae_generator = Generator(d_model, tgt_vocab, lut) if args.auto_encoder else None
+    text_encoder = Encoder(d_model, nb_layers=3)
+    if not ft_sizes:
+        raise ValueError("ft_sizes must list the video feature width (mtn.py:110-120)")
+    vid_W = nn.Linear(ft_sizes[0], d_model)
+    a_W = nn.Linear(ft_sizes[1], d_model) if len(ft_sizes) > 1 else None
+    vid_encoder = VidEncoder8(c(vid_W), c(a_W), None, venc_N, aenc_N, d_model, args)
+    both = bool(args.t2s) and bool(args.s2t)
+    v_layer = VidEncoderLayer4(d_model, c(attn), 6 if both else 3, c(ff), 2 if both else 1, dropout, args)
+    c_layer = CapEncoderLayer(d_model, c(attn), 2, c(ff), dropout)
+    a_layer = AudioEncoderLayer(d_model, c(attn), 2, c(ff), dropout)
+    nb_attn = 3
+    if cenc_N > 0 and venc_N > 0 and args.enc_vc_combine != "none":
+        nb_attn += 1
+    else:
+        nb_attn += (cenc_N > 0) + (aenc_N > 0)
+        if venc_N > 0:
+            nb_attn += 1 if (args.enc_st_combine in ("dyn", "sum", "early_sum", "early_dyn") and both) else 2
+    mm_layer = MultimodalDecoderLayer12(d_model, c(attn), nb_attn, c(ff), dropout, args)
+    decoder = MultimodalDecoder8(v_layer, c_layer, a_layer, mm_layer, venc_N, cenc_N, aenc_N, N, args)
+    model = MTN(args=args, text_encoder=text_encoder, vid_encoder=vid_encoder, text_decoder=None,
+                mutlimodal_decoder=decoder, query_embed=query_embed, his_embed=None, cap_embed=None,
+                tgt_embed=tgt_embed, generator=generator, ae_generator=ae_generator, ptr_gen=args.ptr_gen)
+    for p in model.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+    return model

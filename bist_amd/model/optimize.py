@@ -1,0 +1,79 @@
+"""Noam learning-rate wrapper and the loss/step driver (reference: model/optimize.py)."""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+
+
+class NoamOpt:
+    """lr = factor * d_model^-0.5 * min(step^-0.5, step * warmup^-1.5) (reference: optimize.py:9-34)."""
+
+    def __init__(self, model_size, factor, warmup, optimizer):
+        self.optimizer = optimizer
+        self._step = 0
+        self.warmup = warmup
+        self.factor = factor
+        self.model_size = model_size
+        self._rate = 0
+
+    def rate(self, step=None):
+        step = self._step if step is None else step
+        return self.factor * (self.model_size ** (-0.5) * min(step ** (-0.5), step * self.warmup ** (-1.5)))
+
+    def step(self):
+        self._step += 1
+        rate = self.rate()
+        for group in self.optimizer.param_groups:
+            group["lr"] = rate
+        self._rate = rate
+        self.optimizer.step()
+
+
+class SimpleLossCompute:
+    """Response loss + query auto-encoder losses, backward and optimiser step
+    (reference: optimize.py:36-94).  Every term is normalised on the device (no host sync)."""
+
+    def __init__(self, generator, ae_generator, criterion, opt=None, l=1.0, args=None):
+        self.generator = generator
+        self.ae_generator = ae_generator
+        self.criterion = criterion
+        self.opt = opt
+        self.l = l
+        self.args = args
+
+    def terms(self, ft, batch):
+        """dict name -> device scalar [1], already divided by its token count (optimize.py:50-82)."""
+        a = self.args
+        out = self.generator(ft, batch, a)
+        V = out.size(-1)
+        t = {"out": ops.sum_div(self.criterion.row_losses(out.reshape(-1, V), batch.trg_y.reshape(-1)), batch.ntokens.reshape(1))}
+        if a.auto_encoder:
+            keys = []
+            if a.nb_cenc_blocks > 0:
+                keys.append(("cap_ae", "cap_ft"))
+            if a.nb_venc_blocks > 0 and a.enc_st_combine == "none":
+                if a.s2t:
+                    keys.append(("temporal_ae", "temporal_ft"))
+                if a.t2s:
+                    keys.append(("spatial_ae", "spatial_ft"))
+            q = batch.query.reshape(-1)
+            for name, key in keys:
+                lp = self.ae_generator(ft, batch, a, key)
+                t[name] = ops.sum_div(self.criterion.row_losses(lp.reshape(-1, V), q), batch.qntokens.reshape(1))
+        return t, out
+
+    def __call__(self, ft, batch):
+        t, _ = self.terms(ft, batch)
+        loss = None
+        for v in t.values():
+            loss = v if loss is None else loss + v
+        if self.opt is not None:
+            loss.backward()
+            self.opt.step()
+            self.opt.optimizer.zero_grad()
+        norm, qn = batch.ntokens.float(), batch.qntokens.float()
+        zero = torch.zeros((), device=norm.device)
+        return {"out": t["out"].detach()[0] * norm,
+                "temporal_ae": t["temporal_ae"].detach()[0] * qn if "temporal_ae" in t else zero,
+                "spatial_ae": t["spatial_ae"].detach()[0] * qn if "spatial_ae" in t else zero}

@@ -248,3 +248,78 @@ def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
     check(lib.bist_cast(x.data_ptr(), out.data_ptr(), x.numel(), dtype_code(x.dtype), dtype_code(dtype), _stream()), "bist_cast")
     return out
+
+
+def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """a + b (b broadcast over leading dims when smaller) -- SublayerConnection's residual add."""
+    _dev(a, b)
+    if a.dtype != b.dtype:
+        raise TypeError("bist_amd.add: dtype mismatch")
+    a, b = a.contiguous(), b.contiguous()
+    if a.numel() % b.numel() != 0:
+        raise ValueError("bist_amd.add: b must tile a")
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.bist_add_bcast(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), b.numel(), dtype_code(a.dtype), _stream()),
+          "bist_add_bcast")
+    return out
+
+
+def pointer_mix(logits: Tensor, switch_logits: Tensor, ptr_p: Sequence[Tensor], ptr_text: Sequence[Tensor], Lt: int,
+                sigmoid_switch: bool = False) -> Tensor:
+    """log of the pointer/vocabulary mixture (generator.py:84-127); logits f32 [rows,V] -> f32 [rows,V]."""
+    _dev(logits, switch_logits, *ptr_p, *ptr_text)
+    rows, V = logits.shape
+    n = len(ptr_p)
+    if logits.dtype != torch.float32 or switch_logits.dtype != torch.float32:
+        raise TypeError("bist_amd.pointer_mix: logits and switch logits must be float32")
+    logits, switch_logits = logits.contiguous(), switch_logits.contiguous()
+    ps = [p.reshape(rows, -1).contiguous() for p in ptr_p]
+    ts = [t.contiguous() for t in ptr_text]
+    for p, t in zip(ps, ts):
+        if p.dtype != torch.float32 or t.dtype != torch.int64 or p.shape[1] != t.shape[1]:
+            raise TypeError("bist_amd.pointer_mix: pointer probabilities f32 [rows,L], text int64 [B,L]")
+    out = torch.empty((rows, V), device=logits.device, dtype=torch.float32)
+    pp = (C.c_void_p * n)(*[p.data_ptr() for p in ps])
+    tt = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ll = (C.c_int32 * n)(*[p.shape[1] for p in ps])
+    check(lib.bist_pointer_mix_fwd(logits.data_ptr(), switch_logits.data_ptr(), n, pp, tt, ll, out.data_ptr(), rows, Lt, V,
+                                   1 if sigmoid_switch else 0, _stream()), "bist_pointer_mix_fwd")
+    return out
+
+
+def log_softmax(x: Tensor) -> Tensor:
+    _dev(x)
+    if x.dtype != torch.float32:
+        raise TypeError("bist_amd.log_softmax: float32 only")
+    V = x.shape[-1]
+    x2 = x.reshape(-1, V).contiguous()
+    out = torch.empty_like(x2)
+    check(lib.bist_log_softmax_fwd(x2.data_ptr(), out.data_ptr(), x2.shape[0], V, _stream()), "bist_log_softmax_fwd")
+    return out.view(x.shape)
+
+
+def label_smoothing_rows(logp: Tensor, target: Tensor, smoothing: float, pad: int) -> Tensor:
+    """Per-row KLDiv(sum) against the smoothed one-hot (label_smoothing.py:20-30); logp f32 [rows,V]."""
+    _dev(logp, target)
+    rows, V = logp.shape
+    logp, target = logp.contiguous(), target.contiguous()
+    if logp.dtype != torch.float32 or target.dtype != torch.int64:
+        raise TypeError("bist_amd.label_smoothing_rows: logp f32, target int64")
+    out = torch.empty((rows,), device=logp.device, dtype=torch.float32)
+    check(lib.bist_label_smoothing_fwd(logp.data_ptr(), target.data_ptr(), out.data_ptr(), rows, V, smoothing, pad, _stream()),
+          "bist_label_smoothing_fwd")
+    return out
+
+
+def sum_div(x: Tensor, denom: Optional[Tensor] = None, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """sum(x) / denom (device int64 scalar) as a device f32 scalar, fixed summation order."""
+    _dev(x, denom, out)
+    x = x.contiguous()
+    if x.dtype != torch.float32 or (denom is not None and denom.dtype != torch.int64):
+        raise TypeError("bist_amd.sum_div: x f32, denom int64")
+    if out is None:
+        out = torch.empty((1,), device=x.device, dtype=torch.float32)
+        accumulate = False
+    check(lib.bist_sum_div(x.data_ptr(), x.numel(), _ptr(denom), out.data_ptr(), 1 if accumulate else 0, _stream()), "bist_sum_div")
+    return out

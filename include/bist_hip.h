@@ -160,6 +160,36 @@ int bist_temporal_mask(const void* fts, uint8_t* mask, int64_t BT, int64_t row_e
 int bist_fuse_modalities(const void* score, const void* const* xs, void* out, int64_t rows, int32_t n, int32_t d,
                          int32_t dtype, void* stream);
 
+/* out[i] = a[i] + b[i % nb]: the residual add of SublayerConnection (modules.py:44) when it is
+ * not fused into a GEMM epilogue; nb < n broadcasts b.                                          */
+int bist_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t nb, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Output heads ("next" row (f)-2 of SURVEY.md section 8; needed for the logits parity gate).
+ * ------------------------------------------------------------------------------------------ */
+/* MultiPointerGenerator.forward (model/generator.py:84-127) / PointerGenerator (:36-75) after the
+ * projection GEMMs:  out[row,v] = log( sw[n]*softmax(logits[row])[v]
+ *                                      + sum_j sw[j] * sum_{t: text_j[b,t]==v} p_j[row,t] ),  b = row / Lt,
+ * sw = softmax(switch_logits[row,:n+1]) or, for one source with sigmoid_switch, (1-sig, sig).
+ * logits [rows,V] f32, p_j [rows,L_j] f32 (the pointer attentions' `.attn`), text_j int64 [B,L_j];
+ * ptr_p / ptr_text / ptr_len are HOST arrays of n_ptr entries.                                   */
+int bist_pointer_mix_fwd(const float* logits, const float* switch_logits, int32_t n_ptr, const float* const* ptr_p,
+                         const int64_t* const* ptr_text, const int32_t* ptr_len, float* out, int64_t rows, int32_t Lt,
+                         int32_t V, int32_t sigmoid_switch, void* stream);
+
+/* Generator.forward (model/generator.py:21-27): y = log_softmax(x) over V, f32 [rows,V].        */
+int bist_log_softmax_fwd(const float* x, float* y, int64_t rows, int32_t V, void* stream);
+
+/* LabelSmoothing.forward (model/label_smoothing.py:20-30): per-row KL divergence (sum reduction)
+ * of logp [rows,V] against the smoothed one-hot of target[rows] (pad rows and the pad column
+ * carry no mass).                                                                                */
+int bist_label_smoothing_fwd(const float* logp, const int64_t* target, float* row_loss, int64_t rows, int32_t V,
+                             float smoothing, int32_t pad, void* stream);
+
+/* out[0] (+)= sum(x[0..n)) / denom[0]  (denom: device int64 count or NULL = 1); one workgroup,
+ * fixed summation order.  The `/ norm` of SimpleLossCompute (model/optimize.py:50).               */
+int bist_sum_div(const float* x, int64_t n, const int64_t* denom, float* out, int32_t accumulate, void* stream);
+
 /* dst = cast(src) between f32 and bf16 (n elements). */
 int bist_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, void* stream);
 
