@@ -52,6 +52,21 @@ SIGNATURES = {
     "bist_log_softmax_fwd": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "bist_label_smoothing_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _I32, _P]),
     "bist_sum_div": (C.c_int, [_P, _I64, _P, _P, _I32, _P]),
+    "bist_epilogue_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _I64, _I32, _F, C.c_uint64, _I32, _P]),
+    "bist_group_sum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
+    "bist_col_sum_acc": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
+    "bist_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _I64, _I64, _F, _I32, _P]),
+    "bist_embed_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),
+    "bist_fuse_modalities_bwd": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(C.c_void_p), _I64, _I32, _I32, _I32, _P]),
+    "bist_mha_core_bwd": (C.c_int, [_P] * 9 + [_I32] * 5 + [_I64] * 16 + [_F, _I32, _P]),
+    "bist_st_stage1_pv_bwd": (C.c_int, [_P] * 6 + [_I32] * 6 + [_I64, _I64, _I32, _I32, _P]),
+    "bist_st_stage2_bwd": (C.c_int, [_P] * 6 + [_I32] * 6 + [_P]),
+    "bist_pointer_mix_bwd": (C.c_int, [_P, _P, _I32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                       _P, _P, _P, _P, C.POINTER(C.c_void_p), _I64, _I32, _I32, _I32, _P]),
+    "bist_log_softmax_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
+    "bist_label_smoothing_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _F, _I32, _P]),
+    "bist_cast_from_f32": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "bist_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _I32, _F, _I32, _I32, _P]),
     "bist_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _P]),
 }
 

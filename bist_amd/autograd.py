@@ -1,0 +1,504 @@
+"""torch.autograd.Function wrappers: forward AND backward of every step run on libbist_hip.so.
+
+autograd itself is plumbing here (it records the graph and routes gradient tensors); no gradient is
+computed by an aten kernel except trivial view/concat bookkeeping.  Each backward recomputes what it
+needs from the saved inputs (probabilities are never stored) and calls the kernels declared in
+include/bist_hip.h under "Backward kernels".
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import ACT_NONE, ACT_RELU, check, lib
+from .ops import _ptr, _stream, dtype_code
+
+Tensor = torch.Tensor
+
+
+def _f32_zeros(shape, like: Tensor) -> Tensor:
+    return torch.zeros(shape, device=like.device, dtype=torch.float32)
+
+
+def _to_dtype_from_f32(acc: Tensor, dtype: torch.dtype) -> Tensor:
+    if dtype == torch.float32:
+        return acc
+    out = torch.empty(acc.shape, device=acc.device, dtype=dtype)
+    check(lib.bist_cast_from_f32(acc.data_ptr(), out.data_ptr(), acc.numel(), dtype_code(dtype), _stream()), "bist_cast_from_f32")
+    return out
+
+
+def _mask_u8(mask: Optional[Tensor]):
+    if mask is None:
+        return None
+    m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+    return m if m.stride(-1) == 1 else m.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# linear
+# ----------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = drop(act(alpha * x.W^T + bias)) + residual[row map]   (GEMM epilogue, include/bist_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, act, res_map, alpha, drop_p, drop_seed, out_dtype):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        y = ops.linear(x2, w, bias, act=act, residual=residual, res_map=res_map, alpha=alpha, out_dtype=out_dtype,
+                       drop_p=drop_p, drop_seed=drop_seed)
+        ctx.save_for_backward(x2, w, y if act == ACT_RELU else None)
+        ctx.cfg = (act, res_map, alpha, drop_p, drop_seed, bias is not None, bias.dtype if bias is not None else None,
+                   residual is not None, tuple(residual.shape) if residual is not None else None, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        act, res_map, alpha, drop_p, drop_seed, has_bias, bias_dtype, has_res, res_shape, x_shape = ctx.cfg
+        M, K = x2.shape
+        N = w.shape[0]
+        dy = dy.reshape(M, N)
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        dres = None
+        if has_res and ctx.needs_input_grad[3]:
+            if res_map != (0, 0):
+                outer, inner = res_map
+                G = outer // inner
+                dres = torch.empty((M // G, N), device=dy.device, dtype=dy.dtype)
+                check(lib.bist_group_sum(dy.data_ptr(), dres.data_ptr(), M // outer, G, inner * N, dtype_code(dy.dtype), _stream()),
+                      "bist_group_sum")
+                dres = dres.view(res_shape) if dres.numel() == math.prod(res_shape) else dres
+            else:
+                dres = dy.view(res_shape)
+        dz = dy if dy.dtype == x2.dtype else ops.cast(dy, x2.dtype)
+        if act == ACT_RELU or drop_p > 0:
+            dz2 = torch.empty_like(dz)
+            yy = y if y is not None else dz
+            if y is not None and y.dtype != dz.dtype:
+                raise RuntimeError("relu epilogue backward needs the output in the operand dtype")
+            check(lib.bist_epilogue_bwd(dz.data_ptr(), yy.data_ptr(), dz2.data_ptr(), M, N, N, N, N, act, drop_p, drop_seed,
+                                        dtype_code(dz.dtype), _stream()), "bist_epilogue_bwd")
+            dz = dz2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), device=dz.device, dtype=x2.dtype)
+            ops.gemm(dz, w, dx, M=M, N=K, K=N, a_rs=N, a_ks=1, b_rs=1, b_ks=w.stride(0), ldc=K, alpha=alpha)
+            dx = dx.view(x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), device=dz.device, dtype=w.dtype)
+            ops.gemm(dz, x2, dw, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=K, alpha=alpha)
+        if has_bias and ctx.needs_input_grad[2]:
+            acc = _f32_zeros((N,), dz)
+            check(lib.bist_col_sum_acc(dz.data_ptr(), acc.data_ptr(), M, N, N, dtype_code(dz.dtype), _stream()), "bist_col_sum_acc")
+            db = _to_dtype_from_f32(acc, bias_dtype)
+        return dx, dw, db, dres, None, None, None, None, None, None
+
+
+def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, res_map=(0, 0), alpha=1.0, out=None, out_dtype=None,
+           accumulate=False, drop_p=0.0, drop_seed=0):
+    if not torch.is_grad_enabled():
+        return ops.linear(x, w, bias, act=act, residual=residual, res_map=res_map, alpha=alpha, out=out, out_dtype=out_dtype,
+                          accumulate=accumulate, drop_p=drop_p, drop_seed=drop_seed)
+    if accumulate:                       # out-of-place under autograd: the running sum is the residual
+        residual = out
+    if residual is not None and residual.dim() != 2:
+        residual = residual.reshape(-1, residual.shape[-1])
+    return LinearFn.apply(x, w, bias, residual, act, tuple(res_map), alpha, drop_p, drop_seed, out_dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# batched-GEMM steps of the folded attention
+# ----------------------------------------------------------------------------------------------
+class HeadFoldFn(Function):
+    """Qf[m, hh*d+n] = alpha * sum_c q[m, hh*dk+c] wk[hh*dk+c, n]."""
+
+    @staticmethod
+    def forward(ctx, q, wk, h, alpha):
+        ctx.save_for_backward(q, wk)
+        ctx.cfg = (h, alpha)
+        M, d = q.shape
+        dk = d // h
+        out = torch.empty((M, h * d), device=q.device, dtype=q.dtype)
+        ops.gemm(q, wk, out, M=M, N=d, K=dk, a_rs=q.stride(0), a_ks=1, b_rs=1, b_ks=wk.stride(0), ldc=h * d,
+                 batch=(1, h), a_bs=(0, dk), b_bs=(0, dk * wk.stride(0)), c_bs=(0, d), alpha=alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dqf):
+        q, wk = ctx.saved_tensors
+        h, alpha = ctx.cfg
+        M, d = q.shape
+        dk = d // h
+        dqf = dqf.contiguous()
+        dq = torch.empty((M, d), device=q.device, dtype=q.dtype)
+        ops.gemm(dqf, wk, dq, M=M, N=dk, K=d, a_rs=h * d, b_rs=wk.stride(0), ldc=d, batch=(1, h), a_bs=(0, d),
+                 b_bs=(0, dk * wk.stride(0)), c_bs=(0, dk), alpha=alpha)
+        dwk = torch.empty((d, d), device=q.device, dtype=wk.dtype)
+        ops.gemm(q, dqf, dwk, M=dk, N=d, K=M, a_rs=1, a_ks=q.stride(0), b_rs=1, b_ks=h * d, ldc=d, batch=(1, h),
+                 a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * d), alpha=alpha)
+        return dq, dwk, None, None
+
+
+class HeadUnfoldFn(Function):
+    """O[m, hh*dk+c] = sum_n py[m, hh*d+n] wv[hh*dk+c, n] + bv[hh*dk+c]."""
+
+    @staticmethod
+    def forward(ctx, py, wv, bv, h):
+        ctx.save_for_backward(py, wv)
+        ctx.cfg = (h, bv.dtype)
+        M = py.shape[0]
+        d = wv.shape[1]
+        dk = d // h
+        out = torch.empty((M, d), device=py.device, dtype=py.dtype)
+        ops.gemm(py, wv, out, M=M, N=dk, K=d, a_rs=py.stride(0), b_rs=wv.stride(0), ldc=d, bias=bv, batch=(1, h),
+                 a_bs=(0, d), b_bs=(0, dk * wv.stride(0)), c_bs=(0, dk), bias_bs2=dk)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        py, wv = ctx.saved_tensors
+        h, bdt = ctx.cfg
+        M = py.shape[0]
+        d = wv.shape[1]
+        dk = d // h
+        do = do.contiguous()
+        dpy = torch.empty((M, h * d), device=py.device, dtype=py.dtype)
+        ops.gemm(do, wv, dpy, M=M, N=d, K=dk, a_rs=d, a_ks=1, b_rs=1, b_ks=wv.stride(0), ldc=h * d, batch=(1, h),
+                 a_bs=(0, dk), b_bs=(0, dk * wv.stride(0)), c_bs=(0, d))
+        dwv = torch.empty((d, d), device=py.device, dtype=wv.dtype)
+        ops.gemm(do, py, dwv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=d, batch=(1, h),
+                 a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * d))
+        acc = _f32_zeros((d,), do)
+        check(lib.bist_col_sum_acc(do.data_ptr(), acc.data_ptr(), M, d, d, dtype_code(do.dtype), _stream()), "bist_col_sum_acc")
+        return dpy, dwv, _to_dtype_from_f32(acc, bdt), None
+
+
+class StScoresFn(Function):
+    """scores[b,r,ts] = qf[b,r,:] . vft[b,ts,:]  (f32 out)."""
+
+    @staticmethod
+    def forward(ctx, qf, vft):
+        ctx.save_for_backward(qf, vft)
+        B, R, d = qf.shape
+        TS = vft.shape[1]
+        out = torch.empty((B, R, TS), device=qf.device, dtype=torch.float32)
+        ops.gemm(qf, vft, out, M=R, N=TS, K=d, a_rs=qf.stride(1), b_rs=vft.stride(1), ldc=TS, batch=(B, 1),
+                 a_bs=(qf.stride(0), 0), b_bs=(vft.stride(0), 0), c_bs=(R * TS, 0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dsc):
+        qf, vft = ctx.saved_tensors
+        B, R, d = qf.shape
+        TS = vft.shape[1]
+        g = ops.cast(dsc.contiguous(), qf.dtype)
+        dqf = torch.empty((B, R, d), device=qf.device, dtype=qf.dtype)
+        ops.gemm(g, vft, dqf, M=R, N=d, K=TS, a_rs=TS, a_ks=1, b_rs=1, b_ks=vft.stride(1), ldc=d, batch=(B, 1),
+                 a_bs=(R * TS, 0), b_bs=(vft.stride(0), 0), c_bs=(R * d, 0))
+        dv = torch.empty((B, TS, d), device=qf.device, dtype=vft.dtype)
+        ops.gemm(g, qf, dv, M=TS, N=d, K=R, a_rs=1, a_ks=TS, b_rs=1, b_ks=qf.stride(1), ldc=d, batch=(B, 1),
+                 a_bs=(R * TS, 0), b_bs=(qf.stride(0), 0), c_bs=(TS * d, 0))
+        return dqf, dv
+
+
+class BmmNNFn(Function):
+    """C[b] = A[b] . B[b]   A [Z,M,K], B [Z,K,N] (both row-major) -> [Z,M,N]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        Z, M, K = a.shape
+        N = b.shape[2]
+        out = torch.empty((Z, M, N), device=a.device, dtype=a.dtype)
+        ops.gemm(a, b, out, M=M, N=N, K=K, a_rs=a.stride(1), a_ks=1, b_rs=1, b_ks=b.stride(1), ldc=N, batch=(Z, 1),
+                 a_bs=(a.stride(0), 0), b_bs=(b.stride(0), 0), c_bs=(M * N, 0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        Z, M, K = a.shape
+        N = b.shape[2]
+        dc = dc.contiguous()
+        da = torch.empty((Z, M, K), device=a.device, dtype=a.dtype)       # dA = dC . B^T
+        ops.gemm(dc, b, da, M=M, N=K, K=N, a_rs=N, b_rs=b.stride(1), ldc=K, batch=(Z, 1), a_bs=(M * N, 0),
+                 b_bs=(b.stride(0), 0), c_bs=(M * K, 0))
+        db = torch.empty((Z, K, N), device=a.device, dtype=b.dtype)       # dB = A^T . dC
+        ops.gemm(a, dc, db, M=K, N=N, K=M, a_rs=1, a_ks=a.stride(1), b_rs=1, b_ks=N, ldc=N, batch=(Z, 1),
+                 a_bs=(a.stride(0), 0), b_bs=(M * N, 0), c_bs=(K * N, 0))
+        return da, db
+
+
+# ----------------------------------------------------------------------------------------------
+# row-wise steps
+# ----------------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, a, b, eps):
+        ctx.save_for_backward(x, a)
+        ctx.cfg = (eps, b.dtype)
+        return ops.layernorm(x, a, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a = ctx.saved_tensors
+        eps, bdt = ctx.cfg
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d)
+        dy2 = dy.reshape(-1, d)
+        if dy2.stride(1) != 1:
+            dy2 = dy2.contiguous()
+        dx = torch.empty(x2.shape, device=x.device, dtype=x.dtype)
+        da, db = _f32_zeros((d,), x), _f32_zeros((d,), x)
+        check(lib.bist_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), a.data_ptr(), dx.data_ptr(), da.data_ptr(), db.data_ptr(),
+                                     x2.shape[0], d, dy2.stride(0), x2.stride(0), d, eps, dtype_code(x.dtype), _stream()),
+              "bist_layernorm_bwd")
+        return dx.view(x.shape), _to_dtype_from_f32(da, a.dtype), _to_dtype_from_f32(db, bdt), None
+
+
+class EmbedFn(Function):
+    @staticmethod
+    def forward(ctx, ids, lut, pe):
+        ctx.save_for_backward(ids)
+        ctx.cfg = (tuple(lut.shape), lut.dtype)
+        return ops.embed_pe(ids, lut, pe)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        shape, dt = ctx.cfg
+        dy = dy.contiguous()
+        acc = _f32_zeros(shape, dy)
+        check(lib.bist_embed_bwd(ids.contiguous().data_ptr(), dy.data_ptr(), acc.data_ptr(), ids.numel(), shape[1],
+                                 dtype_code(dy.dtype), _stream()), "bist_embed_bwd")
+        return None, _to_dtype_from_f32(acc, dt), None
+
+
+class FuseFn(Function):
+    @staticmethod
+    def forward(ctx, score, *xs):
+        ctx.save_for_backward(score, *xs)
+        return ops.fuse_modalities(score, xs)
+
+    @staticmethod
+    def backward(ctx, dout):
+        score, *xs = ctx.saved_tensors
+        n, d = score.shape[-1], xs[0].shape[-1]
+        dout = dout.contiguous()
+        score = score.contiguous()
+        xs = [x.contiguous() for x in xs]
+        rows = dout.numel() // d
+        dscore = torch.empty_like(score)
+        dxs = [torch.empty_like(x) for x in xs]
+        xa = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        da = (C.c_void_p * n)(*[x.data_ptr() for x in dxs])
+        check(lib.bist_fuse_modalities_bwd(score.data_ptr(), xa, dout.data_ptr(), dscore.data_ptr(), da, rows, n, d,
+                                           dtype_code(score.dtype), _stream()), "bist_fuse_modalities_bwd")
+        return (dscore, *dxs)
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        if a.shape != b.shape:
+            raise ValueError("AddFn: equal shapes only (broadcast adds carry no gradient on this path)")
+        return ops.add(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class CastFn(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.cast(dy.contiguous(), ctx.src), None
+
+
+# ----------------------------------------------------------------------------------------------
+# attention cores
+# ----------------------------------------------------------------------------------------------
+class MhaCoreFn(Function):
+    """mha_core over (possibly packed) projections.  mode: 'qkv' (a = [N,L,3d]), 'q_kv' (a = q, b = [N,Lk,2d]),
+    'q_k_v' (a, b, c).  Returns (O, P or None); a gradient arriving for P is honoured (pointer generator)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, mode, mask, h, want_p):
+        q, k, v = MhaCoreFn._views(a, b, c, mode)
+        m8 = _mask_u8(mask)
+        o, p = ops.mha_core(q, k, v, m8, h, want_p=want_p)
+        ctx.save_for_backward(a, b, c, m8)
+        ctx.cfg = (mode, h)
+        if p is None:
+            ctx.mark_non_differentiable()
+            return o, None
+        return o, p
+
+    @staticmethod
+    def _views(a, b, c, mode):
+        if mode == "qkv":
+            d = a.shape[-1] // 3
+            return a[..., :d], a[..., d:2 * d], a[..., 2 * d:]
+        if mode == "q_kv":
+            d = a.shape[-1]
+            return a, b[..., :d], b[..., d:]
+        return a, b, c
+
+    @staticmethod
+    def backward(ctx, do, dp):
+        a, b, c, m8 = ctx.saved_tensors
+        mode, h = ctx.cfg
+        q, k, v = MhaCoreFn._views(a, b, c, mode)
+        N, Lq, d = q.shape
+        Lk = k.shape[1]
+        dk_ = d // h
+        ga = torch.empty(a.shape, device=a.device, dtype=a.dtype)
+        gb = torch.empty(b.shape, device=a.device, dtype=b.dtype) if b is not None else None
+        gc = torch.empty(c.shape, device=a.device, dtype=c.dtype) if c is not None else None
+        dq, dkk, dv = MhaCoreFn._views(ga, gb, gc, mode)
+        if do is not None:
+            do = do.contiguous()
+            if do.dtype != q.dtype:
+                do = ops.cast(do, q.dtype)
+        if dp is not None:
+            dp = dp.contiguous().float() if dp.dtype != torch.float32 else dp.contiguous()
+        mbs = mqs = 0
+        if m8 is not None:
+            mbs = m8.stride(0) if m8.shape[0] > 1 else 0
+            mqs = m8.stride(1) if m8.shape[1] > 1 else 0
+        check(lib.bist_mha_core_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(m8), _ptr(do), _ptr(dp),
+                                    dq.data_ptr(), dkk.data_ptr(), dv.data_ptr(), N, Lq, Lk, h, dk_,
+                                    q.stride(1), k.stride(1), v.stride(1), d, q.stride(0), k.stride(0), v.stride(0), Lq * d,
+                                    dq.stride(1), dkk.stride(1), dv.stride(1), dq.stride(0), dkk.stride(0), dv.stride(0),
+                                    mbs, mqs, 1.0 / math.sqrt(dk_), dtype_code(q.dtype), _stream()), "bist_mha_core_bwd")
+        return ga, gb, gc, None, None, None, None
+
+
+class StStage1PvFn(Function):
+    @staticmethod
+    def forward(ctx, scores, v, tmask, dims, direction):
+        B, T, S, Lq, h, dk = dims
+        m8 = _mask_u8(tmask.reshape(B, T)) if tmask is not None else None
+        out = ops.st_stage1_pv(scores, v, m8, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
+        ctx.save_for_backward(scores, v, m8)
+        ctx.cfg = (dims, direction)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        scores, v, m8 = ctx.saved_tensors
+        (B, T, S, Lq, h, dk), direction = ctx.cfg
+        d = h * dk
+        do = do.contiguous()
+        dsc = torch.empty_like(scores)
+        dv = torch.empty((B, T, S, d), device=v.device, dtype=v.dtype)
+        check(lib.bist_st_stage1_pv_bwd(scores.data_ptr(), v.data_ptr(), _ptr(m8), do.data_ptr(), dsc.data_ptr(), dv.data_ptr(),
+                                        B, T, S, Lq, h, dk, v.stride(-2), d, direction, dtype_code(v.dtype), _stream()),
+              "bist_st_stage1_pv_bwd")
+        return dsc, dv, None, None, None
+
+
+class StStage2Fn(Function):
+    @staticmethod
+    def forward(ctx, q2f, y, gmask, h):
+        B, G = y.shape[0], y.shape[1]
+        m8 = _mask_u8(gmask.reshape(B, G)) if gmask is not None else None
+        out = ops.st_stage2(q2f, y, m8, h=h)
+        ctx.save_for_backward(q2f, y, m8)
+        ctx.h = h
+        return out
+
+    @staticmethod
+    def backward(ctx, dpy):
+        q2f, y, m8 = ctx.saved_tensors
+        B, G, Lq, d = y.shape
+        dpy = dpy.contiguous()
+        dq = torch.empty_like(q2f)
+        dy = torch.empty_like(y)
+        check(lib.bist_st_stage2_bwd(q2f.data_ptr(), y.data_ptr(), _ptr(m8), dpy.data_ptr(), dq.data_ptr(), dy.data_ptr(),
+                                     B, G, Lq, ctx.h, d, dtype_code(y.dtype), _stream()), "bist_st_stage2_bwd")
+        return dq, dy, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# output heads and loss
+# ----------------------------------------------------------------------------------------------
+class PointerMixFn(Function):
+    @staticmethod
+    def forward(ctx, logits, sw, Lt, sigmoid_switch, n, *rest):
+        ps, texts = rest[:n], rest[n:]
+        out = ops.pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch)
+        ctx.save_for_backward(logits, sw, out, *ps, *texts)
+        ctx.cfg = (Lt, sigmoid_switch, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Lt, sig, n = ctx.cfg
+        logits, sw, out, *rest = ctx.saved_tensors
+        ps, texts = rest[:n], rest[n:]
+        rows, V = logits.shape
+        dout = dout.contiguous()
+        logits, sw = logits.contiguous(), sw.contiguous()
+        p2 = [p.reshape(rows, -1).contiguous() for p in ps]
+        t2 = [t.contiguous() for t in texts]
+        dlogits, dsw = torch.empty_like(logits), torch.empty_like(sw)
+        dps = [torch.empty_like(p) for p in p2]
+        pp = (C.c_void_p * n)(*[p.data_ptr() for p in p2])
+        tt = (C.c_void_p * n)(*[t.data_ptr() for t in t2])
+        ll = (C.c_int32 * n)(*[p.shape[1] for p in p2])
+        dd = (C.c_void_p * n)(*[p.data_ptr() for p in dps])
+        check(lib.bist_pointer_mix_bwd(logits.data_ptr(), sw.data_ptr(), n, pp, tt, ll, out.data_ptr(), dout.data_ptr(),
+                                       dlogits.data_ptr(), dsw.data_ptr(), dd, rows, Lt, V, 1 if sig else 0, _stream()),
+              "bist_pointer_mix_bwd")
+        return (dlogits, dsw, None, None, None, *[g.view(p.shape) for g, p in zip(dps, ps)], *([None] * n))
+
+
+class LogSoftmaxFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.log_softmax(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        V = y.shape[-1]
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(lib.bist_log_softmax_bwd(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel() // V, V, _stream()), "bist_log_softmax_bwd")
+        return dx
+
+
+class LabelSmoothingLossFn(Function):
+    """sum_rows KL(smoothed target || exp(logp)) / denom  -> device scalar [1]."""
+
+    @staticmethod
+    def forward(ctx, logp, target, denom, smoothing, pad):
+        rows = ops.label_smoothing_rows(logp, target, smoothing, pad)
+        ctx.save_for_backward(target.contiguous(), denom)
+        ctx.cfg = (tuple(logp.shape), smoothing, pad)
+        return ops.sum_div(rows, denom)
+
+    @staticmethod
+    def backward(ctx, gout):
+        target, denom = ctx.saved_tensors
+        (rows, V), smoothing, pad = ctx.cfg
+        gout = gout.contiguous().float()
+        dlogp = torch.empty((rows, V), device=gout.device, dtype=torch.float32)
+        check(lib.bist_label_smoothing_bwd(target.data_ptr(), gout.data_ptr(), _ptr(denom), dlogp.data_ptr(), rows, V, smoothing,
+                                           pad, _stream()), "bist_label_smoothing_bwd")
+        return dlogp, None, None, None, None

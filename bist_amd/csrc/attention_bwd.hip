@@ -1,0 +1,332 @@
+// Backward of the attention cores (training path).  Probabilities are recomputed from the saved
+// inputs (scores or Q/K), never stored by the forward pass.  Softmax backward:
+//   dS = P * (dP - sum_k P dP), and dS = 0 where the score was replaced by the -1e9 mask fill.
+#include "common.hpp"
+
+namespace {
+
+constexpr float MASK_FILL = -1e9f;
+
+// ---------------------------------------------------------------------------------------------
+// mha_core backward: one workgroup per (n, head).  LDS: P[Lq][Lk], dS[Lq][Lk] (floats).
+//   dP = dO V^T (+ dP_ext, the gradient arriving through the `.attn` side channel)
+//   dQ = scale * dS K ; dK = scale * dS^T Q ; dV = P^T dO
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mha_core_bwd_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ V,
+                                                           const unsigned char* __restrict__ mask, const T* __restrict__ dO,
+                                                           const float* __restrict__ dPext, T* __restrict__ dQ, T* __restrict__ dK,
+                                                           T* __restrict__ dV, int Lq, int Lk, int h, int dk, long ldq, long ldk,
+                                                           long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs,
+                                                           long lddq, long lddk, long lddv, long dq_bs, long dk_bs, long dv_bs,
+                                                           long mask_bs, long mask_qs, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* P = smem;
+  float* dS = smem + (long)Lq * Lk;
+  const int hh = blockIdx.x, n = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const T* Qn = Q + n * q_bs + hh * dk;
+  const T* Kn = K + n * k_bs + hh * dk;
+  const T* Vn = V + n * v_bs + hh * dk;
+  const T* dOn = dO ? dO + n * o_bs + hh * dk : nullptr;
+  // phase A: wave per query row
+  for (int i = w; i < Lq; i += 4) {
+    const unsigned char* mrow = mask ? mask + n * mask_bs + (long)i * mask_qs : nullptr;
+    float* p = P + (long)i * Lk;
+    float* ds = dS + (long)i * Lk;
+    float mx = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) {
+      float s = 0.f, dp = 0.f;
+      const T* kr = Kn + (long)j * ldk;
+      const T* vr = Vn + (long)j * ldv;
+      for (int c = 0; c < dk; ++c) {
+        s += to_f(Qn[(long)i * ldq + c]) * to_f(kr[c]);
+        if (dOn) dp += to_f(dOn[(long)i * ldo + c]) * to_f(vr[c]);
+      }
+      s *= scale;
+      if (mrow && mrow[j] == 0) s = MASK_FILL;
+      if (dPext) dp += dPext[(((long)n * h + hh) * Lq + i) * Lk + j];
+      p[j] = s; ds[j] = dp;
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int j = lane; j < Lk; j += 64) { const float e = expf(p[j] - mx); p[j] = e; den += e; }
+    den = wave_sum(den);
+    const float inv = 1.f / den;
+    float dot = 0.f;
+    for (int j = lane; j < Lk; j += 64) { p[j] *= inv; dot += p[j] * ds[j]; }
+    dot = wave_sum(dot);
+    for (int j = lane; j < Lk; j += 64) {
+      float g = p[j] * (ds[j] - dot);
+      if (mrow && mrow[j] == 0) g = 0.f;
+      ds[j] = g * scale;
+    }
+  }
+  __syncthreads();
+  // phase B
+  for (int item = tid; item < Lq * dk; item += 256) {       // dQ[i,c]
+    const int i = item / dk, c = item % dk;
+    float acc = 0.f;
+    for (int j = 0; j < Lk; ++j) acc += dS[(long)i * Lk + j] * to_f(Kn[(long)j * ldk + c]);
+    dQ[n * dq_bs + (long)i * lddq + hh * dk + c] = from_f<T>(acc);
+  }
+  for (int item = tid; item < Lk * dk; item += 256) {       // dK[j,c], dV[j,c]
+    const int j = item / dk, c = item % dk;
+    float ak = 0.f, av = 0.f;
+    for (int i = 0; i < Lq; ++i) {
+      ak += dS[(long)i * Lk + j] * to_f(Qn[(long)i * ldq + c]);
+      if (dOn) av += P[(long)i * Lk + j] * to_f(dOn[(long)i * ldo + c]);
+    }
+    dK[n * dk_bs + (long)j * lddk + hh * dk + c] = from_f<T>(ak);
+    dV[n * dv_bs + (long)j * lddv + hh * dk + c] = from_f<T>(av);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// st1_pv backward: grid (group chunks, h, B), same slab decomposition as the forward.
+// LDS: P[i][gl][K+1], D[i][gl][K+1] (dP then dS), dOs[gl][i][dk]   (floats)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void st1_pv_bwd_kernel(const float* __restrict__ scores, const T* __restrict__ V,
+                                                         const unsigned char* __restrict__ tmask, const T* __restrict__ dO,
+                                                         float* __restrict__ dscores, T* __restrict__ dV, int T_, int S_, int Lq,
+                                                         int h, int dk, long ldv, long lddv, int dir, int Gc) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int G = dir == 0 ? S_ : T_, Kn = dir == 0 ? T_ : S_;
+  const int KP = Kn + 1;
+  const int g0 = blockIdx.x * Gc, hh = blockIdx.y, b = blockIdx.z;
+  const int gc = min(Gc, G - g0);
+  const int tid = threadIdx.x;
+  const long TS_ = (long)T_ * S_;
+  const int d = h * dk;
+  float* P = smem;
+  float* D = smem + (long)Lq * Gc * KP;
+  float* dOs = D + (long)Lq * Gc * KP;
+  const float* sc = scores + (long)b * Lq * h * TS_;
+  float* dsc = dscores + (long)b * Lq * h * TS_;
+  const unsigned char* mk = (dir == 0 && tmask) ? tmask + (long)b * T_ : nullptr;
+  const int total = Lq * gc * Kn;
+  for (int idx = tid; idx < total; idx += 256) {
+    int i, gl, k;
+    if (dir == 0) { gl = idx % gc; const int t2 = idx / gc; k = t2 % Kn; i = t2 / Kn; }
+    else          { k = idx % Kn; const int t2 = idx / Kn; gl = t2 % gc; i = t2 / gc; }
+    const int g = g0 + gl;
+    const long col = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+    float v = sc[((long)i * h + hh) * TS_ + col];
+    if (mk && mk[k] == 0) v = MASK_FILL;
+    P[((long)i * gc + gl) * KP + k] = v;
+  }
+  for (int idx = tid; idx < gc * Lq * dk; idx += 256) {     // dO chunk: [gl][i][c]
+    const int c = idx % dk; const int t2 = idx / dk; const int i = t2 % Lq, gl = t2 / Lq;
+    dOs[idx] = to_f(dO[(((long)b * G + g0 + gl) * Lq + i) * d + hh * dk + c]);
+  }
+  __syncthreads();
+  for (int r = tid; r < Lq * gc; r += 256) {                 // softmax rows
+    float* p = P + (long)r * KP;
+    float mx = -INFINITY;
+    for (int k = 0; k < Kn; ++k) mx = fmaxf(mx, p[k]);
+    float den = 0.f;
+    for (int k = 0; k < Kn; ++k) { const float e = expf(p[k] - mx); p[k] = e; den += e; }
+    const float inv = 1.f / den;
+    for (int k = 0; k < Kn; ++k) p[k] *= inv;
+  }
+  // dP[i][gl][k] = sum_c dO[g,i,c] V[(g,k),c]: thread owns (gl,k), keeps the V row in registers by chunks of 16
+  const T* Vb = V + (long)b * TS_ * ldv + hh * dk;
+  T* dVb = dV + (long)b * TS_ * lddv + hh * dk;
+  for (int idx = tid; idx < Lq * gc * Kn; idx += 256) D[((long)(idx / (gc * Kn)) * gc + (idx / Kn) % gc) * KP + idx % Kn] = 0.f;
+  __syncthreads();
+  for (int item = tid; item < gc * Kn; item += 256) {
+    const int gl = item / Kn, k = item % Kn, g = g0 + gl;
+    const long row = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+    for (int c0 = 0; c0 < dk; c0 += 16) {
+      float vr[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) vr[u] = (c0 + u < dk) ? to_f(Vb[row * ldv + c0 + u]) : 0.f;
+      for (int i = 0; i < Lq; ++i) {
+        const float* go = dOs + ((long)gl * Lq + i) * dk + c0;
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (c0 + u < dk) acc += go[u] * vr[u];
+        D[((long)i * gc + gl) * KP + k] += acc;
+      }
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < Lq * gc; r += 256) {                 // dS = P (dP - sum P dP); masked -> 0
+    float* p = P + (long)r * KP;
+    float* q = D + (long)r * KP;
+    float dot = 0.f;
+    for (int k = 0; k < Kn; ++k) dot += p[k] * q[k];
+    for (int k = 0; k < Kn; ++k) {
+      float gq = p[k] * (q[k] - dot);
+      if (mk && mk[k] == 0) gq = 0.f;
+      q[k] = gq;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < total; idx += 256) {             // write dscores with the forward's gather order
+    int i, gl, k;
+    if (dir == 0) { gl = idx % gc; const int t2 = idx / gc; k = t2 % Kn; i = t2 / Kn; }
+    else          { k = idx % Kn; const int t2 = idx / Kn; gl = t2 % gc; i = t2 / gc; }
+    const int g = g0 + gl;
+    const long col = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+    dsc[((long)i * h + hh) * TS_ + col] = D[((long)i * gc + gl) * KP + k];
+  }
+  for (int item = tid; item < gc * Kn * dk; item += 256) {   // dV[(g,k), c] = sum_i P[i][gl][k] dO[g,i,c]
+    const int c = item % dk; const int t2 = item / dk; const int k = t2 % Kn, gl = t2 / Kn;
+    const int g = g0 + gl;
+    const long row = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+    float acc = 0.f;
+    for (int i = 0; i < Lq; ++i) acc += P[((long)i * gc + gl) * KP + k] * dOs[((long)gl * Lq + i) * dk + c];
+    dVb[row * lddv + c] = from_f<T>(acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// st2 backward: one workgroup per (b, i).  LDS: q2f[h][d], dPY[h][d], P[h][G], dS[h][G].
+// ---------------------------------------------------------------------------------------------
+constexpr int ST2_MAXH = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void st2_bwd_kernel(const T* __restrict__ q2f, const T* __restrict__ Y, const unsigned char* __restrict__ gmask,
+                                                      const T* __restrict__ dPY, T* __restrict__ dq2f, T* __restrict__ dY,
+                                                      int G, int Lq, int h, int d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* qf = smem;
+  float* gp = qf + (long)h * d;
+  float* P = gp + (long)h * d;
+  float* dS = P + (long)h * G;
+  const int i = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long qoff = ((long)b * Lq + i) * h * d;
+  for (int e = tid; e < h * d; e += 256) { qf[e] = to_f(q2f[qoff + e]); gp[e] = to_f(dPY[qoff + e]); }
+  __syncthreads();
+  const long ystride = (long)Lq * d;
+  const T* Yb = Y + ((long)b * G * Lq + i) * d;
+  T* dYb = dY + ((long)b * G * Lq + i) * d;
+  const unsigned char* mk = gmask ? gmask + (long)b * G : nullptr;
+  for (int g = w; g < G; g += 4) {                           // sc and dP for every head
+    const T* yr = Yb + g * ystride;
+    float as[ST2_MAXH], ap[ST2_MAXH];
+#pragma unroll
+    for (int hh = 0; hh < ST2_MAXH; ++hh) { as[hh] = 0.f; ap[hh] = 0.f; }
+    for (int e = lane; e < d; e += 64) {
+      const float y = to_f(yr[e]);
+#pragma unroll
+      for (int hh = 0; hh < ST2_MAXH; ++hh)
+        if (hh < h) { as[hh] += qf[hh * d + e] * y; ap[hh] += gp[hh * d + e] * y; }
+    }
+#pragma unroll
+    for (int hh = 0; hh < ST2_MAXH; ++hh) {
+      if (hh < h) {
+        float s = wave_sum(as[hh]);
+        const float dp = wave_sum(ap[hh]);
+        if (mk && mk[g] == 0) s = MASK_FILL;
+        if (lane == 0) { P[hh * G + g] = s; dS[hh * G + g] = dp; }
+      }
+    }
+  }
+  __syncthreads();
+  for (int hh = w; hh < h; hh += 4) {
+    float* p = P + hh * G;
+    float* q = dS + hh * G;
+    float mx = -INFINITY;
+    for (int g = lane; g < G; g += 64) mx = fmaxf(mx, p[g]);
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int g = lane; g < G; g += 64) { const float e = expf(p[g] - mx); p[g] = e; den += e; }
+    den = wave_sum(den);
+    const float inv = 1.f / den;
+    float dot = 0.f;
+    for (int g = lane; g < G; g += 64) { p[g] *= inv; dot += p[g] * q[g]; }
+    dot = wave_sum(dot);
+    for (int g = lane; g < G; g += 64) {
+      float gq = p[g] * (q[g] - dot);
+      if (mk && mk[g] == 0) gq = 0.f;
+      q[g] = gq;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < d; e += 256) {
+    float aq[ST2_MAXH];
+#pragma unroll
+    for (int hh = 0; hh < ST2_MAXH; ++hh) aq[hh] = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const float y = to_f(Yb[g * ystride + e]);
+      float dy = 0.f;
+#pragma unroll
+      for (int hh = 0; hh < ST2_MAXH; ++hh)
+        if (hh < h) {
+          const float s = dS[hh * G + g];
+          aq[hh] += s * y;
+          dy += s * qf[hh * d + e] + P[hh * G + g] * gp[hh * d + e];
+        }
+      dYb[g * ystride + e] = from_f<T>(dy);
+    }
+#pragma unroll
+    for (int hh = 0; hh < ST2_MAXH; ++hh)
+      if (hh < h) dq2f[qoff + hh * d + e] = from_f<T>(aq[hh]);
+  }
+}
+
+}  // namespace
+
+extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, const uint8_t* mask, const void* dO, const float* dP_ext,
+                                 void* dQ, void* dK, void* dV, int32_t N, int32_t Lq, int32_t Lk, int32_t h, int32_t dk,
+                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                                 int64_t lddq, int64_t lddk, int64_t lddv, int64_t dq_bs, int64_t dk_bs, int64_t dv_bs,
+                                 int64_t mask_bs, int64_t mask_qs, float scale, int32_t dtype, void* stream) {
+  BIST_REQUIRE(Q && K && V && dQ && dK && dV && (dO || dP_ext), "bist_mha_core_bwd: null pointer");
+  BIST_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && h > 0 && dk > 0, "bist_mha_core_bwd: bad shape");
+  const size_t lds = (size_t)2 * Lq * Lk * sizeof(float);
+  BIST_REQUIRE(lds <= 64 * 1024, "bist_mha_core_bwd: Lq*Lk=%d too large for LDS", Lq * Lk);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)h, (unsigned)N);
+#define L(TT) hipLaunchKernelGGL(mha_core_bwd_kernel<TT>, grid, dim3(256), lds, st, (const TT*)Q, (const TT*)K, (const TT*)V, mask, (const TT*)dO, dP_ext, \
+                                 (TT*)dQ, (TT*)dK, (TT*)dV, Lq, Lk, h, dk, (long)ldq, (long)ldk, (long)ldv, (long)ldo, (long)q_bs, (long)k_bs, (long)v_bs, (long)o_bs, \
+                                 (long)lddq, (long)lddk, (long)lddv, (long)dq_bs, (long)dk_bs, (long)dv_bs, (long)mask_bs, (long)mask_qs, scale)
+  if (dtype == BIST_BF16) L(bf16_t); else if (dtype == BIST_F32) L(float);
+  else { bist_set_error("bist_mha_core_bwd: bad dtype %d", dtype); return BIST_EINVAL; }
+#undef L
+  BIST_LAUNCH_CHECK("bist_mha_core_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const uint8_t* tmask, const void* dO, float* dscores, void* dV,
+                                     int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk, int64_t ldv, int64_t lddv,
+                                     int32_t direction, int32_t dtype, void* stream) {
+  BIST_REQUIRE(scores && V && dO && dscores && dV, "bist_st_stage1_pv_bwd: null pointer");
+  BIST_REQUIRE(B > 0 && T > 0 && S > 0 && Lq > 0 && h > 0 && dk > 0, "bist_st_stage1_pv_bwd: bad shape");
+  BIST_REQUIRE(direction == 0 || direction == 1, "bist_st_stage1_pv_bwd: bad direction");
+  const int G = direction == 0 ? S : T, Kn = direction == 0 ? T : S;
+  const long per_g = ((long)2 * Lq * (Kn + 1) + (long)Lq * dk) * sizeof(float);
+  int Gc = (int)((60 * 1024) / per_g);
+  BIST_REQUIRE(Gc >= 1, "bist_st_stage1_pv_bwd: Lq*(2K+dk) does not fit LDS");
+  if (Gc > G) Gc = G;
+  while (Gc > 1 && (long)((G + Gc - 1) / Gc) * h * B < 512) --Gc;
+  const size_t lds = (size_t)per_g * Gc;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((G + Gc - 1) / Gc), (unsigned)h, (unsigned)B);
+#define L(TT) hipLaunchKernelGGL(st1_pv_bwd_kernel<TT>, grid, dim3(256), lds, st, scores, (const TT*)V, tmask, (const TT*)dO, dscores, (TT*)dV, T, S, Lq, h, dk, (long)ldv, (long)lddv, direction, Gc)
+  if (dtype == BIST_BF16) L(bf16_t); else if (dtype == BIST_F32) L(float);
+  else { bist_set_error("bist_st_stage1_pv_bwd: bad dtype %d", dtype); return BIST_EINVAL; }
+#undef L
+  BIST_LAUNCH_CHECK("bist_st_stage1_pv_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t* gmask, const void* dPY, void* dq2f, void* dY,
+                                  int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, int32_t dtype, void* stream) {
+  BIST_REQUIRE(q2f && Y && dPY && dq2f && dY, "bist_st_stage2_bwd: null pointer");
+  BIST_REQUIRE(B > 0 && G > 0 && Lq > 0 && h > 0 && h <= ST2_MAXH && d > 0, "bist_st_stage2_bwd: bad shape");
+  const size_t lds = ((size_t)2 * h * d + (size_t)2 * h * G) * sizeof(float);
+  BIST_REQUIRE(lds <= 64 * 1024, "bist_st_stage2_bwd: h*(d+G) too large for LDS");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)Lq, (unsigned)B);
+#define L(TT) hipLaunchKernelGGL(st2_bwd_kernel<TT>, grid, dim3(256), lds, st, (const TT*)q2f, (const TT*)Y, gmask, (const TT*)dPY, (TT*)dq2f, (TT*)dY, G, Lq, h, d)
+  if (dtype == BIST_BF16) L(bf16_t); else if (dtype == BIST_F32) L(float);
+  else { bist_set_error("bist_st_stage2_bwd: bad dtype %d", dtype); return BIST_EINVAL; }
+#undef L
+  BIST_LAUNCH_CHECK("bist_st_stage2_bwd");
+  return BIST_OK;
+}

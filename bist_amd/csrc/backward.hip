@@ -1,0 +1,269 @@
+// Backward kernels of the row-wise / elementwise steps and the optimiser (training path).
+// Reductions over rows (bias, LayerNorm gain/offset, embedding rows) accumulate into fp32 buffers
+// with global float atomics shaped as contiguous row segments (one dword per lane).
+#include "common.hpp"
+
+namespace {
+
+inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// dz = dy * d(epilogue)/dz for the GEMM epilogue  y = drop(act(z)) [+ residual]:
+//   relu:            dz = dy * [y > 0]            (y is the stored output, no residual allowed)
+//   dropout:         dz = dy * keep(seed, idx)/(1-p)   (relu+dropout: [y>0] already encodes keep)
+template <typename T>
+__global__ void epilogue_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dz, long M, int N,
+                                    long lddy, long ldy, long lddz, int act, float drop_p, unsigned long long seed) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * N) return;
+  const long m = idx / N; const int n = (int)(idx % N);
+  float g = to_f(dy[m * lddy + n]);
+  if (drop_p > 0.f) {
+    const float sc = 1.f / (1.f - drop_p);
+    if (act == BIST_ACT_RELU) g *= sc;
+    else g = drop_keep(seed, (unsigned long long)idx, drop_p) ? g * sc : 0.f;
+  }
+  if (act == BIST_ACT_RELU && !(to_f(y[m * ldy + n]) > 0.f)) g = 0.f;
+  dz[m * lddz + n] = from_f<T>(g);
+}
+
+// out[b, i, :] = sum_g x[b, g, i, :]   (gradient of the expanded-query residual of stage 1)
+template <typename T>
+__global__ void group_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int G, long inner, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long b = idx / inner, r = idx % inner;
+  const T* p = x + b * G * inner + r;
+  float acc = 0.f;
+  for (int g = 0; g < G; ++g) acc += to_f(p[(long)g * inner]);
+  out[idx] = from_f<T>(acc);
+}
+
+// out[n] += sum_m x[m, n]   (bias gradient); grid = (col blocks of 256, row chunks)
+template <typename T>
+__global__ void col_sum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, long ldx, int rows_per_block) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const long m0 = (long)blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float acc = 0.f;
+  for (long m = m0; m < m1; ++m) acc += to_f(x[m * ldx + n]);
+  atomicAdd(out + n, acc);
+}
+
+// LayerNorm backward (forward: y = a*(x-mean)/(std+eps)+b, std unbiased):
+//   g = dy*a;  dx_i = (g_i - mean(g))/s - xc_i * sum_j(g_j xc_j) / ((d-1) * std * s^2),  s = std+eps
+//   da += dy * xc/s ; db += dy          (fp32 atomics, one row per wave, 4 rows per block)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
+                                                            T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
+                                                            long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long r0 = wave * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+  // per-lane partial sums of da/db over this wave's rows (columns lane, lane+64, ...), flushed once
+  constexpr int MAXC = 32;                       // d <= 2048
+  float pa[MAXC], pb[MAXC];
+#pragma unroll
+  for (int u = 0; u < MAXC; ++u) { pa[u] = 0.f; pb[u] = 0.f; }
+  for (long row = r0; row < r1; ++row) {
+    const T* xr = x + row * ldx;
+    const T* gr = dy + row * lddy;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += to_f(xr[c]);
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f, sg = 0.f, sgx = 0.f;
+    for (int c = lane; c < d; c += 64) {
+      const float xc = to_f(xr[c]) - mean, g = to_f(gr[c]) * to_f(a[c]);
+      q += xc * xc; sg += g; sgx += g * xc;
+    }
+    q = wave_sum(q); sg = wave_sum(sg); sgx = wave_sum(sgx);
+    const float stdv = sqrtf(q / (float)(d - 1)), sden = stdv + eps;
+    const float inv = 1.f / sden, mg = sg / (float)d;
+    const float k2 = sgx / ((float)(d - 1) * stdv * sden * sden);
+    T* dxr = dx + row * lddx;
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u) {
+      const int c = lane + u * 64;
+      if (c < d) {
+        const float xc = to_f(xr[c]) - mean, gy = to_f(gr[c]);
+        dxr[c] = from_f<T>((gy * to_f(a[c]) - mg) * inv - xc * k2);
+        pa[u] += gy * xc * inv;
+        pb[u] += gy;
+      }
+    }
+  }
+  if (r0 < r1) {
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u) {
+      const int c = lane + u * 64;
+      if (c < d) { atomicAdd(da + c, pa[u]); atomicAdd(db + c, pb[u]); }
+    }
+  }
+}
+
+// Embedding backward: dlut[ids[row], c] += dy[row, c] * sqrt(d)   (fp32 atomics)
+template <typename T>
+__global__ void embed_bwd_kernel(const long* __restrict__ ids, const T* __restrict__ dy, float* __restrict__ dlut, long rows, int d, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * d) return;
+  const long row = idx / d; const int c = (int)(idx % d);
+  atomicAdd(dlut + ids[row] * d + c, to_f(dy[idx]) * scale);
+}
+
+// Modality fusion backward: out = sum_j w_j x_j, w = softmax(score)
+struct FusePtrs { const void* x[4]; void* dx[4]; };
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(const T* __restrict__ score, FusePtrs p, const T* __restrict__ dout,
+                                                       T* __restrict__ dscore, long rows, int n, int d) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float w[4], dw[4], mx = -INFINITY, den = 0.f;
+  for (int j = 0; j < n; ++j) { w[j] = to_f(score[row * n + j]); mx = fmaxf(mx, w[j]); }
+  for (int j = 0; j < n; ++j) { w[j] = expf(w[j] - mx); den += w[j]; }
+  for (int j = 0; j < n; ++j) { w[j] /= den; dw[j] = 0.f; }
+  for (int c = lane; c < d; c += 64) {
+    const float g = to_f(dout[row * d + c]);
+    for (int j = 0; j < n; ++j) {
+      dw[j] += g * to_f(reinterpret_cast<const T*>(p.x[j])[row * d + c]);
+      reinterpret_cast<T*>(p.dx[j])[row * d + c] = from_f<T>(w[j] * g);
+    }
+  }
+  float dot = 0.f;
+  for (int j = 0; j < n; ++j) { dw[j] = wave_sum(dw[j]); dot += w[j] * dw[j]; }
+  if (lane == 0)
+    for (int j = 0; j < n; ++j) dscore[row * n + j] = from_f<T>(w[j] * (dw[j] - dot));
+}
+
+// dst (T) = cast(src f32) -- used to hand fp32-accumulated gradients back in the parameter dtype
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ s, T* __restrict__ d, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = from_f<T>(s[i]);
+}
+
+// Adam step on fp32 master weights with an optional low-precision working copy:
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
+// (torch.optim.Adam semantics, the optimiser the reference wraps in NoamOpt, train.py:129-130)
+template <typename TG, typename TW>
+__global__ void adam_kernel(float* __restrict__ p, const TG* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            TW* __restrict__ work, long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float gscale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = to_f(g[i]) * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float upd = (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  const float pi = p[i] - lr * upd;
+  p[i] = pi;
+  if (work) work[i] = from_f<TW>(pi);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, NAME, ...)                                                  \
+  if ((dtype) == BIST_BF16) { NAME(bf16_t, __VA_ARGS__); }                            \
+  else if ((dtype) == BIST_F32) { NAME(float, __VA_ARGS__); }                         \
+  else { bist_set_error("%s: bad dtype %d", __func__, (int)(dtype)); return BIST_EINVAL; }
+
+extern "C" int bist_epilogue_bwd(const void* dy, const void* y, void* dz, int64_t M, int32_t N, int64_t lddy, int64_t ldy,
+                                 int64_t lddz, int32_t act, float drop_p, uint64_t drop_seed, int32_t dtype, void* stream) {
+  BIST_REQUIRE(dy && dz && M > 0 && N > 0, "bist_epilogue_bwd: bad argument");
+  BIST_REQUIRE(act != BIST_ACT_RELU || y, "bist_epilogue_bwd: relu needs the forward output");
+  hipStream_t st = (hipStream_t)stream;
+#define L(TT, ...) hipLaunchKernelGGL(epilogue_bwd_kernel<TT>, dim3(blocks_for(M * N, 256)), dim3(256), 0, st, (const TT*)dy, (const TT*)y, (TT*)dz, (long)M, N, (long)lddy, (long)ldy, (long)lddz, act, drop_p, (unsigned long long)drop_seed)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_epilogue_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream) {
+  BIST_REQUIRE(x && out && B > 0 && G > 0 && inner > 0, "bist_group_sum: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long total = B * inner;
+#define L(TT, ...) hipLaunchKernelGGL(group_sum_kernel<TT>, dim3(blocks_for(total, 256)), dim3(256), 0, st, (const TT*)x, (TT*)out, G, (long)inner, total)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_group_sum");
+  return BIST_OK;
+}
+
+extern "C" int bist_col_sum_acc(const void* x, float* out, int64_t M, int32_t N, int64_t ldx, int32_t dtype, void* stream) {
+  BIST_REQUIRE(x && out && M > 0 && N > 0 && ldx >= N, "bist_col_sum_acc: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rpb = (int)((M + 255) / 256);
+  if (rpb < 64) rpb = 64;
+  dim3 grid(blocks_for(N, 256), blocks_for(M, rpb));
+#define L(TT, ...) hipLaunchKernelGGL(col_sum_kernel<TT>, grid, dim3(256), 0, st, (const TT*)x, out, (long)M, N, (long)ldx, rpb)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_col_sum_acc");
+  return BIST_OK;
+}
+
+extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
+                                  int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, int32_t dtype, void* stream) {
+  BIST_REQUIRE(dy && x && a && dx && da && db, "bist_layernorm_bwd: null pointer");
+  BIST_REQUIRE(rows > 0 && d > 1 && d <= 2048, "bist_layernorm_bwd: bad shape rows=%ld d=%d", (long)rows, d);
+  hipStream_t st = (hipStream_t)stream;
+  int rpw = (int)((rows + 4095) / 4096);          // <= 4096 waves flush their partial sums
+  if (rpw < 1) rpw = 1;
+  const unsigned g = blocks_for(blocks_for(rows, rpw), 4);
+#define L(TT, ...) hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3(g), dim3(256), 0, st, (const TT*)dy, (const TT*)x, (const TT*)a, (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_layernorm_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_embed_bwd(const int64_t* ids, const void* dy, float* dlut, int64_t rows, int32_t d, int32_t dtype, void* stream) {
+  BIST_REQUIRE(ids && dy && dlut && rows > 0 && d > 0, "bist_embed_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = sqrtf((float)d);
+#define L(TT, ...) hipLaunchKernelGGL(embed_bwd_kernel<TT>, dim3(blocks_for(rows * d, 256)), dim3(256), 0, st, (const long*)ids, (const TT*)dy, dlut, (long)rows, d, scale)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_embed_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_fuse_modalities_bwd(const void* score, const void* const* xs, const void* dout, void* dscore, void* const* dxs,
+                                        int64_t rows, int32_t n, int32_t d, int32_t dtype, void* stream) {
+  BIST_REQUIRE(score && xs && dout && dscore && dxs && rows > 0 && d > 0 && n >= 1 && n <= 4, "bist_fuse_modalities_bwd: bad argument");
+  FusePtrs p;
+  for (int j = 0; j < 4; ++j) { p.x[j] = j < n ? xs[j] : nullptr; p.dx[j] = j < n ? dxs[j] : nullptr; }
+  hipStream_t st = (hipStream_t)stream;
+#define L(TT, ...) hipLaunchKernelGGL(fuse_bwd_kernel<TT>, dim3(blocks_for(rows, 4)), dim3(256), 0, st, (const TT*)score, p, (const TT*)dout, (TT*)dscore, (long)rows, n, d)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_fuse_modalities_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_cast_from_f32(const float* src, void* dst, int64_t n, int32_t dtype, void* stream) {
+  BIST_REQUIRE(src && dst && n > 0, "bist_cast_from_f32: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+#define L(TT, ...) hipLaunchKernelGGL(cast_from_f32_kernel<TT>, dim3(blocks_for(n, 256)), dim3(256), 0, st, src, (TT*)dst, (long)n)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_cast_from_f32");
+  return BIST_OK;
+}
+
+extern "C" int bist_adam_step(float* p, const void* g, float* m, float* v, void* work, int64_t n, float lr, float beta1, float beta2,
+                              float eps, int32_t step, float grad_scale, int32_t grad_dtype, int32_t work_dtype, void* stream) {
+  BIST_REQUIRE(p && g && m && v && n > 0 && step >= 1, "bist_adam_step: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  const unsigned grid = blocks_for(n, 256);
+#define ADAM(TG, TW) hipLaunchKernelGGL((adam_kernel<TG, TW>), dim3(grid), dim3(256), 0, st, p, (const TG*)g, m, v, (TW*)work, (long)n, lr, beta1, beta2, eps, bc1, bc2, grad_scale)
+  if (grad_dtype == BIST_F32 && (work == nullptr || work_dtype == BIST_F32)) ADAM(float, float);
+  else if (grad_dtype == BIST_F32 && work_dtype == BIST_BF16) ADAM(float, bf16_t);
+  else if (grad_dtype == BIST_BF16 && (work == nullptr || work_dtype == BIST_BF16)) ADAM(bf16_t, bf16_t);
+  else if (grad_dtype == BIST_BF16 && work_dtype == BIST_F32) ADAM(bf16_t, float);
+  else { bist_set_error("bist_adam_step: bad dtype combination"); return BIST_EINVAL; }
+#undef ADAM
+  BIST_LAUNCH_CHECK("bist_adam_step");
+  return BIST_OK;
+}

@@ -151,3 +151,140 @@ extern "C" int bist_sum_div(const float* x, int64_t n, const int64_t* denom, flo
   BIST_LAUNCH_CHECK("bist_sum_div");
   return BIST_OK;
 }
+
+// =============================================================================================
+// backward of the output heads
+// =============================================================================================
+namespace {
+
+// pointer_mix backward.  out = log(mix); given dout:
+//   dmix[v] = dout[v] / mix[v];  dsw[n] = sum_v dmix[v] pv[v];  dlogits = pv * sw[n] * (dmix - dsw[n])
+//   dsw[j] = sum_t dmix[text_j[t]] p_j[t];  dp_j[t] = sw[j] * dmix[text_j[t]];  dsw_logits = softmax backward of sw
+__global__ __launch_bounds__(256) void pointer_mix_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ sw_logits,
+                                                              PtrArgs a, const float* __restrict__ out, const float* __restrict__ dout,
+                                                              float* __restrict__ dlogits, float* __restrict__ dsw_logits,
+                                                              float* dp0, float* dp1, float* dp2, int V, int Lt, int sigmoid_switch) {
+  __shared__ float red[4];
+  __shared__ float dsw_sh[4];
+  const long row = blockIdx.x;
+  const int b = (int)(row / Lt);
+  const float* lg = logits + row * V;
+  const float* o = out + row * V;
+  const float* go = dout + row * V;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, lg[v]);
+  mx = block_reduce(mx, red, true);
+  float den = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) den += expf(lg[v] - mx);
+  den = block_reduce(den, red, false);
+  float sw[4];
+  const int ns = a.n + 1;
+  float sig = 0.f;
+  if (sigmoid_switch) { sig = 1.f / (1.f + expf(-sw_logits[row])); sw[0] = 1.f - sig; sw[1] = sig; }
+  else {
+    float m2 = -INFINITY, d2 = 0.f;
+    for (int j = 0; j < ns; ++j) m2 = fmaxf(m2, sw_logits[row * ns + j]);
+    for (int j = 0; j < ns; ++j) { sw[j] = expf(sw_logits[row * ns + j] - m2); d2 += sw[j]; }
+    for (int j = 0; j < ns; ++j) sw[j] /= d2;
+  }
+  // vocabulary branch
+  float acc = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) acc += go[v] * expf(-o[v]) * (expf(lg[v] - mx) / den);
+  const float dswn = block_reduce(acc, red, false);            // = sum_v dmix pv
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float pv = expf(lg[v] - mx) / den;
+    dlogits[row * V + v] = pv * sw[a.n] * (go[v] * expf(-o[v]) - dswn);
+  }
+  // copy branches (few dozen entries): one wave, lanes over t
+  float* dps[3] = {dp0, dp1, dp2};
+  if (threadIdx.x < 64) {
+    for (int j = 0; j < a.n; ++j) {
+      const float* p = a.s[j].p + row * a.s[j].L;
+      const long* text = a.s[j].text + (long)b * a.s[j].L;
+      float part = 0.f;
+      for (int t = threadIdx.x; t < a.s[j].L; t += 64) {
+        const long v = text[t];
+        const float dm = go[v] * expf(-o[v]);
+        part += dm * p[t];
+        dps[j][row * a.s[j].L + t] = sw[j] * dm;
+      }
+      part = wave_sum(part);
+      if (threadIdx.x == 0) dsw_sh[j] = part;
+    }
+    if (threadIdx.x == 0) {
+      dsw_sh[a.n] = dswn;
+      if (sigmoid_switch) {
+        dsw_logits[row] = (dsw_sh[1] - dsw_sh[0]) * sig * (1.f - sig);
+      } else {
+        float dot = 0.f;
+        for (int j = 0; j < ns; ++j) dot += sw[j] * dsw_sh[j];
+        for (int j = 0; j < ns; ++j) dsw_logits[row * ns + j] = sw[j] * (dsw_sh[j] - dot);
+      }
+    }
+  }
+}
+
+// y = log_softmax(x):  dx = dy - exp(y) * sum(dy)
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, int V) {
+  __shared__ float red[4];
+  const long off = (long)blockIdx.x * V;
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) s += dy[off + v];
+  s = block_reduce(s, red, false);
+  for (int v = threadIdx.x; v < V; v += 256) dx[off + v] = dy[off + v] - expf(y[off + v]) * s;
+}
+
+// loss = sum_rows KL(row) / denom  ->  dlogp[row, v] = -td[row, v] * gout / denom
+__global__ __launch_bounds__(256) void label_smoothing_bwd_kernel(const long* __restrict__ target, const float* __restrict__ gout,
+                                                                  const long* __restrict__ denom, float* __restrict__ dlogp, int V,
+                                                                  float smoothing, int pad) {
+  const long row = blockIdx.x;
+  const long t = target[row];
+  const float sc = -gout[0] / (denom ? (float)denom[0] : 1.f);
+  const float s = smoothing / (float)(V - 2), conf = 1.f - smoothing;
+  float* g = dlogp + row * V;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    float td = 0.f;
+    if (t != pad) td = (v == t) ? conf : (v == pad ? 0.f : s);
+    g[v] = sc * td;
+  }
+}
+
+}  // namespace
+
+extern "C" int bist_pointer_mix_bwd(const float* logits, const float* switch_logits, int32_t n_ptr, const float* const* ptr_p,
+                                    const int64_t* const* ptr_text, const int32_t* ptr_len, const float* out, const float* dout,
+                                    float* dlogits, float* dswitch_logits, float* const* dptr_p, int64_t rows, int32_t Lt, int32_t V,
+                                    int32_t sigmoid_switch, void* stream) {
+  BIST_REQUIRE(logits && switch_logits && out && dout && dlogits && dswitch_logits && dptr_p, "bist_pointer_mix_bwd: null pointer");
+  BIST_REQUIRE(n_ptr >= 1 && n_ptr <= 3 && rows > 0 && Lt > 0 && V > 2, "bist_pointer_mix_bwd: bad argument");
+  PtrArgs a;
+  a.n = n_ptr;
+  float* dps[3] = {nullptr, nullptr, nullptr};
+  for (int j = 0; j < 3; ++j) a.s[j] = PtrSrc{nullptr, nullptr, 0};
+  for (int j = 0; j < n_ptr; ++j) {
+    BIST_REQUIRE(ptr_p[j] && ptr_text[j] && ptr_len[j] > 0 && dptr_p[j], "bist_pointer_mix_bwd: bad pointer source %d", j);
+    a.s[j] = PtrSrc{ptr_p[j], (const long*)ptr_text[j], ptr_len[j]};
+    dps[j] = dptr_p[j];
+  }
+  hipLaunchKernelGGL(pointer_mix_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, switch_logits, a, out, dout,
+                     dlogits, dswitch_logits, dps[0], dps[1], dps[2], V, Lt, sigmoid_switch);
+  BIST_LAUNCH_CHECK("bist_pointer_mix_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_log_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int32_t V, void* stream) {
+  BIST_REQUIRE(y && dy && dx && rows > 0 && V > 0, "bist_log_softmax_bwd: bad argument");
+  hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, y, dy, dx, V);
+  BIST_LAUNCH_CHECK("bist_log_softmax_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_label_smoothing_bwd(const int64_t* target, const float* gout, const int64_t* denom, float* dlogp, int64_t rows,
+                                        int32_t V, float smoothing, int32_t pad, void* stream) {
+  BIST_REQUIRE(target && gout && dlogp && rows > 0 && V > 2, "bist_label_smoothing_bwd: bad argument");
+  hipLaunchKernelGGL(label_smoothing_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const long*)target, gout,
+                     (const long*)denom, dlogp, V, smoothing, pad);
+  BIST_LAUNCH_CHECK("bist_label_smoothing_bwd");
+  return BIST_OK;
+}

@@ -5,63 +5,124 @@ The algebra used here (checked against the oracle in tests/
     bias is constant along the softmax axis, so it cancels -- K is never materialised;
   * in stage 2 the value projection is applied AFTER the weighted sum:
     P (Y W_v^T + b_v) == (P Y) W_v^T + b_v because each row of P sums to one.
-Every function takes and returns device tensors; nothing here touches the CPU.
+Every function takes and returns device tensors; nothing here touches the CPU.  With autograd
+enabled each step is a torch.autograd.Function whose backward also runs on the HIP kernels
+(bist_amd/autograd.py); with autograd disabled the kernels are called directly.
 """
 from __future__ import annotations
 
-import math
-from typing import Optional
+from typing import Optional, Sequence
 
 import torch
 
+from . import autograd as ag
 from . import ops
-from .ops import ACT_NONE, ACT_RELU
+from .ops import ACT_NONE, ACT_RELU  # noqa: F401
 
 Tensor = torch.Tensor
 
-linear = ops.linear
-layernorm = ops.layernorm
-mha_core = ops.mha_core
-st_stage1_pv = ops.st_stage1_pv
-st_stage2 = ops.st_stage2
-embed_pe = ops.embed_pe
-fuse_modalities = ops.fuse_modalities
-add = ops.add
+linear = ag.linear
+
+
+def _grad() -> bool:
+    return torch.is_grad_enabled()
+
+
+def layernorm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
+    return ag.LayerNormFn.apply(x, a, b, eps) if _grad() else ops.layernorm(x, a, b, eps)
 
 
 def head_fold(q: Tensor, wk: Tensor, h: int, alpha: float) -> Tensor:
-    """Qf[m, hh*d + n] = alpha * sum_c q[m, hh*dk + c] * wk[hh*dk + c, n]     q [M,d], wk [d,d] -> [M, h*d].
-
-    One batched GEMM over the heads (B operand read "NN": row stride 1, k stride d)."""
-    M, d = q.shape
-    dk = d // h
-    out = torch.empty((M, h * d), device=q.device, dtype=q.dtype)
-    ops.gemm(q, wk, out, M=M, N=d, K=dk, a_rs=q.stride(0), a_ks=1, b_rs=1, b_ks=wk.stride(0), ldc=h * d,
-             batch=(1, h), a_bs=(0, dk), b_bs=(0, dk * wk.stride(0)), c_bs=(0, d), alpha=alpha)
-    return out
+    """Qf[m, hh*d + n] = alpha * sum_c q[m, hh*dk + c] * wk[hh*dk + c, n]     q [M,d], wk [d,d] -> [M, h*d]
+    (one batched GEMM over the heads; wk is read "NN": row stride 1, k stride d)."""
+    if _grad():
+        return ag.HeadFoldFn.apply(q, wk, h, alpha)
+    return ag.HeadFoldFn.forward(_NoCtx(), q, wk, h, alpha)
 
 
 def head_unfold(py: Tensor, wv: Tensor, bv: Tensor, h: int) -> Tensor:
     """O[m, hh*dk + c] = sum_n py[m, hh*d + n] * wv[hh*dk + c, n] + bv[hh*dk + c]    py [M,h*d] -> [M,d]."""
-    M = py.shape[0]
-    d = wv.shape[1]
-    dk = d // h
-    out = torch.empty((M, d), device=py.device, dtype=py.dtype)
-    ops.gemm(py, wv, out, M=M, N=dk, K=d, a_rs=py.stride(0), b_rs=wv.stride(0), ldc=d, bias=bv,
-             batch=(1, h), a_bs=(0, d), b_bs=(0, dk * wv.stride(0)), c_bs=(0, dk), bias_bs2=dk)
-    return out
+    if _grad():
+        return ag.HeadUnfoldFn.apply(py, wv, bv, h)
+    return ag.HeadUnfoldFn.forward(_NoCtx(), py, wv, bv, h)
 
 
 def st_scores(qf: Tensor, vft: Tensor) -> Tensor:
     """scores[b, r, ts] = qf[b, r, :] . vft[b, ts, :]   qf [B,R,d], vft [B,TS,d] -> f32 [B,R,TS]."""
-    B, R, d = qf.shape
-    TS = vft.shape[1]
-    out = torch.empty((B, R, TS), device=qf.device, dtype=torch.float32)
-    ops.gemm(qf, vft, out, M=R, N=TS, K=d, a_rs=qf.stride(1), b_rs=vft.stride(1), ldc=TS, batch=(B, 1),
-             a_bs=(qf.stride(0), 0), b_bs=(vft.stride(0), 0), c_bs=(R * TS, 0))
-    return out
+    if _grad():
+        return ag.StScoresFn.apply(qf, vft)
+    return ag.StScoresFn.forward(_NoCtx(), qf, vft)
+
+
+def bmm_nn(a: Tensor, b: Tensor) -> Tensor:
+    """C[z] = A[z] . B[z]  (A [Z,M,K], B [Z,K,N]) -- the pointer generator's text vector (generator.py:117-118)."""
+    if _grad():
+        return ag.BmmNNFn.apply(a, b)
+    return ag.BmmNNFn.forward(_NoCtx(), a, b)
+
+
+def mha_packed(a: Tensor, b: Optional[Tensor], c: Optional[Tensor], mode: str, mask: Optional[Tensor], h: int, want_p: bool = False):
+    """Attention core over packed projections (see autograd.MhaCoreFn); returns (ctx [N,Lq,d], P or None)."""
+    if _grad():
+        return ag.MhaCoreFn.apply(a, b, c, mode, mask, h, want_p)
+    q, k, v = ag.MhaCoreFn._views(a, b, c, mode)
+    return ops.mha_core(q, k, v, mask, h, want_p=want_p)
+
+
+def st_stage1_pv(scores, v, tmask, *, B, T, S, Lq, h, dk, direction):
+    if _grad():
+        return ag.StStage1PvFn.apply(scores, v, tmask, (B, T, S, Lq, h, dk), direction)
+    return ops.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
+
+
+def st_stage2(q2f, y, gmask, *, h):
+    return ag.StStage2Fn.apply(q2f, y, gmask, h) if _grad() else ops.st_stage2(q2f, y, gmask, h=h)
+
+
+def embed_pe(ids, lut, pe):
+    return ag.EmbedFn.apply(ids, lut, pe) if _grad() else ops.embed_pe(ids, lut, pe)
+
+
+def fuse_modalities(score, xs: Sequence[Tensor]):
+    return ag.FuseFn.apply(score, *xs) if _grad() else ops.fuse_modalities(score, xs)
+
+
+def add(a, b):
+    if _grad() and (a.requires_grad or b.requires_grad):
+        return ag.AddFn.apply(a, b)
+    return ops.add(a, b)
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    return ag.CastFn.apply(x, dtype) if _grad() else ops.cast(x, dtype)
+
+
+def pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch=False):
+    if _grad():
+        return ag.PointerMixFn.apply(logits, sw, Lt, sigmoid_switch, len(ps), *ps, *texts)
+    return ops.pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch)
+
+
+def log_softmax(x):
+    return ag.LogSoftmaxFn.apply(x) if _grad() else ops.log_softmax(x)
+
+
+def label_smoothing_loss(logp, target, denom, smoothing, pad):
+    """sum_rows KL(row) / denom as a device scalar [1] (denom: device int64 [1] or None)."""
+    if _grad():
+        return ag.LabelSmoothingLossFn.apply(logp, target, denom, smoothing, pad)
+    return ops.sum_div(ops.label_smoothing_rows(logp, target, smoothing, pad), denom)
 
 
 def pack_rows(*ws: Tensor) -> Tensor:
     """Concatenate weight matrices / biases row-wise (device-side data movement only)."""
     return torch.cat(ws, dim=0)
+
+
+class _NoCtx:
+    """Stand-in for the autograd context when a Function's forward is called without autograd."""
+
+    def save_for_backward(self, *a):
+        pass

@@ -75,7 +75,7 @@ class VidEncoder8(nn.Module):
         if self.v_N > 0:
             fts = b.fts
             if fts.dtype != self.W.weight.dtype:
-                fts = Fn.ops.cast(fts, self.W.weight.dtype)
+                fts = Fn.cast(fts, self.W.weight.dtype)
             B, T, S, C = fts.shape
             act = Fn.linear(fts.reshape(B * T * S, C), self.W.weight, self.W.bias, act=Fn.ACT_RELU)
             ft["spatiotemporal_ft"] = self.in_norm(act).view(B, T, S, -1)
@@ -150,9 +150,10 @@ class VidEncoderLayer4(nn.Module):
         B, T, S, d = vft.shape
         if both:
             a1, a4 = self.attn[1], self.attn[4]
-            if torch.is_grad_enabled():
-                w = Fn.pack_rows(a1.linears[2].weight, a4.linears[2].weight)
-                bb = Fn.pack_rows(a1.linears[2].bias, a4.linears[2].bias)
+            if torch.is_grad_enabled():      # training: one GEMM per direction, so each dV is a whole tensor
+                x2 = vft.view(B * T * S, d)
+                return (Fn.linear(x2, a1.linears[2].weight, a1.linears[2].bias).view(B, T, S, d),
+                        Fn.linear(x2, a4.linears[2].weight, a4.linears[2].bias).view(B, T, S, d))
             else:
                 key = tuple((p.data_ptr(), p._version) for p in (a1.linears[2].weight, a4.linears[2].weight,
                                                                  a1.linears[2].bias, a4.linears[2].bias))

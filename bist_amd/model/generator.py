@@ -36,7 +36,7 @@ class Generator(nn.Module):
             logits = Fn.linear(x, self.proj, None, out_dtype=torch.float32)
         else:
             logits = Fn.linear(x, self.proj.weight, self.proj.bias, out_dtype=torch.float32)
-        return ops.log_softmax(logits).view(*x.shape[:-1], -1)
+        return Fn.log_softmax(logits).view(*x.shape[:-1], -1)
 
 
 def _pointer_source(name: str, ft: Dict[str, Tensor], batch):
@@ -56,7 +56,7 @@ def _pointer_probs(attn, x: Tensor, enc: Tensor, mask: Tensor) -> Tensor:
     B, Lt, d = x.shape
     q = Fn.linear(x, attn.linears[0].weight, attn.linears[0].bias).view(B, Lt, d)
     k = Fn.linear(enc, attn.linears[1].weight, attn.linears[1].bias).view(B, enc.shape[1], d)
-    _, p = Fn.mha_core(q, k, k, mask, 1, want_p=True)
+    _, p = Fn.mha_packed(q, k, k, "q_k_v", mask, 1, True)
     attn.attn = p
     return p.view(B, Lt, -1)
 
@@ -65,11 +65,7 @@ def _text_vector(p: Tensor, enc: Tensor) -> Tensor:
     """sum_t p[b,i,t] * enc[b,t,:]  (generator.py:117-118) as a batched GEMM; p f32 [B,Lt,L]."""
     B, Lt, L = p.shape
     d = enc.shape[-1]
-    pc = ops.cast(p, enc.dtype)
-    out = torch.empty((B, Lt, d), device=enc.device, dtype=enc.dtype)
-    ops.gemm(pc, enc, out, M=Lt, N=d, K=L, a_rs=L, a_ks=1, b_rs=1, b_ks=enc.stride(1), ldc=d, batch=(B, 1),
-             a_bs=(Lt * L, 0), b_bs=(enc.stride(0), 0), c_bs=(Lt * d, 0))
-    return out
+    return Fn.bmm_nn(Fn.cast(p, enc.dtype), enc)
 
 
 def _switch_logits(lin: nn.Linear, parts) -> Tensor:
@@ -103,7 +99,7 @@ class PointerGenerator(nn.Module):
         logits = Fn.linear(x, self.vocab_gen, None, out_dtype=torch.float32)
         p = _pointer_probs(self.pointer_attn, x, enc, mask)
         sw = _switch_logits(self.pointer_gen_W, [x, _text_vector(p, enc), ft["encoded_tgt"]])    # generator.py:71
-        return ops.pointer_mix(logits, sw, [p], [text], Lt, sigmoid_switch=True).view(B, Lt, -1)
+        return Fn.pointer_mix(logits, sw, [p], [text], Lt, sigmoid_switch=True).view(B, Lt, -1)
 
 
 class MultiPointerGenerator(nn.Module):
@@ -130,4 +126,4 @@ class MultiPointerGenerator(nn.Module):
             ps.append(p); texts.append(text)
             vec.append(_text_vector(p, enc))
         sw = _switch_logits(self.pointer_gen_W, vec)
-        return ops.pointer_mix(logits, sw, ps, texts, Lt).view(B, Lt, -1)
+        return Fn.pointer_mix(logits, sw, ps, texts, Lt).view(B, Lt, -1)

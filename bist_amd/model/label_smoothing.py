@@ -4,13 +4,14 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import functional as Fn
 
 
 class LabelSmoothing(nn.Module):
     """KLDiv(sum) against confidence on the target, smoothing/(size-2) elsewhere, nothing on the
     padding column or on padded rows (reference: label_smoothing.py:9-30).  Returns a device
-    scalar [1]; the smoothed target distribution is never materialised."""
+    scalar [1]; the smoothed target distribution is never materialised (its gradient, -target, is
+    produced directly by the backward kernel)."""
 
     def __init__(self, size, padding_idx, smoothing=0.0):
         super().__init__()
@@ -20,9 +21,10 @@ class LabelSmoothing(nn.Module):
         self.size = size
         self.true_dist = None
 
-    def row_losses(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    def loss(self, x: torch.Tensor, target: torch.Tensor, denom=None) -> torch.Tensor:
+        """sum over rows / denom (device int64 scalar, optional), differentiable."""
         assert x.size(1) == self.size
-        return ops.label_smoothing_rows(x, target, self.smoothing, self.padding_idx)
+        return Fn.label_smoothing_loss(x, target, denom, self.smoothing, self.padding_idx)
 
     def forward(self, x, target):
-        return ops.sum_div(self.row_losses(x, target))
+        return self.loss(x, target, None)

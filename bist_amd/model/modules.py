@@ -92,28 +92,29 @@ class MultiHeadedAttention(nn.Module):
             cache[tuple(idx)] = (key, w, b)
         return w, b
 
-    def project_qkv(self, query: Tensor, key: Tensor, value: Tensor):
-        """Q, K, V projections as column views of as few GEMM outputs as the aliasing allows."""
+    def context(self, query: Tensor, key: Tensor, value: Tensor, mask: Optional[Tensor]) -> Tensor:
+        """Head-concatenated attention output BEFORE the output projection, [N,Lq,d].
+
+        The Q/K/V projections are as few GEMMs as the aliasing of the arguments allows (one packed
+        [N,L,3d] output for self-attention, q + packed [N,Lk,2d] for cross-attention); the attention
+        core reads them in place as column views."""
         d = self.h * self.d_k
         n, lq = query.shape[0], query.shape[1]
         if query is key and key is value:
             w, b = self._packed((0, 1, 2))
             qkv = Fn.linear(query, w, b).view(n, lq, 3 * d)
-            return qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-        q = Fn.linear(query, self.linears[0].weight, self.linears[0].bias).view(n, lq, d)
-        lk = key.shape[1]
-        if key is value:
-            w, b = self._packed((1, 2))
-            kv = Fn.linear(key, w, b).view(n, lk, 2 * d)
-            return q, kv[..., :d], kv[..., d:]
-        k = Fn.linear(key, self.linears[1].weight, self.linears[1].bias).view(n, lk, d)
-        v = Fn.linear(value, self.linears[2].weight, self.linears[2].bias).view(n, lk, d)
-        return q, k, v
-
-    def context(self, query: Tensor, key: Tensor, value: Tensor, mask: Optional[Tensor]) -> Tensor:
-        """Head-concatenated attention output BEFORE the output projection, [N,Lq,d]."""
-        q, k, v = self.project_qkv(query, key, value)
-        ctx, p = Fn.mha_core(q, k, v, mask, self.h, want_p=self.keep_attn)
+            ctx, p = Fn.mha_packed(qkv, None, None, "qkv", mask, self.h, self.keep_attn)
+        else:
+            q = Fn.linear(query, self.linears[0].weight, self.linears[0].bias).view(n, lq, d)
+            lk = key.shape[1]
+            if key is value:
+                w, b = self._packed((1, 2))
+                kv = Fn.linear(key, w, b).view(n, lk, 2 * d)
+                ctx, p = Fn.mha_packed(q, kv, None, "q_kv", mask, self.h, self.keep_attn)
+            else:
+                k = Fn.linear(key, self.linears[1].weight, self.linears[1].bias).view(n, lk, d)
+                v = Fn.linear(value, self.linears[2].weight, self.linears[2].bias).view(n, lk, d)
+                ctx, p = Fn.mha_packed(q, k, v, "q_k_v", mask, self.h, self.keep_attn)
         self.attn = p
         return ctx
 

@@ -47,7 +47,7 @@ class SimpleLossCompute:
         a = self.args
         out = self.generator(ft, batch, a)
         V = out.size(-1)
-        t = {"out": ops.sum_div(self.criterion.row_losses(out.reshape(-1, V), batch.trg_y.reshape(-1)), batch.ntokens.reshape(1))}
+        t = {"out": self.criterion.loss(out.reshape(-1, V), batch.trg_y.reshape(-1), batch.ntokens.reshape(1))}
         if a.auto_encoder:
             keys = []
             if a.nb_cenc_blocks > 0:
@@ -60,7 +60,7 @@ class SimpleLossCompute:
             q = batch.query.reshape(-1)
             for name, key in keys:
                 lp = self.ae_generator(ft, batch, a, key)
-                t[name] = ops.sum_div(self.criterion.row_losses(lp.reshape(-1, V), q), batch.qntokens.reshape(1))
+                t[name] = self.criterion.loss(lp.reshape(-1, V), q, batch.qntokens.reshape(1))
         return t, out
 
     def __call__(self, ft, batch):

@@ -78,8 +78,18 @@ def gemm_desc(a: Tensor, b: Tensor, c: Tensor, *, M: int, N: int, K: int, a_rs: 
 def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
     """C = epilogue(alpha * A.B^T) with explicit element strides (see include/bist_hip.h)."""
     g = gemm_desc(a, b, c, **kw)
+    if GEMM_TIMING is not None:          # bench.py: HIP events around each launch, on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.bist_gemm(C.byref(g), _stream()), "bist_gemm")
+        e1.record()
+        GEMM_TIMING.append(((g.M, g.N, g.K, g.batch1 * g.batch2), e0, e1))
+        return c
     check(lib.bist_gemm(C.byref(g), _stream()), "bist_gemm")
     return c
+
+
+GEMM_TIMING = None   # set to a list to collect ((M,N,K,batch), start_event, end_event) per GEMM launch
 
 
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE, residual: Optional[Tensor] = None,

@@ -190,6 +190,56 @@ int bist_label_smoothing_fwd(const float* logp, const int64_t* target, float* ro
  * fixed summation order.  The `/ norm` of SimpleLossCompute (model/optimize.py:50).               */
 int bist_sum_div(const float* x, int64_t n, const int64_t* denom, float* out, int32_t accumulate, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward kernels (training step: loss.backward() of model/optimize.py:85 without autograd's
+ * aten kernels).  Probabilities are recomputed from the saved inputs; reductions over rows
+ * accumulate into caller-zeroed fp32 buffers.
+ * ------------------------------------------------------------------------------------------ */
+/* dz = dy * d(epilogue)/dz of bist_gemm's epilogue (relu via the stored output y, dropout via the
+ * regenerated mask of (drop_seed, element index)).                                              */
+int bist_epilogue_bwd(const void* dy, const void* y, void* dz, int64_t M, int32_t N, int64_t lddy, int64_t ldy,
+                      int64_t lddz, int32_t act, float drop_p, uint64_t drop_seed, int32_t dtype, void* stream);
+/* out[b, r] = sum_g x[b, g, r]  (r < inner): gradient of the un-expanded query of stage 1.       */
+int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream);
+/* out[n] += sum_m x[m, n]  (bias gradient, fp32 accumulator).                                    */
+int bist_col_sum_acc(const void* x, float* out, int64_t M, int32_t N, int64_t ldx, int32_t dtype, void* stream);
+/* LayerNorm backward: dx (dtype) and da/db (+=, fp32 [d]).                                       */
+int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
+                       int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, int32_t dtype, void* stream);
+/* dlut[ids[row], :] += dy[row, :] * sqrt(d)  (fp32 accumulator [V, d]).                          */
+int bist_embed_bwd(const int64_t* ids, const void* dy, float* dlut, int64_t rows, int32_t d, int32_t dtype, void* stream);
+int bist_fuse_modalities_bwd(const void* score, const void* const* xs, const void* dout, void* dscore, void* const* dxs,
+                             int64_t rows, int32_t n, int32_t d, int32_t dtype, void* stream);
+/* dQ/dK/dV of bist_mha_core_fwd; dO and/or dP_ext (gradient w.r.t. the returned probabilities,
+ * f32 [N,h,Lq,Lk]) may be NULL (not both).  Gradients are written with their own strides so they
+ * can land in column slices of a packed projection gradient.                                     */
+int bist_mha_core_bwd(const void* Q, const void* K, const void* V, const uint8_t* mask, const void* dO, const float* dP_ext,
+                      void* dQ, void* dK, void* dV, int32_t N, int32_t Lq, int32_t Lk, int32_t h, int32_t dk,
+                      int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                      int64_t lddq, int64_t lddk, int64_t lddv, int64_t dq_bs, int64_t dk_bs, int64_t dv_bs,
+                      int64_t mask_bs, int64_t mask_qs, float scale, int32_t dtype, void* stream);
+/* dscores (f32 [B,Lq*h,T*S]) and dV ([B,T,S,*], row stride lddv) of bist_st_stage1_pv_fwd.        */
+int bist_st_stage1_pv_bwd(const float* scores, const void* V, const uint8_t* tmask, const void* dO, float* dscores, void* dV,
+                          int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk, int64_t ldv, int64_t lddv,
+                          int32_t direction, int32_t dtype, void* stream);
+/* dq2f and dY of bist_st_stage2_fwd.                                                             */
+int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t* gmask, const void* dPY, void* dq2f, void* dY,
+                       int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, int32_t dtype, void* stream);
+int bist_pointer_mix_bwd(const float* logits, const float* switch_logits, int32_t n_ptr, const float* const* ptr_p,
+                         const int64_t* const* ptr_text, const int32_t* ptr_len, const float* out, const float* dout,
+                         float* dlogits, float* dswitch_logits, float* const* dptr_p, int64_t rows, int32_t Lt, int32_t V,
+                         int32_t sigmoid_switch, void* stream);
+int bist_log_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int32_t V, void* stream);
+/* dlogp[row,v] = -smoothed_target[row,v] * gout[0] / denom[0]  (gout, denom: device scalars).     */
+int bist_label_smoothing_bwd(const int64_t* target, const float* gout, const int64_t* denom, float* dlogp, int64_t rows,
+                             int32_t V, float smoothing, int32_t pad, void* stream);
+int bist_cast_from_f32(const float* src, void* dst, int64_t n, int32_t dtype, void* stream);
+/* One Adam step (torch.optim.Adam semantics, the optimiser NoamOpt wraps: train.py:129-130) on fp32
+ * master weights p with moments m, v; g in grad_dtype, scaled by grad_scale first; `work`
+ * (nullable) receives the updated weights in work_dtype (the bf16 copy the kernels read).        */
+int bist_adam_step(float* p, const void* g, float* m, float* v, void* work, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int32_t step, float grad_scale, int32_t grad_dtype, int32_t work_dtype, void* stream);
+
 /* dst = cast(src) between f32 and bf16 (n elements). */
 int bist_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, void* stream);
 

@@ -87,7 +87,7 @@ def test_forward_matches_reference_golden_fp32(hip, golden_dir, tag):
     crit = LabelSmoothing(dm["V"], O.PAD_ID, 0.1)
     with torch.no_grad():
         terms, _ = SimpleLossCompute(model.generator, model.ae_generator, crit, None, args=_args(cfg)).terms(ft, b)
-    for name, val in terms.items():
+    for name, val in terms.items():  # device scalars
         ref = float(g[f"{tag}_loss_{name}"])
         assert abs(val.item() - ref) <= 1e-3 * max(1.0, abs(ref)), (name, val.item(), ref)
 
