@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the BiST hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A *step* is one training step of the reference's loop (train.py:29-37: forward, pointer-generator
+log-probs, 4 label-smoothed losses, backward, Adam with the Noam rate) on one synthetic batch of
+BASELINE.json configs[1]: L=6, d_model=512, h=8, ResNeXt features [B=16, T=32, 7x7, 2048] bf16 already
+resident in HBM, 20-token queries.  With N GPUs every rank runs its own B=16 batch (weak scaling,
+batch-data-parallel), gradients are summed by one RCCL all-reduce of the flat gradient buffer.
+
+value       = target tokens (non-pad trg_y, the quantity train.py:36 accumulates) of all ranks / second.
+roofline    = the dominant kernel by FLOPs, the video input projection GEMM (P0: [B*T*S,2048]x[2048,512],
+              bist_gemm LDS-DMA MFMA kernel): algorithmic 2*M*N*K FLOPs / its mean launch duration,
+              measured with HIP events on the launch stream inside the timed steps, against the dense
+              bf16 MFMA peak.  `attn_fwd` adds the north_star's second figure: the fused BiST attention
+              forward (F_P0 + F_VL of SURVEY.md 8d) timed on the same batch.
+cpu_baseline= the CPU oracle's (oracle/bist_oracle.py, a port) training step (fwd + loss + backward; no
+              optimiser) on a bounded sample of the same workload on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+CFG = dict(L=6, d=512, h=8, B=16, T=32, S=49, C=2048, Lq=20, Lh=60, Lc=25, Lt=20, V=3000)
+
+
+def model_args(L, d, h, dropout):
+    return argparse.Namespace(d_model=d, att_h=h, nb_blocks=L, nb_venc_blocks=L, nb_cenc_blocks=L, nb_aenc_blocks=0,
+                              t2s=1, s2t=1, ptr_gen=1, ptr_ft="query,cap", mask_unk=1, auto_encoder=1,
+                              include_caption="summary", enc_st_combine="none", dec_st_combine="seq",
+                              enc_vc_combine="dyn", dropout=dropout, d_ff=4 * d)
+
+
+def flops_alg(B, T, S, C, d, Lq, h):
+    """Algorithmic FLOPs of SURVEY.md 8(d): (F_P0, F_VL) for one forward."""
+    f_p0 = 2.0 * B * T * S * C * d
+    a1 = 4 * B * S * T * d * d + 2 * B * Lq * d * d + 4 * B * S * Lq * T * d + 2 * B * S * Lq * d * d
+    a2 = 4 * B * Lq * S * d * d + 4 * B * Lq * S * d + 4 * B * Lq * d * d
+    a4 = 4 * B * T * S * d * d + 2 * B * Lq * d * d + 4 * B * T * Lq * S * d + 2 * B * T * Lq * d * d
+    a5 = 4 * B * Lq * T * d * d + 4 * B * Lq * T * d + 4 * B * Lq * d * d
+    a03 = 2 * (8 * B * Lq * d * d + 4 * B * Lq * Lq * d)
+    ff = 2 * (16 * B * Lq * d * d)
+    return f_p0, float(a1 + a2 + a4 + a5 + a03 + ff)
+
+
+def cpu_baseline(sample_B, steps, dropout):
+    """The oracle (port of the reference) on the host cores: forward + losses + backward at the bench geometry."""
+    from oracle import bist_oracle as O
+    c = CFG
+    cfg = O.Cfg(d_model=c["d"], att_h=c["h"], nb_blocks=c["L"], nb_venc_blocks=c["L"], nb_cenc_blocks=c["L"])
+    torch.manual_seed(1)
+    shapes = O.state_shapes(cfg, c["V"], c["C"])
+    sd = {}
+    for k, s in shapes.items():
+        t = torch.randn(s) * (0.02 if len(s) > 1 else 0.01)
+        if k.endswith(".a_2"):
+            t = 1 + t
+        sd[k] = t.requires_grad_(True)
+    for alias in ("tgt_embed.0.lut.weight", "generator.vocab_gen", "ae_generator.proj"):
+        sd[alias] = sd["query_embed.0.lut.weight"]
+    ob = O.det_batch(sample_B, c["T"], c["S"], c["C"], c["Lq"], c["Lh"], c["Lc"], c["Lt"], c["V"], seed=99)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        ft = O.mtn_forward(sd, cfg, ob)
+        O.loss_compute(sd, cfg, ft, ob, c["V"])["total"].backward()
+        for v in sd.values():
+            v.grad = None
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": float(ob.ntokens) / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fwd+loss+bwd (no optimiser), B={sample_B} clips of the same geometry, median of {steps} steps, fp32",
+            "s_per_step": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=CFG["B"], help="clips per GPU")
+    ap.add_argument("--T", type=int, default=CFG["T"])
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import bist_amd.model as M
+    from bist_amd import functional as Fn, ops
+    from bist_amd.data.synthetic import synthetic_batch
+    from bist_amd.train import Trainer
+
+    c = dict(CFG, B=a.batch, T=a.T)
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    args = model_args(c["L"], c["d"], c["h"], a.dropout)
+    torch.manual_seed(1)                         # identical initial weights on every rank
+    model = M.make_model(c["V"], c["V"], args, ft_sizes=[c["C"]]).cuda()
+    model.train()
+    Fn.manual_seed(1234 + rank)
+    trainer = Trainer(model, args, c["V"], compute_dtype=dtype)
+    batch = synthetic_batch(c["B"], T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"],
+                            seed=1234 + rank, dtype=dtype)
+    ntok = int(batch.ntokens.item())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        trainer.step(batch)
+    torch.cuda.synchronize(); barrier()
+    ops.GEMM_TIMING, ops.GEMM_TIMING_SHAPE = [], (c["B"] * c["T"] * c["S"], c["d"], c["C"])   # bracket only the P0 GEMM
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.step(batch)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    timing, ops.GEMM_TIMING, ops.GEMM_TIMING_SHAPE = ops.GEMM_TIMING, None, None
+
+    tot = torch.tensor([dt, float(ntok)], device="cuda", dtype=torch.float64)
+    if world > 1:
+        tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tot.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, ntok_all = float(tmax[0]), float(tsum[1])
+    else:
+        ntok_all = float(ntok)
+
+    # dominant kernel: the P0 GEMM (M = B*T*S, N = d, K = C), forward launches only
+    M_p0 = c["B"] * c["T"] * c["S"]
+    p0 = [e0.elapsed_time(e1) for (m, n, k, z), e0, e1 in timing if (m, n, k, z) == (M_p0, c["d"], c["C"], 1)]
+    p0_ms = sum(p0) / max(1, len(p0))
+    p0_flops = 2.0 * M_p0 * c["d"] * c["C"]
+    achieved = p0_flops / (p0_ms * 1e-3) / 1e12 if p0_ms > 0 else 0.0
+
+    # fused BiST attention forward (F_P0 + F_VL): P0 + one VidEncoderLayer4, eval mode, same batch
+    model.eval()
+    with torch.no_grad():
+        ft = model.encode(batch)
+        q = ft["encoded_query"]
+        vl = model.mutlimodal_decoder.v_layers[0]
+
+        def attn_fwd():
+            f = model.vid_encoder(batch, {})
+            f.update(encoded_query=q)
+            vl({"t2s": q, "s2t": q}, f, batch)
+        for _ in range(3):
+            attn_fwd()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            attn_fwd()
+        e1.record(); torch.cuda.synchronize()
+        attn_ms = e0.elapsed_time(e1) / 10
+    f_p0, f_vl = flops_alg(c["B"], c["T"], c["S"], c["C"], c["d"], c["Lq"], c["h"])
+    attn_tflops = (f_p0 + f_vl) / (attn_ms * 1e-3) / 1e12
+
+    out = {
+        "metric": "training-step tokens/sec (BiST hot path: fwd + pointer-generator losses + bwd + Adam)",
+        "value": ntok_all * a.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 6-layer d_model=512 nhead=8 MTN, synthetic ResNeXt feats "
+                               f"[B={c['B']}/GPU,T={c['T']},7x7,2048] {a.dtype} + 20-token queries, dropout={a.dropout}",
+                   "global_batch": c["B"] * world, "tokens_per_step": ntok_all, "parallelism": f"dp{world}",
+                   "clips_per_s": c["B"] * world * a.steps / dt},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "kernel": f"gemm_fast_kernel<bf16> P0 [{M_p0}x{c['C']}]x[{c['C']}x{c['d']}]", "avg_launch_ms": p0_ms,
+                     "launches_timed": len(p0)},
+        "attn_fwd": {"what": "fused BiST attention forward F_P0+F_VL (SURVEY 8d), one layer, eval", "gflop_alg": (f_p0 + f_vl) / 1e9,
+                     "ms": attn_ms, "tflops": attn_tflops, "frac_of_mfma_peak": attn_tflops / MFMA_BF16_PEAK_TFLOPS},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, 3, a.dropout)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

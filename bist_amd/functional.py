@@ -116,6 +116,28 @@ def label_smoothing_loss(logp, target, denom, smoothing, pad):
     return ops.sum_div(ops.label_smoothing_rows(logp, target, smoothing, pad), denom)
 
 
+# ---- dropout seeds: every dropout site draws a fresh 64-bit seed; the mask itself is a pure function of
+# (seed, element index) generated inside the kernels (forward epilogue and its backward).
+_SEED = [0x5EED, 0]
+
+
+def manual_seed(seed: int) -> None:
+    _SEED[0], _SEED[1] = int(seed) & 0xFFFFFFFF, 0
+
+
+def next_seed() -> int:
+    _SEED[1] += 1
+    return ((_SEED[0] << 32) ^ (_SEED[1] * 0x9E3779B1)) & 0x7FFFFFFFFFFFFFFF
+
+
+def drop_args(module) -> dict:
+    """kwargs for linear(): the dropout of a SublayerConnection / nn.Dropout holder in training mode."""
+    p = float(getattr(module, "p", 0.0))
+    if module.training and p > 0.0:
+        return {"drop_p": p, "drop_seed": next_seed()}
+    return {}
+
+
 def pack_rows(*ws: Tensor) -> Tensor:
     """Concatenate weight matrices / biases row-wise (device-side data movement only)."""
     return torch.cat(ws, dim=0)

@@ -86,18 +86,18 @@ def _self_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Tens
     """x + MHA(LN(x), LN(x), LN(x), mask): A0/A3 and every other self-attention sublayer."""
     xn = sub.norm(x)
     ctx = attn.context(xn, xn, xn, mask)
-    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x).view_as(x)
+    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x, **Fn.drop_args(sub)).view_as(x)
 
 
 def _cross_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Tensor, mem: Tensor, mask: Optional[Tensor]) -> Tensor:
     """x + MHA(LN(x), mem, mem, mask) -- only the query stream is normalised (modules.py:44)."""
     ctx = attn.context(sub.norm(x), mem, mem, mask)
-    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x).view_as(x)
+    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x, **Fn.drop_args(sub)).view_as(x)
 
 
 def _feed_forward(sub: SublayerConnection, ff: PositionwiseFeedForward, x: Tensor) -> Tensor:
     """x + FFN(LN(x)); the residual is the second GEMM's epilogue."""
-    return ff(sub.norm(x), residual=x)
+    return ff(sub.norm(x), residual=x, out_drop=Fn.drop_args(sub))
 
 
 class VidEncoderLayer4(nn.Module):
@@ -129,7 +129,7 @@ class VidEncoderLayer4(nn.Module):
         scores = Fn.st_scores(qf, vft.view(B, T * S, d))
         o = Fn.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
         G = o.shape[1]
-        y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=x, res_map=(G * Lq, Lq))
+        y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=x, res_map=(G * Lq, Lq), **Fn.drop_args(sub))
         return y.view(B, G, Lq, d)
 
     # -- stage 2 ------------------------------------------------------------------------------
@@ -142,7 +142,7 @@ class VidEncoderLayer4(nn.Module):
         q2f = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq, h, d)
         py = Fn.st_stage2(q2f, y, gmask, h=h)
         ctx = Fn.head_unfold(py.view(B * Lq, h * d), attn.linears[2].weight, attn.linears[2].bias, h)
-        return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x).view(B, Lq, d)
+        return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x, **Fn.drop_args(sub)).view(B, Lq, d)
 
     def value_projection(self, vft: Tensor):
         """V of A1 and A4 in one GEMM over the video tensor: returns (v_t2s, v_s2t) column views."""

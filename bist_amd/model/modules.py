@@ -135,9 +135,12 @@ class PositionwiseFeedForward(nn.Module):
         self.w_2 = nn.Linear(d_ff, d_out)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
-        hdn = Fn.linear(x, self.w_1.weight, self.w_1.bias, act=Fn.ACT_RELU)
-        out = Fn.linear(hdn, self.w_2.weight, self.w_2.bias, residual=residual)
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None, out_drop: Optional[dict] = None) -> Tensor:
+        inner = {}
+        if self.training and self.dropout.p > 0:          # dropout(relu(w_1 x)), modules.py:113
+            inner = {"drop_p": float(self.dropout.p), "drop_seed": Fn.next_seed()}
+        hdn = Fn.linear(x, self.w_1.weight, self.w_1.bias, act=Fn.ACT_RELU, **inner)
+        out = Fn.linear(hdn, self.w_2.weight, self.w_2.bias, residual=residual, **(out_drop or {}))
         return out.view(*x.shape[:-1], -1)
 
 

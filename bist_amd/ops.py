@@ -78,7 +78,8 @@ def gemm_desc(a: Tensor, b: Tensor, c: Tensor, *, M: int, N: int, K: int, a_rs: 
 def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
     """C = epilogue(alpha * A.B^T) with explicit element strides (see include/bist_hip.h)."""
     g = gemm_desc(a, b, c, **kw)
-    if GEMM_TIMING is not None:          # bench.py: HIP events around each launch, on the launch stream
+    if GEMM_TIMING is not None and (GEMM_TIMING_SHAPE is None or GEMM_TIMING_SHAPE == (g.M, g.N, g.K)):
+        # bench.py: HIP events around the launch, on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib.bist_gemm(C.byref(g), _stream()), "bist_gemm")
@@ -89,7 +90,8 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
     return c
 
 
-GEMM_TIMING = None   # set to a list to collect ((M,N,K,batch), start_event, end_event) per GEMM launch
+GEMM_TIMING = None        # set to a list to collect ((M,N,K,batch), start_event, end_event) per GEMM launch
+GEMM_TIMING_SHAPE = None  # optional (M,N,K): only launches of this shape are bracketed
 
 
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE, residual: Optional[Tensor] = None,
