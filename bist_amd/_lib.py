@@ -26,6 +26,7 @@ class BistGemm(C.Structure):
         ("alpha", C.c_float), ("act", C.c_int32), ("res_outer", C.c_int32), ("res_inner", C.c_int32),
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

@@ -1,29 +1,36 @@
 // GEMM for the BiST hot path on gfx950:  C = epilogue(alpha * A . B^T), fp32 accumulate on MFMA.
 //
 // One 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 4x4 MFMA
-// fragments of 16x16).  LDS holds the A and B tiles as [128 rows][128 bytes] (64 bf16 or 32 f32
-// along K), 16-byte chunks XOR-swizzled by ((row>>1)&7) so that the ds_read_b128 fragment reads
-// are bank-conflict free.  The byte geometry is identical for both dtypes: a lane's 16-byte
-// fragment read feeds one v_mfma_f32_16x16x32_bf16 (8 bf16) or four v_mfma_f32_16x16x4_f32
-// (4 f32, one per instruction; A and B use the same k permutation so the dot product is intact).
+// fragments of 16x16).  Every operand tile is 16 KiB of LDS per stage and is filled by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave instruction, LDS image lane-linear, any swizzle applied
+// on the per-lane SOURCE address), double-buffered with one barrier per K tile and the next tile's
+// DMA in flight under the MFMAs.  Two operand layouts, chosen per operand from its strides:
 //
-// Two loaders share the compute and the epilogue:
-//   fast: K-contiguous 16-byte-aligned operands, K % (128/sizeof T) == 0 -> LDS-DMA
-//         (global_load_lds_dwordx4: 8 rows x 128 B per wave instruction, the swizzle applied on
-//         the per-lane SOURCE address, LDS image lane-linear), double-buffered, one barrier per
-//         K tile with the next tile's DMA in flight under the MFMAs;
-//   gen : any element strides / any K (zero-filled tails), register staged, single buffer.
+//   K-contiguous ("N"):  x.W^T of nn.Linear.  LDS image [128 rows][128 B of K], 16-byte chunks
+//       XOR-swizzled by ((row>>1)&7); fragments by ds_read_b128 (conflict-free).  One 16-byte read
+//       feeds one v_mfma_f32_16x16x32_bf16 (8 bf16) or four v_mfma_f32_16x16x4_f32.
+//   row-contiguous ("T"): the backward products x^T.dy and dy.W read their operands in place, no
+//       transpose pass.  LDS image [K rows][128 elements]; bf16 fragments by ds_read_b64_tr_b16 (the
+//       hardware transposing read: 4 K-rows x 16 columns per 16-lane group), f32 fragments by
+//       ds_read_b32; 16-byte pieces XOR-swizzled by K-row so both are conflict-free.
 //
-// Workgroup ids are remapped so that each XCD (blocks b, b+8, ... share one) walks a contiguous
-// range of tiles: neighbouring tiles share an A row panel, which then stays in that XCD's L2.
+// Split-K: problems with few output tiles and a long K (weight gradients: 512x512 outputs, K = B*T*S)
+// are cut along K over several workgroups that write fp32 partial slabs to a caller-provided
+// workspace; a second small kernel sums the slabs and applies the epilogue.
+//
+// A generic register-staged kernel (any strides, any K, zero-filled tails) remains as the fallback.
+// Workgroup ids are remapped so that each XCD (blocks b, b+8, ... share one) walks a contiguous range
+// of tiles: neighbouring tiles share an A row panel, which then stays in that XCD's L2.
 #include "common.hpp"
 
 namespace {
 
 constexpr int BM = 128, BN = 128;
-constexpr int ROW_BYTES = 128;                 // K extent of a tile in bytes
+constexpr int ROW_BYTES = 128;                 // K extent of an "N" tile in bytes
 constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand per stage
 constexpr int NTHREADS = 256;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct GemmK {   // device-side argument block (by value)
   const char* A; const char* B; char* C; const char* bias; const char* residual;
@@ -34,6 +41,7 @@ struct GemmK {   // device-side argument block (by value)
   float alpha; int act; int res_outer, res_inner;
   float drop_p; unsigned long long drop_seed;
   int tiles_m, tiles_n;
+  int split_k; float* ws;            // split_k > 1: raw fp32 partial tiles go to ws[z][split][M][N]
 };
 
 template <typename T> struct Mma;
@@ -51,29 +59,63 @@ template <> struct Mma<float> {
   }
 };
 
-// tile id -> (z, tm, tn) with the XCD-contiguous remap (bijective for any grid size)
-__device__ __forceinline__ void tile_coords(const GemmK& g, int& z, int& tm, int& tn) {
+// tile id -> (z, split, tm, tn) with the XCD-contiguous remap (bijective for any grid size)
+__device__ __forceinline__ void tile_coords(const GemmK& g, int& z, int& sp, int& tm, int& tn) {
   const unsigned nwg = gridDim.x, bid = blockIdx.x;
   const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
-  const unsigned lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  tn = lid % g.tiles_n;
-  const unsigned t2 = lid / g.tiles_n;
-  tm = t2 % g.tiles_m;
-  z = t2 / g.tiles_m;
+  unsigned lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  tn = lid % g.tiles_n; lid /= g.tiles_n;
+  tm = lid % g.tiles_m; lid /= g.tiles_m;
+  sp = lid % g.split_k;
+  z = lid / g.split_k;
 }
 
-// MFMAs of one K tile: lds_a / lds_b point at the [128][128 B] swizzled images.
-template <typename T>
+// ---- fragment loads -----------------------------------------------------------------------------
+// 16 rows starting at `row0` (multiple of 16) of the operand tile at `tile`, K step ks (64 bytes of K
+// for "N" tiles, 32 bf16 / 16 f32 K-rows for "T" tiles).  The returned uint4 is what Mma<T>::step eats:
+// lane (x = lane&15, kg = lane>>4) holds row x, k = 8*kg..8*kg+7 (bf16) or k = 4*kg+i for MFMA i (f32).
+template <typename T, bool TR>
+__device__ __forceinline__ uint4 load_frag(const char* tile, int row0, int ks, int lane) {
+  const int x = lane & 15, kg = lane >> 4;
+  if constexpr (!TR) {
+    const int off = ((ks * 4 + kg) ^ (x >> 1)) << 4;
+    return *reinterpret_cast<const uint4*>(tile + (row0 + x) * ROW_BYTES + off);
+  } else if constexpr (sizeof(T) == 2) {
+    // [64 k-rows][256 B]; piece (16 B = 8 rows) index c stored at c ^ (2*(k&3)) ^ (8*((k>>3)&1))
+    const int q = x >> 2, p = x & 3;
+    const int kb = ks * 32 + kg * 8;
+    const int c = (row0 >> 3) + (p >> 1);
+    const int pos = c ^ (2 * q) ^ (8 * (kg & 1));
+    const char* a0 = tile + (kb + q) * 256 + pos * 16 + (p & 1) * 8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 256));
+    uint4 r;
+    r.x = __builtin_bit_cast(uint2, lo).x; r.y = __builtin_bit_cast(uint2, lo).y;
+    r.z = __builtin_bit_cast(uint2, hi).x; r.w = __builtin_bit_cast(uint2, hi).y;
+    return r;
+  } else {
+    // [32 k-rows][512 B]; piece (16 B = 4 rows) index c stored at c ^ (4*((k>>2)&7))
+    const int kb = ks * 16 + kg * 4;                 // k = kb + i for MFMA i; (k>>2) = ks*4 + kg for all i
+    const int pos = (((row0 + x) >> 2) ^ (4 * ((ks * 4 + kg) & 7)));
+    const char* a0 = tile + kb * 512 + pos * 16 + (x & 3) * 4;
+    uint4 r;
+    r.x = *reinterpret_cast<const unsigned*>(a0);
+    r.y = *reinterpret_cast<const unsigned*>(a0 + 512);
+    r.z = *reinterpret_cast<const unsigned*>(a0 + 1024);
+    r.w = *reinterpret_cast<const unsigned*>(a0 + 1536);
+    return r;
+  }
+}
+
+template <typename T, bool ATR, bool BTR>
 __device__ __forceinline__ void compute_tile(const char* lds_a, const char* lds_b, f32x4 (&acc)[4][4], int wm, int wn, int lane) {
-  const int lr = lane & 15, lg = lane >> 4, sw = lr >> 1;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const int off = ((ks * 4 + lg) ^ sw) << 4;
     uint4 af[4], bf[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      af[i] = *reinterpret_cast<const uint4*>(lds_a + (wm * 64 + i * 16 + lr) * ROW_BYTES + off);
-      bf[i] = *reinterpret_cast<const uint4*>(lds_b + (wn * 64 + i * 16 + lr) * ROW_BYTES + off);
+      af[i] = load_frag<T, ATR>(lds_a, wm * 64 + i * 16, ks, lane);
+      bf[i] = load_frag<T, BTR>(lds_b, wn * 64 + i * 16, ks, lane);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -82,15 +124,81 @@ __device__ __forceinline__ void compute_tile(const char* lds_a, const char* lds_
   }
 }
 
+// ---- per-lane LDS-DMA source pointers ---------------------------------------------------------------
+// Wave w issues instructions j = 0..3 into LDS bytes [(w*4+j)*1024, +1024) of the operand tile.
+template <typename T, bool TR>
+struct Stager {
+  const char* p[4];
+  long step;
+  __device__ __forceinline__ void init(const char* base, long rs, long ks_stride, int r0, int rows, int k0, int w, int lane) {
+    constexpr int SZ = (int)sizeof(T);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int inst = w * 4 + j;
+      if constexpr (!TR) {
+        const int row = inst * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((j & 1) << 2) | (lane >> 4));          // inverse of the read swizzle
+        const int rr = min(r0 + row, rows - 1);                                   // tails re-read a valid row
+        p[j] = base + ((long)rr * rs + k0) * SZ + chunk * 16;
+      } else if constexpr (SZ == 2) {
+        const int krow = lane >> 4, k = inst * 4 + krow;
+        int c = (lane & 15) ^ (2 * krow) ^ (8 * ((inst >> 1) & 1));
+        if (r0 + c * 8 >= rows) c = 0;                                            // rows % 8 == 0: whole piece in or out
+        p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 8) * SZ;
+      } else {
+        const int krow = lane >> 5, k = inst * 2 + krow;
+        int c = (lane & 31) ^ (4 * ((inst >> 1) & 7));
+        if (r0 + c * 4 >= rows) c = 0;
+        p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 4) * SZ;
+      }
+    }
+    step = TR ? (long)(ROW_BYTES / SZ) * ks_stride * SZ : ROW_BYTES;
+  }
+  __device__ __forceinline__ void issue(char* lds_tile, int w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p[j]), LDS_PTR(lds_tile + (w * 4 + j) * 1024), 16, 0, 0);
+      p[j] += step;
+    }
+  }
+};
+
 template <typename T, typename TO>
-__device__ __forceinline__ void epilogue(const GemmK& g, f32x4 (&acc)[4][4], int z1, int z2, int m0, int n0, int wm, int wn, int lane) {
+__device__ __forceinline__ float epilogue_value(const GemmK& g, float acc, float bv, const TO* res, int m, int n, unsigned long long zoff) {
+  float v = acc * g.alpha + bv;
+  if (g.act == BIST_ACT_RELU) v = fmaxf(v, 0.f);
+  if (g.drop_p > 0.f) v = drop_keep(g.drop_seed, zoff + (unsigned long long)m * g.N + n, g.drop_p) ? v * (1.f / (1.f - g.drop_p)) : 0.f;
+  if (res) {
+    const long rr = g.res_outer > 0 ? (long)(m / g.res_outer) * g.res_inner + (m % g.res_inner) : (long)m;
+    v += to_f(res[rr * g.ldr + n]);
+  }
+  return v;
+}
+
+template <typename T, typename TO>
+__device__ __forceinline__ void epilogue(const GemmK& g, f32x4 (&acc)[4][4], int z1, int z2, int sp, int m0, int n0, int wm, int wn, int lane) {
   const int lr = lane & 15, lg = lane >> 4;
+  const long zlin = z1 * (long)g.batch2 + z2;
+  if (g.split_k > 1) {            // raw partial sums; the reduce kernel applies the epilogue
+    float* W = g.ws + ((zlin * g.split_k + sp) * (long)g.M) * g.N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + lr;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 64 + i * 16 + lg * 4 + r;
+          if (m < g.M) W[(long)m * g.N + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   TO* C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
   const T* bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
   const TO* res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
-  const bool drop = g.drop_p > 0.f;
-  const float keep_scale = drop ? 1.f / (1.f - g.drop_p) : 1.f;
-  const unsigned long long zoff = (unsigned long long)(z1 * (long)g.batch2 + z2) * (unsigned long long)g.M * (unsigned long long)g.N;
+  const unsigned long long zoff = (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wn * 64 + j * 16 + lr;
@@ -102,60 +210,37 @@ __device__ __forceinline__ void epilogue(const GemmK& g, f32x4 (&acc)[4][4], int
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 64 + i * 16 + lg * 4 + r;
         if (m >= g.M) continue;
-        float v = acc[i][j][r] * g.alpha + bv;
-        if (g.act == BIST_ACT_RELU) v = fmaxf(v, 0.f);
-        if (drop) v = drop_keep(g.drop_seed, zoff + (unsigned long long)m * g.N + n, g.drop_p) ? v * keep_scale : 0.f;
-        if (res) {
-          const long rr = g.res_outer > 0 ? (long)(m / g.res_outer) * g.res_inner + (m % g.res_inner) : (long)m;
-          v += to_f(res[rr * g.ldr + n]);
-        }
-        C[(long)m * g.ldc + n] = from_f<TO>(v);
+        C[(long)m * g.ldc + n] = from_f<TO>(epilogue_value<T, TO>(g, acc[i][j][r], bv, res, m, n, zoff));
       }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// fast kernel: LDS-DMA staging, double buffer
+// fast kernel: LDS-DMA staging of both operands, double buffer, optional split-K
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename TO>
+template <typename T, typename TO, bool ATR, bool BTR>
 __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
   // one LDS object per stage: the compiler tracks in-flight LDS-DMA per object, so the
   // fragment reads of stage s need not wait for the DMA that is filling stage s^1
   __shared__ __attribute__((aligned(16))) char lds0[2 * TILE_BYTES];   // [A|B]
   __shared__ __attribute__((aligned(16))) char lds1[2 * TILE_BYTES];
-  int z, tm, tn;
-  tile_coords(g, z, tm, tn);
+  int z, sp, tm, tn;
+  tile_coords(g, z, sp, tm, tn);
   const int z1 = z / g.batch2, z2 = z % g.batch2;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
 
-  const char* Az = g.A + (z1 * g.a_bs1 + z2 * g.a_bs2) * (long)sizeof(T);
-  const char* Bz = g.B + (z1 * g.b_bs1 + z2 * g.b_bs2) * (long)sizeof(T);
-  // per-lane source pointers: wave w stages row groups w*4+j (8 rows each) of both operands
-  const char* pa[4];
-  const char* pb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (w * 4 + j) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ (((j & 1) << 2) | (lane >> 4));     // inverse of the read swizzle
-    const int ma = min(m0 + row, g.M - 1), nb = min(n0 + row, g.N - 1);  // tails re-read a valid row
-    pa[j] = Az + (long)ma * g.a_rs * (long)sizeof(T) + chunk * 16;
-    pb[j] = Bz + (long)nb * g.b_rs * (long)sizeof(T) + chunk * 16;
-  }
-  auto issue = [&](char* stage_base) {
-    char* la = stage_base + (w * 4) * 1024;
-    char* lb = la + TILE_BYTES;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(pa[j]), LDS_PTR(la + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(pb[j]), LDS_PTR(lb + j * 1024), 16, 0, 0);
-      pa[j] += ROW_BYTES;
-      pb[j] += ROW_BYTES;
-    }
-  };
+  const int nk_all = g.K / BK;
+  const int kt0 = (int)((long)nk_all * sp / g.split_k), kt1 = (int)((long)nk_all * (sp + 1) / g.split_k);
+  const int nk = kt1 - kt0;
+
+  Stager<T, ATR> sa;
+  Stager<T, BTR> sb;
+  sa.init(g.A + (z1 * g.a_bs1 + z2 * g.a_bs2) * (long)sizeof(T), g.a_rs, g.a_ks, m0, g.M, kt0 * BK, w, lane);
+  sb.init(g.B + (z1 * g.b_bs1 + z2 * g.b_bs2) * (long)sizeof(T), g.b_rs, g.b_ks, n0, g.N, kt0 * BK, w, lane);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -163,19 +248,37 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K / BK;
-  issue(lds0);
+  if (nk > 0) { sa.issue(lds0, w); sb.issue(lds0 + TILE_BYTES, w); }
   for (int kt = 0; kt < nk; kt += 2) {
     __syncthreads();                     // waits vmcnt(0): tile kt has landed, tile kt-1 fully consumed
-    if (kt + 1 < nk) issue(lds1);
-    compute_tile<T>(lds0, lds0 + TILE_BYTES, acc, wm, wn, lane);
+    if (kt + 1 < nk) { sa.issue(lds1, w); sb.issue(lds1 + TILE_BYTES, w); }
+    compute_tile<T, ATR, BTR>(lds0, lds0 + TILE_BYTES, acc, wm, wn, lane);
     if (kt + 1 < nk) {
       __syncthreads();
-      if (kt + 2 < nk) issue(lds0);
-      compute_tile<T>(lds1, lds1 + TILE_BYTES, acc, wm, wn, lane);
+      if (kt + 2 < nk) { sa.issue(lds0, w); sb.issue(lds0 + TILE_BYTES, w); }
+      compute_tile<T, ATR, BTR>(lds1, lds1 + TILE_BYTES, acc, wm, wn, lane);
     }
   }
-  epilogue<T, TO>(g, acc, z1, z2, m0, n0, wm, wn, lane);
+  epilogue<T, TO>(g, acc, z1, z2, sp, m0, n0, wm, wn, lane);
+}
+
+// sums the split-K slabs and applies the epilogue: one thread per output element
+template <typename T, typename TO>
+__global__ void splitk_reduce_kernel(const GemmK g, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long mn = (long)g.M * g.N;
+  const long zlin = idx / mn, r = idx % mn;
+  const int m = (int)(r / g.N), n = (int)(r % g.N);
+  const int z1 = (int)(zlin / g.batch2), z2 = (int)(zlin % g.batch2);
+  const float* W = g.ws + zlin * g.split_k * mn + r;
+  float acc = 0.f;
+  for (int s = 0; s < g.split_k; ++s) acc += W[(long)s * mn];
+  TO* C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
+  const T* bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
+  const TO* res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
+  const float bv = bias ? to_f(bias[n]) : 0.f;
+  C[(long)m * g.ldc + n] = from_f<TO>(epilogue_value<T, TO>(g, acc, bv, res, m, n, (unsigned long long)zlin * mn));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,8 +287,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
 template <typename T, typename TO>
 __global__ __launch_bounds__(NTHREADS) void gemm_gen_kernel(const GemmK g) {
   __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
-  int z, tm, tn;
-  tile_coords(g, z, tm, tn);
+  int z, sp, tm, tn;
+  tile_coords(g, z, sp, tm, tn);
   const int z1 = z / g.batch2, z2 = z % g.batch2;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -229,33 +332,70 @@ __global__ __launch_bounds__(NTHREADS) void gemm_gen_kernel(const GemmK g) {
       *reinterpret_cast<T*>(lds + TILE_BYTES + row * ROW_BYTES + ((((kb >> 4) ^ ((row >> 1) & 7)) << 4) | (kb & 15))) = rb[e];
     }
     __syncthreads();
-    compute_tile<T>(lds, lds + TILE_BYTES, acc, wm, wn, lane);
+    compute_tile<T, false, false>(lds, lds + TILE_BYTES, acc, wm, wn, lane);
   }
-  epilogue<T, TO>(g, acc, z1, z2, m0, n0, wm, wn, lane);
+  epilogue<T, TO>(g, acc, z1, z2, 0, m0, n0, wm, wn, lane);
 }
 
-bool fast_ok(const BistGemm* g) {
+// ---- host side ------------------------------------------------------------------------------------
+struct Plan { bool fast; bool atr, btr; int split; size_t ws_bytes; };
+
+Plan make_plan(const BistGemm* g) {
+  Plan p{false, false, false, 1, 0};
   const long sz = g->in_dtype == BIST_BF16 ? 2 : 4;
-  const long bk = ROW_BYTES / sz;
+  const long bk = ROW_BYTES / sz, piece = 16 / sz;
   auto al16 = [&](long elems) { return (elems * sz) % 16 == 0; };
-  return g->a_ks == 1 && g->b_ks == 1 && g->K % bk == 0 && al16(g->a_rs) && al16(g->b_rs) && al16(g->a_bs1) &&
-         al16(g->a_bs2) && al16(g->b_bs1) && al16(g->b_bs2) && ((uintptr_t)g->A % 16 == 0) && ((uintptr_t)g->B % 16 == 0);
+  auto layout_ok = [&](long rs, long ks, long rows, bool& tr) {
+    if (ks == 1 && al16(rs)) { tr = false; return true; }                         // K-contiguous
+    if (rs == 1 && al16(ks) && rows % piece == 0) { tr = true; return true; }     // row-contiguous
+    return false;
+  };
+  const bool ok = g->K % bk == 0 && layout_ok(g->a_rs, g->a_ks, g->M, p.atr) && layout_ok(g->b_rs, g->b_ks, g->N, p.btr) &&
+                  al16(g->a_bs1) && al16(g->a_bs2) && al16(g->b_bs1) && al16(g->b_bs2) &&
+                  ((uintptr_t)g->A % 16 == 0) && ((uintptr_t)g->B % 16 == 0);
+  p.fast = ok;
+  if (!ok) return p;
+  const long tiles = (long)((g->M + BM - 1) / BM) * ((g->N + BN - 1) / BN) * g->batch1 * g->batch2;
+  const long nk = g->K / bk;
+  if (g->workspace && tiles < 192 && nk >= 16) {
+    long s = (512 + tiles - 1) / tiles;
+    if (s > nk / 4) s = nk / 4;
+    if (s > 64) s = 64;
+    const size_t need = (size_t)s * g->M * g->N * sizeof(float) * g->batch1 * g->batch2;
+    if (s > 1 && need <= (size_t)g->workspace_bytes) { p.split = (int)s; p.ws_bytes = need; }
+  }
+  return p;
 }
 
 template <typename T, typename TO>
-int launch(const BistGemm* g, const GemmK& k, hipStream_t st) {
-  const long nwg = (long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2;
-  if (fast_ok(g))
-    hipLaunchKernelGGL((gemm_fast_kernel<T, TO>), dim3((unsigned)nwg), dim3(NTHREADS), 0, st, k);
-  else
-    hipLaunchKernelGGL((gemm_gen_kernel<T, TO>), dim3((unsigned)nwg), dim3(NTHREADS), 0, st, k);
+int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
+  const Plan p = make_plan(g);
+  k.split_k = p.split;
+  k.ws = p.split > 1 ? (float*)g->workspace : nullptr;
+  const long nwg = (long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2 * p.split;
+  if (nwg >= (1L << 31)) { bist_set_error("bist_gemm: grid too large"); return BIST_EINVAL; }
+  const dim3 grid((unsigned)nwg), block(NTHREADS);
+  if (!p.fast) hipLaunchKernelGGL((gemm_gen_kernel<T, TO>), grid, block, 0, st, k);
+  else if (!p.atr && !p.btr) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, false, false>), grid, block, 0, st, k);
+  else if (!p.atr && p.btr) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, false, true>), grid, block, 0, st, k);
+  else if (p.atr && !p.btr) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, true, false>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((gemm_fast_kernel<T, TO, true, true>), grid, block, 0, st, k);
   BIST_LAUNCH_CHECK("bist_gemm");
+  if (p.split > 1) {
+    const long total = (long)g->M * g->N * g->batch1 * g->batch2;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T, TO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k, total);
+    BIST_LAUNCH_CHECK("bist_gemm(split-K reduce)");
+  }
   return BIST_OK;
 }
 
 }  // namespace
 
-extern "C" int bist_gemm_is_fast(const BistGemm* g) { return g && fast_ok(g) ? 1 : 0; }
+extern "C" int bist_gemm_is_fast(const BistGemm* g) {
+  if (!g) return 0;
+  const Plan p = make_plan(g);
+  return p.fast ? (p.split > 1 ? 2 : 1) : 0;
+}
 
 extern "C" int bist_gemm(const BistGemm* g, void* stream) {
   BIST_REQUIRE(g != nullptr, "bist_gemm: null descriptor");
@@ -266,6 +406,7 @@ extern "C" int bist_gemm(const BistGemm* g, void* stream) {
   BIST_REQUIRE(g->out_dtype == BIST_F32 || g->out_dtype == g->in_dtype, "bist_gemm: out_dtype must be f32 or equal in_dtype");
   BIST_REQUIRE(g->drop_p >= 0.f && g->drop_p < 1.f, "bist_gemm: drop_p out of range");
   BIST_REQUIRE((g->res_outer == 0) == (g->res_inner == 0) && g->res_outer >= 0, "bist_gemm: bad residual row map");
+  BIST_REQUIRE(g->workspace_bytes >= 0 && (g->workspace || g->workspace_bytes == 0), "bist_gemm: bad workspace");
   GemmK k;
   k.A = (const char*)g->A; k.B = (const char*)g->B; k.C = (char*)g->C;
   k.bias = (const char*)g->bias; k.residual = (const char*)g->residual;
@@ -277,8 +418,7 @@ extern "C" int bist_gemm(const BistGemm* g, void* stream) {
   k.alpha = g->alpha; k.act = g->act; k.res_outer = g->res_outer; k.res_inner = g->res_inner;
   k.drop_p = g->drop_p; k.drop_seed = g->drop_seed;
   k.tiles_m = (g->M + BM - 1) / BM; k.tiles_n = (g->N + BN - 1) / BN;
-  const long nwg = (long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2;
-  BIST_REQUIRE(nwg < (1L << 31), "bist_gemm: grid too large");
+  k.split_k = 1; k.ws = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (g->in_dtype == BIST_BF16) {
     if (g->out_dtype == BIST_BF16) return launch<bf16_t, bf16_t>(g, k, st);

@@ -72,7 +72,23 @@ def gemm_desc(a: Tensor, b: Tensor, c: Tensor, *, M: int, N: int, K: int, a_rs: 
     g.res_outer, g.res_inner = res_map
     g.in_dtype, g.out_dtype = dtype_code(a.dtype), dtype_code(c.dtype)
     g.drop_p, g.drop_seed = drop_p, drop_seed
+    ws = _workspace(a.device)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     return g
+
+
+_WS = {}
+WORKSPACE_BYTES = 64 << 20
+
+
+def _workspace(device) -> Tensor:
+    """Per-device fp32 scratch for split-K partial tiles (allocated once; the library never allocates)."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.empty(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)
+        _WS[key] = ws
+    return ws
 
 
 def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:

@@ -78,11 +78,16 @@ typedef struct BistGemm {
    * mask keyed by (drop_seed, element index) so backward can regenerate it. 0 disables.      */
   float drop_p;
   uint64_t drop_seed;
+  /* Optional split-K scratch (caller-owned device memory, fp32 partial tiles).  When given and the
+   * problem has few output tiles and a long K (weight gradients), K is cut over several workgroups
+   * and a second kernel sums the slabs; NULL / 0 disables split-K.                              */
+  void* workspace;
+  int64_t workspace_bytes;
 } BistGemm;
 
 int bist_gemm(const BistGemm* g, void* stream);
-/* Which kernel bist_gemm would pick for this problem: 1 = LDS-DMA MFMA tile kernel,
- * 0 = generic strided kernel (host-side query, used by tests and the bench report).          */
+/* Which kernel bist_gemm would pick for this problem: 1 = LDS-DMA MFMA tile kernel, 2 = the same
+ * with split-K, 0 = generic strided kernel (host-side query, used by tests and the bench report). */
 int bist_gemm_is_fast(const BistGemm* g);
 
 /* ------------------------------------------------------------------------------------------

@@ -85,6 +85,44 @@ def test_gemm_generic_strides(ops, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("M,N,K", [(256, 192, 128), (136, 520, 320), (128, 128, 64)])
+def test_gemm_fast_transposed_operands(ops, dtype, tol, M, N, K):
+    """row-contiguous operands (the backward products) take the LDS-DMA kernel with the transposing
+    fragment reads (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32) -- no generic fallback."""
+    from bist_amd import _lib
+    a, b = _rand(M, K, seed=50), _rand(N, K, seed=51, scale=K ** -0.5)
+    ref = _q(a, dtype) @ _q(b, dtype).t()
+    ad, bd = a.to(dtype).cuda(), b.to(dtype).cuda()
+    at, bt = a.t().contiguous().to(dtype).cuda(), b.t().contiguous().to(dtype).cuda()      # stored [K, M] / [K, N]
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    for name, (A, ars, aks), (Bm, brs, bks) in [("TN", (at, 1, M), (bd, K, 1)), ("NT'", (ad, K, 1), (bt, 1, N)),
+                                               ("TT", (at, 1, M), (bt, 1, N))]:
+        g = ops.gemm_desc(A, Bm, out, M=M, N=N, K=K, a_rs=ars, a_ks=aks, b_rs=brs, b_ks=bks, ldc=N)
+        assert _lib.lib.bist_gemm_is_fast(g) >= 1, name
+        out.zero_()
+        ops.gemm(A, Bm, out, M=M, N=N, K=K, a_rs=ars, a_ks=aks, b_rs=brs, b_ks=bks, ldc=N)
+        _cmp(out, ref, tol, f"transposed {name}")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, BF16_TOL)])
+def test_gemm_split_k_weight_gradient_shape(ops, dtype, tol):
+    """dW = dY^T X with a long reduction (K = rows): few output tiles -> split-K over the workspace."""
+    from bist_amd import _lib
+    rows, N, Kd = 6400, 128, 192
+    dy, x = _rand(rows, N, seed=52, scale=rows ** -0.5), _rand(rows, Kd, seed=53)
+    ref = _q(dy, dtype).t() @ _q(x, dtype)
+    dyd, xd = dy.to(dtype).cuda(), x.to(dtype).cuda()
+    out = torch.empty(N, Kd, device="cuda", dtype=dtype)
+    kw = dict(M=N, N=Kd, K=rows, a_rs=1, a_ks=N, b_rs=1, b_ks=Kd, ldc=Kd, alpha=0.5)
+    assert _lib.lib.bist_gemm_is_fast(ops.gemm_desc(dyd, xd, out, **kw)) == 2
+    ops.gemm(dyd, xd, out, **kw)
+    _cmp(out, 0.5 * ref, tol, "split-K dW")
+    bias = _rand(Kd, seed=54)
+    ops.gemm(dyd, xd, out, bias=bias.to(dtype).cuda(), act=ops.ACT_RELU, **kw)
+    _cmp(out, (0.5 * ref + _q(bias, dtype)).clamp_min(0), tol, "split-K + epilogue")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
 def test_gemm_batched_head_fold(ops, dtype, tol):
     # the K-fold: Qf[(b,i), hh*d + n] = sum_c Q[(b,i), hh*dk + c] * Wk[hh*dk + c, n]   (batch over heads)
     Bq, h, dk = 37, 4, 16
