@@ -55,7 +55,7 @@ def test_gemm_fast_linear(ops, dtype, tol, M, N, K):
     xd, wd, bd, rd = (t.to(dtype).cuda() for t in (x, w, b, r))
     from bist_amd import _lib
     g = ops.gemm_desc(xd, wd, torch.empty(M, N, device="cuda", dtype=dtype), M=M, N=N, K=K, a_rs=K, b_rs=K, ldc=N)
-    assert _lib.lib.bist_gemm_is_fast(g) == 1
+    assert _lib.lib.bist_gemm_is_fast(g) >= 1          # 1 = LDS-DMA kernel, 2 = the same with split-K
     ref = _q(x, dtype) @ _q(w, dtype).t() + _q(b, dtype)
     _cmp(ops.linear(xd, wd, bd), ref, tol, "linear")
     _cmp(ops.linear(xd, wd, bd, act=ops.ACT_RELU), ref.clamp_min(0), tol, "linear+relu")
