@@ -108,9 +108,11 @@ __device__ __forceinline__ uint4 load_frag(const char* tile, int row0, int ks, i
 }
 
 template <typename T, bool ATR, bool BTR>
-__device__ __forceinline__ void compute_tile(const char* lds_a, const char* lds_b, f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+__device__ __forceinline__ void compute_tile(const char* lds_a, const char* lds_b, f32x4 (&acc)[4][4], int wm, int wn, int lane,
+                                             bool half = false) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
+    if (ks == 1 && half) break;            // K tail of half a tile: only the first 64 bytes / K-rows are valid
     uint4 af[4], bf[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -129,6 +131,7 @@ __device__ __forceinline__ void compute_tile(const char* lds_a, const char* lds_
 template <typename T, bool TR>
 struct Stager {
   const char* p[4];
+  long fix[4];      // byte delta applied on a trailing HALF tile so that no lane reads past the K extent
   long step;
   __device__ __forceinline__ void init(const char* base, long rs, long ks_stride, int r0, int rows, int k0, int w, int lane) {
     constexpr int SZ = (int)sizeof(T);
@@ -140,24 +143,27 @@ struct Stager {
         const int chunk = (lane & 7) ^ (((j & 1) << 2) | (lane >> 4));          // inverse of the read swizzle
         const int rr = min(r0 + row, rows - 1);                                   // tails re-read a valid row
         p[j] = base + ((long)rr * rs + k0) * SZ + chunk * 16;
+        fix[j] = chunk >= 4 ? -64 : 0;
       } else if constexpr (SZ == 2) {
         const int krow = lane >> 4, k = inst * 4 + krow;
         int c = (lane & 15) ^ (2 * krow) ^ (8 * ((inst >> 1) & 1));
         if (r0 + c * 8 >= rows) c = 0;                                            // rows % 8 == 0: whole piece in or out
         p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 8) * SZ;
+        fix[j] = k >= 32 ? -32 * ks_stride * SZ : 0;
       } else {
         const int krow = lane >> 5, k = inst * 2 + krow;
         int c = (lane & 31) ^ (4 * ((inst >> 1) & 7));
         if (r0 + c * 4 >= rows) c = 0;
         p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 4) * SZ;
+        fix[j] = k >= 16 ? -16 * ks_stride * SZ : 0;
       }
     }
     step = TR ? (long)(ROW_BYTES / SZ) * ks_stride * SZ : ROW_BYTES;
   }
-  __device__ __forceinline__ void issue(char* lds_tile, int w) {
+  __device__ __forceinline__ void issue(char* lds_tile, int w, bool half = false) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(p[j]), LDS_PTR(lds_tile + (w * 4 + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p[j] + (half ? fix[j] : 0)), LDS_PTR(lds_tile + (w * 4 + j) * 1024), 16, 0, 0);
       p[j] += step;
     }
   }
@@ -219,12 +225,14 @@ __device__ __forceinline__ void epilogue(const GemmK& g, f32x4 (&acc)[4][4], int
 // ---------------------------------------------------------------------------------------------
 // fast kernel: LDS-DMA staging of both operands, double buffer, optional split-K
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename TO, bool ATR, bool BTR>
+template <typename T, typename TO, bool ATR, bool BTR, int NS>
 __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
   // one LDS object per stage: the compiler tracks in-flight LDS-DMA per object, so the
-  // fragment reads of stage s need not wait for the DMA that is filling stage s^1
+  // fragment reads of stage s need not wait for the DMA that is filling another stage
   __shared__ __attribute__((aligned(16))) char lds0[2 * TILE_BYTES];   // [A|B]
   __shared__ __attribute__((aligned(16))) char lds1[2 * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds2[NS > 2 ? 2 * TILE_BYTES : 16];
+  __shared__ __attribute__((aligned(16))) char lds3[NS > 2 ? 2 * TILE_BYTES : 16];
   int z, sp, tm, tn;
   tile_coords(g, z, sp, tm, tn);
   const int z1 = z / g.batch2, z2 = z % g.batch2;
@@ -233,7 +241,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
   const int wm = w >> 1, wn = w & 1;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
 
-  const int nk_all = g.K / BK;
+  const int nk_all = (g.K + BK - 1) / BK;                 // a trailing half tile counts as one
+  const bool half_tail = (g.K % BK) != 0;
   const int kt0 = (int)((long)nk_all * sp / g.split_k), kt1 = (int)((long)nk_all * (sp + 1) / g.split_k);
   const int nk = kt1 - kt0;
 
@@ -248,15 +257,44 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) { sa.issue(lds0, w); sb.issue(lds0 + TILE_BYTES, w); }
-  for (int kt = 0; kt < nk; kt += 2) {
-    __syncthreads();                     // waits vmcnt(0): tile kt has landed, tile kt-1 fully consumed
-    if (kt + 1 < nk) { sa.issue(lds1, w); sb.issue(lds1 + TILE_BYTES, w); }
-    compute_tile<T, ATR, BTR>(lds0, lds0 + TILE_BYTES, acc, wm, wn, lane);
-    if (kt + 1 < nk) {
-      __syncthreads();
-      if (kt + 2 < nk) { sa.issue(lds0, w); sb.issue(lds0 + TILE_BYTES, w); }
-      compute_tile<T, ATR, BTR>(lds1, lds1 + TILE_BYTES, acc, wm, wn, lane);
+  auto is_half = [&](int kt) { return half_tail && (kt0 + kt == nk_all - 1); };
+  auto stage_in = [&](char* st, int kt) { const bool hf = is_half(kt); sa.issue(st, w, hf); sb.issue(st + TILE_BYTES, w, hf); };
+
+  if constexpr (NS == 2) {
+    if (nk > 0) stage_in(lds0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+      __syncthreads();                     // waits vmcnt(0): tile kt has landed, tile kt-1 fully consumed
+      if (kt + 1 < nk) stage_in(lds1, kt + 1);
+      compute_tile<T, ATR, BTR>(lds0, lds0 + TILE_BYTES, acc, wm, wn, lane, is_half(kt));
+      if (kt + 1 < nk) {
+        __syncthreads();
+        if (kt + 2 < nk) stage_in(lds0, kt + 2);
+        compute_tile<T, ATR, BTR>(lds1, lds1 + TILE_BYTES, acc, wm, wn, lane, is_half(kt + 1));
+      }
+    }
+  } else {
+    // 4-stage ring for latency-bound launches (few workgroups, one per CU): three tiles of DMA stay in
+    // flight across the barriers.  Each wave first waits for ITS OWN pieces of tile kt with a counted
+    // vmcnt (8 DMA instructions per tile per wave), then the raw barrier makes every wave's pieces
+    // visible; the stage refilled after the barrier is the one all waves finished reading before it.
+    if (nk > 0) stage_in(lds0, 0);
+    if (nk > 1) stage_in(lds1, 1);
+    if (nk > 2) stage_in(lds2, 2);
+    auto phase = [&](char* cur, char* refill, int kt) {
+      const int ahead = min(kt + 2, nk - 1) - kt;          // tiles issued after kt that may stay in flight
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 3 < nk) stage_in(refill, kt + 3);
+      compute_tile<T, ATR, BTR>(cur, cur + TILE_BYTES, acc, wm, wn, lane, is_half(kt));
+    };
+    for (int kt = 0; kt < nk; kt += 4) {
+      phase(lds0, lds3, kt);
+      if (kt + 1 < nk) phase(lds1, lds0, kt + 1);
+      if (kt + 2 < nk) phase(lds2, lds1, kt + 2);
+      if (kt + 3 < nk) phase(lds3, lds2, kt + 3);
     }
   }
   epilogue<T, TO>(g, acc, z1, z2, sp, m0, n0, wm, wn, lane);
@@ -338,10 +376,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_gen_kernel(const GemmK g) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-struct Plan { bool fast; bool atr, btr; int split; size_t ws_bytes; };
+struct Plan { bool fast; bool atr, btr; int split; size_t ws_bytes; int stages; };
 
 Plan make_plan(const BistGemm* g) {
-  Plan p{false, false, false, 1, 0};
+  Plan p{false, false, false, 1, 0, 2};
   const long sz = g->in_dtype == BIST_BF16 ? 2 : 4;
   const long bk = ROW_BYTES / sz, piece = 16 / sz;
   auto al16 = [&](long elems) { return (elems * sz) % 16 == 0; };
@@ -350,13 +388,13 @@ Plan make_plan(const BistGemm* g) {
     if (rs == 1 && al16(ks) && rows % piece == 0) { tr = true; return true; }     // row-contiguous
     return false;
   };
-  const bool ok = g->K % bk == 0 && layout_ok(g->a_rs, g->a_ks, g->M, p.atr) && layout_ok(g->b_rs, g->b_ks, g->N, p.btr) &&
+  const bool ok = g->K % (bk / 2) == 0 && layout_ok(g->a_rs, g->a_ks, g->M, p.atr) && layout_ok(g->b_rs, g->b_ks, g->N, p.btr) &&
                   al16(g->a_bs1) && al16(g->a_bs2) && al16(g->b_bs1) && al16(g->b_bs2) &&
                   ((uintptr_t)g->A % 16 == 0) && ((uintptr_t)g->B % 16 == 0);
   p.fast = ok;
   if (!ok) return p;
   const long tiles = (long)((g->M + BM - 1) / BM) * ((g->N + BN - 1) / BN) * g->batch1 * g->batch2;
-  const long nk = g->K / bk;
+  const long nk = (g->K + bk - 1) / bk;
   if (g->workspace && tiles < 192 && nk >= 16) {
     long s = (512 + tiles - 1) / tiles;
     if (s > nk / 4) s = nk / 4;
@@ -364,6 +402,8 @@ Plan make_plan(const BistGemm* g) {
     const size_t need = (size_t)s * g->M * g->N * sizeof(float) * g->batch1 * g->batch2;
     if (s > 1 && need <= (size_t)g->workspace_bytes) { p.split = (int)s; p.ws_bytes = need; }
   }
+  // one workgroup per CU or fewer: nothing else hides the DMA latency, so run the deep ring
+  if (tiles * p.split <= 320 && nk / p.split >= 3) p.stages = 4;
   return p;
 }
 
@@ -375,11 +415,17 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
   const long nwg = (long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2 * p.split;
   if (nwg >= (1L << 31)) { bist_set_error("bist_gemm: grid too large"); return BIST_EINVAL; }
   const dim3 grid((unsigned)nwg), block(NTHREADS);
+#define FAST(ATR_, BTR_)                                                                                         \
+  do {                                                                                                           \
+    if (p.stages == 4) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, ATR_, BTR_, 4>), grid, block, 0, st, k);      \
+    else hipLaunchKernelGGL((gemm_fast_kernel<T, TO, ATR_, BTR_, 2>), grid, block, 0, st, k);                    \
+  } while (0)
   if (!p.fast) hipLaunchKernelGGL((gemm_gen_kernel<T, TO>), grid, block, 0, st, k);
-  else if (!p.atr && !p.btr) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, false, false>), grid, block, 0, st, k);
-  else if (!p.atr && p.btr) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, false, true>), grid, block, 0, st, k);
-  else if (p.atr && !p.btr) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, true, false>), grid, block, 0, st, k);
-  else hipLaunchKernelGGL((gemm_fast_kernel<T, TO, true, true>), grid, block, 0, st, k);
+  else if (!p.atr && !p.btr) FAST(false, false);
+  else if (!p.atr && p.btr) FAST(false, true);
+  else if (p.atr && !p.btr) FAST(true, false);
+  else FAST(true, true);
+#undef FAST
   BIST_LAUNCH_CHECK("bist_gemm");
   if (p.split > 1) {
     const long total = (long)g->M * g->N * g->batch1 * g->batch2;
