@@ -55,6 +55,10 @@ class LinearFn(Function):
         ctx.save_for_backward(x2, w, y if act == ACT_RELU else None)
         ctx.cfg = (act, res_map, alpha, drop_p, drop_seed, bias is not None, bias.dtype if bias is not None else None,
                    residual is not None, tuple(residual.shape) if residual is not None else None, tuple(x.shape))
+        # trainer-owned gradient destinations (bist_amd/train.py): weight gradients are accumulated by the
+        # GEMM straight into the flat gradient buffer, bias gradients into the fp32 accumulator
+        ctx.w_dst = getattr(w, "_grad_view", None)
+        ctx.b_dst = getattr(bias, "_acc32", None) if bias is not None else None
         return y
 
     @staticmethod
@@ -92,12 +96,17 @@ class LinearFn(Function):
             ops.gemm(dz, w, dx, M=M, N=K, K=N, a_rs=N, a_ks=1, b_rs=1, b_ks=w.stride(0), ldc=K, alpha=alpha)
             dx = dx.view(x_shape)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((N, K), device=dz.device, dtype=w.dtype)
-            ops.gemm(dz, x2, dw, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=K, alpha=alpha)
+            if ctx.w_dst is not None:            # dW accumulates in place: C = alpha * dz^T x + C
+                gv = ctx.w_dst
+                ops.gemm(dz, x2, gv, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=gv.stride(0), alpha=alpha,
+                         residual=gv, ldr=gv.stride(0))
+            else:
+                dw = torch.empty((N, K), device=dz.device, dtype=w.dtype)
+                ops.gemm(dz, x2, dw, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=K, alpha=alpha)
         if has_bias and ctx.needs_input_grad[2]:
-            acc = _f32_zeros((N,), dz)
+            acc = ctx.b_dst if ctx.b_dst is not None else _f32_zeros((N,), dz)
             check(lib.bist_col_sum_acc(dz.data_ptr(), acc.data_ptr(), M, N, N, dtype_code(dz.dtype), _stream()), "bist_col_sum_acc")
-            db = _to_dtype_from_f32(acc, bias_dtype)
+            db = None if ctx.b_dst is not None else _to_dtype_from_f32(acc, bias_dtype)
         return dx, dw, db, dres, None, None, None, None, None, None
 
 
@@ -123,6 +132,7 @@ class HeadFoldFn(Function):
     def forward(ctx, q, wk, h, alpha):
         ctx.save_for_backward(q, wk)
         ctx.cfg = (h, alpha)
+        ctx.w_dst = getattr(wk, "_grad_view", None)
         M, d = q.shape
         dk = d // h
         out = torch.empty((M, h * d), device=q.device, dtype=q.dtype)
@@ -140,6 +150,12 @@ class HeadFoldFn(Function):
         dq = torch.empty((M, d), device=q.device, dtype=q.dtype)
         ops.gemm(dqf, wk, dq, M=M, N=dk, K=d, a_rs=h * d, b_rs=wk.stride(0), ldc=d, batch=(1, h), a_bs=(0, d),
                  b_bs=(0, dk * wk.stride(0)), c_bs=(0, dk), alpha=alpha)
+        gv = ctx.w_dst
+        if gv is not None:
+            ops.gemm(q, dqf, gv, M=dk, N=d, K=M, a_rs=1, a_ks=q.stride(0), b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
+                     a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), alpha=alpha, residual=gv, ldr=gv.stride(0),
+                     r_bs=(0, dk * gv.stride(0)))
+            return dq, None, None, None
         dwk = torch.empty((d, d), device=q.device, dtype=wk.dtype)
         ops.gemm(q, dqf, dwk, M=dk, N=d, K=M, a_rs=1, a_ks=q.stride(0), b_rs=1, b_ks=h * d, ldc=d, batch=(1, h),
                  a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * d), alpha=alpha)
@@ -153,6 +169,7 @@ class HeadUnfoldFn(Function):
     def forward(ctx, py, wv, bv, h):
         ctx.save_for_backward(py, wv)
         ctx.cfg = (h, bv.dtype)
+        ctx.w_dst, ctx.b_dst = getattr(wv, "_grad_view", None), getattr(bv, "_acc32", None)
         M = py.shape[0]
         d = wv.shape[1]
         dk = d // h
@@ -172,12 +189,19 @@ class HeadUnfoldFn(Function):
         dpy = torch.empty((M, h * d), device=py.device, dtype=py.dtype)
         ops.gemm(do, wv, dpy, M=M, N=d, K=dk, a_rs=d, a_ks=1, b_rs=1, b_ks=wv.stride(0), ldc=h * d, batch=(1, h),
                  a_bs=(0, dk), b_bs=(0, dk * wv.stride(0)), c_bs=(0, d))
-        dwv = torch.empty((d, d), device=py.device, dtype=wv.dtype)
-        ops.gemm(do, py, dwv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=d, batch=(1, h),
-                 a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * d))
-        acc = _f32_zeros((d,), do)
+        gv = ctx.w_dst
+        if gv is not None:
+            ops.gemm(do, py, gv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
+                     a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), residual=gv, ldr=gv.stride(0),
+                     r_bs=(0, dk * gv.stride(0)))
+            dwv = None
+        else:
+            dwv = torch.empty((d, d), device=py.device, dtype=wv.dtype)
+            ops.gemm(do, py, dwv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=d, batch=(1, h),
+                     a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * d))
+        acc = ctx.b_dst if ctx.b_dst is not None else _f32_zeros((d,), do)
         check(lib.bist_col_sum_acc(do.data_ptr(), acc.data_ptr(), M, d, d, dtype_code(do.dtype), _stream()), "bist_col_sum_acc")
-        return dpy, dwv, _to_dtype_from_f32(acc, bdt), None
+        return dpy, dwv, (None if ctx.b_dst is not None else _to_dtype_from_f32(acc, bdt)), None
 
 
 class StScoresFn(Function):
@@ -244,6 +268,7 @@ class LayerNormFn(Function):
     def forward(ctx, x, a, b, eps):
         ctx.save_for_backward(x, a)
         ctx.cfg = (eps, b.dtype)
+        ctx.a_dst, ctx.b_dst = getattr(a, "_acc32", None), getattr(b, "_acc32", None)
         return ops.layernorm(x, a, b, eps)
 
     @staticmethod
@@ -256,10 +281,13 @@ class LayerNormFn(Function):
         if dy2.stride(1) != 1:
             dy2 = dy2.contiguous()
         dx = torch.empty(x2.shape, device=x.device, dtype=x.dtype)
-        da, db = _f32_zeros((d,), x), _f32_zeros((d,), x)
+        direct = ctx.a_dst is not None and ctx.b_dst is not None
+        da, db = (ctx.a_dst, ctx.b_dst) if direct else (_f32_zeros((d,), x), _f32_zeros((d,), x))
         check(lib.bist_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), a.data_ptr(), dx.data_ptr(), da.data_ptr(), db.data_ptr(),
                                      x2.shape[0], d, dy2.stride(0), x2.stride(0), d, eps, dtype_code(x.dtype), _stream()),
               "bist_layernorm_bwd")
+        if direct:
+            return dx.view(x.shape), None, None, None
         return dx.view(x.shape), _to_dtype_from_f32(da, a.dtype), _to_dtype_from_f32(db, bdt), None
 
 
@@ -268,6 +296,7 @@ class EmbedFn(Function):
     def forward(ctx, ids, lut, pe):
         ctx.save_for_backward(ids)
         ctx.cfg = (tuple(lut.shape), lut.dtype)
+        ctx.dst = getattr(lut, "_acc32", None)
         return ops.embed_pe(ids, lut, pe)
 
     @staticmethod
@@ -275,10 +304,10 @@ class EmbedFn(Function):
         (ids,) = ctx.saved_tensors
         shape, dt = ctx.cfg
         dy = dy.contiguous()
-        acc = _f32_zeros(shape, dy)
+        acc = ctx.dst if ctx.dst is not None else _f32_zeros(shape, dy)
         check(lib.bist_embed_bwd(ids.contiguous().data_ptr(), dy.data_ptr(), acc.data_ptr(), ids.numel(), shape[1],
                                  dtype_code(dy.dtype), _stream()), "bist_embed_bwd")
-        return None, _to_dtype_from_f32(acc, dt), None
+        return None, (None if ctx.dst is not None else _to_dtype_from_f32(acc, dt)), None
 
 
 class FuseFn(Function):

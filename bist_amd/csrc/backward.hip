@@ -141,6 +141,13 @@ __global__ void cast_from_f32_kernel(const float* __restrict__ s, T* __restrict_
   if (i < n) d[i] = from_f<T>(s[i]);
 }
 
+// dst[i] += src[i] (fp32 accumulator -> gradient buffer in the compute dtype)
+template <typename T>
+__global__ void add_f32_into_kernel(const float* __restrict__ s, T* __restrict__ d, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = from_f<T>(to_f(d[i]) + s[i]);
+}
+
 // Adam step on fp32 master weights with an optional low-precision working copy:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
 // (torch.optim.Adam semantics, the optimiser the reference wraps in NoamOpt, train.py:129-130)
@@ -248,6 +255,16 @@ extern "C" int bist_cast_from_f32(const float* src, void* dst, int64_t n, int32_
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_cast_from_f32");
+  return BIST_OK;
+}
+
+extern "C" int bist_add_f32_into(const float* src, void* dst, int64_t n, int32_t dtype, void* stream) {
+  BIST_REQUIRE(src && dst && n > 0, "bist_add_f32_into: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+#define L(TT, ...) hipLaunchKernelGGL(add_f32_into_kernel<TT>, dim3(blocks_for(n, 256)), dim3(256), 0, st, src, (TT*)dst, (long)n)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_add_f32_into");
   return BIST_OK;
 }
 

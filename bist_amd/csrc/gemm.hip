@@ -22,6 +22,7 @@
 // Workgroup ids are remapped so that each XCD (blocks b, b+8, ... share one) walks a contiguous range
 // of tiles: neighbouring tiles share an A row panel, which then stays in that XCD's L2.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -402,8 +403,10 @@ Plan make_plan(const BistGemm* g) {
     const size_t need = (size_t)s * g->M * g->N * sizeof(float) * g->batch1 * g->batch2;
     if (s > 1 && need <= (size_t)g->workspace_bytes) { p.split = (int)s; p.ws_bytes = need; }
   }
-  // one workgroup per CU or fewer: nothing else hides the DMA latency, so run the deep ring
-  if (tiles * p.split <= 320 && nk / p.split >= 3) p.stages = 4;
+  // The 4-stage ring (128 KiB LDS, one workgroup per CU) measured SLOWER than the 2-stage kernel at two
+  // workgroups per CU on every shape of this path (scripts/bench_gemm.py, round 1), so it is opt-in only.
+  static const int force_stages = [] { const char* e = getenv("BIST_GEMM_STAGES"); return e ? atoi(e) : 0; }();   // tuning aid
+  if (force_stages == 2 || force_stages == 4) p.stages = force_stages;
   return p;
 }
 

@@ -80,6 +80,9 @@ class MultiHeadedAttention(nn.Module):
 
     # -- packed projection weights (device-side concatenation, cached while parameters are unchanged)
     def _packed(self, idx):
+        pk = self.__dict__.get("_pk")
+        if pk is not None:               # bist_amd.train.Trainer laid the projections out contiguously:
+            return pk[tuple(idx)]        # the packed operands (and their gradients) are plain views
         ws = [self.linears[i].weight for i in idx]
         bs = [self.linears[i].bias for i in idx]
         key = (tuple(idx),) + tuple((w.data_ptr(), w._version) for w in ws + bs)

@@ -3,27 +3,41 @@ reference's ``run_epoch`` loop (train.py:29-37) + ``SimpleLossCompute`` (model/o
 ``NoamOpt.step`` (optimize.py:19-26) for one batch.
 
 MI355X layout: all parameters live in ONE flat buffer in the compute dtype (the tensors the kernels
-read; each ``nn.Parameter`` is a view into it), all gradients in ONE flat buffer of the same dtype
-(each ``.grad`` is a view, autograd accumulates in place), and the fp32 master weights and Adam
-moments in three more flat buffers.  A step is therefore one memset, one (optional) RCCL all-reduce
-over xGMI of the whole gradient buffer and one fused Adam kernel that also refreshes the low-precision
-copy -- no per-parameter launches, no NCCL-style per-tensor collectives.
+read; each ``nn.Parameter`` is a view into it), all gradients in ONE flat buffer of the same dtype, and
+the fp32 master weights and Adam moments in three more flat buffers.  The layout is chosen for the
+kernels, not for registration order:
+
+  * region 0 (prefix): every 1-D parameter (biases, LayerNorm gains/offsets) and the shared embedding
+    matrix -- the gradients that are reduced over rows with fp32 atomics.  A parallel fp32 accumulator
+    ``acc32`` covers exactly this prefix; the backward kernels add into it directly and one kernel
+    folds it into the gradient buffer per step.
+  * the Q/K/V projection weights (and biases) of each attention are adjacent, so the packed [3d,d] /
+    [2d,d] operands of the fused projection GEMMs are plain views -- no concatenation, and their
+    gradients land in place.
+
+Weight gradients are written by the backward GEMMs straight into the flat gradient buffer
+(C = dY^T X + C), so a step is: two memsets, forward+backward, one fold kernel, one (optional) RCCL
+all-reduce over xGMI of the whole gradient buffer, one fused Adam kernel that also refreshes the
+low-precision weights.  No per-parameter optimiser launches, no per-tensor collectives.
 """
 from __future__ import annotations
 
-import math
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
 
-from . import functional as Fn
 from ._lib import check, lib
 from .model.label_smoothing import LabelSmoothing
+from .model.modules import MultiHeadedAttention
 from .model.optimize import SimpleLossCompute
 from .ops import _stream, dtype_code
 
 ALIGN = 64      # elements; keeps every parameter view 16-byte aligned for the LDS-DMA GEMM path
+
+
+def _round(n: int) -> int:
+    return (n + ALIGN - 1) // ALIGN * ALIGN
 
 
 class Trainer:
@@ -36,29 +50,85 @@ class Trainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self._step = 0
-        params, seen = [], set()
+
+        params: List[torch.nn.Parameter] = []
+        seen = set()
         for p in model.parameters():
             if id(p) not in seen:
                 seen.add(id(p)); params.append(p)
         dev = params[0].device
-        offs, n = [], 0
+        lut = model.query_embed[0].lut.weight
+        attns = [m for m in model.modules() if isinstance(m, MultiHeadedAttention)]
+
+        # ---- layout -------------------------------------------------------------------------------
+        order: List[torch.nn.Parameter] = []
+        placed = set()
+
+        def place(p):
+            if id(p) not in placed:
+                placed.add(id(p)); order.append(p)
+        for m in attns:                                   # region 0: packed attention biases first ...
+            for j in range(3):
+                place(m.linears[j].bias)
+        for p in params:                                  # ... then every other 1-D parameter ...
+            if p.dim() == 1:
+                place(p)
+        place(lut)                                        # ... and the shared embedding matrix
+        n_prefix_params = len(order)
+        for m in attns:                                   # packed attention weights
+            for j in range(3):
+                place(m.linears[j].weight)
         for p in params:
-            offs.append(n)
-            n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            place(p)
+
+        offs, n = {}, 0
+        packed_w, packed_b = {}, {}
+        for idx, p in enumerate(order):
+            offs[id(p)] = n
+            is_pack_member = any(p is m.linears[j].bias or p is m.linears[j].weight for m in attns for j in (0, 1))
+            # members 0 and 1 of a packed triple are NOT padded, so [W0;W1;W2] is contiguous
+            n += p.numel() if is_pack_member else _round(p.numel())
+            if idx == n_prefix_params - 1:
+                self.n32 = n                               # end of the fp32-accumulated prefix
         self.numel = n
+        for m in attns:                                   # a packed member must start 16-byte aligned
+            for t in ("bias", "weight"):
+                o0 = offs[id(getattr(m.linears[0], t))]
+                nn_ = getattr(m.linears[0], t).numel()
+                assert offs[id(getattr(m.linears[1], t))] == o0 + nn_ and offs[id(getattr(m.linears[2], t))] == o0 + 2 * nn_
+                assert (o0 * 2) % 16 == 0 and (nn_ * 2) % 16 == 0, "attention width must keep packed views 16-byte aligned"
+
+        # ---- buffers ------------------------------------------------------------------------------
         self.master = torch.zeros(n, device=dev, dtype=torch.float32)
-        for p, o in zip(params, offs):
+        for p in order:
+            o = offs[id(p)]
             self.master[o:o + p.numel()].copy_(p.detach().reshape(-1).float())
         self.flat_param = self.master if compute_dtype == torch.float32 else self.master.to(compute_dtype)
         self.flat_grad = torch.zeros(n, device=dev, dtype=compute_dtype)
+        self.acc32 = torch.zeros(self.n32, device=dev, dtype=torch.float32)
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
-        for p, o in zip(params, offs):
-            p.data = self.flat_param[o:o + p.numel()].view(p.shape)
-            p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
-        for b in model.buffers():          # the PE table stays fp32
-            pass
-        self.params = params
+
+        for p in order:
+            o, k = offs[id(p)], p.numel()
+            p.data = self.flat_param[o:o + k].view(p.shape)
+            p.grad = None
+            p._grad_view = self.flat_grad[o:o + k].view(p.shape)       # GEMM backward accumulates here
+            if o < self.n32:
+                p._acc32 = self.acc32[o:o + k].view(p.shape)           # atomically reduced gradients go here
+        for m in attns:                                                # packed projection operands as plain views
+            d_out, d_in = m.linears[0].weight.shape
+            ow, ob = offs[id(m.linears[0].weight)], offs[id(m.linears[0].bias)]
+            pk = {}
+            for idx in ((0, 1, 2), (1, 2)):
+                r0, r1 = idx[0] * d_out, (idx[-1] + 1) * d_out
+                w = self.flat_param[ow + r0 * d_in: ow + r1 * d_in].view(r1 - r0, d_in).requires_grad_(True)
+                b = self.flat_param[ob + r0: ob + r1].requires_grad_(True)
+                w._grad_view = self.flat_grad[ow + r0 * d_in: ow + r1 * d_in].view(r1 - r0, d_in)
+                b._acc32 = self.acc32[ob + r0: ob + r1]
+                pk[idx] = (w, b)
+            m._pk = pk
+        self.params = order
         self.criterion = LabelSmoothing(vocab_size, pad, smoothing)
         self.loss_compute = SimpleLossCompute(model.generator, model.ae_generator, self.criterion, opt=None, args=args)
 
@@ -75,11 +145,23 @@ class Trainer:
             loss = t if loss is None else loss + t
         return loss, terms
 
-    def step(self, batch) -> Dict[str, torch.Tensor]:
-        """One optimiser step; returns the (detached, device-side) loss terms."""
+    def backward(self, batch):
+        """forward + backward; leaves the complete gradient in ``flat_grad`` (no optimiser step)."""
         self.flat_grad.zero_()
+        self.acc32.zero_()
         loss, terms = self.forward_loss(batch)
         loss.backward()
+        for p in self.params:                 # anything autograd still produced itself (views, fallbacks)
+            if p.grad is not None:
+                p._grad_view.add_(p.grad)
+                p.grad = None
+        check(lib.bist_add_f32_into(self.acc32.data_ptr(), self.flat_grad.data_ptr(), self.n32, dtype_code(self.compute_dtype),
+                                    _stream()), "bist_add_f32_into")
+        return terms
+
+    def step(self, batch) -> Dict[str, torch.Tensor]:
+        """One optimiser step; returns the (detached, device-side) loss terms."""
+        terms = self.backward(batch)
         if self.world > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
         self._step += 1

@@ -239,6 +239,9 @@ int bist_log_softmax_bwd(const float* y, const float* dy, float* dx, int64_t row
 int bist_label_smoothing_bwd(const int64_t* target, const float* gout, const int64_t* denom, float* dlogp, int64_t rows,
                              int32_t V, float smoothing, int32_t pad, void* stream);
 int bist_cast_from_f32(const float* src, void* dst, int64_t n, int32_t dtype, void* stream);
+/* dst[i] += src[i]: folds the fp32 accumulators of the atomically-reduced gradients (biases, LayerNorm
+ * gains, embedding rows) into the gradient buffer once per step.                                   */
+int bist_add_f32_into(const float* src, void* dst, int64_t n, int32_t dtype, void* stream);
 /* One Adam step (torch.optim.Adam semantics, the optimiser NoamOpt wraps: train.py:129-130) on fp32
  * master weights p with moments m, v; g in grad_dtype, scaled by grad_scale first; `work`
  * (nullable) receives the updated weights in work_dtype (the bf16 copy the kernels read).        */

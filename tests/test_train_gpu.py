@@ -278,6 +278,35 @@ def test_adam_matches_torch(env):
     assert (p.cpu() - ref.detach()).abs().max().item() < 1e-6
 
 
+def test_trainer_flat_gradients_equal_autograd(env):
+    """The trainer writes weight gradients straight into its flat buffer (GEMM accumulate, fp32 atomics for
+    biases/LayerNorm/embedding); the result must equal what plain autograd produces for the same model."""
+    import copy
+    import bist_amd.model as M
+    from bist_amd.data.synthetic import synthetic_batch
+    from bist_amd.model.label_smoothing import LabelSmoothing
+    from bist_amd.model.optimize import SimpleLossCompute
+    from bist_amd.train import Trainer
+    cfg = O.Cfg(d_model=64, att_h=4, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    args = _args(cfg)
+    torch.manual_seed(0)
+    ref_model = M.make_model(80, 80, args, ft_sizes=[64]).cuda().eval()
+    model = copy.deepcopy(ref_model)
+    b = synthetic_batch(3, T=6, S=9, C=64, Lq=7, Lh=9, Lc=6, Lt=6, vocab=80, dtype=torch.float32)
+    lc = SimpleLossCompute(ref_model.generator, ref_model.ae_generator, LabelSmoothing(80, 1, 0.1), None, args=args)
+    terms, _ = lc.terms(ref_model.forward(b), b)
+    sum(terms.values()).backward()
+    tr = Trainer(model, args, 80, compute_dtype=torch.float32)
+    tr.backward(b)
+    ref = dict(ref_model.named_parameters())
+    worst = {}
+    for name, p in model.named_parameters():
+        g, r = p._grad_view.double(), ref[name].grad.double()
+        worst[name] = ((g - r).abs().max() / max(1e-6, r.abs().max())).item()
+    bad = {k: v for k, v in worst.items() if not v <= 2e-4}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_trainer_reduces_loss(env, dtype):
     import bist_amd.model as M
