@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--no-graph", action="store_true", help="launch the ~2.7k kernels of a step eagerly instead of replaying a hipGraph")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,7 +122,7 @@ def main():
     model = M.make_model(c["V"], c["V"], args, ft_sizes=[c["C"]]).cuda()
     model.train()
     Fn.manual_seed(1234 + rank)
-    trainer = Trainer(model, args, c["V"], compute_dtype=dtype)
+    trainer = Trainer(model, args, c["V"], compute_dtype=dtype, use_graph=not a.no_graph)
     batch = synthetic_batch(c["B"], T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"],
                             seed=1234 + rank, dtype=dtype)
     ntok = int(batch.ntokens.item())

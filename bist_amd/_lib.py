@@ -25,7 +25,7 @@ class BistGemm(C.Structure):
         ("bias_bs2", C.c_int64),
         ("alpha", C.c_float), ("act", C.c_int32), ("res_outer", C.c_int32), ("res_inner", C.c_int32),
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
-        ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_ctr", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
@@ -53,7 +53,7 @@ SIGNATURES = {
     "bist_log_softmax_fwd": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "bist_label_smoothing_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _I32, _P]),
     "bist_sum_div": (C.c_int, [_P, _I64, _P, _P, _I32, _P]),
-    "bist_epilogue_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _I64, _I32, _F, C.c_uint64, _I32, _P]),
+    "bist_epilogue_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _I64, _I32, _F, C.c_uint64, _P, _I32, _P]),
     "bist_group_sum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
     "bist_col_sum_acc": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
     "bist_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _I64, _I64, _F, _I32, _P]),

@@ -88,7 +88,8 @@ class LinearFn(Function):
             if y is not None and y.dtype != dz.dtype:
                 raise RuntimeError("relu epilogue backward needs the output in the operand dtype")
             check(lib.bist_epilogue_bwd(dz.data_ptr(), yy.data_ptr(), dz2.data_ptr(), M, N, N, N, N, act, drop_p, drop_seed,
-                                        dtype_code(dz.dtype), _stream()), "bist_epilogue_bwd")
+                                        _ptr(ops.DROP_CTR) if drop_p > 0 else None, dtype_code(dz.dtype), _stream()),
+                  "bist_epilogue_bwd")
             dz = dz2
         dx = dw = db = None
         if ctx.needs_input_grad[0]:

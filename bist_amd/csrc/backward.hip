@@ -12,12 +12,14 @@ inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / 
 //   dropout:         dz = dy * keep(seed, idx)/(1-p)   (relu+dropout: [y>0] already encodes keep)
 template <typename T>
 __global__ void epilogue_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dz, long M, int N,
-                                    long lddy, long ldy, long lddz, int act, float drop_p, unsigned long long seed) {
+                                    long lddy, long ldy, long lddz, int act, float drop_p, unsigned long long seed0,
+                                    const unsigned long long* __restrict__ ctr) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * N) return;
   const long m = idx / N; const int n = (int)(idx % N);
   float g = to_f(dy[m * lddy + n]);
   if (drop_p > 0.f) {
+    const unsigned long long seed = seed0 + (ctr ? ctr[0] * 0xD1B54A32D192ED03ULL : 0ULL);
     const float sc = 1.f / (1.f - drop_p);
     if (act == BIST_ACT_RELU) g *= sc;
     else g = drop_keep(seed, (unsigned long long)idx, drop_p) ? g * sc : 0.f;
@@ -174,11 +176,12 @@ __global__ void adam_kernel(float* __restrict__ p, const TG* __restrict__ g, flo
   else { bist_set_error("%s: bad dtype %d", __func__, (int)(dtype)); return BIST_EINVAL; }
 
 extern "C" int bist_epilogue_bwd(const void* dy, const void* y, void* dz, int64_t M, int32_t N, int64_t lddy, int64_t ldy,
-                                 int64_t lddz, int32_t act, float drop_p, uint64_t drop_seed, int32_t dtype, void* stream) {
+                                 int64_t lddz, int32_t act, float drop_p, uint64_t drop_seed, const uint64_t* drop_ctr, int32_t dtype,
+                                 void* stream) {
   BIST_REQUIRE(dy && dz && M > 0 && N > 0, "bist_epilogue_bwd: bad argument");
   BIST_REQUIRE(act != BIST_ACT_RELU || y, "bist_epilogue_bwd: relu needs the forward output");
   hipStream_t st = (hipStream_t)stream;
-#define L(TT, ...) hipLaunchKernelGGL(epilogue_bwd_kernel<TT>, dim3(blocks_for(M * N, 256)), dim3(256), 0, st, (const TT*)dy, (const TT*)y, (TT*)dz, (long)M, N, (long)lddy, (long)ldy, (long)lddz, act, drop_p, (unsigned long long)drop_seed)
+#define L(TT, ...) hipLaunchKernelGGL(epilogue_bwd_kernel<TT>, dim3(blocks_for(M * N, 256)), dim3(256), 0, st, (const TT*)dy, (const TT*)y, (TT*)dz, (long)M, N, (long)lddy, (long)ldy, (long)lddz, act, drop_p, (unsigned long long)drop_seed, (const unsigned long long*)drop_ctr)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_epilogue_bwd");

@@ -40,7 +40,7 @@ struct GemmK {   // device-side argument block (by value)
   int batch2;
   long a_bs1, a_bs2, b_bs1, b_bs2, c_bs1, c_bs2, r_bs1, r_bs2, bias_bs2;
   float alpha; int act; int res_outer, res_inner;
-  float drop_p; unsigned long long drop_seed;
+  float drop_p; unsigned long long drop_seed; const unsigned long long* drop_ctr;
   int tiles_m, tiles_n;
   int split_k; float* ws;            // split_k > 1: raw fp32 partial tiles go to ws[z][split][M][N]
 };
@@ -174,7 +174,10 @@ template <typename T, typename TO>
 __device__ __forceinline__ float epilogue_value(const GemmK& g, float acc, float bv, const TO* res, int m, int n, unsigned long long zoff) {
   float v = acc * g.alpha + bv;
   if (g.act == BIST_ACT_RELU) v = fmaxf(v, 0.f);
-  if (g.drop_p > 0.f) v = drop_keep(g.drop_seed, zoff + (unsigned long long)m * g.N + n, g.drop_p) ? v * (1.f / (1.f - g.drop_p)) : 0.f;
+  if (g.drop_p > 0.f) {
+    const unsigned long long seed = g.drop_seed + (g.drop_ctr ? g.drop_ctr[0] * 0xD1B54A32D192ED03ULL : 0ULL);
+    v = drop_keep(seed, zoff + (unsigned long long)m * g.N + n, g.drop_p) ? v * (1.f / (1.f - g.drop_p)) : 0.f;
+  }
   if (res) {
     const long rr = g.res_outer > 0 ? (long)(m / g.res_outer) * g.res_inner + (m % g.res_inner) : (long)m;
     v += to_f(res[rr * g.ldr + n]);
@@ -465,7 +468,7 @@ extern "C" int bist_gemm(const BistGemm* g, void* stream) {
   k.a_bs1 = g->a_bs1; k.a_bs2 = g->a_bs2; k.b_bs1 = g->b_bs1; k.b_bs2 = g->b_bs2;
   k.c_bs1 = g->c_bs1; k.c_bs2 = g->c_bs2; k.r_bs1 = g->r_bs1; k.r_bs2 = g->r_bs2; k.bias_bs2 = g->bias_bs2;
   k.alpha = g->alpha; k.act = g->act; k.res_outer = g->res_outer; k.res_inner = g->res_inner;
-  k.drop_p = g->drop_p; k.drop_seed = g->drop_seed;
+  k.drop_p = g->drop_p; k.drop_seed = g->drop_seed; k.drop_ctr = (const unsigned long long*)g->drop_ctr;
   k.tiles_m = (g->M + BM - 1) / BM; k.tiles_n = (g->N + BN - 1) / BN;
   k.split_k = 1; k.ws = nullptr;
   hipStream_t st = (hipStream_t)stream;

@@ -72,11 +72,13 @@ def gemm_desc(a: Tensor, b: Tensor, c: Tensor, *, M: int, N: int, K: int, a_rs: 
     g.res_outer, g.res_inner = res_map
     g.in_dtype, g.out_dtype = dtype_code(a.dtype), dtype_code(c.dtype)
     g.drop_p, g.drop_seed = drop_p, drop_seed
+    g.drop_ctr = DROP_CTR.data_ptr() if (DROP_CTR is not None and drop_p > 0) else None
     ws = _workspace(a.device)
     g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     return g
 
 
+DROP_CTR = None   # optional device int64 step counter mixed into every dropout seed (set by the trainer)
 _WS = {}
 WORKSPACE_BYTES = 64 << 20
 

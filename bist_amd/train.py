@@ -31,6 +31,7 @@ from ._lib import check, lib
 from .model.label_smoothing import LabelSmoothing
 from .model.modules import MultiHeadedAttention
 from .model.optimize import SimpleLossCompute
+from . import ops
 from .ops import _stream, dtype_code
 
 ALIGN = 64      # elements; keeps every parameter view 16-byte aligned for the LDS-DMA GEMM path
@@ -43,8 +44,10 @@ def _round(n: int) -> int:
 class Trainer:
     def __init__(self, model: torch.nn.Module, args, vocab_size: int, *, compute_dtype: torch.dtype = torch.bfloat16,
                  warmup: int = 4000, factor: float = 1.0, smoothing: float = 0.1, pad: int = 1,
-                 betas=(0.9, 0.98), eps: float = 1e-9, process_group=None):
+                 betas=(0.9, 0.98), eps: float = 1e-9, process_group=None, use_graph: bool = False):
         self.model, self.args = model, args
+        self.use_graph = use_graph
+        self._graph = self._graph_key = self._static_batch = self._static_terms = None
         self.compute_dtype = compute_dtype
         self.warmup, self.factor, self.betas, self.eps = warmup, factor, betas, eps
         self.pg = process_group
@@ -129,6 +132,9 @@ class Trainer:
                 pk[idx] = (w, b)
             m._pk = pk
         self.params = order
+        # device-side step counter mixed into every dropout seed, so that a captured graph draws new masks
+        self.drop_ctr = torch.zeros(1, device=dev, dtype=torch.int64)
+        ops.DROP_CTR = self.drop_ctr
         self.criterion = LabelSmoothing(vocab_size, pad, smoothing)
         self.loss_compute = SimpleLossCompute(model.generator, model.ae_generator, self.criterion, opt=None, args=args)
 
@@ -159,12 +165,47 @@ class Trainer:
                                     _stream()), "bist_add_f32_into")
         return terms
 
+    # ---- hipGraph path: forward + backward + gradient fold captured once per batch geometry ----------------
+    _BATCH_FIELDS = ("query", "his", "cap", "trg", "trg_y", "fts", "query_mask", "his_mask", "cap_mask", "temporal_mask",
+                     "trg_mask", "trg_mean_mask", "ntokens", "qntokens")
+
+    def _shape_key(self, batch):
+        return tuple((f, tuple(getattr(batch, f).shape), getattr(batch, f).dtype) for f in self._BATCH_FIELDS
+                     if getattr(batch, f, None) is not None)
+
+    def _capture(self, batch, key):
+        """Record the ~2.7k launches of forward+backward into one hipGraph (the batch tensors become the graph's
+        static inputs).  Warm-up runs on a side stream first, as graph capture requires."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.backward(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            terms = self.backward(batch)
+        self._graph, self._graph_key, self._static_batch, self._static_terms = graph, key, batch, terms
+
+    def _graph_backward(self, batch):
+        key = self._shape_key(batch)
+        if self._graph is None or key != self._graph_key:
+            self._capture(batch, key)
+        elif batch is not self._static_batch:
+            for f in self._BATCH_FIELDS:
+                src = getattr(batch, f, None)
+                if src is not None:
+                    getattr(self._static_batch, f).copy_(src, non_blocking=True)
+        self._graph.replay()
+        return self._static_terms
+
     def step(self, batch) -> Dict[str, torch.Tensor]:
         """One optimiser step; returns the (detached, device-side) loss terms."""
-        terms = self.backward(batch)
+        self._step += 1
+        self.drop_ctr.fill_(self._step)
+        terms = self._graph_backward(batch) if self.use_graph else self.backward(batch)
         if self.world > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-        self._step += 1
         work = None if self.compute_dtype == torch.float32 else self.flat_param
         check(lib.bist_adam_step(self.master.data_ptr(), self.flat_grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                  work.data_ptr() if work is not None else None, self.numel, self.rate(), self.betas[0],

@@ -78,6 +78,9 @@ typedef struct BistGemm {
    * mask keyed by (drop_seed, element index) so backward can regenerate it. 0 disables.      */
   float drop_p;
   uint64_t drop_seed;
+  /* Optional device-side step counter mixed into the seed (seed + ctr[0]*odd constant): lets a
+   * captured hipGraph draw a fresh mask on every replay.  NULL = seed only.                     */
+  const uint64_t* drop_ctr;
   /* Optional split-K scratch (caller-owned device memory, fp32 partial tiles).  When given and the
    * problem has few output tiles and a long K (weight gradients), K is cut over several workgroups
    * and a second kernel sums the slabs; NULL / 0 disables split-K.                              */
@@ -203,7 +206,8 @@ int bist_sum_div(const float* x, int64_t n, const int64_t* denom, float* out, in
 /* dz = dy * d(epilogue)/dz of bist_gemm's epilogue (relu via the stored output y, dropout via the
  * regenerated mask of (drop_seed, element index)).                                              */
 int bist_epilogue_bwd(const void* dy, const void* y, void* dz, int64_t M, int32_t N, int64_t lddy, int64_t ldy,
-                      int64_t lddz, int32_t act, float drop_p, uint64_t drop_seed, int32_t dtype, void* stream);
+                      int64_t lddz, int32_t act, float drop_p, uint64_t drop_seed, const uint64_t* drop_ctr, int32_t dtype,
+                      void* stream);
 /* out[b, r] = sum_g x[b, g, r]  (r < inner): gradient of the un-expanded query of stage 1.       */
 int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream);
 /* out[n] += sum_m x[m, n]  (bias gradient, fp32 accumulator).                                    */

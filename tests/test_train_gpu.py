@@ -308,6 +308,26 @@ def test_trainer_flat_gradients_equal_autograd(env):
     assert not bad, bad
 
 
+def test_trainer_graph_replay_matches_eager(env):
+    """Two identical trainers, one replaying a captured hipGraph: same losses step for step (dropout off)."""
+    import copy
+    import bist_amd.model as M
+    from bist_amd.data.synthetic import synthetic_batch
+    from bist_amd.train import Trainer
+    cfg = O.Cfg(d_model=64, att_h=4, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    args = _args(cfg)
+    torch.manual_seed(0)
+    m1 = M.make_model(80, 80, args, ft_sizes=[64]).cuda().eval()
+    m2 = copy.deepcopy(m1)
+    b = synthetic_batch(4, T=6, S=9, C=64, Lq=7, Lh=9, Lc=6, Lt=6, vocab=80, dtype=torch.float32)
+    t1 = Trainer(m1, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0)
+    t2 = Trainer(m2, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=True)
+    l1 = [t1.step(b)["out"].item() for _ in range(6)]
+    l2 = [t2.step(b)["out"].item() for _ in range(6)]
+    assert all(abs(a - c) <= 2e-3 * abs(a) for a, c in zip(l1, l2)), (l1, l2)
+    assert l1[-1] < l1[0]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_trainer_reduces_loss(env, dtype):
     import bist_amd.model as M
