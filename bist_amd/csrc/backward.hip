@@ -40,15 +40,20 @@ __global__ void group_sum_kernel(const T* __restrict__ x, T* __restrict__ out, i
   out[idx] = from_f<T>(acc);
 }
 
-// out[n] += sum_m x[m, n]   (bias gradient); grid = (col blocks of 256, row chunks)
+// out[n] += sum_m x[m, n]   (bias gradient).  Block = 64 columns x 4 row lanes; grid = (column blocks, row chunks);
+// the four row lanes are combined through LDS, then one atomic per column per block.
 template <typename T>
-__global__ void col_sum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, long ldx, int rows_per_block) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+__global__ __launch_bounds__(256) void col_sum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, long ldx, int rows_per_block) {
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
   const long m0 = (long)blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
   float acc = 0.f;
-  for (long m = m0; m < m1; ++m) acc += to_f(x[m * ldx + n]);
-  atomicAdd(out + n, acc);
+  if (n < N)
+    for (long m = m0 + rl; m < m1; m += 4) acc += to_f(x[m * ldx + n]);
+  part[rl][c] = acc;
+  __syncthreads();
+  if (rl == 0 && n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
 // LayerNorm backward (forward: y = a*(x-mean)/(std+eps)+b, std unbiased):
@@ -202,10 +207,11 @@ extern "C" int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, in
 extern "C" int bist_col_sum_acc(const void* x, float* out, int64_t M, int32_t N, int64_t ldx, int32_t dtype, void* stream) {
   BIST_REQUIRE(x && out && M > 0 && N > 0 && ldx >= N, "bist_col_sum_acc: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  int rpb = (int)((M + 255) / 256);
-  if (rpb < 64) rpb = 64;
-  dim3 grid(blocks_for(N, 256), blocks_for(M, rpb));
-#define L(TT, ...) hipLaunchKernelGGL(col_sum_kernel<TT>, grid, dim3(256), 0, st, (const TT*)x, out, (long)M, N, (long)ldx, rpb)
+  const long cb = blocks_for(N, 64);
+  long rpb = (M * cb + 1023) / 1024;                 // aim at ~1024 workgroups
+  if (rpb < 16) rpb = 16;
+  dim3 grid((unsigned)cb, blocks_for(M, (int)rpb));
+#define L(TT, ...) hipLaunchKernelGGL(col_sum_kernel<TT>, grid, dim3(256), 0, st, (const TT*)x, out, (long)M, N, (long)ldx, (int)rpb)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_col_sum_acc");

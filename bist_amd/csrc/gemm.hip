@@ -43,6 +43,7 @@ struct GemmK {   // device-side argument block (by value)
   float drop_p; unsigned long long drop_seed; const unsigned long long* drop_ctr;
   int tiles_m, tiles_n;
   int split_k; float* ws;            // split_k > 1: raw fp32 partial tiles go to ws[z][split][M][N]
+  int vec_c, vec_r;                  // 16-byte aligned output / residual rows: vector epilogue allowed
 };
 
 template <typename T> struct Mma;
@@ -226,6 +227,95 @@ __device__ __forceinline__ void epilogue(const GemmK& g, f32x4 (&acc)[4][4], int
   }
 }
 
+// Staged epilogue of the fast kernel.  The accumulators go to LDS as f32 (one [64 rows][128 cols] image per
+// wave-row half, reusing the two operand stages; 16-byte chunks XOR-swizzled by row so the scattered
+// fragment writes do not collide), then every thread streams 8 (bf16 out) or 4 (f32 out) consecutive
+// columns of a row: bias / activation / dropout / residual in registers, one 16-byte load of the residual
+// and one 16-byte store per item.  Versus storing straight from the MFMA layout (2-byte stores, 32-byte
+// runs) this cuts the store instructions 8x and makes every global access a full 16 bytes per lane.
+template <typename T, typename TO>
+__device__ __forceinline__ void epilogue_staged(const GemmK& g, f32x4 (&acc)[4][4], char* lds_lo, char* lds_hi, int z1, int z2,
+                                                int sp, int m0, int n0, int wm, int wn, int lane, int tid) {
+  const int lr = lane & 15, lg = lane >> 4;
+  __syncthreads();                               // every wave is done reading the operand stages
+  {
+    float* buf = reinterpret_cast<float*>(wm == 0 ? lds_lo : lds_hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i * 16 + lg * 4 + r, col = wn * 64 + j * 16 + lr;
+          const int pos = (col >> 2) ^ (((row >> 2) & 7) << 2);
+          buf[row * 128 + pos * 4 + (col & 3)] = acc[i][j][r];
+        }
+  }
+  __syncthreads();
+  const long zlin = z1 * (long)g.batch2 + z2;
+  const bool split = g.split_k > 1;
+  constexpr int VW = 16 / (int)sizeof(TO);       // columns per item: 8 (bf16) or 4 (f32)
+  const int vw = split ? 4 : VW;                 // split-K slabs are always f32
+  const int ipr = 128 / vw;
+  TO* C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
+  float* W = split ? g.ws + ((zlin * g.split_k + sp) * (long)g.M) * g.N : nullptr;
+  const T* bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
+  const TO* res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
+  const unsigned long long zoff = (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N;
+  for (int item = tid; item < 128 * ipr; item += NTHREADS) {
+    const int row = item / ipr, col0 = (item % ipr) * vw;
+    const int m = m0 + row, n = n0 + col0;
+    if (m >= g.M || n >= g.N) continue;
+    const float* src = reinterpret_cast<const float*>(row < 64 ? lds_lo : lds_hi) + (row & 63) * 128;
+    const int sw = (((row & 63) >> 2) & 7) << 2;
+    float v[8];
+    {
+      const float4 a = *reinterpret_cast<const float4*>(src + (((col0 >> 2)) ^ sw) * 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+      if (vw == 8) {
+        const float4 b = *reinterpret_cast<const float4*>(src + (((col0 >> 2) + 1) ^ sw) * 4);
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
+    }
+    const bool full = n + vw <= g.N;
+    if (split) {
+      float* dst = W + (long)m * g.N + n;
+      if (full && (g.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      else for (int e = 0; e < 4 && n + e < g.N; ++e) dst[e] = v[e];
+      continue;
+    }
+    const long rr = g.res_outer > 0 ? (long)(m / g.res_outer) * g.res_inner + (m % g.res_inner) : (long)m;
+    float rv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+    if (res) {
+      const TO* rp = res + rr * g.ldr + n;
+      if (full && g.vec_r) {
+        const uint4 q = *reinterpret_cast<const uint4*>(rp);
+        const TO* qe = reinterpret_cast<const TO*>(&q);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) rv[e] = to_f(qe[e]);
+      } else {
+        for (int e = 0; e < VW && n + e < g.N; ++e) rv[e] = to_f(rp[e]);
+      }
+    }
+    TO out[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      float x = v[e] * g.alpha + ((bias && n + e < g.N) ? to_f(bias[n + e]) : 0.f);
+      if (g.act == BIST_ACT_RELU) x = fmaxf(x, 0.f);
+      if (g.drop_p > 0.f) {
+        const unsigned long long seed = g.drop_seed + (g.drop_ctr ? g.drop_ctr[0] * 0xD1B54A32D192ED03ULL : 0ULL);
+        x = drop_keep(seed, zoff + (unsigned long long)m * g.N + n + e, g.drop_p) ? x * (1.f / (1.f - g.drop_p)) : 0.f;
+      }
+      out[e] = from_f<TO>(x + rv[e]);
+    }
+    TO* dst = C + (long)m * g.ldc + n;
+    if (full && g.vec_c) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
+    else for (int e = 0; e < VW && n + e < g.N; ++e) dst[e] = out[e];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fast kernel: LDS-DMA staging of both operands, double buffer, optional split-K
 // ---------------------------------------------------------------------------------------------
@@ -301,7 +391,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
       if (kt + 3 < nk) phase(lds3, lds2, kt + 3);
     }
   }
-  epilogue<T, TO>(g, acc, z1, z2, sp, m0, n0, wm, wn, lane);
+  epilogue_staged<T, TO>(g, acc, lds0, lds1, z1, z2, sp, m0, n0, wm, wn, lane, tid);
 }
 
 // sums the split-K slabs and applies the epilogue: one thread per output element
@@ -471,6 +561,12 @@ extern "C" int bist_gemm(const BistGemm* g, void* stream) {
   k.drop_p = g->drop_p; k.drop_seed = g->drop_seed; k.drop_ctr = (const unsigned long long*)g->drop_ctr;
   k.tiles_m = (g->M + BM - 1) / BM; k.tiles_n = (g->N + BN - 1) / BN;
   k.split_k = 1; k.ws = nullptr;
+  {
+    const long so = g->out_dtype == BIST_BF16 ? 2 : 4;
+    auto al = [&](long elems) { return (elems * so) % 16 == 0; };
+    k.vec_c = ((uintptr_t)g->C % 16 == 0) && al(g->ldc) && al(g->c_bs1) && al(g->c_bs2);
+    k.vec_r = g->residual && ((uintptr_t)g->residual % 16 == 0) && al(g->ldr) && al(g->r_bs1) && al(g->r_bs2);
+  }
   hipStream_t st = (hipStream_t)stream;
   if (g->in_dtype == BIST_BF16) {
     if (g->out_dtype == BIST_BF16) return launch<bf16_t, bf16_t>(g, k, st);
