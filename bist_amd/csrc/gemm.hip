@@ -23,6 +23,7 @@
 // of tiles: neighbouring tiles share an A row panel, which then stays in that XCD's L2.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -229,10 +230,101 @@ __device__ __forceinline__ void epilogue(const GemmK& g, f32x4 (&acc)[4][4], int
 
 // Staged epilogue of the fast kernel.  The accumulators go to LDS as f32 (one [64 rows][128 cols] image per
 // wave-row half, reusing the two operand stages; 16-byte chunks XOR-swizzled by row so the scattered
-// fragment writes do not collide), then every thread streams 8 (bf16 out) or 4 (f32 out) consecutive
-// columns of a row: bias / activation / dropout / residual in registers, one 16-byte load of the residual
-// and one 16-byte store per item.  Versus storing straight from the MFMA layout (2-byte stores, 32-byte
-// runs) this cuts the store instructions 8x and makes every global access a full 16 bytes per lane.
+// fragment writes do not collide), then every thread streams ONE fixed group of 8 (bf16 out) or 4 (f32 out)
+// columns down the rows: its bias values are loaded once, every row is one 16-byte residual load and one
+// 16-byte store, and the row loop is fully unrolled so all loads are in flight together.  Versus storing
+// straight from the MFMA layout (2-byte stores, 32-byte runs) this cuts the store instructions 8x.
+template <typename T, typename TO, bool SPLIT>
+__device__ __forceinline__ void stream_out(const GemmK& g, const char* lds_lo, const char* lds_hi, int z1, int z2, int sp,
+                                           int m0, int n0, int tid) {
+  using TS = typename std::conditional<SPLIT, float, TO>::type;      // element type actually stored
+  constexpr int VW = 16 / (int)sizeof(TS);          // columns per thread: 8 (bf16) or 4 (f32)
+  constexpr int IPR = 128 / VW;                     // threads per row
+  constexpr int RPP = NTHREADS / IPR;               // rows per pass
+  constexpr int NPASS = 128 / RPP;
+  const int col0 = (tid % IPR) * VW, rbase = tid / IPR;
+  const int n = n0 + col0;
+  if (n >= g.N) return;
+  const bool full = n + VW <= g.N;
+  const long zlin = z1 * (long)g.batch2 + z2;
+  const unsigned long long zoff = (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N;
+  TS* out_base;
+  long ld_out;
+  bool vec_out;
+  if constexpr (SPLIT) {
+    out_base = g.ws + ((zlin * g.split_k + sp) * (long)g.M) * g.N;
+    ld_out = g.N; vec_out = (g.N & 3) == 0;
+  } else {
+    out_base = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
+    ld_out = g.ldc; vec_out = g.vec_c != 0;
+  }
+  float bv[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) bv[e] = 0.f;
+  const TO* res = nullptr;
+  if constexpr (!SPLIT) {
+    if (g.bias) {
+      const T* bias = reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 + n;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) if (n + e < g.N) bv[e] = to_f(bias[e]);
+    }
+    if (g.residual) res = reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2;
+  }
+  const unsigned long long seed = g.drop_seed + ((g.drop_p > 0.f && g.drop_ctr) ? g.drop_ctr[0] * 0xD1B54A32D192ED03ULL : 0ULL);
+  const float keep_scale = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
+#pragma unroll
+  for (int it = 0; it < NPASS; ++it) {
+    const int row = rbase + it * RPP;
+    const int m = m0 + row;
+    if (m >= g.M) continue;
+    const float* src = reinterpret_cast<const float*>(row < 64 ? lds_lo : lds_hi) + (row & 63) * 128;
+    const int sw = (((row & 63) >> 2) & 7) << 2;
+    float v[VW];
+#pragma unroll
+    for (int q = 0; q < VW / 4; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(src + (((col0 >> 2) + q) ^ sw) * 4);
+      v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+    }
+    TS o[VW];
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) o[e] = v[e];
+    } else {
+      float rv[VW];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) rv[e] = 0.f;
+      if (res) {
+        const long rr = g.res_outer > 0 ? (long)(m / g.res_outer) * g.res_inner + (m % g.res_inner) : (long)m;
+        const TO* rp = res + rr * g.ldr + n;
+        if (full && g.vec_r) {
+          const uint4 qv = *reinterpret_cast<const uint4*>(rp);
+          TO qe[VW];
+          *reinterpret_cast<uint4*>(qe) = qv;
+#pragma unroll
+          for (int e = 0; e < VW; ++e) rv[e] = to_f(qe[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VW; ++e) if (n + e < g.N) rv[e] = to_f(rp[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        float x = v[e] * g.alpha + bv[e];
+        if (g.act == BIST_ACT_RELU) x = fmaxf(x, 0.f);
+        if (g.drop_p > 0.f) x = drop_keep(seed, zoff + (unsigned long long)m * g.N + n + e, g.drop_p) ? x * keep_scale : 0.f;
+        o[e] = from_f<TO>(x + rv[e]);
+      }
+    }
+    TS* dst = out_base + (long)m * ld_out + n;
+    if (full && vec_out) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) if (n + e < g.N) dst[e] = o[e];
+    }
+  }
+}
+
 template <typename T, typename TO>
 __device__ __forceinline__ void epilogue_staged(const GemmK& g, f32x4 (&acc)[4][4], char* lds_lo, char* lds_hi, int z1, int z2,
                                                 int sp, int m0, int n0, int wm, int wn, int lane, int tid) {
@@ -252,68 +344,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmK& g, f32x4 (&acc)[4][
         }
   }
   __syncthreads();
-  const long zlin = z1 * (long)g.batch2 + z2;
-  const bool split = g.split_k > 1;
-  constexpr int VW = 16 / (int)sizeof(TO);       // columns per item: 8 (bf16) or 4 (f32)
-  const int vw = split ? 4 : VW;                 // split-K slabs are always f32
-  const int ipr = 128 / vw;
-  TO* C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
-  float* W = split ? g.ws + ((zlin * g.split_k + sp) * (long)g.M) * g.N : nullptr;
-  const T* bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
-  const TO* res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
-  const unsigned long long zoff = (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N;
-  for (int item = tid; item < 128 * ipr; item += NTHREADS) {
-    const int row = item / ipr, col0 = (item % ipr) * vw;
-    const int m = m0 + row, n = n0 + col0;
-    if (m >= g.M || n >= g.N) continue;
-    const float* src = reinterpret_cast<const float*>(row < 64 ? lds_lo : lds_hi) + (row & 63) * 128;
-    const int sw = (((row & 63) >> 2) & 7) << 2;
-    float v[8];
-    {
-      const float4 a = *reinterpret_cast<const float4*>(src + (((col0 >> 2)) ^ sw) * 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-      if (vw == 8) {
-        const float4 b = *reinterpret_cast<const float4*>(src + (((col0 >> 2) + 1) ^ sw) * 4);
-        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-      }
-    }
-    const bool full = n + vw <= g.N;
-    if (split) {
-      float* dst = W + (long)m * g.N + n;
-      if (full && (g.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-      else for (int e = 0; e < 4 && n + e < g.N; ++e) dst[e] = v[e];
-      continue;
-    }
-    const long rr = g.res_outer > 0 ? (long)(m / g.res_outer) * g.res_inner + (m % g.res_inner) : (long)m;
-    float rv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) rv[e] = 0.f;
-    if (res) {
-      const TO* rp = res + rr * g.ldr + n;
-      if (full && g.vec_r) {
-        const uint4 q = *reinterpret_cast<const uint4*>(rp);
-        const TO* qe = reinterpret_cast<const TO*>(&q);
-#pragma unroll
-        for (int e = 0; e < VW; ++e) rv[e] = to_f(qe[e]);
-      } else {
-        for (int e = 0; e < VW && n + e < g.N; ++e) rv[e] = to_f(rp[e]);
-      }
-    }
-    TO out[VW];
-#pragma unroll
-    for (int e = 0; e < VW; ++e) {
-      float x = v[e] * g.alpha + ((bias && n + e < g.N) ? to_f(bias[n + e]) : 0.f);
-      if (g.act == BIST_ACT_RELU) x = fmaxf(x, 0.f);
-      if (g.drop_p > 0.f) {
-        const unsigned long long seed = g.drop_seed + (g.drop_ctr ? g.drop_ctr[0] * 0xD1B54A32D192ED03ULL : 0ULL);
-        x = drop_keep(seed, zoff + (unsigned long long)m * g.N + n + e, g.drop_p) ? x * (1.f / (1.f - g.drop_p)) : 0.f;
-      }
-      out[e] = from_f<TO>(x + rv[e]);
-    }
-    TO* dst = C + (long)m * g.ldc + n;
-    if (full && g.vec_c) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
-    else for (int e = 0; e < VW && n + e < g.N; ++e) dst[e] = out[e];
-  }
+  if (g.split_k > 1) stream_out<T, TO, true>(g, lds_lo, lds_hi, z1, z2, sp, m0, n0, tid);
+  else stream_out<T, TO, false>(g, lds_lo, lds_hi, z1, z2, sp, m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
