@@ -138,6 +138,22 @@ def drop_args(module) -> dict:
     return {}
 
 
+# ---- branch concurrency: t2s / s2t / caption reasoning are independent chains of small kernels; each gets
+# its own HIP stream (fork = side.wait_stream(main), join = main.wait_stream(side)).  Captured into a
+# hipGraph the forks become parallel branches of the graph.
+CONCURRENT = True
+_SIDE = {}
+
+
+def side_stream(i: int):
+    key = (torch.cuda.current_device(), i)
+    st = _SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream()
+        _SIDE[key] = st
+    return st
+
+
 def pack_rows(*ws: Tensor) -> Tensor:
     """Concatenate weight matrices / biases row-wise (device-side data movement only)."""
     return torch.cat(ws, dim=0)

@@ -124,13 +124,22 @@ class MultimodalDecoder8(nn.Module):
         q = ft["encoded_query"]
         in_ft = {"t2s": q, "s2t": q, "audio": q, "cap": q}
         for l, layer in enumerate(self.layers):
+            fork_cap = self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda
+            if fork_cap:                     # the caption reasoning layer is independent of the visual one
+                main, side = torch.cuda.current_stream(), Fn.side_stream(1)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    in_ft = self.c_layers[l](in_ft, ft, b)
+                    ft["cap_ft"] = self.cap_out_norm(in_ft["cap"])                           # decoder.py:132
             if self.v_N > 0:
                 in_ft = self.v_layers[l](in_ft, ft, b)
                 if self.args.s2t:
                     ft["temporal_ft"] = self.temporal_out_norm(in_ft["s2t"])                 # decoder.py:127
                 if self.args.t2s:
                     ft["spatial_ft"] = self.spatial_out_norm(in_ft["t2s"])                   # :129
-            if self.c_N > 0:
+            if fork_cap:
+                main.wait_stream(side)
+            elif self.c_N > 0:
                 in_ft = self.c_layers[l](in_ft, ft, b)
                 ft["cap_ft"] = self.cap_out_norm(in_ft["cap"])                               # :132
             self._fuse(ft)

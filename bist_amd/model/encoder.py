@@ -174,18 +174,32 @@ class VidEncoderLayer4(nn.Module):
         t2s_on = (not hasattr(self.args, "t2s")) or self.args.t2s
         s2t_on = (not hasattr(self.args, "s2t")) or self.args.s2t
         v_t2s, v_s2t = self.value_projection(vft)
-        ai = si = fi = 0
-        if t2s_on:
+        def t2s_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
             y = self._stage1(ai + 1, si + 1, x, vft, v_t2s, b.temporal_mask, 0)                   # A1
             z = self._stage2(ai + 2, si + 2, x, y, None)                                          # A2
             in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
-            ai, si, fi = ai + 3, si + 4, fi + 1
-        if s2t_on:
+
+        def s2t_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
             y = self._stage1(ai + 1, si + 1, x, vft, v_s2t, None, 1)                              # A4
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
+
+        if t2s_on and s2t_on and Fn.CONCURRENT and vft.is_cuda:
+            main, side = torch.cuda.current_stream(), Fn.side_stream(0)
+            side.wait_stream(main)                    # fork: the two directions share only read-only inputs
+            with torch.cuda.stream(side):
+                s2t_branch(3, 4, 1)
+            t2s_branch(0, 0, 0)
+            main.wait_stream(side)                    # join
+        else:
+            ai = si = fi = 0
+            if t2s_on:
+                t2s_branch(ai, si, fi)
+                ai, si, fi = ai + 3, si + 4, fi + 1
+            if s2t_on:
+                s2t_branch(ai, si, fi)
         return in_ft
 
 
