@@ -84,8 +84,9 @@ WORKSPACE_BYTES = 64 << 20
 
 
 def _workspace(device) -> Tensor:
-    """Per-device fp32 scratch for split-K partial tiles (allocated once; the library never allocates)."""
-    key = (device.type, device.index)
+    """Per-(device, stream) fp32 scratch for split-K partial tiles (allocated once; the library never
+    allocates).  One buffer per stream: GEMMs of concurrent branches must not share partial slabs."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)
