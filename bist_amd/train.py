@@ -31,7 +31,7 @@ from ._lib import check, lib
 from .model.label_smoothing import LabelSmoothing
 from .model.modules import MultiHeadedAttention
 from .model.optimize import SimpleLossCompute
-from . import ops
+from . import ops, parallel
 from .ops import _stream, dtype_code
 
 ALIGN = 64      # elements; keeps every parameter view 16-byte aligned for the LDS-DMA GEMM path
@@ -140,8 +140,7 @@ class Trainer:
 
     # NoamOpt.rate (optimize.py:28-34)
     def rate(self, step: Optional[int] = None) -> float:
-        step = self._step if step is None else step
-        return self.factor * (self.args.d_model ** -0.5 * min(step ** -0.5, step * self.warmup ** -1.5))
+        return parallel.noam_rate(self._step if step is None else step, self.args.d_model, self.factor, self.warmup)
 
     def forward_loss(self, batch):
         ft = self.model.forward(batch)
@@ -204,11 +203,10 @@ class Trainer:
         self._step += 1
         self.drop_ctr.fill_(self._step)
         terms = self._graph_backward(batch) if self.use_graph else self.backward(batch)
-        if self.world > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+        grad_scale = parallel.exchange_gradients(self.flat_grad, self.pg)      # one RCCL all-reduce of the flat buffer
         work = None if self.compute_dtype == torch.float32 else self.flat_param
         check(lib.bist_adam_step(self.master.data_ptr(), self.flat_grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                  work.data_ptr() if work is not None else None, self.numel, self.rate(), self.betas[0],
-                                 self.betas[1], self.eps, self._step, 1.0 / self.world, dtype_code(self.compute_dtype),
+                                 self.betas[1], self.eps, self._step, grad_scale, dtype_code(self.compute_dtype),
                                  dtype_code(self.compute_dtype), _stream()), "bist_adam_step")
         return {k: v.detach() for k, v in terms.items()}
