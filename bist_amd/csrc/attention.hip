@@ -9,6 +9,7 @@
 // All softmaxes use the reference's masking rule: masked scores are REPLACED by -1e9
 // (model/modules.py:60), never -inf, so a fully masked row yields the uniform distribution.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -243,6 +244,12 @@ extern "C" int bist_st_stage1_pv_fwd(const void* scores, const void* V, const ui
   BIST_REQUIRE(direction == 0 || direction == 1, "bist_st_stage1_pv_fwd: direction must be 0 (t2s) or 1 (s2t)");
   BIST_REQUIRE(sc_dtype == BIST_F32 || sc_dtype == dtype, "bist_st_stage1_pv_fwd: scores must be f32 or the value dtype");
   BIST_REQUIRE(ldv >= (int64_t)h * dk, "bist_st_stage1_pv_fwd: ldv too small");
+  if (dtype == BIST_BF16 && !getenv("BIST_ST1_VALU")) {          // matrix-core path (attention_mfma.hip)
+    const int r = bist_st1_mfma(scores, sc_dtype == BIST_F32, V, tmask, O, nullptr, nullptr, nullptr, B, T, S, Lq, h, dk, ldv, 0,
+                                direction, 0, (hipStream_t)stream);
+    if (r == 1) return BIST_OK;
+    if (r < 0) { bist_set_error("bist_st_stage1_pv_fwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+  }
   const int G = direction == 0 ? S : T, Kn = direction == 0 ? T : S;
   // groups per workgroup: as many as fit a 60 KiB slab, but keep >= ~2 workgroups per CU in flight
   int Gc = (int)((60 * 1024) / ((long)Lq * (Kn + 1) * sizeof(float)));

@@ -2,6 +2,7 @@
 // inputs (scores or Q/K), never stored by the forward pass.  Softmax backward:
 //   dS = P * (dP - sum_k P dP), and dS = 0 where the score was replaced by the -1e9 mask fill.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -298,6 +299,12 @@ extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const u
   BIST_REQUIRE(scores && V && dO && dscores && dV, "bist_st_stage1_pv_bwd: null pointer");
   BIST_REQUIRE(B > 0 && T > 0 && S > 0 && Lq > 0 && h > 0 && dk > 0, "bist_st_stage1_pv_bwd: bad shape");
   BIST_REQUIRE(direction == 0 || direction == 1, "bist_st_stage1_pv_bwd: bad direction");
+  if (dtype == BIST_BF16 && !getenv("BIST_ST1_VALU")) {          // matrix-core path (attention_mfma.hip)
+    const int r = bist_st1_mfma(scores, 1, V, tmask, nullptr, dO, dscores, dV, B, T, S, Lq, h, dk, ldv, lddv, direction, 1,
+                                (hipStream_t)stream);
+    if (r == 1) return BIST_OK;
+    if (r < 0) { bist_set_error("bist_st_stage1_pv_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+  }
   const int G = direction == 0 ? S : T, Kn = direction == 0 ? T : S;
   const long per_g = ((long)2 * Lq * (Kn + 1) + (long)Lq * dk) * sizeof(float);
   int Gc = (int)((60 * 1024) / per_g);

@@ -32,6 +32,11 @@ void bist_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// MFMA implementation of the stage-1 core (attention_mfma.hip): 1 = launched, 0 = shape outside its envelope, -1 = error
+int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsigned char* tmask, void* O, const void* dO,
+                  float* dscores, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
+                  int bwd, hipStream_t st);
+
 // ---- element conversion ----------------------------------------------------------------------
 __device__ __forceinline__ float to_f(float x) { return x; }
 __device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }

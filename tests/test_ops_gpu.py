@@ -225,7 +225,8 @@ def test_mha_core(ops, dtype, tol, N, Lq, Lk, h, dk, mk):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
-@pytest.mark.parametrize("B,T,S,Lq,h,dk", [(2, 6, 9, 7, 4, 16), (2, 8, 49, 20, 8, 8), (1, 32, 49, 20, 8, 64)])
+@pytest.mark.parametrize("B,T,S,Lq,h,dk", [(2, 6, 9, 7, 4, 16), (2, 8, 49, 20, 8, 8), (1, 32, 49, 20, 8, 64), (2, 128, 49, 20, 8, 64),
+                                         (2, 20, 49, 32, 2, 64)])
 @pytest.mark.parametrize("direction", [0, 1])
 def test_st_stage1_pv(ops, dtype, tol, B, T, S, Lq, h, dk, direction):
     d = h * dk

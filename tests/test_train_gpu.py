@@ -143,6 +143,36 @@ def test_stage1_backward(env):
                                              direction=direction), ref(direction), [sc, v], f"stage1 dir{direction}")
 
 
+@pytest.mark.parametrize("B,T,S,Lq,h", [(2, 32, 49, 20, 8), (1, 128, 49, 20, 2), (2, 20, 49, 32, 2)])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_stage1_backward_bf16_matrix_core_path(env, B, T, S, Lq, h, direction):
+    """bf16 stage-1 core (MFMA kernels, dk = 64) forward and backward against fp64 on the bf16-rounded inputs."""
+    ag, Fn, ops = env
+    dk = 64
+    d = h * dk
+    sc = _rand(B, Lq * h, T * S, seed=60, scale=2.0).float().double()
+    v = _rand(B, T, S, d, seed=61).to(torch.bfloat16).double()
+    go = _rand(B, S if direction == 0 else T, Lq, d, seed=62).to(torch.bfloat16).double()
+    tm = torch.ones(B, 1, T, dtype=torch.bool); tm[0, 0, T // 2:] = False
+    scr, vr = sc.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    s5, v5 = scr.view(B, Lq, h, T, S), vr.view(B, T, S, h, dk)
+    if direction == 0:
+        p = torch.softmax(s5.masked_fill(tm.view(B, 1, 1, T, 1) == 0, -1e9), dim=3)
+        ref = torch.einsum("bihts,btshc->bsihc", p, v5).reshape(B, S, Lq, d)
+    else:
+        ref = torch.einsum("bihts,btshc->btihc", torch.softmax(s5, dim=4), v5).reshape(B, T, Lq, d)
+    (ref * go).sum().backward()
+    scd = sc.float().cuda().requires_grad_(True)
+    vd = v.to(torch.bfloat16).cuda().requires_grad_(True)
+    out = Fn.st_stage1_pv(scd, vd, tm.cuda() if direction == 0 else None, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
+    (out.double() * go.cuda()).sum().backward()
+    _close(out, ref.detach(), "st1 bf16 fwd", 1.5e-2)
+    _close(scd.grad, scr.grad, "st1 bf16 dscores", 2e-2)
+    _close(vd.grad, vr.grad, "st1 bf16 dV", 2e-2)
+    if direction == 0:
+        assert scd.grad.view(B, Lq, h, T, S)[0, :, :, T // 2:, :].abs().max().item() == 0.0   # masked keys get no gradient
+
+
 def test_stage2_backward(env):
     ag, Fn, ops = env
     B, G, Lq, h, d = 2, 9, 5, 4, 64
