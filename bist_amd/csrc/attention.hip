@@ -276,6 +276,11 @@ extern "C" int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t*
   BIST_REQUIRE(q2f && Y && PY, "bist_st_stage2_fwd: null pointer");
   BIST_REQUIRE(B > 0 && G > 0 && Lq > 0 && h > 0 && d > 0, "bist_st_stage2_fwd: bad shape");
   BIST_REQUIRE(h <= ST2_MAXH, "bist_st_stage2_fwd: at most %d heads", ST2_MAXH);
+  if (dtype == BIST_BF16 && !getenv("BIST_ST2_VALU")) {          // matrix-core path (attention_mfma.hip)
+    const int r = bist_st2_mfma(q2f, Y, gmask, PY, nullptr, nullptr, nullptr, B, G, Lq, h, d, 0, (hipStream_t)stream);
+    if (r == 1) return BIST_OK;
+    if (r < 0) { bist_set_error("bist_st_stage2_fwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+  }
   const size_t lds = ((size_t)h * d + (size_t)h * G) * sizeof(float);
   BIST_REQUIRE(lds <= 64 * 1024, "bist_st_stage2_fwd: h*(d+G) too large for LDS");
   hipStream_t st = (hipStream_t)stream;

@@ -326,6 +326,11 @@ extern "C" int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t*
                                   int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, int32_t dtype, void* stream) {
   BIST_REQUIRE(q2f && Y && dPY && dq2f && dY, "bist_st_stage2_bwd: null pointer");
   BIST_REQUIRE(B > 0 && G > 0 && Lq > 0 && h > 0 && h <= ST2_MAXH && d > 0, "bist_st_stage2_bwd: bad shape");
+  if (dtype == BIST_BF16 && !getenv("BIST_ST2_VALU")) {          // matrix-core path (attention_mfma.hip)
+    const int r = bist_st2_mfma(q2f, Y, gmask, nullptr, dPY, dq2f, dY, B, G, Lq, h, d, 1, (hipStream_t)stream);
+    if (r == 1) return BIST_OK;
+    if (r < 0) { bist_set_error("bist_st_stage2_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+  }
   const size_t lds = ((size_t)2 * h * d + (size_t)2 * h * G) * sizeof(float);
   BIST_REQUIRE(lds <= 64 * 1024, "bist_st_stage2_bwd: h*(d+G) too large for LDS");
   hipStream_t st = (hipStream_t)stream;

@@ -69,17 +69,36 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
   }
   const TS* sc = reinterpret_cast<const TS*>(a.scores) + (long)b * Lq * h * TS_;
   const unsigned char* mk = (dir == 0 && a.tmask) ? a.tmask + (long)b * T_ : nullptr;
-  // ---- A: score slab --------------------------------------------------------------------------------
-  const int total = Lq * gc * Kn;
-  for (int idx = tid; idx < total; idx += 256) {
-    int i, gl, k;
-    if (dir == 0) { gl = idx % gc; const int t2 = idx / gc; k = t2 % Kn; i = t2 / Kn; }
-    else          { k = idx % Kn; const int t2 = idx / Kn; gl = t2 % gc; i = t2 / gc; }
-    const int g = g0 + gl;
-    const long col = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
-    float v = to_f(sc[((long)i * h + hh) * TS_ + col]);
-    if (mk && mk[k] == 0) v = MASK_FILL;
-    slab[((long)i * gc + gl) * KP + k] = v;
+  // ---- A: score slab (no integer division in the inner loops) ------------------------------------------
+  if (dir == 1) {
+    // group = frame t, keys = regions: for a fixed query row the gc*S scores are one contiguous run
+    const int run = gc * Kn;
+    for (int i = w; i < Lq; i += 4) {
+      const TS* src = sc + ((long)i * h + hh) * TS_ + (long)g0 * S_;
+      float* dst = slab + (long)i * gc * KP;
+      int gl = 0, k = lane;                          // lane-strided walk over (gl, k) without div/mod
+      while (k >= Kn) { k -= Kn; ++gl; }
+      for (int e = lane; e < run; e += 64) {
+        dst[gl * KP + k] = to_f(src[e]);
+        k += 64;
+        while (k >= Kn) { k -= Kn; ++gl; }
+      }
+    }
+  } else {
+    // group = region s, keys = frames: scores of (k, g0..g0+gc) are gc contiguous floats; lane = (k & 7, gl)
+    const int gl = lane & 7, kk = lane >> 3;
+    const int kb = (Kn + 7) >> 3;                     // blocks of 8 keys
+    for (int kblk = w; kblk < kb; kblk += 4) {
+      const int k = kblk * 8 + kk;
+      const bool ok = gl < gc && k < Kn;
+      const bool masked = ok && mk && mk[k] == 0;
+      for (int i = 0; i < Lq; ++i) {
+        if (ok) {
+          const float v = masked ? MASK_FILL : to_f(sc[((long)i * h + hh) * TS_ + (long)k * S_ + g0 + gl]);
+          slab[((long)i * gc + gl) * KP + k] = v;
+        }
+      }
+    }
   }
   __syncthreads();
   // ---- B: softmax rows -> slab (f32) and pimg (bf16) -------------------------------------------------
@@ -233,7 +252,177 @@ int launch_one(const St1Args& a, int B, size_t lds, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 
+// =====================================================================================================
+// Stage 2 on the matrix cores (bf16, d = 512-class widths: d % 128 == 0, d <= 512, h <= 8, G <= 64).
+// One workgroup per (clip b, query position i).  LDS images (bf16, 16-byte chunks XOR-swizzled by row & 7 so
+// that both the row reads and the transposing reads are at most 2-way conflicted):
+//   yimg [64 rows g][d]   the G stage-1 outputs of this position (read ONCE from HBM, rows >= G zero)
+//   qg   [32 rows][d]     rows 0-7 folded query q2f, (backward) rows 8-15 dPY, rest zero
+// forward :  sc[hh,g] = q2f[hh,:].Y[g,:]  -> softmax over g (mask -> -1e9)  -> PY[hh,:] = sum_g P[hh,g] Y[g,:]
+// backward:  sc, dP[hh,g] = dPY[hh,:].Y[g,:];  dS = P (dP - sum P dP);  dq2f[hh,:] = sum_g dS[hh,g] Y[g,:]
+//            dY[g,:] = sum_hh dS[hh,g] q2f[hh,:] + P[hh,g] dPY[hh,:]      (one K = 16 product against qg)
+// =====================================================================================================
+__device__ __forceinline__ int swz_off(int row, int e, int pitch) {          // element offset of (row, e)
+  return row * pitch + ((((e >> 3) ^ (row & 7)) << 3) | (e & 7));
+}
+__device__ __forceinline__ uint4 sfrag_rows(const bf16_t* img, int pitch, int row, int k0, int lane) {
+  return *reinterpret_cast<const uint4*>(img + swz_off(row, k0 + (lane >> 4) * 8, pitch));
+}
+__device__ __forceinline__ uint4 sfrag_cols(const bf16_t* img, int pitch, int col0, int k0, int lane) {
+  const int x = lane & 15, kg = lane >> 4, q = x >> 2, pp = x & 3;
+  const int r0 = k0 + kg * 8 + q;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + swz_off(r0, col0 + 4 * pp, pitch)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + swz_off(r0 + 4, col0 + 4 * pp, pitch)));
+  uint4 r;
+  r.x = __builtin_bit_cast(uint2, lo).x; r.y = __builtin_bit_cast(uint2, lo).y;
+  r.z = __builtin_bit_cast(uint2, hi).x; r.w = __builtin_bit_cast(uint2, hi).y;
+  return r;
+}
+
+struct St2Args {
+  const bf16_t* q2f; const bf16_t* Y; const unsigned char* gmask;
+  bf16_t* PY;                                         // forward
+  const bf16_t* dPY; bf16_t* dq2f; bf16_t* dY;        // backward
+  int G, Lq, h, d;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int G = a.G, Lq = a.Lq, h = a.h, d = a.d;
+  const int i = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int x = lane & 15, lg = lane >> 4;
+  bf16_t* yimg = reinterpret_cast<bf16_t*>(smem);                  // [64][d]
+  constexpr int QROWS = BWD ? 32 : 8;                              // forward only needs the 8 query rows
+  bf16_t* qg = yimg + 64 * d;                                      // [QROWS][d]
+  float* scf = reinterpret_cast<float*>(qg + QROWS * d);           // [8][64] scores -> probabilities
+  float* dpf = scf + 8 * 64;                                       // [8][64] dP -> dS          (backward)
+  bf16_t* pimg = reinterpret_cast<bf16_t*>(dpf + 8 * 64);          // [32][64]: rows 0-7 A-operand of PY / dq2f (P or dS);
+                                                                   //           backward: rows 0-7 dS, 8-15 P, rest zero
+  const int cpr = d >> 3;                                          // 16-byte chunks per row
+  const long qoff = ((long)b * Lq + i) * h * d;
+  const long ystride = (long)Lq * d;
+  const bf16_t* Yb = a.Y + ((long)b * G * Lq + i) * d;
+  // ---- stage the images ---------------------------------------------------------------------------------
+  for (int idx = tid; idx < 64 * cpr; idx += 256) {
+    const int row = idx / cpr, c = idx - row * cpr;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < G) v = *reinterpret_cast<const uint4*>(Yb + row * ystride + c * 8);
+    *reinterpret_cast<uint4*>(yimg + row * d + ((c ^ (row & 7)) << 3)) = v;
+  }
+  for (int idx = tid; idx < QROWS * cpr; idx += 256) {
+    const int row = idx / cpr, c = idx - row * cpr;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < h) v = *reinterpret_cast<const uint4*>(a.q2f + qoff + (long)row * d + c * 8);
+    else if (BWD && row >= 8 && row < 8 + h) v = *reinterpret_cast<const uint4*>(a.dPY + qoff + (long)(row - 8) * d + c * 8);
+    *reinterpret_cast<uint4*>(qg + row * d + ((c ^ (row & 7)) << 3)) = v;
+  }
+  for (int idx = tid; idx < 32 * 64 / 8; idx += 256) reinterpret_cast<uint4*>(pimg)[idx] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  // ---- scores (and dP): wave w owns keys g = 16w .. 16w+15 --------------------------------------------------
+  {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acd = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < d / 32; ++ks) {
+      const uint4 bfr = sfrag_rows(yimg, d, 16 * w + x, ks * 32, lane);
+      acc = mfma_bf16(sfrag_rows(qg, d, x & 7, ks * 32, lane), bfr, acc);
+      if constexpr (BWD) acd = mfma_bf16(sfrag_rows(qg, d, 8 + (x & 7), ks * 32, lane), bfr, acd);
+    }
+    const int g = 16 * w + x;
+    if (lg < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int hh = lg * 4 + r;
+        float s = acc[r];
+        if (g >= G) s = -INFINITY;
+        else if (a.gmask && a.gmask[(long)b * G + g] == 0) s = MASK_FILL;
+        scf[hh * 64 + g] = s;
+        if constexpr (BWD) dpf[hh * 64 + g] = acd[r];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- softmax over g (wave w: heads 2w, 2w+1; lanes = keys) ----------------------------------------------
+  for (int hh = 2 * w; hh < 2 * w + 2; ++hh) {
+    if (hh < h) {
+      const float s = scf[hh * 64 + lane];
+      const float mx = wave_max(s);
+      const float e = lane < G ? expf(s - mx) : 0.f;
+      const float p = e / wave_sum(e);
+      scf[hh * 64 + lane] = p;
+      if constexpr (!BWD) {
+        pimg[hh * 64 + lane] = (bf16_t)p;
+      } else {
+        const float dp = lane < G ? dpf[hh * 64 + lane] : 0.f;
+        const float dot = wave_sum(p * dp);
+        float ds = p * (dp - dot);
+        if (lane >= G || (a.gmask && a.gmask[(long)b * G + lane] == 0)) ds = 0.f;
+        pimg[hh * 64 + lane] = (bf16_t)ds;
+        pimg[(8 + hh) * 64 + lane] = (bf16_t)p;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- PY (forward) / dq2f (backward): [8 heads] x [d]; wave w owns columns [w*d/4, (w+1)*d/4) -------------------
+  {
+    const int nf = d / 64;                           // 16-column fragments per wave
+    bf16_t* outp = (BWD ? a.dq2f : a.PY) + qoff;
+    for (int f = 0; f < nf; ++f) {
+      const int col0 = (w * nf + f) * 16;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc = mfma_bf16(frag_rows(pimg, 64, 0, ks * 32, lane & ~8), sfrag_cols(yimg, d, col0, ks * 32, lane), acc);
+      if (lg < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hh = lg * 4 + r;
+          if (hh < h) outp[(long)hh * d + col0 + x] = (bf16_t)acc[r];
+        }
+      }
+    }
+  }
+  if constexpr (BWD) {
+    // ---- dY[g, :] = [dS; P]^T (K = 16 heads') x [q2f; dPY]: wave w owns columns as above, all 4 key fragments ----
+    const int nf = d / 64;
+    bf16_t* dYb = a.dY + ((long)b * G * Lq + i) * d;
+    for (int f = 0; f < nf; ++f) {
+      const int col0 = (w * nf + f) * 16;
+      const uint4 bfr = sfrag_cols(qg, d, col0, 0, lane);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = mfma_bf16(frag_cols(pimg, 64, mi * 16, 0, lane), bfr, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int g = mi * 16 + lg * 4 + r;
+          if (g < G) dYb[g * ystride + col0 + x] = (bf16_t)acc[r];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// returns 1 if launched, 0 if outside the envelope, -1 on launch error
+int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, void* PY, const void* dPY, void* dq2f, void* dY,
+                  int B, int G, int Lq, int h, int d, int bwd, hipStream_t st) {
+  if (G > 64 || h > 8 || d > 512 || (d % 128) != 0) return 0;
+  if (((uintptr_t)q2f | (uintptr_t)Y | (uintptr_t)(bwd ? dPY : q2f)) % 16) return 0;
+  const size_t lds = (size_t)64 * d * 2 + (size_t)(bwd ? 32 : 8) * d * 2 + 2 * 8 * 64 * 4 + 32 * 64 * 2;
+  St2Args a{(const bf16_t*)q2f, (const bf16_t*)Y, gmask, (bf16_t*)PY, (const bf16_t*)dPY, (bf16_t*)dq2f, (bf16_t*)dY, G, Lq, h, d};
+  static bool attr_f = false, attr_b = false;
+  dim3 grid((unsigned)Lq, (unsigned)B);
+  if (bwd) {
+    if (!attr_b) { hipFuncSetAttribute(reinterpret_cast<const void*>(&st2_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_b = true; }
+    hipLaunchKernelGGL(st2_mfma_kernel<true>, grid, dim3(256), lds, st, a);
+  } else {
+    if (!attr_f) { hipFuncSetAttribute(reinterpret_cast<const void*>(&st2_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_f = true; }
+    hipLaunchKernelGGL(st2_mfma_kernel<false>, grid, dim3(256), lds, st, a);
+  }
+  return hipGetLastError() == hipSuccess ? 1 : -1;
+}
 
 // returns 1 if launched, 0 if the shape is outside this kernel's envelope (caller falls back), -1 on launch error
 int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsigned char* tmask, void* O, const void* dO,
@@ -248,9 +437,8 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
   const long fixed = 4L * kpad * 64 * 2 + (bwd ? 4L * 32 * 64 * 2 : 0) + 16;
   int Gc = (int)((150 * 1024 - fixed) / per_g);
   if (Gc < 1) return 0;
-  if (Gc > 8) Gc = 8;                       // two groups per wave is enough to amortise phases A/B
+  if (Gc > 4) Gc = 4;                       // one group per wave: <= 80 KiB of LDS, two workgroups per CU
   if (Gc > G) Gc = G;
-  while (Gc > 4 && (long)((G + Gc - 1) / Gc) * h * B < 1024) --Gc;
   const size_t lds = (size_t)(((long)Lq * Gc * (Kn + 1) * 4 + 15) / 16 * 16) + (size_t)Gc * 32 * kpad * 2 + (size_t)fixed;
   St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc};
 #define GO(TS_, KS_)                                                                   \

@@ -37,6 +37,9 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
                   float* dscores, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
                   int bwd, hipStream_t st);
 
+int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, void* PY, const void* dPY, void* dq2f, void* dY,
+                  int B, int G, int Lq, int h, int d, int bwd, hipStream_t st);
+
 // ---- element conversion ----------------------------------------------------------------------
 __device__ __forceinline__ float to_f(float x) { return x; }
 __device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }

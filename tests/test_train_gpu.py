@@ -185,6 +185,31 @@ def test_stage2_backward(env):
     _check(lambda q, y: Fn.st_stage2(q, y, gm.cuda(), h=h), ref, [q2f, y], "stage2")
 
 
+@pytest.mark.parametrize("B,G,Lq,h,d,masked", [(2, 49, 20, 8, 512, False), (2, 32, 20, 8, 512, True), (1, 64, 7, 4, 128, True)])
+def test_stage2_bf16_matrix_core_path(env, B, G, Lq, h, d, masked):
+    """bf16 stage-2 kernels (MFMA, swizzled LDS images) forward and backward against fp64 on the rounded inputs."""
+    ag, Fn, ops = env
+    q2f = _rand(B, Lq, h, d, seed=70, scale=d ** -0.5).to(torch.bfloat16).double()
+    y = _rand(B, G, Lq, d, seed=71).to(torch.bfloat16).double()
+    go = _rand(B, Lq, h, d, seed=72).to(torch.bfloat16).double()
+    gm = None
+    if masked:
+        gm = torch.ones(B, 1, G, dtype=torch.bool); gm[0, 0, G // 3:] = False
+    qr, yr = q2f.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    sc = torch.einsum("bihe,bgie->bihg", qr, yr)
+    if gm is not None:
+        sc = sc.masked_fill(gm.view(B, 1, 1, G) == 0, -1e9)
+    ref = torch.einsum("bihg,bgie->bihe", torch.softmax(sc, -1), yr)
+    (ref * go).sum().backward()
+    qd = q2f.to(torch.bfloat16).cuda().requires_grad_(True)
+    yd = y.to(torch.bfloat16).cuda().requires_grad_(True)
+    out = Fn.st_stage2(qd, yd, None if gm is None else gm.cuda(), h=h)
+    (out.double() * go.cuda()).sum().backward()
+    _close(out, ref.detach(), "st2 bf16 fwd", 1.5e-2)
+    _close(qd.grad, qr.grad, "st2 bf16 dq2f", 2.5e-2)
+    _close(yd.grad, yr.grad, "st2 bf16 dY", 2.5e-2)
+
+
 def test_fold_scores_bmm_backward(env):
     ag, Fn, ops = env
     M, h, dk = 23, 4, 16
