@@ -13,6 +13,7 @@
 // Nothing is permuted or expanded in HBM: group g of direction 0 (t2s) is video column s with keys t
 // (rows t*S+s of V), of direction 1 (s2t) it is frame t with keys s (rows t*S+s, contiguous).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -44,6 +45,7 @@ struct St1Args {
   bf16_t* O;                      // forward output
   const bf16_t* dO; float* dscores; bf16_t* dV;   // backward
   int T, S, Lq, h; long ldv, lddv; int dir, Gc;
+  int dbg;      // timing ablation only (BIST_ST1_DBG): bit0 skip slab gather, bit1 skip softmax, bit2 skip phase C
 };
 
 template <typename TS, int KSTEPS, bool BWD>
@@ -63,63 +65,90 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
   bf16_t* pimg = reinterpret_cast<bf16_t*>(smem + slab_bytes);               // [Gc][32][KPAD]
   bf16_t* vimg = pimg + Gc * 32 * KPAD;                                      // [4 waves][KPAD][64]
   bf16_t* doimg = vimg + 4 * KPAD * DK;                                      // [4 waves][32][64]   (backward only)
-  {
-    const int n16 = (Gc * 32 * KPAD + 4 * KPAD * DK + (BWD ? 4 * 32 * DK : 0)) / 8;
-    for (int i = tid; i < n16; i += 256) reinterpret_cast<uint4*>(pimg)[i] = make_uint4(0, 0, 0, 0);
+  bf16_t* vt = vimg + w * KPAD * DK;
+  bf16_t* dt = doimg + w * 32 * DK;
+  {   // zero what the phases below do not overwrite: the P images, the key-padding rows of the V tiles, the query-padding
+      // rows of the dO tiles (padding must be finite: it meets zero probabilities / zero rows in the MFMAs)
+    for (int q = tid; q < Gc * 32 * KPAD / 8; q += 256) reinterpret_cast<uint4*>(pimg)[q] = make_uint4(0, 0, 0, 0);
+    for (int q = lane; q < (KPAD - Kn) * 8; q += 64) reinterpret_cast<uint4*>(vt + Kn * DK)[q] = make_uint4(0, 0, 0, 0);
+    if constexpr (BWD)
+      for (int q = lane; q < (32 - Lq) * 8; q += 64) reinterpret_cast<uint4*>(dt + Lq * DK)[q] = make_uint4(0, 0, 0, 0);
   }
   const TS* sc = reinterpret_cast<const TS*>(a.scores) + (long)b * Lq * h * TS_;
   const unsigned char* mk = (dir == 0 && a.tmask) ? a.tmask + (long)b * T_ : nullptr;
-  // ---- A: score slab (no integer division in the inner loops) ------------------------------------------
-  if (dir == 1) {
-    // group = frame t, keys = regions: for a fixed query row the gc*S scores are one contiguous run
+  // ---- A: score slab ---------------------------------------------------------------------------------------
+  if (a.dbg & 1) {
+  } else if (dir == 1) {
+    // group = frame t, keys = regions: for a fixed query row the gc*S scores are ONE contiguous run -> 16-byte loads
     const int run = gc * Kn;
+    const TS* base = sc + (long)hh * TS_ + (long)g0 * S_;
+    const bool vec = sizeof(TS) == 4 && (TS_ & 3) == 0 && (((long)g0 * S_) & 3) == 0 && ((uintptr_t)sc & 15) == 0;
+    int gl0 = 0, k0 = 4 * lane;                       // (group, key) of this lane's first element, found once
+    while (k0 >= Kn) { k0 -= Kn; ++gl0; }
     for (int i = w; i < Lq; i += 4) {
-      const TS* src = sc + ((long)i * h + hh) * TS_ + (long)g0 * S_;
+      const TS* src = base + (long)i * h * TS_;
       float* dst = slab + (long)i * gc * KP;
-      int gl = 0, k = lane;                          // lane-strided walk over (gl, k) without div/mod
-      while (k >= Kn) { k -= Kn; ++gl; }
-      for (int e = lane; e < run; e += 64) {
-        dst[gl * KP + k] = to_f(src[e]);
-        k += 64;
+      if (vec && run <= 256) {
+        const int e = 4 * lane;
+        if (e < run) {
+          float v[4];
+          if (e + 3 < run) { const float4 q = *reinterpret_cast<const float4*>(src + e); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+          else { for (int j = 0; j < 4; ++j) v[j] = e + j < run ? to_f(src[e + j]) : 0.f; }
+          int gl = gl0, k = k0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (e + j < run) dst[gl * KP + k] = v[j];
+            if (++k == Kn) { k = 0; ++gl; }
+          }
+        }
+      } else {
+        int gl = 0, k = lane;
         while (k >= Kn) { k -= Kn; ++gl; }
-      }
-    }
-  } else {
-    // group = region s, keys = frames: scores of (k, g0..g0+gc) are gc contiguous floats; lane = (k & 7, gl)
-    const int gl = lane & 7, kk = lane >> 3;
-    const int kb = (Kn + 7) >> 3;                     // blocks of 8 keys
-    for (int kblk = w; kblk < kb; kblk += 4) {
-      const int k = kblk * 8 + kk;
-      const bool ok = gl < gc && k < Kn;
-      const bool masked = ok && mk && mk[k] == 0;
-      for (int i = 0; i < Lq; ++i) {
-        if (ok) {
-          const float v = masked ? MASK_FILL : to_f(sc[((long)i * h + hh) * TS_ + (long)k * S_ + g0 + gl]);
-          slab[((long)i * gc + gl) * KP + k] = v;
+        for (int e = lane; e < run; e += 64) {
+          dst[gl * KP + k] = to_f(src[e]);
+          k += 64;
+          while (k >= Kn) { k -= Kn; ++gl; }
         }
       }
     }
+  } else {
+    // group = region s, keys = frames: the gc scores of one (query row, key) are adjacent; lane = (key & 15, group)
+    const int gl = lane & 3, kk = lane >> 2;
+    for (int kb0 = 0; kb0 < Kn; kb0 += 16) {
+      const int k = kb0 + kk;
+      const bool ok = gl < gc && k < Kn;
+      const bool masked = ok && mk && mk[k] == 0;
+      for (int i = w; i < Lq; i += 4)
+        if (ok) slab[((long)i * gc + gl) * KP + k] = masked ? MASK_FILL : to_f(sc[((long)i * h + hh) * TS_ + (long)k * S_ + g0 + gl]);
+    }
   }
   __syncthreads();
-  // ---- B: softmax rows -> slab (f32) and pimg (bf16) -------------------------------------------------
-  for (int r = tid; r < Lq * gc; r += 256) {
-    const int i = r / gc, gl = r % gc;
-    float* p = slab + (long)r * KP;
-    float mx = -INFINITY;
-    for (int k = 0; k < Kn; ++k) mx = fmaxf(mx, p[k]);
-    float den = 0.f;
-    for (int k = 0; k < Kn; ++k) { const float e = expf(p[k] - mx); p[k] = e; den += e; }
-    const float inv = 1.f / den;
-    bf16_t* pi = pimg + ((long)gl * 32 + i) * KPAD;
-    for (int k = 0; k < Kn; ++k) { const float q = p[k] * inv; p[k] = q; pi[k] = (bf16_t)q; }
+  // ---- B: softmax rows -> slab (f32) and pimg (bf16); four lanes share a row ------------------------------------
+  {
+    const int rows = (a.dbg & 2) ? 0 : Lq * gc;
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+      const int r = r0 + (tid >> 2), part = tid & 3;
+      const bool act = r < rows;
+      float* p = slab + (long)(act ? r : 0) * KP;
+      float mx = -INFINITY;
+      for (int k = part; k < Kn; k += 4) mx = fmaxf(mx, p[k]);
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      float den = 0.f;
+      if (act) for (int k = part; k < Kn; k += 4) { const float e = expf(p[k] - mx); p[k] = e; den += e; }
+      den += __shfl_xor(den, 1, 64); den += __shfl_xor(den, 2, 64);
+      if (act) {
+        const float inv = 1.f / den;
+        const int i = r / gc, gl = r - i * gc;
+        bf16_t* pi = pimg + ((long)gl * 32 + i) * KPAD;
+        for (int k = part; k < Kn; k += 4) { const float q = p[k] * inv; p[k] = q; pi[k] = (bf16_t)q; }
+      }
+    }
   }
   __syncthreads();
   // ---- C: one wave per group -------------------------------------------------------------------------
   const bf16_t* Vb = a.V + (long)b * TS_ * a.ldv + hh * DK;
-  bf16_t* vt = vimg + w * KPAD * DK;
-  bf16_t* dt = doimg + w * 32 * DK;
   const int x = lane & 15, lg = lane >> 4;
-  for (int gl = w; gl < gc; gl += 4) {
+  for (int gl = w; gl < ((a.dbg & 4) ? 0 : gc); gl += 4) {
     const int g = g0 + gl;
     for (int k = lane >> 3; k < Kn; k += 8) {                      // V tile: 8 rows x 128 B per wave instruction
       const long row = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
@@ -144,17 +173,16 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_bf16(af[mi], bfr[ni], acc[mi][ni]);
       }
-      bf16_t* Ob = a.O + (((long)b * G + g) * Lq) * d + hh * DK;
+      // the V tile is consumed: reuse it to turn the fragment layout into 128-byte output rows
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = mi * 16 + lg * 4 + r;
-          if (i < Lq) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) Ob[(long)i * d + ni * 16 + x] = (bf16_t)acc[mi][ni][r];
-          }
-        }
+          for (int ni = 0; ni < 4; ++ni) vt[(mi * 16 + lg * 4 + r) * DK + ni * 16 + x] = (bf16_t)acc[mi][ni][r];
+      bf16_t* Ob = a.O + (((long)b * G + g) * Lq) * d + hh * DK;
+      for (int i = lane >> 3; i < Lq; i += 8)
+        *reinterpret_cast<uint4*>(Ob + (long)i * d + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(vt + i * DK + (lane & 7) * 8);
     } else {
       const bf16_t* dOb = a.dO + (((long)b * G + g) * Lq) * d + hh * DK;
       for (int i = lane >> 3; i < Lq; i += 8)                       // dO tile [Lq][64]; rows >= Lq stay zero
@@ -225,16 +253,15 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
       }
       bf16_t* dVb = a.dV + (long)b * TS_ * a.lddv + hh * DK;
 #pragma unroll
-      for (int mi = 0; mi < NKF; ++mi)
+      for (int mi = 0; mi < NKF; ++mi)                  // V tile consumed by dP: stage dV through it
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = mi * 16 + lg * 4 + r;
-          if (k < Kn) {
-            const long row = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) dVb[row * a.lddv + ni * 16 + x] = (bf16_t)dv[mi][ni][r];
-          }
-        }
+          for (int ni = 0; ni < 4; ++ni) vt[(mi * 16 + lg * 4 + r) * DK + ni * 16 + x] = (bf16_t)dv[mi][ni][r];
+      for (int k = lane >> 3; k < Kn; k += 8) {
+        const long row = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+        *reinterpret_cast<uint4*>(dVb + row * a.lddv + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(vt + k * DK + (lane & 7) * 8);
+      }
     }
   }
 }
@@ -440,7 +467,8 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
   if (Gc > 4) Gc = 4;                       // one group per wave: <= 80 KiB of LDS, two workgroups per CU
   if (Gc > G) Gc = G;
   const size_t lds = (size_t)(((long)Lq * Gc * (Kn + 1) * 4 + 15) / 16 * 16) + (size_t)Gc * 32 * kpad * 2 + (size_t)fixed;
-  St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc};
+  static const int dbg = [] { const char* e = getenv("BIST_ST1_DBG"); return e ? atoi(e) : 0; }();
+  St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc, dbg};
 #define GO(TS_, KS_)                                                                   \
   return bwd ? launch_one<TS_, KS_, true>(a, B, lds, st) : launch_one<TS_, KS_, false>(a, B, lds, st)
   if (sc_is_f32) {
