@@ -74,6 +74,21 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
     if constexpr (BWD)
       for (int q = lane; q < (32 - Lq) * 8; q += 64) reinterpret_cast<uint4*>(dt + Lq * DK)[q] = make_uint4(0, 0, 0, 0);
   }
+  // This wave's group (one per wave: Gc <= 4): start its V tile (and dO tile) now, so the HBM latency hides
+  // behind the slab gather and the softmax.  LDS image as it lies in HBM: [k][64 channels].
+  const bf16_t* Vb = a.V + (long)b * TS_ * a.ldv + hh * DK;
+  if (w < gc && !(a.dbg & 4)) {
+    const int g = g0 + w;
+    for (int k = lane >> 3; k < Kn; k += 8) {                      // 8 rows x 128 B per wave instruction
+      const long row = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+      *reinterpret_cast<uint4*>(vt + k * DK + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(Vb + row * a.ldv + (lane & 7) * 8);
+    }
+    if constexpr (BWD) {
+      const bf16_t* dOb = a.dO + (((long)b * G + g) * Lq) * d + hh * DK;
+      for (int i = lane >> 3; i < Lq; i += 8)                       // dO tile [Lq][64]; rows >= Lq stay zero
+        *reinterpret_cast<uint4*>(dt + i * DK + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(dOb + (long)i * d + (lane & 7) * 8);
+    }
+  }
   const TS* sc = reinterpret_cast<const TS*>(a.scores) + (long)b * Lq * h * TS_;
   const unsigned char* mk = (dir == 0 && a.tmask) ? a.tmask + (long)b * T_ : nullptr;
   // ---- A: score slab ---------------------------------------------------------------------------------------
@@ -118,42 +133,59 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
       const int k = kb0 + kk;
       const bool ok = gl < gc && k < Kn;
       const bool masked = ok && mk && mk[k] == 0;
-      for (int i = w; i < Lq; i += 4)
-        if (ok) slab[((long)i * gc + gl) * KP + k] = masked ? MASK_FILL : to_f(sc[((long)i * h + hh) * TS_ + (long)k * S_ + g0 + gl]);
+      const TS* src = sc + (long)hh * TS_ + (long)k * S_ + g0 + gl;
+      float v[8];                                    // this wave's rows i = w, w+4, ... (Lq <= 32): all loads in flight together
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = w + 4 * u;
+        v[u] = (ok && !masked && i < Lq) ? to_f(src[(long)i * h * TS_]) : MASK_FILL;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = w + 4 * u;
+        if (ok && i < Lq) slab[((long)i * gc + gl) * KP + k] = v[u];
+      }
     }
   }
   __syncthreads();
-  // ---- B: softmax rows -> slab (f32) and pimg (bf16); four lanes share a row ------------------------------------
+  // ---- B: softmax rows -> slab (f32) and pimg (bf16); four lanes share a row, each keeps its slice in registers ----
   {
+    constexpr int PER = (KPAD + 3) / 4;              // keys per lane (k = part, part+4, ...)
     const int rows = (a.dbg & 2) ? 0 : Lq * gc;
     for (int r0 = 0; r0 < rows; r0 += 64) {
       const int r = r0 + (tid >> 2), part = tid & 3;
       const bool act = r < rows;
       float* p = slab + (long)(act ? r : 0) * KP;
+      float v[PER];
       float mx = -INFINITY;
-      for (int k = part; k < Kn; k += 4) mx = fmaxf(mx, p[k]);
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int k = part + 4 * u;
+        v[u] = (act && k < Kn) ? p[k] : -INFINITY;
+        mx = fmaxf(mx, v[u]);
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
       float den = 0.f;
-      if (act) for (int k = part; k < Kn; k += 4) { const float e = expf(p[k] - mx); p[k] = e; den += e; }
+#pragma unroll
+      for (int u = 0; u < PER; ++u) { v[u] = act ? expf(v[u] - mx) : 0.f; den += v[u]; }
       den += __shfl_xor(den, 1, 64); den += __shfl_xor(den, 2, 64);
       if (act) {
         const float inv = 1.f / den;
         const int i = r / gc, gl = r - i * gc;
         bf16_t* pi = pimg + ((long)gl * 32 + i) * KPAD;
-        for (int k = part; k < Kn; k += 4) { const float q = p[k] * inv; p[k] = q; pi[k] = (bf16_t)q; }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int k = part + 4 * u;
+          if (k < Kn) { const float q = v[u] * inv; p[k] = q; pi[k] = (bf16_t)q; }
+        }
       }
     }
   }
   __syncthreads();
   // ---- C: one wave per group -------------------------------------------------------------------------
-  const bf16_t* Vb = a.V + (long)b * TS_ * a.ldv + hh * DK;
   const int x = lane & 15, lg = lane >> 4;
-  for (int gl = w; gl < ((a.dbg & 4) ? 0 : gc); gl += 4) {
+  for (int gl = w; gl < ((a.dbg & 4) ? 0 : gc); gl += 4) {          // runs at most once (Gc <= 4)
     const int g = g0 + gl;
-    for (int k = lane >> 3; k < Kn; k += 8) {                      // V tile: 8 rows x 128 B per wave instruction
-      const long row = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
-      *reinterpret_cast<uint4*>(vt + k * DK + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(Vb + row * a.ldv + (lane & 7) * 8);
-    }
     const bf16_t* pg = pimg + (long)gl * 32 * KPAD;
     if constexpr (!BWD) {
       f32x4 acc[2][4];
@@ -184,9 +216,6 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
       for (int i = lane >> 3; i < Lq; i += 8)
         *reinterpret_cast<uint4*>(Ob + (long)i * d + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(vt + i * DK + (lane & 7) * 8);
     } else {
-      const bf16_t* dOb = a.dO + (((long)b * G + g) * Lq) * d + hh * DK;
-      for (int i = lane >> 3; i < Lq; i += 8)                       // dO tile [Lq][64]; rows >= Lq stay zero
-        *reinterpret_cast<uint4*>(dt + i * DK + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(dOb + (long)i * d + (lane & 7) * 8);
       // dP = dO . V^T   (M = i, N = k, K = c)
       f32x4 dp[2][NKF];
 #pragma unroll
