@@ -26,6 +26,45 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   for (int c = lane; c < d; c += 64) yr[c] = from_f<T>(to_f(a[c]) * (to_f(xr[c]) - mean) * inv + to_f(b[c]));
 }
 
+// Vectorised variant for rows that are a whole number of KiB (d = 512 bf16, 256/512 f32, ...): every lane owns
+// NV 16-byte vectors of the row, which is read from HBM exactly once and kept in registers for both
+// reductions (two-pass variance, like torch.std) and the output.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ b,
+                                                            T* __restrict__ y, long rows, int d, long ldx, long ldy, float eps) {
+  constexpr int E = 16 / (int)sizeof(T);             // elements per 16-byte vector
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  float v[NV * E];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const uint4 q = *reinterpret_cast<const uint4*>(xr + (j * 64 + lane) * E);
+    const T* qe = reinterpret_cast<const T*>(&q);
+#pragma unroll
+    for (int e = 0; e < E; ++e) { v[j * E + e] = to_f(qe[e]); s += v[j * E + e]; }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < NV * E; ++u) { v[u] -= mean; q2 += v[u] * v[u]; }
+  const float inv = 1.f / (sqrtf(wave_sum(q2) / (float)(d - 1)) + eps);
+  T* yr = y + row * ldy;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c0 = (j * 64 + lane) * E;
+    const uint4 qa = *reinterpret_cast<const uint4*>(a + c0), qb = *reinterpret_cast<const uint4*>(b + c0);
+    const T* ae = reinterpret_cast<const T*>(&qa);
+    const T* be = reinterpret_cast<const T*>(&qb);
+    T o[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[e] = from_f<T>(to_f(ae[e]) * v[j * E + e] * inv + to_f(be[e]));
+    *reinterpret_cast<uint4*>(yr + c0) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
 // Embeddings*sqrt(d) + PositionalEncoding (modules.py:121-123, 141-144); pe is the f32 table.
 template <typename T>
 __global__ void embed_pe_kernel(const long* __restrict__ ids, const T* __restrict__ lut, const float* __restrict__ pe,
@@ -37,17 +76,28 @@ __global__ void embed_pe_kernel(const long* __restrict__ ids, const T* __restric
   y[idx] = from_f<T>(to_f(lut[id * d + c]) * scale + pe[(row % L) * (long)d + c]);
 }
 
-// temporal_mask[row] = (sum of the row's S*C features != 0)  (data/dataset.py:79)
+// temporal_mask[row] = (sum of the row's S*C features != 0)  (data/dataset.py:79); one 256-thread block per row
 template <typename T>
 __global__ __launch_bounds__(256) void temporal_mask_kernel(const T* __restrict__ f, unsigned char* __restrict__ m, long rows, long n) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  __shared__ float red[4];
+  const long row = blockIdx.x;
   const T* p = f + row * n;
   float s = 0.f;
-  for (long c = lane; c < n; c += 64) s += to_f(p[c]);
+  constexpr int E = 16 / (int)sizeof(T);
+  if ((n % E) == 0 && ((uintptr_t)p % 16) == 0) {
+    for (long c = threadIdx.x; c < n / E; c += 256) {
+      const uint4 q = reinterpret_cast<const uint4*>(p)[c];
+      const T* qe = reinterpret_cast<const T*>(&q);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += to_f(qe[e]);
+    }
+  } else {
+    for (long c = threadIdx.x; c < n; c += 256) s += to_f(p[c]);
+  }
   s = wave_sum(s);
-  if (lane == 0) m[row] = s != 0.f ? 1 : 0;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) m[row] = (red[0] + red[1] + red[2] + red[3]) != 0.f ? 1 : 0;
 }
 
 // Dynamic modality fusion (decoder.py:155-159): out = sum_j softmax(score[row,:n])_j * x_j[row,:]
@@ -88,7 +138,16 @@ extern "C" int bist_layernorm_fwd(const void* x, const void* a, const void* b, v
   BIST_REQUIRE(rows > 0 && d > 1 && ldx >= d && ldy >= d, "bist_layernorm_fwd: bad shape rows=%ld d=%d", (long)rows, d);
   hipStream_t st = (hipStream_t)stream;
   const unsigned g = blocks_for(rows, 4);
-  if (dtype == BIST_BF16)
+  const long sz = dtype == BIST_BF16 ? 2 : 4;
+  const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)a | (uintptr_t)b) % 16 == 0) && (ldx * sz) % 16 == 0 && (ldy * sz) % 16 == 0;
+  const long nv = (d * sz) % 1024 == 0 ? d * sz / 1024 : 0;     // 16-byte vectors per lane
+  if (al && dtype == BIST_BF16 && nv == 1)
+    hipLaunchKernelGGL((layernorm_vec_kernel<bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, d, ldx, ldy, eps);
+  else if (al && dtype == BIST_F32 && nv == 1)
+    hipLaunchKernelGGL((layernorm_vec_kernel<float, 1>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)b, (float*)y, rows, d, ldx, ldy, eps);
+  else if (al && dtype == BIST_F32 && nv == 2)
+    hipLaunchKernelGGL((layernorm_vec_kernel<float, 2>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)b, (float*)y, rows, d, ldx, ldy, eps);
+  else if (dtype == BIST_BF16)
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, d, ldx, ldy, eps);
   else if (dtype == BIST_F32)
     hipLaunchKernelGGL(layernorm_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)b, (float*)y, rows, d, ldx, ldy, eps);
@@ -116,7 +175,7 @@ extern "C" int bist_embed_pe_fwd(const int64_t* ids, const void* lut, const floa
 extern "C" int bist_temporal_mask(const void* fts, uint8_t* mask, int64_t BT, int64_t row_elems, int32_t dtype, void* stream) {
   BIST_REQUIRE(fts && mask && BT > 0 && row_elems > 0, "bist_temporal_mask: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  const unsigned g = blocks_for(BT, 4);
+  const unsigned g = (unsigned)BT;
   if (dtype == BIST_BF16)
     hipLaunchKernelGGL(temporal_mask_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)fts, mask, BT, row_elems);
   else if (dtype == BIST_F32)

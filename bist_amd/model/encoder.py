@@ -127,6 +127,9 @@ class VidEncoderLayer4(nn.Module):
         q = Fn.linear(sub.norm(x), attn.linears[0].weight, attn.linears[0].bias)                  # [B*Lq, d]
         qf = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq * h, d)   # rows (i, hh)
         scores = Fn.st_scores(qf, vft.view(B, T * S, d))
+        v_ready = self.__dict__.get("_v_ready")
+        if v_ready is not None:
+            torch.cuda.current_stream().wait_stream(v_ready)      # V comes from the value-projection stream
         o = Fn.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
         G = o.shape[1]
         y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=x, res_map=(G * Lq, Lq), **Fn.drop_args(sub))
@@ -173,7 +176,20 @@ class VidEncoderLayer4(nn.Module):
         vft = ft["spatiotemporal_ft"]
         t2s_on = (not hasattr(self.args, "t2s")) or self.args.t2s
         s2t_on = (not hasattr(self.args, "s2t")) or self.args.s2t
-        v_t2s, v_s2t = self.value_projection(vft)
+        concurrent = t2s_on and s2t_on and Fn.CONCURRENT and vft.is_cuda
+        v_stream = None
+        if concurrent:
+            # The value projections are the layer's big GEMMs and depend on the video tensor only: they run on
+            # their own stream, under the query-side chains (self-attention, LayerNorm, Q projection, fold) of the
+            # two directions, and are awaited just before the stage-1 cores.
+            main, v_stream = torch.cuda.current_stream(), Fn.side_stream(2)
+            v_stream.wait_stream(main)
+            with torch.cuda.stream(v_stream):
+                v_t2s, v_s2t = self.value_projection(vft)
+        else:
+            v_t2s, v_s2t = self.value_projection(vft)
+        self._v_ready = v_stream
+
         def t2s_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
             y = self._stage1(ai + 1, si + 1, x, vft, v_t2s, b.temporal_mask, 0)                   # A1
@@ -186,13 +202,15 @@ class VidEncoderLayer4(nn.Module):
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
 
-        if t2s_on and s2t_on and Fn.CONCURRENT and vft.is_cuda:
-            main, side = torch.cuda.current_stream(), Fn.side_stream(0)
+        if concurrent:
+            side = Fn.side_stream(0)
             side.wait_stream(main)                    # fork: the two directions share only read-only inputs
             with torch.cuda.stream(side):
                 s2t_branch(3, 4, 1)
             t2s_branch(0, 0, 0)
             main.wait_stream(side)                    # join
+            main.wait_stream(v_stream)
+            self._v_ready = None
         else:
             ai = si = fi = 0
             if t2s_on:
