@@ -178,11 +178,14 @@ class VidEncoderLayer4(nn.Module):
         s2t_on = (not hasattr(self.args, "s2t")) or self.args.s2t
         concurrent = t2s_on and s2t_on and Fn.CONCURRENT and vft.is_cuda
         v_stream = None
-        if concurrent:
+        main = torch.cuda.current_stream() if concurrent else None
+        if concurrent and not torch.is_grad_enabled():
+            # (inference only: with autograd the extra stream's backward work is not joined back before the end of a
+            # hipGraph capture -- capture_end crashes in the HIP runtime -- so training keeps V on the main stream)
             # The value projections are the layer's big GEMMs and depend on the video tensor only: they run on
             # their own stream, under the query-side chains (self-attention, LayerNorm, Q projection, fold) of the
             # two directions, and are awaited just before the stage-1 cores.
-            main, v_stream = torch.cuda.current_stream(), Fn.side_stream(2)
+            v_stream = Fn.side_stream(2)
             v_stream.wait_stream(main)
             with torch.cuda.stream(v_stream):
                 v_t2s, v_s2t = self.value_projection(vft)
@@ -209,7 +212,8 @@ class VidEncoderLayer4(nn.Module):
                 s2t_branch(3, 4, 1)
             t2s_branch(0, 0, 0)
             main.wait_stream(side)                    # join
-            main.wait_stream(v_stream)
+            if v_stream is not None:
+                main.wait_stream(v_stream)
             self._v_ready = None
         else:
             ai = si = fi = 0
