@@ -279,6 +279,12 @@ extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, co
                                  int64_t mask_bs, int64_t mask_qs, float scale, int32_t dtype, void* stream) {
   BIST_REQUIRE(Q && K && V && dQ && dK && dV && (dO || dP_ext), "bist_mha_core_bwd: null pointer");
   BIST_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && h > 0 && dk > 0, "bist_mha_core_bwd: bad shape");
+  if (dtype == BIST_BF16 && !getenv("BIST_MHA_VALU")) {          // matrix-core path (attention_mfma.hip)
+    const int r = bist_mha_bwd_mfma(Q, K, V, mask, dO, dP_ext, dQ, dK, dV, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs,
+                                    lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, (hipStream_t)stream);
+    if (r == 1) return BIST_OK;
+    if (r < 0) { bist_set_error("bist_mha_core_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+  }
   const size_t lds = (size_t)2 * Lq * Lk * sizeof(float);
   BIST_REQUIRE(lds <= 64 * 1024, "bist_mha_core_bwd: Lq*Lk=%d too large for LDS", Lq * Lk);
   hipStream_t st = (hipStream_t)stream;

@@ -459,7 +459,175 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
   }
 }
 
+// =====================================================================================================
+// Small multi-head attention BACKWARD on the matrix cores (bf16, dk = 64, Lq <= 32, Lk <= 64): one wave per
+// (sequence n, head).  Q/K/V/dO tiles are staged in LDS as they lie in HBM ([rows][64]); every product is a
+// handful of 16x16x32 MFMAs, the transposed operands (K, Q, dO as "B", dS/P as "A^T") come from
+// ds_read_b64_tr_b16:
+//   S = Q K^T, dP = dO V^T (+ dP_ext) -> softmax / softmax-backward in the accumulator layout
+//   dQ = scale dS K,  dK = scale dS^T Q,  dV = P^T dO
+// =====================================================================================================
+struct MhaBwdArgs {
+  const bf16_t *Q, *K, *V, *dO; const unsigned char* mask; const float* dPext;
+  bf16_t *dQ, *dK, *dV;
+  int Lq, Lk, h;
+  long ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs;
+  float scale;
+};
+
+__global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t qimg[32 * 64], kimg[64 * 64], vimg[64 * 64], gimg[32 * 64], pimg[32 * 64], simg[32 * 64];
+  const int hh = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  const int x = lane & 15, lg = lane >> 4;
+  const int Lq = a.Lq, Lk = a.Lk;
+  const bf16_t* Qn = a.Q + n * a.q_bs + hh * 64;
+  const bf16_t* Kn = a.K + n * a.k_bs + hh * 64;
+  const bf16_t* Vn = a.V + n * a.v_bs + hh * 64;
+  const bf16_t* Gn = a.dO ? a.dO + n * a.o_bs + hh * 64 : nullptr;
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  for (int r = lane >> 3; r < 32; r += 8) {
+    const int c = (lane & 7) * 8;
+    *reinterpret_cast<uint4*>(qimg + r * 64 + c) = r < Lq ? *reinterpret_cast<const uint4*>(Qn + (long)r * a.ldq + c) : z4;
+    *reinterpret_cast<uint4*>(gimg + r * 64 + c) = (Gn && r < Lq) ? *reinterpret_cast<const uint4*>(Gn + (long)r * a.ldo + c) : z4;
+  }
+  for (int r = lane >> 3; r < 64; r += 8) {
+    const int c = (lane & 7) * 8;
+    *reinterpret_cast<uint4*>(kimg + r * 64 + c) = r < Lk ? *reinterpret_cast<const uint4*>(Kn + (long)r * a.ldk + c) : z4;
+    *reinterpret_cast<uint4*>(vimg + r * 64 + c) = r < Lk ? *reinterpret_cast<const uint4*>(Vn + (long)r * a.ldv + c) : z4;
+  }
+  // S = Q K^T and dP = dO V^T   (rows i, cols j)
+  f32x4 S[2][4], D[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) { S[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; D[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 aq[2], ag[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) { aq[mi] = frag_rows(qimg, 64, mi * 16, ks * 32, lane); ag[mi] = frag_rows(gimg, 64, mi * 16, ks * 32, lane); }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const uint4 bk = frag_rows(kimg, 64, ni * 16, ks * 32, lane), bv = frag_rows(vimg, 64, ni * 16, ks * 32, lane);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) { S[mi][ni] = mfma_bf16(aq[mi], bk, S[mi][ni]); D[mi][ni] = mfma_bf16(ag[mi], bv, D[mi][ni]); }
+    }
+  }
+  // softmax and its backward in the accumulator layout: row i = mi*16 + lg*4 + r, col j = ni*16 + x
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = mi * 16 + lg * 4 + r;
+      const bool row_ok = i < Lq;
+      const unsigned char* mrow = (a.mask && row_ok) ? a.mask + n * a.mask_bs + (long)i * a.mask_qs : nullptr;
+      float sv[4], dv[4];
+      bool msk[4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int j = ni * 16 + x;
+        msk[ni] = mrow && j < Lk && mrow[j] == 0;
+        float sc = S[mi][ni][r] * a.scale;
+        if (msk[ni]) sc = MASK_FILL;
+        if (j >= Lk) sc = -INFINITY;
+        sv[ni] = sc;
+        dv[ni] = D[mi][ni][r];
+        if (a.dPext && row_ok && j < Lk) dv[ni] += a.dPext[(((long)n * a.h + hh) * Lq + i) * Lk + j];
+        mx = fmaxf(mx, sc);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+      float den = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) { sv[ni] = (ni * 16 + x < Lk) ? expf(sv[ni] - mx) : 0.f; den += sv[ni]; }
+      den += __shfl_xor(den, 1, 64); den += __shfl_xor(den, 2, 64); den += __shfl_xor(den, 4, 64); den += __shfl_xor(den, 8, 64);
+      const float inv = 1.f / den;
+      float dot = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) { sv[ni] *= inv; dot += sv[ni] * dv[ni]; }
+      dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int j = ni * 16 + x;
+        float ds = sv[ni] * (dv[ni] - dot) * a.scale;
+        if (msk[ni] || !row_ok || j >= Lk) ds = 0.f;
+        pimg[i * 64 + j] = (bf16_t)(row_ok ? sv[ni] : 0.f);
+        simg[i * 64 + j] = (bf16_t)ds;
+      }
+    }
+  // dQ = dS K  (M = i, N = c, K = j);  dK = dS^T Q, dV = P^T dO  (M = j, N = c, K = i)
+  f32x4 dq[2][4], dkk[4][4], dvv[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      if (mi < 2) dq[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dkk[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; dvv[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 as[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) as[mi] = frag_rows(simg, 64, mi * 16, ks * 32, lane);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const uint4 bk = frag_cols(kimg, 64, ni * 16, ks * 32, lane);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) dq[mi][ni] = mfma_bf16(as[mi], bk, dq[mi][ni]);
+    }
+  }
+  {
+    uint4 bq[4], bg[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) { bq[ni] = frag_cols(qimg, 64, ni * 16, 0, lane); bg[ni] = frag_cols(gimg, 64, ni * 16, 0, lane); }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const uint4 as = frag_cols(simg, 64, mi * 16, 0, lane), ap = frag_cols(pimg, 64, mi * 16, 0, lane);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) { dkk[mi][ni] = mfma_bf16(as, bq[ni], dkk[mi][ni]); dvv[mi][ni] = mfma_bf16(ap, bg[ni], dvv[mi][ni]); }
+    }
+  }
+  // stores through LDS (the staged tiles are dead): dQ -> qimg, dK -> kimg, dV -> vimg, then 16-byte rows
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int row = mi * 16 + lg * 4 + r, col = ni * 16 + x;
+        if (mi < 2) qimg[row * 64 + col] = (bf16_t)dq[mi][ni][r];
+        kimg[row * 64 + col] = (bf16_t)dkk[mi][ni][r];
+        vimg[row * 64 + col] = (bf16_t)dvv[mi][ni][r];
+      }
+  bf16_t* dQn = a.dQ + n * a.dq_bs + hh * 64;
+  bf16_t* dKn = a.dK + n * a.dk_bs + hh * 64;
+  bf16_t* dVn = a.dV + n * a.dv_bs + hh * 64;
+  for (int r = lane >> 3; r < Lq; r += 8)
+    *reinterpret_cast<uint4*>(dQn + (long)r * a.lddq + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(qimg + r * 64 + (lane & 7) * 8);
+  for (int r = lane >> 3; r < Lk; r += 8) {
+    *reinterpret_cast<uint4*>(dKn + (long)r * a.lddk + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(kimg + r * 64 + (lane & 7) * 8);
+    *reinterpret_cast<uint4*>(dVn + (long)r * a.lddv + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(vimg + r * 64 + (lane & 7) * 8);
+  }
+}
+
 }  // namespace
+
+// returns 1 if launched, 0 if outside the envelope, -1 on launch error
+int bist_mha_bwd_mfma(const void* Q, const void* K, const void* V, const unsigned char* mask, const void* dO, const float* dPext,
+                      void* dQ, void* dK, void* dV, int N, int Lq, int Lk, int h, int dk, long ldq, long ldk, long ldv, long ldo,
+                      long q_bs, long k_bs, long v_bs, long o_bs, long lddq, long lddk, long lddv, long dq_bs, long dk_bs, long dv_bs,
+                      long mask_bs, long mask_qs, float scale, hipStream_t st) {
+  if (dk != 64 || Lq > 32 || Lk > 64) return 0;
+  auto al8 = [](long v) { return (v % 8) == 0; };
+  if (!(al8(ldq) && al8(ldk) && al8(ldv) && al8(lddq) && al8(lddk) && al8(lddv) && al8(q_bs) && al8(k_bs) && al8(v_bs) && al8(dq_bs) &&
+        al8(dk_bs) && al8(dv_bs) && (!dO || (al8(ldo) && al8(o_bs))))) return 0;
+  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV | (uintptr_t)dO) % 16) return 0;
+  MhaBwdArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, mask, dPext, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV,
+               Lq, Lk, h, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale};
+  hipLaunchKernelGGL(mha_bwd_mfma_kernel, dim3((unsigned)h, (unsigned)N), dim3(64), 0, st, a);
+  return hipGetLastError() == hipSuccess ? 1 : -1;
+}
 
 // returns 1 if launched, 0 if outside the envelope, -1 on launch error
 int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, void* PY, const void* dPY, void* dq2f, void* dY,

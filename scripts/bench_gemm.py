@@ -35,11 +35,19 @@ for name, M, N, K, lay in SHAPES:
     for _ in range(5):
         ops.gemm(a, b, c, M=M, N=N, K=K, ldc=N, **kw)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     iters = 50
-    e0.record()
-    for _ in range(iters):
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
         ops.gemm(a, b, c, M=M, N=N, K=K, ldc=N, **kw)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()          # replay from a graph: GPU time per launch, no host launch overhead
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            ops.gemm(a, b, c, M=M, N=N, K=K, ldc=N, **kw)
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     print(f"{name:38s} plan={plan} {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s")

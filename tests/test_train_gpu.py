@@ -122,6 +122,31 @@ def test_mha_core_backward_all_packings(env):
            lambda q, k, v: _ref_attn(q, k, v, causal, h), [q, k, v], "mha q_k_v + p_attn grad")
 
 
+@pytest.mark.parametrize("N,Lq,Lk,h,mk", [(3, 20, 20, 8, "key"), (2, 20, 60, 8, "key"), (2, 12, 12, 4, "causal"), (2, 32, 64, 2, None)])
+def test_mha_core_backward_bf16_matrix_core_path(env, N, Lq, Lk, h, mk):
+    """bf16 small-attention backward (one wave per head on the MFMA units, dk = 64) against fp64 on the rounded inputs,
+    including a gradient arriving through the probabilities (the pointer generator's use)."""
+    ag, Fn, ops = env
+    d = h * 64
+    q = _rand(N, Lq, d, seed=80).to(torch.bfloat16).double()
+    kv = _rand(N, Lk, 2 * d, seed=81).to(torch.bfloat16).double()
+    mask = None
+    if mk == "key":
+        mask = torch.ones(N, 1, Lk, dtype=torch.bool); mask[0, 0, Lk // 2:] = False; mask[N - 1] = False
+    elif mk == "causal":
+        mask = torch.tril(torch.ones(1, Lq, Lk, dtype=torch.bool)).expand(N, Lq, Lk)
+    qr, kvr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    ro, rp = _ref_attn(qr, kvr[..., :d], kvr[..., d:], mask, h)
+    wo, wp = _rand(N, Lq, d, seed=82).to(torch.bfloat16).double(), _rand(N, h, Lq, Lk, seed=83)
+    ((ro * wo).sum() + (rp * wp).sum()).backward()
+    qd, kvd = q.to(torch.bfloat16).cuda().requires_grad_(True), kv.to(torch.bfloat16).cuda().requires_grad_(True)
+    o, p = Fn.mha_packed(qd, kvd, None, "q_kv", None if mask is None else mask.cuda(), h, True)
+    ((o.double() * wo.cuda()).sum() + (p.double() * wp.cuda()).sum()).backward()
+    _close(o, ro.detach(), "mha bf16 out", 1.5e-2)
+    _close(qd.grad, qr.grad, "mha bf16 dQ", 3e-2)
+    _close(kvd.grad, kvr.grad, "mha bf16 dKV", 3e-2)
+
+
 def test_stage1_backward(env):
     ag, Fn, ops = env
     B, T, S, Lq, h, dk = 2, 6, 9, 5, 4, 16
