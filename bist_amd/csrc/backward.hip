@@ -107,6 +107,69 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+// Vectorised LayerNorm backward for rows that are a whole number of KiB: each lane owns NV 16-byte vectors of
+// the row (x and dy read once, kept in registers); the gain/offset gradients are summed over the block's rows in
+// registers, combined across the 4 waves through LDS, and leave as ONE atomic per column per block.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
+                                                                T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
+                                                                long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave) {
+  constexpr int E = 16 / (int)sizeof(T), NE = NV * E;
+  __shared__ float red[2][4][64 * NE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long wave = (long)blockIdx.x * 4 + w;
+  const long r0 = wave * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+  float av[NE], pa[NE], pb[NE];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const uint4 q = *reinterpret_cast<const uint4*>(a + (j * 64 + lane) * E);
+    const T* qe = reinterpret_cast<const T*>(&q);
+#pragma unroll
+    for (int e = 0; e < E; ++e) { av[j * E + e] = to_f(qe[e]); pa[j * E + e] = 0.f; pb[j * E + e] = 0.f; }
+  }
+  for (long row = r0; row < r1; ++row) {
+    float xv[NE], gv[NE];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const uint4 qx = *reinterpret_cast<const uint4*>(x + row * ldx + (j * 64 + lane) * E);
+      const uint4 qg = *reinterpret_cast<const uint4*>(dy + row * lddy + (j * 64 + lane) * E);
+      const T* xe = reinterpret_cast<const T*>(&qx);
+      const T* ge = reinterpret_cast<const T*>(&qg);
+#pragma unroll
+      for (int e = 0; e < E; ++e) { xv[j * E + e] = to_f(xe[e]); gv[j * E + e] = to_f(ge[e]); s += xv[j * E + e]; }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f, sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) { xv[u] -= mean; const float g = gv[u] * av[u]; q += xv[u] * xv[u]; sg += g; sgx += g * xv[u]; }
+    q = wave_sum(q); sg = wave_sum(sg); sgx = wave_sum(sgx);
+    const float stdv = sqrtf(q / (float)(d - 1)), sden = stdv + eps;
+    const float inv = 1.f / sden, mg = sg / (float)d, k2 = sgx / ((float)(d - 1) * stdv * sden * sden);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      T o[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int u = j * E + e;
+        o[e] = from_f<T>((gv[u] * av[u] - mg) * inv - xv[u] * k2);
+        pa[u] += gv[u] * xv[u] * inv;
+        pb[u] += gv[u];
+      }
+      *reinterpret_cast<uint4*>(dx + row * lddx + (j * 64 + lane) * E) = *reinterpret_cast<const uint4*>(o);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NE; ++u) { red[0][w][u * 64 + lane] = pa[u]; red[1][w][u * 64 + lane] = pb[u]; }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * NE; idx += 256) {
+    const int u = idx >> 6, ln = idx & 63;
+    const int c = ((u / E) * 64 + ln) * E + (u % E);                    // column owned by (lane ln, register u)
+    atomicAdd(da + c, red[0][0][idx] + red[0][1][idx] + red[0][2][idx] + red[0][3][idx]);
+    atomicAdd(db + c, red[1][0][idx] + red[1][1][idx] + red[1][2][idx] + red[1][3][idx]);
+  }
+}
+
 // Embedding backward: dlut[ids[row], c] += dy[row, c] * sqrt(d)   (fp32 atomics)
 template <typename T>
 __global__ void embed_bwd_kernel(const long* __restrict__ ids, const T* __restrict__ dy, float* __restrict__ dlut, long rows, int d, float scale) {
@@ -223,6 +286,22 @@ extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, 
   BIST_REQUIRE(dy && x && a && dx && da && db, "bist_layernorm_bwd: null pointer");
   BIST_REQUIRE(rows > 0 && d > 1 && d <= 2048, "bist_layernorm_bwd: bad shape rows=%ld d=%d", (long)rows, d);
   hipStream_t st = (hipStream_t)stream;
+  const long sz = dtype == BIST_BF16 ? 2 : 4;
+  const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)a | (uintptr_t)dx) % 16 == 0) && (lddy * sz) % 16 == 0 &&
+                  (ldx * sz) % 16 == 0 && (lddx * sz) % 16 == 0;
+  if (al && (d * sz) == 1024) {                   // d = 512 bf16 / 256 f32: one 16-byte vector per lane
+    int rpw2 = (int)((rows + 1023) / 1024);       // ~1024 waves: enough parallelism for dx, few atomics per column
+    if (rpw2 < 2) rpw2 = 2;
+    const unsigned g2 = blocks_for(blocks_for(rows, rpw2), 4);
+    if (dtype == BIST_BF16)
+      hipLaunchKernelGGL((layernorm_bwd_vec_kernel<bf16_t, 1>), dim3(g2), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)a,
+                         (bf16_t*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2);
+    else
+      hipLaunchKernelGGL((layernorm_bwd_vec_kernel<float, 1>), dim3(g2), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)a,
+                         (float*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2);
+    BIST_LAUNCH_CHECK("bist_layernorm_bwd");
+    return BIST_OK;
+  }
   int rpw = (int)((rows + 4095) / 4096);          // <= 4096 waves flush their partial sums
   if (rpw < 1) rpw = 1;
   const unsigned g = blocks_for(blocks_for(rows, rpw), 4);

@@ -501,6 +501,146 @@ __global__ __launch_bounds__(NTHREADS) void gemm_gen_kernel(const GemmK g) {
   epilogue<T, TO>(g, acc, z1, z2, 0, m0, n0, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// skinny products (unbatched): one side of the product is <= 8 wide, so a 128x128 MFMA tile would be >90 %
+// padding.  These are the modality-fusion and pointer-switch logits (N = 1..4), their input gradients
+// (K = 1..4) and their weight gradients (M = 1..4, K = rows).  All three are bandwidth/latency bound VALU
+// kernels that touch each operand element once.
+// ---------------------------------------------------------------------------------------------
+constexpr int SKINNY = 8;
+
+// N <= 8, both operands contiguous along K: one wave per output row, lanes stride K, wave-reduce per column.
+template <typename T, typename TO, bool VEC>
+__global__ __launch_bounds__(256) void skinny_n_kernel(const GemmK g) {
+  const int lane = threadIdx.x & 63;
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= g.M) return;
+  const T* A = reinterpret_cast<const T*>(g.A) + m * g.a_rs;
+  const T* B = reinterpret_cast<const T*>(g.B);
+  float acc[SKINNY];
+#pragma unroll
+  for (int n = 0; n < SKINNY; ++n) acc[n] = 0.f;
+  if (VEC) {
+    constexpr int E = 16 / (int)sizeof(T);
+    for (int k = lane * E; k < g.K; k += 64 * E) {
+      const uint4 qa = *reinterpret_cast<const uint4*>(A + k);
+      const T* ae = reinterpret_cast<const T*>(&qa);
+#pragma unroll
+      for (int n = 0; n < SKINNY; ++n)
+        if (n < g.N) {
+          const uint4 qb = *reinterpret_cast<const uint4*>(B + n * g.b_rs + k);
+          const T* be = reinterpret_cast<const T*>(&qb);
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[n] += to_f(ae[e]) * to_f(be[e]);
+        }
+    }
+  } else {
+    for (int k = lane; k < g.K; k += 64) {
+      const float a = to_f(A[k]);
+#pragma unroll
+      for (int n = 0; n < SKINNY; ++n)
+        if (n < g.N) acc[n] += a * to_f(B[n * g.b_rs + k]);
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int n = 0; n < SKINNY; ++n)
+    if (n < g.N) { const float v = wave_sum(acc[n]); if (lane == n) mine = v; }
+  if (lane < g.N) {
+    const T* bias = reinterpret_cast<const T*>(g.bias);
+    const TO* res = reinterpret_cast<const TO*>(g.residual);
+    reinterpret_cast<TO*>(g.C)[m * g.ldc + lane] =
+        from_f<TO>(epilogue_value<T, TO>(g, mine, bias ? to_f(bias[lane]) : 0.f, res, (int)m, lane, 0ULL));
+  }
+}
+
+// K <= 8, any strides: one thread per output element (n fastest, so stores coalesce).
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void skinny_k_kernel(const GemmK g) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)g.M * g.N) return;
+  const int m = (int)(idx / g.N), n = (int)(idx % g.N);
+  const T* A = reinterpret_cast<const T*>(g.A) + (long)m * g.a_rs;
+  const T* B = reinterpret_cast<const T*>(g.B) + (long)n * g.b_rs;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < SKINNY; ++k)
+    if (k < g.K) acc += to_f(A[k * g.a_ks]) * to_f(B[k * g.b_ks]);
+  const T* bias = reinterpret_cast<const T*>(g.bias);
+  const TO* res = reinterpret_cast<const TO*>(g.residual);
+  reinterpret_cast<TO*>(g.C)[(long)m * g.ldc + n] = from_f<TO>(epilogue_value<T, TO>(g, acc, bias ? to_f(bias[n]) : 0.f, res, m, n, 0ULL));
+}
+
+// One side <= 8 and a long K, the wide operand contiguous along its row index: a workgroup owns 64 wide
+// indices x 16 K-lanes; every thread keeps the <= 8 partial sums in registers, LDS combines the K-lanes.
+template <typename T, typename TO, bool SMALL_M>
+__global__ __launch_bounds__(1024) void skinny_tn_kernel(const GemmK g) {
+  __shared__ float red[16][SKINNY][64];
+  const int gl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int NS = SMALL_M ? g.M : g.N, NB = SMALL_M ? g.N : g.M;
+  const T* P = reinterpret_cast<const T*>(SMALL_M ? g.B : g.A);     // wide operand
+  const T* Q = reinterpret_cast<const T*>(SMALL_M ? g.A : g.B);     // narrow operand
+  const long p_ks = SMALL_M ? g.b_ks : g.a_ks;
+  const long q_rs = SMALL_M ? g.a_rs : g.b_rs, q_ks = SMALL_M ? g.a_ks : g.b_ks;
+  const int gi = blockIdx.x * 64 + gl;
+  float acc[SKINNY];
+#pragma unroll
+  for (int s = 0; s < SKINNY; ++s) acc[s] = 0.f;
+  if (gi < NB) {
+#pragma unroll 4
+    for (int k = kl; k < g.K; k += 16) {
+      const float p = to_f(P[(long)k * p_ks + gi]);
+#pragma unroll
+      for (int s = 0; s < SKINNY; ++s)
+        if (s < NS) acc[s] += p * to_f(Q[s * q_rs + (long)k * q_ks]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SKINNY; ++s) red[kl][s][gl] = acc[s];
+  __syncthreads();
+  const T* bias = reinterpret_cast<const T*>(g.bias);
+  const TO* res = reinterpret_cast<const TO*>(g.residual);
+  for (int idx = threadIdx.x; idx < 64 * NS; idx += 1024) {
+    const int s = idx >> 6, l2 = idx & 63, g2 = blockIdx.x * 64 + l2;
+    if (g2 >= NB) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += red[j][s][l2];
+    const int m = SMALL_M ? s : g2, n = SMALL_M ? g2 : s;
+    reinterpret_cast<TO*>(g.C)[(long)m * g.ldc + n] = from_f<TO>(epilogue_value<T, TO>(g, v, bias ? to_f(bias[n]) : 0.f, res, m, n, 0ULL));
+  }
+}
+
+// 0: not a skinny shape; 1: K-skinny; 2: N-skinny row reduce; 3: M-skinny; 4: N-skinny with a transposed A
+int skinny_kind(const BistGemm* g) {
+  if (g->batch1 != 1 || g->batch2 != 1) return 0;
+  if (g->K <= SKINNY) return 1;
+  if (g->N <= SKINNY && g->a_ks == 1 && g->b_ks == 1) return 2;
+  if (g->M <= SKINNY && g->b_rs == 1) return 3;
+  if (g->N <= SKINNY && g->a_rs == 1) return 4;
+  return 0;
+}
+
+template <typename T, typename TO>
+int launch_skinny(const BistGemm* g, const GemmK& k, int kind, hipStream_t st) {
+  if (kind == 1) {
+    const long total = (long)g->M * g->N;
+    hipLaunchKernelGGL((skinny_k_kernel<T, TO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k);
+  } else if (kind == 2) {
+    const long sz = sizeof(T), E = 16 / sz;
+    const bool vec = ((uintptr_t)g->A % 16 == 0) && ((uintptr_t)g->B % 16 == 0) && (g->a_rs % E == 0) && (g->b_rs % E == 0) && (g->K % E == 0);
+    const dim3 grid((unsigned)((g->M + 3) / 4));
+    if (vec) hipLaunchKernelGGL((skinny_n_kernel<T, TO, true>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((skinny_n_kernel<T, TO, false>), grid, dim3(256), 0, st, k);
+  } else if (kind == 3) {
+    hipLaunchKernelGGL((skinny_tn_kernel<T, TO, true>), dim3((unsigned)((g->N + 63) / 64)), dim3(1024), 0, st, k);
+  } else {
+    hipLaunchKernelGGL((skinny_tn_kernel<T, TO, false>), dim3((unsigned)((g->M + 63) / 64)), dim3(1024), 0, st, k);
+  }
+  BIST_LAUNCH_CHECK("bist_gemm(skinny)");
+  return BIST_OK;
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 struct Plan { bool fast; bool atr, btr; int split; size_t ws_bytes; int stages; };
 
@@ -537,6 +677,7 @@ Plan make_plan(const BistGemm* g) {
 
 template <typename T, typename TO>
 int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
+  if (const int sk = skinny_kind(g)) return launch_skinny<T, TO>(g, k, sk, st);
   const Plan p = make_plan(g);
   k.split_k = p.split;
   k.ws = p.split > 1 ? (float*)g->workspace : nullptr;
@@ -567,6 +708,7 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
 
 extern "C" int bist_gemm_is_fast(const BistGemm* g) {
   if (!g) return 0;
+  if (skinny_kind(g)) return 3;
   const Plan p = make_plan(g);
   return p.fast ? (p.split > 1 ? 2 : 1) : 0;
 }

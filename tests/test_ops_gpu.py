@@ -123,6 +123,43 @@ def test_gemm_split_k_weight_gradient_shape(ops, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("rows,d,n", [(320, 512, 3), (77, 100, 1), (1280, 512, 4), (5, 512, 8)])
+def test_gemm_skinny_products(ops, dtype, tol, rows, d, n):
+    """the fusion / switch logits (N <= 8), their input gradient (K <= 8) and weight gradient (M <= 8,
+    K = rows) skip the 128x128 MFMA tile (decoder.py:153, generator.py:71/117)."""
+    from bist_amd import _lib
+    x, w, bias = _rand(rows, d, seed=60), _rand(n, d, seed=61, scale=d ** -0.5), _rand(n, seed=62)
+    dl = _rand(rows, n, seed=63)
+    xd, wd, bd, dld = x.to(dtype).cuda(), w.to(dtype).cuda(), bias.to(dtype).cuda(), dl.to(dtype).cuda()
+    xq, wq, dlq = _q(x, dtype), _q(w, dtype), _q(dl, dtype)
+    # logits = x W^T + b, accumulated on a previous partial sum
+    prev = _rand(rows, n, seed=64)
+    out = torch.empty(rows, n, device="cuda", dtype=torch.float32)
+    kw = dict(M=rows, N=n, K=d, a_rs=d, a_ks=1, b_rs=d, b_ks=1, ldc=n)
+    assert _lib.lib.bist_gemm_is_fast(ops.gemm_desc(xd, wd, out, **kw)) == 3
+    ops.gemm(xd, wd, out, bias=bd, residual=prev.cuda(), ldr=n, **kw)
+    _cmp(out, xq @ wq.t() + _q(bias, dtype) + prev, tol, "skinny N")
+    # column slice of a wider weight (the concat-free fusion): row stride 3d
+    wide = _rand(n, 3 * d, seed=65, scale=d ** -0.5)
+    wided = wide.to(dtype).cuda()
+    ops.gemm(xd, wided[:, d:2 * d], out, M=rows, N=n, K=d, a_rs=d, a_ks=1, b_rs=3 * d, b_ks=1, ldc=n)
+    _cmp(out, xq @ _q(wide, dtype)[:, d:2 * d].t(), tol, "skinny N, sliced weight")
+    # dx = dl W  (K = n)
+    dx = torch.empty(rows, d, device="cuda", dtype=dtype)
+    ops.gemm(dld, wd, dx, M=rows, N=d, K=n, a_rs=n, a_ks=1, b_rs=1, b_ks=d, ldc=d, alpha=0.5)
+    _cmp(dx, 0.5 * (dlq @ wq), tol, "skinny K")
+    # dW = dl^T x  (M = n, K = rows), accumulated in place in fp32
+    acc = _rand(n, d, seed=66).cuda()
+    want = acc.cpu() + dlq.t() @ xq
+    ops.gemm(dld, xd, acc, M=n, N=d, K=rows, a_rs=1, a_ks=n, b_rs=1, b_ks=d, ldc=d, residual=acc, ldr=d)
+    _cmp(acc, want, tol * max(1.0, rows ** 0.5 / 4), "skinny M")
+    # the mirrored orientation: C[d, n] = x^T dl
+    outT = torch.empty(d, n, device="cuda", dtype=dtype)
+    ops.gemm(xd, dld, outT, M=d, N=n, K=rows, a_rs=1, a_ks=d, b_rs=1, b_ks=n, ldc=n)
+    _cmp(outT, xq.t() @ dlq, tol * max(1.0, rows ** 0.5 / 4), "skinny N, transposed A")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
 def test_gemm_batched_head_fold(ops, dtype, tol):
     # the K-fold: Qf[(b,i), hh*d + n] = sum_c Q[(b,i), hh*dk + c] * Wk[hh*dk + c, n]   (batch over heads)
     Bq, h, dk = 37, 4, 16
