@@ -45,6 +45,7 @@ struct GemmK {   // device-side argument block (by value)
   int tiles_m, tiles_n;
   int split_k; float* ws;            // split_k > 1: raw fp32 partial tiles go to ws[z][split][M][N]
   int vec_c, vec_r;                  // 16-byte aligned output / residual rows: vector epilogue allowed
+  int dbg;                           // BIST_GEMM_DBG ablation aid (0 in production): 1 exit at entry, 2 skip the K loop, 3 skip the epilogue
 };
 
 template <typename T> struct Mma;
@@ -234,14 +235,14 @@ __device__ __forceinline__ void epilogue(const GemmK& g, f32x4 (&acc)[4][4], int
 // columns down the rows: its bias values are loaded once, every row is one 16-byte residual load and one
 // 16-byte store, and the row loop is fully unrolled so all loads are in flight together.  Versus storing
 // straight from the MFMA layout (2-byte stores, 32-byte runs) this cuts the store instructions 8x.
-template <typename T, typename TO, bool SPLIT>
+template <typename T, typename TO, bool SPLIT, int TILE = 128>
 __device__ __forceinline__ void stream_out(const GemmK& g, const char* lds_lo, const char* lds_hi, int z1, int z2, int sp,
                                            int m0, int n0, int tid) {
   using TS = typename std::conditional<SPLIT, float, TO>::type;      // element type actually stored
   constexpr int VW = 16 / (int)sizeof(TS);          // columns per thread: 8 (bf16) or 4 (f32)
-  constexpr int IPR = 128 / VW;                     // threads per row
+  constexpr int IPR = TILE / VW;                    // threads per row
   constexpr int RPP = NTHREADS / IPR;               // rows per pass
-  constexpr int NPASS = 128 / RPP;
+  constexpr int NPASS = TILE / RPP;
   const int col0 = (tid % IPR) * VW, rbase = tid / IPR;
   const int n = n0 + col0;
   if (n >= g.N) return;
@@ -277,8 +278,9 @@ __device__ __forceinline__ void stream_out(const GemmK& g, const char* lds_lo, c
     const int row = rbase + it * RPP;
     const int m = m0 + row;
     if (m >= g.M) continue;
-    const float* src = reinterpret_cast<const float*>(row < 64 ? lds_lo : lds_hi) + (row & 63) * 128;
-    const int sw = (((row & 63) >> 2) & 7) << 2;
+    const float* src = TILE == 128 ? reinterpret_cast<const float*>(row < 64 ? lds_lo : lds_hi) + (row & 63) * 128
+                                   : reinterpret_cast<const float*>(lds_lo) + row * 64;      // 64-tile: one [64][64] image
+    const int sw = TILE == 128 ? (((row & 63) >> 2) & 7) << 2 : ((row >> 2) & 3) << 2;
     float v[VW];
 #pragma unroll
     for (int q = 0; q < VW / 4; ++q) {
@@ -359,6 +361,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
   __shared__ __attribute__((aligned(16))) char lds1[2 * TILE_BYTES];
   __shared__ __attribute__((aligned(16))) char lds2[NS > 2 ? 2 * TILE_BYTES : 16];
   __shared__ __attribute__((aligned(16))) char lds3[NS > 2 ? 2 * TILE_BYTES : 16];
+  if (g.dbg == 1) return;
   int z, sp, tm, tn;
   tile_coords(g, z, sp, tm, tn);
   const int z1 = z / g.batch2, z2 = z % g.batch2;
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
   const int nk_all = (g.K + BK - 1) / BK;                 // a trailing half tile counts as one
   const bool half_tail = (g.K % BK) != 0;
   const int kt0 = (int)((long)nk_all * sp / g.split_k), kt1 = (int)((long)nk_all * (sp + 1) / g.split_k);
-  const int nk = kt1 - kt0;
+  const int nk = g.dbg == 2 ? 0 : kt1 - kt0;
 
   Stager<T, ATR> sa;
   Stager<T, BTR> sb;
@@ -398,6 +401,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
         compute_tile<T, ATR, BTR>(lds1, lds1 + TILE_BYTES, acc, wm, wn, lane, is_half(kt + 1));
       }
     }
+  } else if constexpr (NS == 22) {
+    // paired double buffer for latency-bound launches (few workgroups, one per CU): every barrier hands over
+    // TWO K tiles, so the load -> barrier -> compute chain is half as long; 128 KiB of LDS, one workgroup per CU
+    if (nk > 0) stage_in(lds0, 0);
+    if (nk > 1) stage_in(lds1, 1);
+    for (int kt = 0; kt < nk; kt += 4) {
+      __syncthreads();
+      if (kt + 2 < nk) stage_in(lds2, kt + 2);
+      if (kt + 3 < nk) stage_in(lds3, kt + 3);
+      compute_tile<T, ATR, BTR>(lds0, lds0 + TILE_BYTES, acc, wm, wn, lane, is_half(kt));
+      if (kt + 1 < nk) compute_tile<T, ATR, BTR>(lds1, lds1 + TILE_BYTES, acc, wm, wn, lane, is_half(kt + 1));
+      if (kt + 2 < nk) {
+        __syncthreads();
+        if (kt + 4 < nk) stage_in(lds0, kt + 4);
+        if (kt + 5 < nk) stage_in(lds1, kt + 5);
+        compute_tile<T, ATR, BTR>(lds2, lds2 + TILE_BYTES, acc, wm, wn, lane, is_half(kt + 2));
+        if (kt + 3 < nk) compute_tile<T, ATR, BTR>(lds3, lds3 + TILE_BYTES, acc, wm, wn, lane, is_half(kt + 3));
+      }
+    }
   } else {
     // 4-stage ring for latency-bound launches (few workgroups, one per CU): three tiles of DMA stay in
     // flight across the barriers.  Each wave first waits for ITS OWN pieces of tile kt with a counted
@@ -423,7 +445,189 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
       if (kt + 3 < nk) phase(lds3, lds2, kt + 3);
     }
   }
+  if (g.dbg == 3) { if (acc[0][0][0] == 123.456f) g.C[0] = 1; return; }
   epilogue_staged<T, TO>(g, acc, lds0, lds1, z1, z2, sp, m0, n0, wm, wn, lane, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64x64-tile kernel for launches that cannot fill the chip with 128x128 tiles (the M = B*Lq = 320-row
+// products of the decoder / query streams: 12 big tiles on 256 CUs).  Same LDS-DMA staging and the same
+// two operand layouts, but a workgroup owns a 64x64 tile (4 waves as 2x2, 32x32 each), so the launch has 4x
+// the workgroups, several of them share a CU (32 KiB of LDS each) and hide each other's load and LDS
+// latency, and M = 320 is an exact multiple of the tile.  Measured with BIST_GEMM_DBG on the 128 tile at
+// 12 workgroups: 1.8 us launch + 5 us serial K loop (one wave per SIMD) + 4 us epilogue.
+//   "N" image: [64 rows][128 B of K], chunk ^ ((row>>1)&7)                    (as the 128 tile)
+//   "T" image, bf16: [64 K-rows][128 B = 64 elements], piece ^ 2*f(k), f = ((k>>1)&1) | 2*((k>>3)&1)
+//   "T" image, f32:  [32 K-rows][256 B = 64 elements], piece ^ 4*((k>>2)&3)
+// ---------------------------------------------------------------------------------------------
+constexpr int T64 = 64;
+constexpr int T64_BYTES = T64 * ROW_BYTES;      // 8 KiB per operand per stage
+
+template <typename T, bool TR>
+__device__ __forceinline__ uint4 load_frag64(const char* tile, int row0, int ks, int lane) {
+  const int x = lane & 15, kg = lane >> 4;
+  if constexpr (!TR) {
+    const int off = ((ks * 4 + kg) ^ (x >> 1)) << 4;
+    return *reinterpret_cast<const uint4*>(tile + (row0 + x) * ROW_BYTES + off);
+  } else if constexpr (sizeof(T) == 2) {
+    const int q = x >> 2, p = x & 3;
+    const int kb = ks * 32 + kg * 8;
+    const int c = (row0 >> 3) + (p >> 1);
+    const int pos = c ^ (((q >> 1) | ((kg & 1) << 1)) << 1);
+    const char* a0 = tile + (kb + q) * 128 + pos * 16 + (p & 1) * 8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 128));
+    uint4 r;
+    r.x = __builtin_bit_cast(uint2, lo).x; r.y = __builtin_bit_cast(uint2, lo).y;
+    r.z = __builtin_bit_cast(uint2, hi).x; r.w = __builtin_bit_cast(uint2, hi).y;
+    return r;
+  } else {
+    const int kb = ks * 16 + kg * 4;
+    const int pos = ((row0 + x) >> 2) ^ (kg << 2);
+    const char* a0 = tile + kb * 256 + pos * 16 + (x & 3) * 4;
+    uint4 r;
+    r.x = *reinterpret_cast<const unsigned*>(a0);
+    r.y = *reinterpret_cast<const unsigned*>(a0 + 256);
+    r.z = *reinterpret_cast<const unsigned*>(a0 + 512);
+    r.w = *reinterpret_cast<const unsigned*>(a0 + 768);
+    return r;
+  }
+}
+
+// Wave w issues instructions j = 0..1 into LDS bytes [(w*2+j)*1024, +1024) of the operand tile.
+template <typename T, bool TR>
+struct Stager64 {
+  const char* p[2];
+  long fix[2];
+  long step;
+  __device__ __forceinline__ void init(const char* base, long rs, long ks_stride, int r0, int rows, int k0, int w, int lane) {
+    constexpr int SZ = (int)sizeof(T);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int inst = w * 2 + j;
+      if constexpr (!TR) {
+        const int row = inst * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((j & 1) << 2) | (lane >> 4));
+        const int rr = min(r0 + row, rows - 1);
+        p[j] = base + ((long)rr * rs + k0) * SZ + chunk * 16;
+        fix[j] = chunk >= 4 ? -64 : 0;
+      } else if constexpr (SZ == 2) {
+        const int k = inst * 8 + (lane >> 3);
+        int c = (lane & 7) ^ ((((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1);
+        if (r0 + c * 8 >= rows) c = 0;
+        p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 8) * SZ;
+        fix[j] = k >= 32 ? -32 * ks_stride * SZ : 0;
+      } else {
+        const int k = inst * 4 + (lane >> 4);
+        int c = (lane & 15) ^ ((inst & 3) << 2);
+        if (r0 + c * 4 >= rows) c = 0;
+        p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 4) * SZ;
+        fix[j] = k >= 16 ? -16 * ks_stride * SZ : 0;
+      }
+    }
+    step = TR ? (long)(ROW_BYTES / SZ) * ks_stride * SZ : ROW_BYTES;
+  }
+  __device__ __forceinline__ void issue(char* lds_tile, int w, bool half = false) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p[j] + (half ? fix[j] : 0)), LDS_PTR(lds_tile + (w * 2 + j) * 1024), 16, 0, 0);
+      p[j] += step;
+    }
+  }
+};
+
+template <typename T, typename TO, bool ATR, bool BTR, bool PAIR>
+__global__ __launch_bounds__(NTHREADS) void gemm_t64_kernel(const GemmK g) {
+  __shared__ __attribute__((aligned(16))) char lds0[2 * T64_BYTES];   // [A|B]; also the f32 [64][64] epilogue image
+  __shared__ __attribute__((aligned(16))) char lds1[2 * T64_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds2[PAIR ? 2 * T64_BYTES : 16];   // PAIR: every barrier hands over two K tiles
+  __shared__ __attribute__((aligned(16))) char lds3[PAIR ? 2 * T64_BYTES : 16];
+  int z, sp, tm, tn;
+  tile_coords(g, z, sp, tm, tn);
+  const int z1 = z / g.batch2, z2 = z % g.batch2;
+  const int m0 = tm * T64, n0 = tn * T64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  constexpr int BK = ROW_BYTES / (int)sizeof(T);
+  const int nk = (g.K + BK - 1) / BK;
+  const bool half_tail = (g.K % BK) != 0;
+
+  Stager64<T, ATR> sa;
+  Stager64<T, BTR> sb;
+  sa.init(g.A + (z1 * g.a_bs1 + z2 * g.a_bs2) * (long)sizeof(T), g.a_rs, g.a_ks, m0, g.M, 0, w, lane);
+  sb.init(g.B + (z1 * g.b_bs1 + z2 * g.b_bs2) * (long)sizeof(T), g.b_rs, g.b_ks, n0, g.N, 0, w, lane);
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto is_half = [&](int kt) { return half_tail && kt == nk - 1; };
+  auto stage_in = [&](char* st, int kt) { const bool hf = is_half(kt); sa.issue(st, w, hf); sb.issue(st + T64_BYTES, w, hf); };
+  auto compute = [&](const char* st, bool half) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1 && half) break;
+      uint4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = load_frag64<T, ATR>(st, wm * 32 + i * 16, ks, lane);
+        bf[i] = load_frag64<T, BTR>(st + T64_BYTES, wn * 32 + i * 16, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) Mma<T>::step(af[i], bf[j], acc[i][j]);
+    }
+  };
+  stage_in(lds0, 0);
+  if constexpr (!PAIR) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      __syncthreads();
+      if (kt + 1 < nk) stage_in(lds1, kt + 1);
+      compute(lds0, is_half(kt));
+      if (kt + 1 < nk) {
+        __syncthreads();
+        if (kt + 2 < nk) stage_in(lds0, kt + 2);
+        compute(lds1, is_half(kt + 1));
+      }
+    }
+  } else {
+    if (nk > 1) stage_in(lds1, 1);
+    for (int kt = 0; kt < nk; kt += 4) {
+      __syncthreads();
+      if (kt + 2 < nk) stage_in(lds2, kt + 2);
+      if (kt + 3 < nk) stage_in(lds3, kt + 3);
+      compute(lds0, is_half(kt));
+      if (kt + 1 < nk) compute(lds1, is_half(kt + 1));
+      if (kt + 2 < nk) {
+        __syncthreads();
+        if (kt + 4 < nk) stage_in(lds0, kt + 4);
+        if (kt + 5 < nk) stage_in(lds1, kt + 5);
+        compute(lds2, is_half(kt + 2));
+        if (kt + 3 < nk) compute(lds3, is_half(kt + 3));
+      }
+    }
+  }
+  // epilogue: accumulators -> f32 [64][64] image in lds0 (16-byte chunk ^ 4*((row>>2)&3)), then 16-byte rows out
+  __syncthreads();
+  {
+    float* buf = reinterpret_cast<float*>(lds0);
+    const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * 32 + i * 16 + lg * 4 + r, col = wn * 32 + j * 16 + lr;
+          const int pos = (col >> 2) ^ (((row >> 2) & 3) << 2);
+          buf[row * 64 + pos * 4 + (col & 3)] = acc[i][j][r];
+        }
+  }
+  __syncthreads();
+  stream_out<T, TO, false, 64>(g, lds0, lds0, z1, z2, 0, m0, n0, tid);
 }
 
 // sums the split-K slabs and applies the epilogue: one thread per output element
@@ -642,10 +846,10 @@ int launch_skinny(const BistGemm* g, const GemmK& k, int kind, hipStream_t st) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-struct Plan { bool fast; bool atr, btr; int split; size_t ws_bytes; int stages; };
+struct Plan { bool fast; bool atr, btr; int split; size_t ws_bytes; int stages; bool t64; };
 
 Plan make_plan(const BistGemm* g) {
-  Plan p{false, false, false, 1, 0, 2};
+  Plan p{false, false, false, 1, 0, 2, false};
   const long sz = g->in_dtype == BIST_BF16 ? 2 : 4;
   const long bk = ROW_BYTES / sz, piece = 16 / sz;
   auto al16 = [&](long elems) { return (elems * sz) % 16 == 0; };
@@ -661,6 +865,8 @@ Plan make_plan(const BistGemm* g) {
   if (!ok) return p;
   const long tiles = (long)((g->M + BM - 1) / BM) * ((g->N + BN - 1) / BN) * g->batch1 * g->batch2;
   const long nk = (g->K + bk - 1) / bk;
+  static const int no_t64 = [] { const char* e = getenv("BIST_GEMM_NO_T64"); return e ? atoi(e) : 0; }();      // tuning aid
+  if (!no_t64 && tiles < 128 && nk <= 64) { p.t64 = true; return p; }      // cannot fill half the chip: 64x64 tiles, no split
   if (g->workspace && tiles < 192 && nk >= 16) {
     long s = (512 + tiles - 1) / tiles;
     if (s > nk / 4) s = nk / 4;
@@ -671,7 +877,13 @@ Plan make_plan(const BistGemm* g) {
   // The 4-stage ring (128 KiB LDS, one workgroup per CU) measured SLOWER than the 2-stage kernel at two
   // workgroups per CU on every shape of this path (scripts/bench_gemm.py, round 1), so it is opt-in only.
   static const int force_stages = [] { const char* e = getenv("BIST_GEMM_STAGES"); return e ? atoi(e) : 0; }();   // tuning aid
-  if (force_stages == 2 || force_stages == 4) p.stages = force_stages;
+  {
+    // few workgroups (at most one per CU) and several K tiles: the paired double buffer halves the barrier chain
+    const long wgs = tiles * p.split;
+    const long nk_per = ((g->K + bk - 1) / bk) / p.split;
+    if (wgs <= 256 && nk_per >= 3) p.stages = 22;
+  }
+  if (force_stages == 2 || force_stages == 4 || force_stages == 22) p.stages = force_stages;
   return p;
 }
 
@@ -687,8 +899,27 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
 #define FAST(ATR_, BTR_)                                                                                         \
   do {                                                                                                           \
     if (p.stages == 4) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, ATR_, BTR_, 4>), grid, block, 0, st, k);      \
+    else if (p.stages == 22) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, ATR_, BTR_, 22>), grid, block, 0, st, k); \
     else hipLaunchKernelGGL((gemm_fast_kernel<T, TO, ATR_, BTR_, 2>), grid, block, 0, st, k);                    \
   } while (0)
+  if (p.fast && p.t64) {
+    k.tiles_m = (g->M + T64 - 1) / T64; k.tiles_n = (g->N + T64 - 1) / T64;
+    const dim3 g64((unsigned)((long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2));
+    const long bk64 = ROW_BYTES / (long)sizeof(T);
+    const bool pair = (g->K + bk64 - 1) / bk64 >= 12;           // long K: halve the barrier chain (64 KiB of LDS)
+#define GO64(ATR_, BTR_)                                                                                  \
+  do {                                                                                                    \
+    if (pair) hipLaunchKernelGGL((gemm_t64_kernel<T, TO, ATR_, BTR_, true>), g64, block, 0, st, k);       \
+    else hipLaunchKernelGGL((gemm_t64_kernel<T, TO, ATR_, BTR_, false>), g64, block, 0, st, k);           \
+  } while (0)
+    if (!p.atr && !p.btr) GO64(false, false);
+    else if (!p.atr && p.btr) GO64(false, true);
+    else if (p.atr && !p.btr) GO64(true, false);
+    else GO64(true, true);
+#undef GO64
+    BIST_LAUNCH_CHECK("bist_gemm(64-tile)");
+    return BIST_OK;
+  }
   if (!p.fast) hipLaunchKernelGGL((gemm_gen_kernel<T, TO>), grid, block, 0, st, k);
   else if (!p.atr && !p.btr) FAST(false, false);
   else if (!p.atr && p.btr) FAST(false, true);
@@ -735,6 +966,7 @@ extern "C" int bist_gemm(const BistGemm* g, void* stream) {
   k.drop_p = g->drop_p; k.drop_seed = g->drop_seed; k.drop_ctr = (const unsigned long long*)g->drop_ctr;
   k.tiles_m = (g->M + BM - 1) / BM; k.tiles_n = (g->N + BN - 1) / BN;
   k.split_k = 1; k.ws = nullptr;
+  { static const int dbg = [] { const char* e = getenv("BIST_GEMM_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
   {
     const long so = g->out_dtype == BIST_BF16 ? 2 : 4;
     auto al = [&](long elems) { return (elems * so) % 16 == 0; };

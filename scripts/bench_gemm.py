@@ -9,6 +9,12 @@ SHAPES = [  # (name, M, N, K, layout)  layout: NT = x.W^T, NN = dy.W, TN = dy^T.
     ("small fwd  M=320  N=512  K=2048", 320, 512, 2048, "NT"),
     ("small fwd  M=320  N=1536 K=512", 320, 1536, 512, "NT"),
     ("small fwd  M=1280 N=512  K=512", 1280, 512, 512, "NT"),
+    ("small fwd  M=320  N=2048 K=512", 320, 2048, 512, "NT"),
+    ("small dx   M=320  N=512  K=512", 320, 512, 512, "NN"),
+    ("small dx   M=320  N=512  K=2048", 320, 512, 2048, "NN"),
+    ("small dx   M=320  N=2048 K=512", 320, 2048, 512, "NN"),
+    ("dW small   M=512 N=2048 K=320", 512, 2048, 320, "TN"),
+    ("dW small   M=2048 N=512 K=320", 2048, 512, 320, "TN"),
     ("P0   B=16  M=25088 N=512 K=2048", 25088, 512, 2048, "NT"),
     ("P0   B=64  M=100352 N=512 K=2048", 100352, 512, 2048, "NT"),
     ("V    B=16  M=25088 N=512 K=512", 25088, 512, 512, "NT"),
@@ -20,6 +26,8 @@ SHAPES = [  # (name, M, N, K, layout)  layout: NT = x.W^T, NN = dy.W, TN = dy^T.
     ("dW small   M=512 N=512 K=320", 512, 512, 320, "TN"),
 ]
 dt = torch.bfloat16
+if os.environ.get('SMALL'):
+    SHAPES = [x for x in SHAPES if 'small' in x[0]]
 for name, M, N, K, lay in SHAPES:
     if lay == "NT":
         a, b = torch.randn(M, K, device="cuda").to(dt), torch.randn(N, K, device="cuda").to(dt)
