@@ -630,6 +630,152 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_kernel(const GemmK g) {
   stream_out<T, TO, false, 64>(g, lds0, lds0, z1, z2, 0, m0, n0, tid);
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// The fragment reads of load_frag64 as inline asm on 32-bit LDS addresses (same geometry, same swizzles).  issue()
+// starts the read(s); the values may only be touched after a manual s_waitcnt lgkmcnt and tie(), which pins the
+// use behind that wait.
+template <typename T, bool TR> struct FragRd;
+template <typename T> struct FragRd<T, false> {           // K-contiguous image [64 rows][128 B]
+  static constexpr int NREAD = 1;
+  u32x4 v;
+  __device__ __forceinline__ void issue(unsigned tile, int row0, int ks, int lane) {
+    const int x = lane & 15, kg = lane >> 4;
+    const unsigned a = tile + (unsigned)((row0 + x) * ROW_BYTES + (((ks * 4 + kg) ^ (x >> 1)) << 4));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  }
+  __device__ __forceinline__ void tie() { asm volatile("" : "+v"(v)); }
+  __device__ __forceinline__ uint4 get() const { return __builtin_bit_cast(uint4, v); }
+};
+template <> struct FragRd<bf16_t, true> {                  // [64 K-rows][128 B], transposing 64-bit reads
+  static constexpr int NREAD = 2;
+  u32x2 lo, hi;
+  __device__ __forceinline__ void issue(unsigned tile, int row0, int ks, int lane) {
+    const int x = lane & 15, kg = lane >> 4, q = x >> 2, p = x & 3;
+    const int kb = ks * 32 + kg * 8;
+    const int c = (row0 >> 3) + (p >> 1);
+    const int pos = c ^ (((q >> 1) | ((kg & 1) << 1)) << 1);
+    const unsigned a = tile + (unsigned)((kb + q) * 128 + pos * 16 + (p & 1) * 8);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(hi) : "v"(a) : "memory");
+  }
+  __device__ __forceinline__ void tie() { asm volatile("" : "+v"(lo), "+v"(hi)); }
+  __device__ __forceinline__ uint4 get() const { uint4 r; r.x = lo.x; r.y = lo.y; r.z = hi.x; r.w = hi.y; return r; }
+};
+template <> struct FragRd<float, true> {                   // [32 K-rows][256 B], four 32-bit reads one K-row apart
+  static constexpr int NREAD = 4;
+  unsigned r0, r1, r2, r3;
+  __device__ __forceinline__ void issue(unsigned tile, int row0, int ks, int lane) {
+    const int x = lane & 15, kg = lane >> 4;
+    const int kb = ks * 16 + kg * 4;
+    const int pos = ((row0 + x) >> 2) ^ (kg << 2);
+    const unsigned a = tile + (unsigned)(kb * 256 + pos * 16 + (x & 3) * 4);
+    asm volatile("ds_read_b32 %0, %1" : "=v"(r0) : "v"(a) : "memory");
+    asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(r1) : "v"(a) : "memory");
+    asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(r2) : "v"(a) : "memory");
+    asm volatile("ds_read_b32 %0, %1 offset:768" : "=v"(r3) : "v"(a) : "memory");
+  }
+  __device__ __forceinline__ void tie() { asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)); }
+  __device__ __forceinline__ uint4 get() const { uint4 r; r.x = r0; r.y = r1; r.z = r2; r.w = r3; return r; }
+};
+
+// All-in-flight variant of the 64-tile kernel for a compile-time number of K tiles (NK = 5: K = 320, NK = 8:
+// K = 512 in bf16 -- the d_model-wide products of the hot path).  A small product in the middle of a training
+// step finds its weight in HBM (the parameters alone exceed the 256 MiB MALL), so a 2-deep pipeline pays the
+// DRAM latency on every K tile (scripts/bench_chain.py: 5.3 us hot -> 9.0 us cold).  Here every tile has its
+// own LDS stage (NK x 16 KiB), all DMAs are issued up front, and tile t is consumed as soon as each wave's own
+// share of it has landed (counted vmcnt, 4 DMA instructions per tile per wave) and the barrier has published
+// the other waves' shares: the DRAM latency is paid once.
+template <typename T, typename TO, bool ATR, bool BTR, int NK>
+__global__ __launch_bounds__(NTHREADS) void gemm_t64_pre_kernel(const GemmK g) {
+  // the f32 epilogue image is its own (largest, hence first-placed) LDS object: the object at LDS address 0 loses
+  // its identity in the compiler's LDS-DMA tracking and would make the first fragment read wait for ALL DMAs
+  __shared__ __attribute__((aligned(16))) char ebuf[2 * T64_BYTES + 64];
+  __shared__ __attribute__((aligned(16))) char l0[2 * T64_BYTES];
+  __shared__ __attribute__((aligned(16))) char l1[2 * T64_BYTES];
+  __shared__ __attribute__((aligned(16))) char l2[2 * T64_BYTES];
+  __shared__ __attribute__((aligned(16))) char l3[2 * T64_BYTES];
+  __shared__ __attribute__((aligned(16))) char l4[2 * T64_BYTES];
+  __shared__ __attribute__((aligned(16))) char l5[NK > 5 ? 2 * T64_BYTES : 16];
+  __shared__ __attribute__((aligned(16))) char l6[NK > 6 ? 2 * T64_BYTES : 16];
+  __shared__ __attribute__((aligned(16))) char l7[NK > 7 ? 2 * T64_BYTES : 16];
+  int z, sp, tm, tn;
+  tile_coords(g, z, sp, tm, tn);
+  const int z1 = z / g.batch2, z2 = z % g.batch2;
+  const int m0 = tm * T64, n0 = tn * T64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+
+  Stager64<T, ATR> sa;
+  Stager64<T, BTR> sb;
+  sa.init(g.A + (z1 * g.a_bs1 + z2 * g.a_bs2) * (long)sizeof(T), g.a_rs, g.a_ks, m0, g.M, 0, w, lane);
+  sb.init(g.B + (z1 * g.b_bs1 + z2 * g.b_bs2) * (long)sizeof(T), g.b_rs, g.b_ks, n0, g.N, 0, w, lane);
+#define PRE_IN(L_, t_) if constexpr ((t_) < NK) { sa.issue(L_, w); sb.issue(L_ + T64_BYTES, w); }
+  PRE_IN(l0, 0) PRE_IN(l1, 1) PRE_IN(l2, 2) PRE_IN(l3, 3) PRE_IN(l4, 4) PRE_IN(l5, 5) PRE_IN(l6, 6) PRE_IN(l7, 7)
+#undef PRE_IN
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Fragment reads as inline asm (FragRd): the compiler's waitcnt pass would make the first LDS read wait for EVERY
+  // DMA in flight (vmcnt(0)); with the reads opaque to it, the counted waits below are the only ones.  All reads
+  // of a tile (2 K steps x (2 A + 2 B)) are issued together; the second K step's land under the first's MFMAs.
+  const unsigned lds_a0 = (unsigned)(size_t)LDS_PTR(l0);
+  auto compute = [&](unsigned tile_off) {
+    FragRd<T, ATR> af[2][2];
+    FragRd<T, BTR> bf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[ks][i].issue(lds_a0 + tile_off, wm * 32 + i * 16, ks, lane);
+        bf[ks][i].issue(lds_a0 + tile_off + T64_BYTES, wn * 32 + i * 16, ks, lane);
+      }
+    constexpr int SECOND = 2 * FragRd<T, ATR>::NREAD + 2 * FragRd<T, BTR>::NREAD;     // reads of K step 1 still in flight
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(SECOND < 15 ? SECOND : 15) : "memory");  // the counter saturates at 15
+    af[0][0].tie(); af[0][1].tie(); bf[0][0].tie(); bf[0][1].tie();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) Mma<T>::step(af[0][i].get(), bf[0][j].get(), acc[i][j]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    af[1][0].tie(); af[1][1].tie(); bf[1][0].tie(); bf[1][1].tie();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) Mma<T>::step(af[1][i].get(), bf[1][j].get(), acc[i][j]);
+  };
+#define PRE_USE(L_, t_)                                                              \
+  if constexpr ((t_) < NK) {                                                         \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NK - 1 - (t_))) : "memory");       \
+    __builtin_amdgcn_s_barrier();                                                    \
+    asm volatile("" ::: "memory");                                                   \
+    compute((unsigned)(size_t)LDS_PTR(L_) - (unsigned)(size_t)LDS_PTR(l0));          \
+  }
+  PRE_USE(l0, 0) PRE_USE(l1, 1) PRE_USE(l2, 2) PRE_USE(l3, 3) PRE_USE(l4, 4) PRE_USE(l5, 5) PRE_USE(l6, 6) PRE_USE(l7, 7)
+#undef PRE_USE
+  __syncthreads();
+  {
+    float* buf = reinterpret_cast<float*>(ebuf);
+    const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * 32 + i * 16 + lg * 4 + r, col = wn * 32 + j * 16 + lr;
+          const int pos = (col >> 2) ^ (((row >> 2) & 3) << 2);
+          buf[row * 64 + pos * 4 + (col & 3)] = acc[i][j][r];
+        }
+  }
+  __syncthreads();
+  stream_out<T, TO, false, 64>(g, ebuf, ebuf, z1, z2, 0, m0, n0, tid);
+}
+
 // sums the split-K slabs and applies the epilogue: one thread per output element
 template <typename T, typename TO>
 __global__ void splitk_reduce_kernel(const GemmK g, long total) {
@@ -906,10 +1052,15 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
     k.tiles_m = (g->M + T64 - 1) / T64; k.tiles_n = (g->N + T64 - 1) / T64;
     const dim3 g64((unsigned)((long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2));
     const long bk64 = ROW_BYTES / (long)sizeof(T);
-    const bool pair = (g->K + bk64 - 1) / bk64 >= 12;           // long K: halve the barrier chain (64 KiB of LDS)
+    const long nk64 = (g->K + bk64 - 1) / bk64;
+    const bool pair = nk64 >= 12;                               // long K: halve the barrier chain (64 KiB of LDS)
+    static const int no_pre = [] { const char* e = getenv("BIST_GEMM_NO_PRE"); return e ? atoi(e) : 0; }();      // tuning aid
+    const bool whole = g->K % bk64 == 0 && g64.x <= 256 && !no_pre;       // one workgroup per CU: NK x 16 KiB of LDS is free
 #define GO64(ATR_, BTR_)                                                                                  \
   do {                                                                                                    \
-    if (pair) hipLaunchKernelGGL((gemm_t64_kernel<T, TO, ATR_, BTR_, true>), g64, block, 0, st, k);       \
+    if (whole && nk64 == 8) hipLaunchKernelGGL((gemm_t64_pre_kernel<T, TO, ATR_, BTR_, 8>), g64, block, 0, st, k);      \
+    else if (whole && nk64 == 5) hipLaunchKernelGGL((gemm_t64_pre_kernel<T, TO, ATR_, BTR_, 5>), g64, block, 0, st, k); \
+    else if (pair) hipLaunchKernelGGL((gemm_t64_kernel<T, TO, ATR_, BTR_, true>), g64, block, 0, st, k);       \
     else hipLaunchKernelGGL((gemm_t64_kernel<T, TO, ATR_, BTR_, false>), g64, block, 0, st, k);           \
   } while (0)
     if (!p.atr && !p.btr) GO64(false, false);

@@ -11,6 +11,7 @@ enabled each step is a torch.autograd.Function whose backward also runs on the H
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -141,7 +142,7 @@ def drop_args(module) -> dict:
 # ---- branch concurrency: t2s / s2t / caption reasoning are independent chains of small kernels; each gets
 # its own HIP stream (fork = side.wait_stream(main), join = main.wait_stream(side)).  Captured into a
 # hipGraph the forks become parallel branches of the graph.
-CONCURRENT = True
+CONCURRENT = os.environ.get("BIST_CONCURRENT", "1") != "0"      # tuning aid: BIST_CONCURRENT=0 keeps one stream
 _SIDE = {}
 
 

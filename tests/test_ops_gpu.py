@@ -85,7 +85,8 @@ def test_gemm_generic_strides(ops, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
-@pytest.mark.parametrize("M,N,K", [(256, 192, 128), (136, 520, 320), (128, 128, 64), (192, 264, 832), (1288, 1408, 160)])
+@pytest.mark.parametrize("M,N,K", [(256, 192, 128), (136, 520, 320), (128, 128, 64), (192, 264, 832), (1288, 1408, 160),
+                                   (200, 136, 256), (136, 264, 512), (72, 200, 160)])
 def test_gemm_fast_transposed_operands(ops, dtype, tol, M, N, K):
     """row-contiguous operands (the backward products) take the LDS-DMA kernel with the transposing
     fragment reads (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32) -- no generic fallback."""
