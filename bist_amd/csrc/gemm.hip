@@ -23,6 +23,7 @@
 // of tiles: neighbouring tiles share an A row panel, which then stays in that XCD's L2.
 #include "common.hpp"
 #include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 namespace {
@@ -132,10 +133,12 @@ __device__ __forceinline__ void compute_tile(const char* lds_a, const char* lds_
 
 // ---- per-lane LDS-DMA source pointers ---------------------------------------------------------------
 // Wave w issues instructions j = 0..3 into LDS bytes [(w*4+j)*1024, +1024) of the operand tile.
+__device__ uint4 g_zero16;        // 16 zero bytes: the DMA source of every lane that falls past K on a trailing partial tile
+
 template <typename T, bool TR>
 struct Stager {
   const char* p[4];
-  long fix[4];      // byte delta applied on a trailing HALF tile so that no lane reads past the K extent
+  int kofs[4];      // this lane's K offset (elements) inside a tile, per instruction: lanes with kofs >= K remainder read zeros
   long step;
   __device__ __forceinline__ void init(const char* base, long rs, long ks_stride, int r0, int rows, int k0, int w, int lane) {
     constexpr int SZ = (int)sizeof(T);
@@ -147,29 +150,36 @@ struct Stager {
         const int chunk = (lane & 7) ^ (((j & 1) << 2) | (lane >> 4));          // inverse of the read swizzle
         const int rr = min(r0 + row, rows - 1);                                   // tails re-read a valid row
         p[j] = base + ((long)rr * rs + k0) * SZ + chunk * 16;
-        fix[j] = chunk >= 4 ? -64 : 0;
+        kofs[j] = chunk * (16 / SZ);
       } else if constexpr (SZ == 2) {
         const int krow = lane >> 4, k = inst * 4 + krow;
         int c = (lane & 15) ^ (2 * krow) ^ (8 * ((inst >> 1) & 1));
         if (r0 + c * 8 >= rows) c = 0;                                            // rows % 8 == 0: whole piece in or out
         p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 8) * SZ;
-        fix[j] = k >= 32 ? -32 * ks_stride * SZ : 0;
+        kofs[j] = k;
       } else {
         const int krow = lane >> 5, k = inst * 2 + krow;
         int c = (lane & 31) ^ (4 * ((inst >> 1) & 7));
         if (r0 + c * 4 >= rows) c = 0;
         p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 4) * SZ;
-        fix[j] = k >= 16 ? -16 * ks_stride * SZ : 0;
+        kofs[j] = k;
       }
     }
     step = TR ? (long)(ROW_BYTES / SZ) * ks_stride * SZ : ROW_BYTES;
   }
-  __device__ __forceinline__ void issue(char* lds_tile, int w, bool half = false) {
+  __device__ __forceinline__ void issue(char* lds_tile, int w) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(p[j] + (half ? fix[j] : 0)), LDS_PTR(lds_tile + (w * 4 + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p[j]), LDS_PTR(lds_tile + (w * 4 + j) * 1024), 16, 0, 0);
       p[j] += step;
     }
+  }
+  // trailing partial tile: only the first `krem` K elements exist
+  __device__ __forceinline__ void issue_tail(char* lds_tile, int w, int krem) {
+    const char* zp = reinterpret_cast<const char*>(&g_zero16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(kofs[j] < krem ? p[j] : zp), LDS_PTR(lds_tile + (w * 4 + j) * 1024), 16, 0, 0);
   }
 };
 
@@ -370,8 +380,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
   const int wm = w >> 1, wn = w & 1;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
 
-  const int nk_all = (g.K + BK - 1) / BK;                 // a trailing half tile counts as one
-  const bool half_tail = (g.K % BK) != 0;
+  const int nk_all = (g.K + BK - 1) / BK;                 // a trailing partial tile counts as one
+  const int k_tail = g.K % BK;                            // != 0: the last tile holds only k_tail K elements (rest zero-filled)
   const int kt0 = (int)((long)nk_all * sp / g.split_k), kt1 = (int)((long)nk_all * (sp + 1) / g.split_k);
   const int nk = g.dbg == 2 ? 0 : kt1 - kt0;
 
@@ -386,8 +396,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto is_half = [&](int kt) { return half_tail && (kt0 + kt == nk_all - 1); };
-  auto stage_in = [&](char* st, int kt) { const bool hf = is_half(kt); sa.issue(st, w, hf); sb.issue(st + TILE_BYTES, w, hf); };
+  auto is_tail = [&](int kt) { return k_tail != 0 && (kt0 + kt == nk_all - 1); };
+  auto is_half = [&](int kt) { return is_tail(kt) && k_tail <= BK / 2; };      // second K step is all zeros: skip it
+  auto stage_in = [&](char* st, int kt) {
+    if (is_tail(kt)) { sa.issue_tail(st, w, k_tail); sb.issue_tail(st + TILE_BYTES, w, k_tail); }
+    else { sa.issue(st, w); sb.issue(st + TILE_BYTES, w); }
+  };
 
   if constexpr (NS == 2) {
     if (nk > 0) stage_in(lds0, 0);
@@ -498,7 +512,7 @@ __device__ __forceinline__ uint4 load_frag64(const char* tile, int row0, int ks,
 template <typename T, bool TR>
 struct Stager64 {
   const char* p[2];
-  long fix[2];
+  int kofs[2];
   long step;
   __device__ __forceinline__ void init(const char* base, long rs, long ks_stride, int r0, int rows, int k0, int w, int lane) {
     constexpr int SZ = (int)sizeof(T);
@@ -510,29 +524,35 @@ struct Stager64 {
         const int chunk = (lane & 7) ^ (((j & 1) << 2) | (lane >> 4));
         const int rr = min(r0 + row, rows - 1);
         p[j] = base + ((long)rr * rs + k0) * SZ + chunk * 16;
-        fix[j] = chunk >= 4 ? -64 : 0;
+        kofs[j] = chunk * (16 / SZ);
       } else if constexpr (SZ == 2) {
         const int k = inst * 8 + (lane >> 3);
         int c = (lane & 7) ^ ((((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1);
         if (r0 + c * 8 >= rows) c = 0;
         p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 8) * SZ;
-        fix[j] = k >= 32 ? -32 * ks_stride * SZ : 0;
+        kofs[j] = k;
       } else {
         const int k = inst * 4 + (lane >> 4);
         int c = (lane & 15) ^ ((inst & 3) << 2);
         if (r0 + c * 4 >= rows) c = 0;
         p[j] = base + ((long)(k0 + k) * ks_stride + r0 + c * 4) * SZ;
-        fix[j] = k >= 16 ? -16 * ks_stride * SZ : 0;
+        kofs[j] = k;
       }
     }
     step = TR ? (long)(ROW_BYTES / SZ) * ks_stride * SZ : ROW_BYTES;
   }
-  __device__ __forceinline__ void issue(char* lds_tile, int w, bool half = false) {
+  __device__ __forceinline__ void issue(char* lds_tile, int w) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(p[j] + (half ? fix[j] : 0)), LDS_PTR(lds_tile + (w * 2 + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p[j]), LDS_PTR(lds_tile + (w * 2 + j) * 1024), 16, 0, 0);
       p[j] += step;
     }
+  }
+  __device__ __forceinline__ void issue_tail(char* lds_tile, int w, int krem) {
+    const char* zp = reinterpret_cast<const char*>(&g_zero16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(kofs[j] < krem ? p[j] : zp), LDS_PTR(lds_tile + (w * 2 + j) * 1024), 16, 0, 0);
   }
 };
 
@@ -550,7 +570,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_kernel(const GemmK g) {
   const int wm = w >> 1, wn = w & 1;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
   const int nk = (g.K + BK - 1) / BK;
-  const bool half_tail = (g.K % BK) != 0;
+  const int k_tail = g.K % BK;
 
   Stager64<T, ATR> sa;
   Stager64<T, BTR> sb;
@@ -563,8 +583,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_kernel(const GemmK g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto is_half = [&](int kt) { return half_tail && kt == nk - 1; };
-  auto stage_in = [&](char* st, int kt) { const bool hf = is_half(kt); sa.issue(st, w, hf); sb.issue(st + T64_BYTES, w, hf); };
+  auto is_tail = [&](int kt) { return k_tail != 0 && kt == nk - 1; };
+  auto is_half = [&](int kt) { return is_tail(kt) && k_tail <= BK / 2; };
+  auto stage_in = [&](char* st, int kt) {
+    if (is_tail(kt)) { sa.issue_tail(st, w, k_tail); sb.issue_tail(st + T64_BYTES, w, k_tail); }
+    else { sa.issue(st, w); sb.issue(st + T64_BYTES, w); }
+  };
   auto compute = [&](const char* st, bool half) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1004,7 +1028,10 @@ Plan make_plan(const BistGemm* g) {
     if (rs == 1 && al16(ks) && rows % piece == 0) { tr = true; return true; }     // row-contiguous
     return false;
   };
-  const bool ok = g->K % (bk / 2) == 0 && layout_ok(g->a_rs, g->a_ks, g->M, p.atr) && layout_ok(g->b_rs, g->b_ks, g->N, p.btr) &&
+  // a K-contiguous operand is staged in 16-byte pieces along K: K must be whole pieces (any K for row-contiguous ones);
+  // a trailing partial K tile is zero-filled by the stager
+  const bool lay = layout_ok(g->a_rs, g->a_ks, g->M, p.atr) && layout_ok(g->b_rs, g->b_ks, g->N, p.btr);
+  const bool ok = lay && ((p.atr && p.btr) || g->K % piece == 0) &&
                   al16(g->a_bs1) && al16(g->a_bs2) && al16(g->b_bs1) && al16(g->b_bs2) &&
                   ((uintptr_t)g->A % 16 == 0) && ((uintptr_t)g->B % 16 == 0);
   p.fast = ok;
@@ -1071,7 +1098,12 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
     BIST_LAUNCH_CHECK("bist_gemm(64-tile)");
     return BIST_OK;
   }
-  if (!p.fast) hipLaunchKernelGGL((gemm_gen_kernel<T, TO>), grid, block, 0, st, k);
+  if (!p.fast) {
+    static const bool trace = getenv("BIST_GEMM_TRACE") != nullptr;      // development aid: which shapes miss the fast paths
+    if (trace) fprintf(stderr, "bist_gemm generic: M=%d N=%d K=%d batch=%dx%d a=(%ld,%ld) b=(%ld,%ld) ldc=%ld in=%d out=%d\n", g->M, g->N, g->K,
+                       g->batch1, g->batch2, g->a_rs, g->a_ks, g->b_rs, g->b_ks, g->ldc, g->in_dtype, g->out_dtype);
+    hipLaunchKernelGGL((gemm_gen_kernel<T, TO>), grid, block, 0, st, k);
+  }
   else if (!p.atr && !p.btr) FAST(false, false);
   else if (!p.atr && p.btr) FAST(false, true);
   else if (p.atr && !p.btr) FAST(true, false);

@@ -42,8 +42,9 @@ def _q(x, dtype):
     return x.to(dtype).double()
 
 
-CASES = [  # (M, N, K) -- K multiples of 64 take the LDS-DMA kernel for both dtypes
+CASES = [  # (M, N, K) -- K multiples of 8 take the LDS-DMA kernels for both dtypes
     (128, 128, 64), (300, 200, 128), (77, 513, 192), (1, 5, 64), (257, 129, 512), (320, 192, 1056), (1300, 1200, 96),
+    (320, 192, 3000), (130, 70, 200), (64, 64, 8),     # K tails: the stager zero-fills the trailing partial tile
 ]
 
 
@@ -86,7 +87,7 @@ def test_gemm_generic_strides(ops, dtype, tol):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
 @pytest.mark.parametrize("M,N,K", [(256, 192, 128), (136, 520, 320), (128, 128, 64), (192, 264, 832), (1288, 1408, 160),
-                                   (200, 136, 256), (136, 264, 512), (72, 200, 160)])
+                                   (200, 136, 256), (136, 264, 512), (72, 200, 160), (1024, 512, 400), (72, 136, 40)])
 def test_gemm_fast_transposed_operands(ops, dtype, tol, M, N, K):
     """row-contiguous operands (the backward products) take the LDS-DMA kernel with the transposing
     fragment reads (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32) -- no generic fallback."""
