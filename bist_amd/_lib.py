@@ -30,6 +30,10 @@ class BistGemm(C.Structure):
     ]
 
 
+class BistColSum(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64), ("N", C.c_int32), ("ldx", C.c_int64)]
+
+
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); exactly the declarations of include/bist_hip.h
@@ -56,7 +60,8 @@ SIGNATURES = {
     "bist_epilogue_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _I64, _I32, _F, C.c_uint64, _P, _I32, _P]),
     "bist_group_sum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
     "bist_col_sum_acc": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
-    "bist_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _I64, _I64, _F, _I32, _P]),
+    "bist_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _I64, _I64, _F, _P, _I64, _I32, _P]),
+    "bist_col_sum_multi": (C.c_int, [C.POINTER(BistColSum), _I32, _I32, _P]),
     "bist_embed_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),
     "bist_fuse_modalities_bwd": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(C.c_void_p), _I64, _I32, _I32, _I32, _P]),
     "bist_mha_core_bwd": (C.c_int, [_P] * 9 + [_I32] * 5 + [_I64] * 16 + [_F, _I32, _P]),

@@ -106,7 +106,10 @@ class LinearFn(Function):
                 ops.gemm(dz, x2, dw, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=K, alpha=alpha)
         if has_bias and ctx.needs_input_grad[2]:
             acc = ctx.b_dst if ctx.b_dst is not None else _f32_zeros((N,), dz)
-            check(lib.bist_col_sum_acc(dz.data_ptr(), acc.data_ptr(), M, N, N, dtype_code(dz.dtype), _stream()), "bist_col_sum_acc")
+            if ctx.b_dst is not None and ops.COLSUM_QUEUE is not None:
+                ops.COLSUM_QUEUE.append((dz, acc, M, N))     # the trainer sums all bias gradients in a few batched launches
+            else:
+                check(lib.bist_col_sum_acc(dz.data_ptr(), acc.data_ptr(), M, N, N, dtype_code(dz.dtype), _stream()), "bist_col_sum_acc")
             db = None if ctx.b_dst is not None else _to_dtype_from_f32(acc, bias_dtype)
         return dx, dw, db, dres, None, None, None, None, None, None
 
@@ -264,6 +267,34 @@ class BmmNNFn(Function):
 # ----------------------------------------------------------------------------------------------
 # row-wise steps
 # ----------------------------------------------------------------------------------------------
+def _ln_backward(ctx, dy, dres):
+    x, a = ctx.saved_tensors
+    eps, bdt = ctx.cfg
+    d = x.shape[-1]
+    x2 = x.reshape(-1, d)
+    if dy is None:                          # only the residual branch carried a gradient
+        dy = torch.zeros_like(x)
+    dy2 = dy.reshape(-1, d)
+    if dy2.stride(1) != 1:
+        dy2 = dy2.contiguous()
+    add2 = None
+    if dres is not None:
+        add2 = dres.reshape(-1, d)
+        if add2.stride(1) != 1 or add2.dtype != x.dtype:
+            add2 = add2.to(x.dtype).contiguous()
+    dx = torch.empty(x2.shape, device=x.device, dtype=x.dtype)
+    direct = ctx.a_dst is not None and ctx.b_dst is not None
+    da, db = (ctx.a_dst, ctx.b_dst) if direct else (_f32_zeros((d,), x), _f32_zeros((d,), x))
+    check(lib.bist_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), a.data_ptr(), dx.data_ptr(), da.data_ptr(), db.data_ptr(),
+                                 x2.shape[0], d, dy2.stride(0), x2.stride(0), d, eps,
+                                 add2.data_ptr() if add2 is not None else None, add2.stride(0) if add2 is not None else 0,
+                                 dtype_code(x.dtype), _stream()),
+          "bist_layernorm_bwd")
+    if direct:
+        return dx.view(x.shape), None, None, None
+    return dx.view(x.shape), _to_dtype_from_f32(da, a.dtype), _to_dtype_from_f32(db, bdt), None
+
+
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, a, b, eps):
@@ -274,22 +305,25 @@ class LayerNormFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, a = ctx.saved_tensors
-        eps, bdt = ctx.cfg
-        d = x.shape[-1]
-        x2 = x.reshape(-1, d)
-        dy2 = dy.reshape(-1, d)
-        if dy2.stride(1) != 1:
-            dy2 = dy2.contiguous()
-        dx = torch.empty(x2.shape, device=x.device, dtype=x.dtype)
-        direct = ctx.a_dst is not None and ctx.b_dst is not None
-        da, db = (ctx.a_dst, ctx.b_dst) if direct else (_f32_zeros((d,), x), _f32_zeros((d,), x))
-        check(lib.bist_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), a.data_ptr(), dx.data_ptr(), da.data_ptr(), db.data_ptr(),
-                                     x2.shape[0], d, dy2.stride(0), x2.stride(0), d, eps, dtype_code(x.dtype), _stream()),
-              "bist_layernorm_bwd")
-        if direct:
-            return dx.view(x.shape), None, None, None
-        return dx.view(x.shape), _to_dtype_from_f32(da, a.dtype), _to_dtype_from_f32(db, bdt), None
+        return _ln_backward(ctx, dy, None)
+
+
+class LayerNormResFn(Function):
+    """(LN(x), x): the second output is x itself, handed to the sublayer's residual add.  Its gradient comes
+    back HERE, so the LayerNorm backward kernel adds it to dx (x + sublayer(LN(x)), modules.py:44) and
+    autograd never launches a separate add for the two uses of x."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, eps):
+        ctx.save_for_backward(x, a)
+        ctx.cfg = (eps, b.dtype)
+        ctx.a_dst, ctx.b_dst = getattr(a, "_acc32", None), getattr(b, "_acc32", None)
+        ctx.set_materialize_grads(False)
+        return ops.layernorm(x, a, b, eps), x
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        return _ln_backward(ctx, dy, dres)
 
 
 class EmbedFn(Function):

@@ -30,26 +30,31 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const T* __restrict__
   const T* Kn = K + n * k_bs + hh * dk;
   const T* Vn = V + n * v_bs + hh * dk;
   const T* dOn = dO ? dO + n * o_bs + hh * dk : nullptr;
-  // phase A: wave per query row
+  // phase A: wave per query row; the lanes stride the head dimension (coalesced) and every (i, j) dot product is a
+  // wave reduction -- with dk = 512 (the single-head pointer attention) a lane-per-key loop would be 512 serial,
+  // uncoalesced steps.  Every column-chunk workgroup (blockIdx.z) repeats this phase; it is small.
   for (int i = w; i < Lq; i += 4) {
     const unsigned char* mrow = mask ? mask + n * mask_bs + (long)i * mask_qs : nullptr;
     float* p = P + (long)i * Lk;
     float* ds = dS + (long)i * Lk;
-    float mx = -INFINITY;
-    for (int j = lane; j < Lk; j += 64) {
+    for (int j = 0; j < Lk; ++j) {
       float s = 0.f, dp = 0.f;
       const T* kr = Kn + (long)j * ldk;
       const T* vr = Vn + (long)j * ldv;
-      for (int c = 0; c < dk; ++c) {
+      for (int c = lane; c < dk; c += 64) {
         s += to_f(Qn[(long)i * ldq + c]) * to_f(kr[c]);
         if (dOn) dp += to_f(dOn[(long)i * ldo + c]) * to_f(vr[c]);
       }
-      s *= scale;
-      if (mrow && mrow[j] == 0) s = MASK_FILL;
-      if (dPext) dp += dPext[(((long)n * h + hh) * Lq + i) * Lk + j];
-      p[j] = s; ds[j] = dp;
-      mx = fmaxf(mx, s);
+      s = wave_sum(s); dp = wave_sum(dp);
+      if (lane == 0) {
+        s *= scale;
+        if (mrow && mrow[j] == 0) s = MASK_FILL;
+        if (dPext) dp += dPext[(((long)n * h + hh) * Lq + i) * Lk + j];
+        p[j] = s; ds[j] = dp;
+      }
     }
+    float mx = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) mx = fmaxf(mx, p[j]);
     mx = wave_max(mx);
     float den = 0.f;
     for (int j = lane; j < Lk; j += 64) { const float e = expf(p[j] - mx); p[j] = e; den += e; }
@@ -65,15 +70,16 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const T* __restrict__
     }
   }
   __syncthreads();
-  // phase B
-  for (int item = tid; item < Lq * dk; item += 256) {       // dQ[i,c]
-    const int i = item / dk, c = item % dk;
+  // phase B: this workgroup's chunk of the head columns [c0, c0 + cw)
+  const int cw = dk / (int)gridDim.z, c0 = (int)blockIdx.z * cw;
+  for (int item = tid; item < Lq * cw; item += 256) {       // dQ[i,c]
+    const int i = item / cw, c = c0 + item % cw;
     float acc = 0.f;
     for (int j = 0; j < Lk; ++j) acc += dS[(long)i * Lk + j] * to_f(Kn[(long)j * ldk + c]);
     dQ[n * dq_bs + (long)i * lddq + hh * dk + c] = from_f<T>(acc);
   }
-  for (int item = tid; item < Lk * dk; item += 256) {       // dK[j,c], dV[j,c]
-    const int j = item / dk, c = item % dk;
+  for (int item = tid; item < Lk * cw; item += 256) {       // dK[j,c], dV[j,c]
+    const int j = item / cw, c = c0 + item % cw;
     float ak = 0.f, av = 0.f;
     for (int i = 0; i < Lq; ++i) {
       ak += dS[(long)i * Lk + j] * to_f(Qn[(long)i * ldq + c]);
@@ -288,7 +294,8 @@ extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, co
   const size_t lds = (size_t)2 * Lq * Lk * sizeof(float);
   BIST_REQUIRE(lds <= 64 * 1024, "bist_mha_core_bwd: Lq*Lk=%d too large for LDS", Lq * Lk);
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)h, (unsigned)N);
+  const int cs = (dk % 64 == 0 && (long)h * N * (dk / 64) <= 4096) ? dk / 64 : 1;      // column chunks of 64: more workgroups for wide heads
+  dim3 grid((unsigned)h, (unsigned)N, (unsigned)cs);
 #define L(TT) hipLaunchKernelGGL(mha_core_bwd_kernel<TT>, grid, dim3(256), lds, st, (const TT*)Q, (const TT*)K, (const TT*)V, mask, (const TT*)dO, dP_ext, \
                                  (TT*)dQ, (TT*)dK, (TT*)dV, Lq, Lk, h, dk, (long)ldq, (long)ldk, (long)ldv, (long)ldo, (long)q_bs, (long)k_bs, (long)v_bs, (long)o_bs, \
                                  (long)lddq, (long)lddk, (long)lddv, (long)dq_bs, (long)dk_bs, (long)dv_bs, (long)mask_bs, (long)mask_qs, scale)

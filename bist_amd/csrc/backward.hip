@@ -56,13 +56,43 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const T* __restrict__ x, f
   if (rl == 0 && n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
+// Several bias gradients in one launch: the trainer queues the (dz, accumulator) pairs of a whole backward pass and
+// flushes them in batches of COLSUM_JOBS; block -> job through the prefix table carried in the kernel arguments.
+constexpr int COLSUM_JOBS = 48;
+struct ColSumBatch {
+  const void* x[COLSUM_JOBS]; float* out[COLSUM_JOBS];
+  int M[COLSUM_JOBS], N[COLSUM_JOBS], ld[COLSUM_JOBS], rpb[COLSUM_JOBS], cb[COLSUM_JOBS];
+  int first[COLSUM_JOBS + 1];        // first block of every job; first[n] = total
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void col_sum_multi_kernel(const ColSumBatch b) {
+  __shared__ float part[4][64];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.first[j + 1]) ++j;
+  const int lb = (int)blockIdx.x - b.first[j];
+  const int bx = lb % b.cb[j], by = lb / b.cb[j];
+  const T* x = reinterpret_cast<const T*>(b.x[j]);
+  const int M = b.M[j], N = b.N[j], ld = b.ld[j], rpb = b.rpb[j];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = bx * 64 + c;
+  const int m0 = by * rpb, m1 = min(M, m0 + rpb);
+  float acc = 0.f;
+  if (n < N)
+    for (int m = m0 + rl; m < m1; m += 4) acc += to_f(x[(long)m * ld + n]);
+  part[rl][c] = acc;
+  __syncthreads();
+  if (rl == 0 && n < N) atomicAdd(b.out[j] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+
 // LayerNorm backward (forward: y = a*(x-mean)/(std+eps)+b, std unbiased):
 //   g = dy*a;  dx_i = (g_i - mean(g))/s - xc_i * sum_j(g_j xc_j) / ((d-1) * std * s^2),  s = std+eps
 //   da += dy * xc/s ; db += dy          (fp32 atomics, one row per wave, 4 rows per block)
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
                                                             T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
-                                                            long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave) {
+                                                            long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
+                                                            const T* __restrict__ dx_add, long ldadd) {
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long r0 = wave * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
@@ -92,7 +122,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       const int c = lane + u * 64;
       if (c < d) {
         const float xc = to_f(xr[c]) - mean, gy = to_f(gr[c]);
-        dxr[c] = from_f<T>((gy * to_f(a[c]) - mg) * inv - xc * k2);
+        const float add = dx_add ? to_f(dx_add[row * ldadd + c]) : 0.f;
+        dxr[c] = from_f<T>((gy * to_f(a[c]) - mg) * inv - xc * k2 + add);
         pa[u] += gy * xc * inv;
         pb[u] += gy;
       }
@@ -113,7 +144,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
                                                                 T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
-                                                                long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave) {
+                                                                long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
+                                                                const T* __restrict__ dx_add, long ldadd) {
   constexpr int E = 16 / (int)sizeof(T), NE = NV * E;
   __shared__ float red[2][4][64 * NE];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -148,11 +180,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
     const float inv = 1.f / sden, mg = sg / (float)d, k2 = sgx / ((float)(d - 1) * stdv * sden * sden);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      T o[E];
+      T o[E], ad[E];
+      if (dx_add) *reinterpret_cast<uint4*>(ad) = *reinterpret_cast<const uint4*>(dx_add + row * ldadd + (j * 64 + lane) * E);
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int u = j * E + e;
-        o[e] = from_f<T>((gv[u] * av[u] - mg) * inv - xv[u] * k2);
+        o[e] = from_f<T>((gv[u] * av[u] - mg) * inv - xv[u] * k2 + (dx_add ? to_f(ad[e]) : 0.f));
         pa[u] += gv[u] * xv[u] * inv;
         pb[u] += gv[u];
       }
@@ -281,31 +314,59 @@ extern "C" int bist_col_sum_acc(const void* x, float* out, int64_t M, int32_t N,
   return BIST_OK;
 }
 
+extern "C" int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t dtype, void* stream) {
+  BIST_REQUIRE(jobs && njobs > 0, "bist_col_sum_multi: bad argument");
+  BIST_REQUIRE(dtype == BIST_BF16 || dtype == BIST_F32, "bist_col_sum_multi: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < njobs; base += COLSUM_JOBS) {
+    ColSumBatch b;
+    b.n = njobs - base < COLSUM_JOBS ? njobs - base : COLSUM_JOBS;
+    int total = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const BistColSum& q = jobs[base + i];
+      BIST_REQUIRE(q.x && q.out && q.M > 0 && q.N > 0 && q.ldx >= q.N && q.M < (1L << 31) && q.ldx < (1L << 31), "bist_col_sum_multi: bad job %d", base + i);
+      const long cb = blocks_for(q.N, 64);
+      long rpb = (q.M * cb + 255) / 256;               // ~256 workgroups per job
+      if (rpb < 16) rpb = 16;
+      b.x[i] = q.x; b.out[i] = q.out; b.M[i] = (int)q.M; b.N[i] = q.N; b.ld[i] = (int)q.ldx; b.rpb[i] = (int)rpb; b.cb[i] = (int)cb;
+      b.first[i] = total;
+      total += (int)(cb * blocks_for(q.M, (int)rpb));
+    }
+    b.first[b.n] = total;
+    if (dtype == BIST_BF16) hipLaunchKernelGGL(col_sum_multi_kernel<bf16_t>, dim3((unsigned)total), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL(col_sum_multi_kernel<float>, dim3((unsigned)total), dim3(256), 0, st, b);
+    BIST_LAUNCH_CHECK("bist_col_sum_multi");
+  }
+  return BIST_OK;
+}
+
 extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
-                                  int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, int32_t dtype, void* stream) {
+                                  int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
+                                  int32_t dtype, void* stream) {
   BIST_REQUIRE(dy && x && a && dx && da && db, "bist_layernorm_bwd: null pointer");
   BIST_REQUIRE(rows > 0 && d > 1 && d <= 2048, "bist_layernorm_bwd: bad shape rows=%ld d=%d", (long)rows, d);
   hipStream_t st = (hipStream_t)stream;
   const long sz = dtype == BIST_BF16 ? 2 : 4;
-  const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)a | (uintptr_t)dx) % 16 == 0) && (lddy * sz) % 16 == 0 &&
-                  (ldx * sz) % 16 == 0 && (lddx * sz) % 16 == 0;
+  BIST_REQUIRE(!dx_add || ldadd >= d, "bist_layernorm_bwd: bad dx_add stride");
+  const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)a | (uintptr_t)dx | (uintptr_t)dx_add) % 16 == 0) && (lddy * sz) % 16 == 0 &&
+                  (ldx * sz) % 16 == 0 && (lddx * sz) % 16 == 0 && (!dx_add || (ldadd * sz) % 16 == 0);
   if (al && (d * sz) == 1024) {                   // d = 512 bf16 / 256 f32: one 16-byte vector per lane
     int rpw2 = (int)((rows + 1023) / 1024);       // ~1024 waves: enough parallelism for dx, few atomics per column
     if (rpw2 < 2) rpw2 = 2;
     const unsigned g2 = blocks_for(blocks_for(rows, rpw2), 4);
     if (dtype == BIST_BF16)
       hipLaunchKernelGGL((layernorm_bwd_vec_kernel<bf16_t, 1>), dim3(g2), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)a,
-                         (bf16_t*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2);
+                         (bf16_t*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2, (const bf16_t*)dx_add, (long)ldadd);
     else
       hipLaunchKernelGGL((layernorm_bwd_vec_kernel<float, 1>), dim3(g2), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)a,
-                         (float*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2);
+                         (float*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2, (const float*)dx_add, (long)ldadd);
     BIST_LAUNCH_CHECK("bist_layernorm_bwd");
     return BIST_OK;
   }
   int rpw = (int)((rows + 4095) / 4096);          // <= 4096 waves flush their partial sums
   if (rpw < 1) rpw = 1;
   const unsigned g = blocks_for(blocks_for(rows, rpw), 4);
-#define L(TT, ...) hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3(g), dim3(256), 0, st, (const TT*)dy, (const TT*)x, (const TT*)a, (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw)
+#define L(TT, ...) hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3(g), dim3(256), 0, st, (const TT*)dy, (const TT*)x, (const TT*)a, (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw, (const TT*)dx_add, (long)ldadd)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_layernorm_bwd");

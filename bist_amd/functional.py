@@ -33,6 +33,14 @@ def layernorm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
     return ag.LayerNormFn.apply(x, a, b, eps) if _grad() else ops.layernorm(x, a, b, eps)
 
 
+def layernorm_res(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6):
+    """(LN(x), x) for x + sublayer(LN(x)): hand the second value to the residual add, so that its gradient
+    is folded into the LayerNorm backward kernel instead of a separate accumulation pass."""
+    if _grad() and x.requires_grad:
+        return ag.LayerNormResFn.apply(x, a, b, eps)
+    return layernorm(x, a, b, eps), x
+
+
 def head_fold(q: Tensor, wk: Tensor, h: int, alpha: float) -> Tensor:
     """Qf[m, hh*d + n] = alpha * sum_c q[m, hh*dk + c] * wk[hh*dk + c, n]     q [M,d], wk [d,d] -> [M, h*d]
     (one batched GEMM over the heads; wk is read "NN": row stride 1, k stride d)."""

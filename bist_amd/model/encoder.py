@@ -84,20 +84,22 @@ class VidEncoder8(nn.Module):
 
 def _self_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Tensor, mask: Optional[Tensor]) -> Tensor:
     """x + MHA(LN(x), LN(x), LN(x), mask): A0/A3 and every other self-attention sublayer."""
-    xn = sub.norm(x)
+    xn, xr = sub.norm.with_residual(x)
     ctx = attn.context(xn, xn, xn, mask)
-    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x, **Fn.drop_args(sub)).view_as(x)
+    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, **Fn.drop_args(sub)).view_as(x)
 
 
 def _cross_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Tensor, mem: Tensor, mask: Optional[Tensor]) -> Tensor:
     """x + MHA(LN(x), mem, mem, mask) -- only the query stream is normalised (modules.py:44)."""
-    ctx = attn.context(sub.norm(x), mem, mem, mask)
-    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x, **Fn.drop_args(sub)).view_as(x)
+    xn, xr = sub.norm.with_residual(x)
+    ctx = attn.context(xn, mem, mem, mask)
+    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, **Fn.drop_args(sub)).view_as(x)
 
 
 def _feed_forward(sub: SublayerConnection, ff: PositionwiseFeedForward, x: Tensor) -> Tensor:
     """x + FFN(LN(x)); the residual is the second GEMM's epilogue."""
-    return ff(sub.norm(x), residual=x, out_drop=Fn.drop_args(sub))
+    xn, xr = sub.norm.with_residual(x)
+    return ff(xn, residual=xr, out_drop=Fn.drop_args(sub))
 
 
 class VidEncoderLayer4(nn.Module):
@@ -124,7 +126,8 @@ class VidEncoderLayer4(nn.Module):
         attn, sub = self.attn[ai], self.sublayer[si]
         B, T, S, d = vft.shape
         Lq, h, dk = x.shape[1], attn.h, attn.d_k
-        q = Fn.linear(sub.norm(x), attn.linears[0].weight, attn.linears[0].bias)                  # [B*Lq, d]
+        xn, xr = sub.norm.with_residual(x)
+        q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)                           # [B*Lq, d]
         qf = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq * h, d)   # rows (i, hh)
         scores = Fn.st_scores(qf, vft.view(B, T * S, d))
         v_ready = self.__dict__.get("_v_ready")
@@ -132,7 +135,7 @@ class VidEncoderLayer4(nn.Module):
             torch.cuda.current_stream().wait_stream(v_ready)      # V comes from the value-projection stream
         o = Fn.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
         G = o.shape[1]
-        y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=x, res_map=(G * Lq, Lq), **Fn.drop_args(sub))
+        y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=xr, res_map=(G * Lq, Lq), **Fn.drop_args(sub))
         return y.view(B, G, Lq, d)
 
     # -- stage 2 ------------------------------------------------------------------------------
@@ -141,11 +144,12 @@ class VidEncoderLayer4(nn.Module):
         attn, sub = self.attn[ai], self.sublayer[si]
         B, G, Lq, d = y.shape
         h, dk = attn.h, attn.d_k
-        q = Fn.linear(sub.norm(x), attn.linears[0].weight, attn.linears[0].bias)
+        xn, xr = sub.norm.with_residual(x)
+        q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)
         q2f = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq, h, d)
         py = Fn.st_stage2(q2f, y, gmask, h=h)
         ctx = Fn.head_unfold(py.view(B * Lq, h * d), attn.linears[2].weight, attn.linears[2].bias, h)
-        return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=x, **Fn.drop_args(sub)).view(B, Lq, d)
+        return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, **Fn.drop_args(sub)).view(B, Lq, d)
 
     def value_projection(self, vft: Tensor):
         """V of A1 and A4 in one GEMM over the video tensor: returns (v_t2s, v_s2t) column views."""

@@ -36,6 +36,10 @@ class LayerNorm(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         return Fn.layernorm(x, self.a_2, self.b_2, self.eps)
 
+    def with_residual(self, x: Tensor):
+        """(LN(x), x'): use x' as the residual operand of the sublayer's last GEMM (see Fn.layernorm_res)."""
+        return Fn.layernorm_res(x, self.a_2, self.b_2, self.eps)
+
 
 class SublayerConnection(nn.Module):
     """x + dropout(sublayer(norm(x)))   (reference: modules.py:33-44).

@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, BF16, F32, BistGemm, check, lib
+from ._lib import ACT_NONE, ACT_RELU, BF16, F32, BistColSum, BistGemm, check, lib
 
 Tensor = torch.Tensor
 
@@ -107,6 +107,26 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
         return c
     check(lib.bist_gemm(C.byref(g), _stream()), "bist_gemm")
     return c
+
+
+COLSUM_QUEUE = None       # trainer: list of (dz, acc32 view, M, N) bias-gradient jobs, flushed by col_sum_flush()
+
+
+def col_sum_flush() -> None:
+    """Run every queued bias gradient (autograd.LinearFn) in batched launches on the current stream."""
+    global COLSUM_QUEUE
+    q = COLSUM_QUEUE
+    if not q:
+        return
+    by_dtype = {}
+    for dz, acc, M, N in q:
+        by_dtype.setdefault(dz.dtype, []).append((dz, acc, M, N))
+    for dt, jobs in by_dtype.items():
+        arr = (BistColSum * len(jobs))()
+        for i, (dz, acc, M, N) in enumerate(jobs):
+            arr[i].x, arr[i].out, arr[i].M, arr[i].N, arr[i].ldx = dz.data_ptr(), acc.data_ptr(), M, N, N
+        check(lib.bist_col_sum_multi(arr, len(jobs), dtype_code(dt), _stream()), "bist_col_sum_multi")
+    q.clear()
 
 
 GEMM_TIMING = None        # set to a list to collect ((M,N,K,batch), start_event, end_event) per GEMM launch

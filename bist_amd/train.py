@@ -155,8 +155,13 @@ class Trainer:
         self.flat_grad.zero_()
         self.acc32.zero_()
         loss, terms = self.forward_loss(batch)
-        loss.backward()
-        for p in self.params:                 # anything autograd still produced itself (views, fallbacks)
+        ops.COLSUM_QUEUE = []                 # bias gradients: queued by LinearFn.backward, summed in a few launches below
+        try:
+            loss.backward()
+            ops.col_sum_flush()
+        finally:
+            ops.COLSUM_QUEUE = None
+        for p in self.params:                # anything autograd still produced itself (views, fallbacks)
             if p.grad is not None:
                 p._grad_view.add_(p.grad)
                 p.grad = None

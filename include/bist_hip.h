@@ -212,9 +212,19 @@ int bist_epilogue_bwd(const void* dy, const void* y, void* dz, int64_t M, int32_
 int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream);
 /* out[n] += sum_m x[m, n]  (bias gradient, fp32 accumulator).                                    */
 int bist_col_sum_acc(const void* x, float* out, int64_t M, int32_t N, int64_t ldx, int32_t dtype, void* stream);
-/* LayerNorm backward: dx (dtype) and da/db (+=, fp32 [d]).                                       */
+/* Several bias gradients in one launch (the trainer queues the weight-gradient GEMMs' dz operands of a
+ * whole backward pass): out[n] += sum_m x[m, n] per job.  All jobs share one dtype.               */
+typedef struct BistColSum {
+  const void* x; float* out;
+  int64_t M; int32_t N; int64_t ldx;
+} BistColSum;
+int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t dtype, void* stream);
+/* LayerNorm backward: dx (dtype) and da/db (+=, fp32 [d]).  dx_add (nullable, [rows, ldadd]) is added
+ * to dx: the gradient arriving on the residual branch of x + sublayer(LN(x)) (modules.py:44), so the
+ * two gradients of x are never summed by a separate pass.                                          */
 int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
-                       int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, int32_t dtype, void* stream);
+                       int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
+                       int32_t dtype, void* stream);
 /* dlut[ids[row], :] += dy[row, :] * sqrt(d)  (fp32 accumulator [V, d]).                          */
 int bist_embed_bwd(const int64_t* ids, const void* dy, float* dlut, int64_t rows, int32_t d, int32_t dtype, void* stream);
 int bist_fuse_modalities_bwd(const void* score, const void* const* xs, const void* dout, void* dscore, void* const* dxs,

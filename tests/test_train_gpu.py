@@ -92,6 +92,36 @@ def test_layernorm_backward(env):
         return a * (x - m) / (x.std(-1, keepdim=True) + 1e-6) + b
     _check(lambda x, a, b: Fn.layernorm(x, a, b), ref, [x, a, b], "layernorm")
 
+    # x + sublayer(LN(x)) with the residual handed out by the LayerNorm: its gradient is added inside the
+    # LayerNorm backward kernel (modules.py:44); d = 64 takes the generic kernel, d = 256 (fp32) the vector one
+    for d in (64, 256):
+        x, a, b = _rand(37, d, seed=7, scale=2.0) + 0.3, 1 + 0.1 * _rand(d, seed=8), 0.1 * _rand(d, seed=9)
+        w = _rand(d, d, seed=10, scale=d ** -0.5)
+
+        def hip(x, a, b, w):
+            xn, xr = Fn.layernorm_res(x, a, b)
+            return Fn.linear(xn, w, None, residual=xr), xr * 2.0
+
+        _check(hip, lambda x, a, b, w: (x + ref(x, a, b) @ w.t(), x * 2.0), [x, a, b, w], f"layernorm+residual d={d}")
+
+
+def test_bias_gradients_batched(env):
+    """bist_col_sum_multi: the queued bias gradients of a backward pass in one launch per 48 jobs."""
+    ag, Fn, ops = env
+    import ctypes
+    from bist_amd import _lib
+    for dtype in (torch.float32, torch.bfloat16):
+        shapes = [(320, 512), (77, 3), (1, 70), (2500, 130)] * 15            # 60 jobs: two launches
+        xs = [(_rand(m, n, seed=200 + i)).float().to(dtype).cuda() for i, (m, n) in enumerate(shapes)]
+        outs = [torch.full((n,), 0.5, device="cuda") for _, n in shapes]
+        ops.COLSUM_QUEUE = [(x, o, x.shape[0], x.shape[1]) for x, o in zip(xs, outs)]
+        try:
+            ops.col_sum_flush()
+        finally:
+            ops.COLSUM_QUEUE = None
+        for x, o in zip(xs, outs):
+            _close(o, 0.5 + x.double().cpu().sum(0), "col_sum_multi", 2e-5 if dtype == torch.float32 else 2e-3)
+
 
 def _ref_attn(q, k, v, mask, h):
     N, Lq, d = q.shape
