@@ -37,11 +37,30 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const T* __restrict__
     const unsigned char* mrow = mask ? mask + n * mask_bs + (long)i * mask_qs : nullptr;
     float* p = P + (long)i * Lk;
     float* ds = dS + (long)i * Lk;
+    // the query row and its output gradient live in registers (lane owns columns lane, lane+64, ...: dk <= 512);
+    // per key all 2*DKC loads are issued together, so a (i, j) pair costs one memory latency, not dk/64 of them
+    constexpr int DKC = 8;
+    float qv[DKC], gv[DKC];
+#pragma unroll
+    for (int t = 0; t < DKC; ++t) {
+      const int c = lane + t * 64;
+      qv[t] = c < dk ? to_f(Qn[(long)i * ldq + c]) : 0.f;
+      gv[t] = (dOn && c < dk) ? to_f(dOn[(long)i * ldo + c]) : 0.f;
+    }
     for (int j = 0; j < Lk; ++j) {
-      float s = 0.f, dp = 0.f;
       const T* kr = Kn + (long)j * ldk;
       const T* vr = Vn + (long)j * ldv;
-      for (int c = lane; c < dk; c += 64) {
+      float kv[DKC], vv[DKC];
+#pragma unroll
+      for (int t = 0; t < DKC; ++t) {
+        const int c = lane + t * 64;
+        kv[t] = c < dk ? to_f(kr[c]) : 0.f;
+        vv[t] = (dOn && c < dk) ? to_f(vr[c]) : 0.f;
+      }
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int t = 0; t < DKC; ++t) { s += qv[t] * kv[t]; dp += gv[t] * vv[t]; }
+      for (int c = lane + DKC * 64; c < dk; c += 64) {          // dk > 512: the rest the slow way
         s += to_f(Qn[(long)i * ldq + c]) * to_f(kr[c]);
         if (dOn) dp += to_f(dOn[(long)i * ldo + c]) * to_f(vr[c]);
       }

@@ -800,6 +800,121 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_pre_kernel(const GemmK g) {
   stream_out<T, TO, false, 64>(g, ebuf, ebuf, z1, z2, 0, m0, n0, tid);
 }
 
+// Ring variant of the all-in-flight kernel for ANY number of K tiles (the K = 2048 products of the feed-forward
+// blocks at M = 320: 32 tiles): 8 stages of 16 KiB in ONE LDS array, 6 tiles in flight, two tiles per barrier.  An
+// iteration waits for its own share of its tile pair (counted vmcnt), the barrier publishes the others' shares AND
+// proves that every wave is done with the previous pair, whose stages are then refilled with tiles t+6, t+7.  Fragment reads are inline asm (FragRd), so the
+// compiler sees no LDS read of the ring and adds no waits of its own.
+template <typename T, typename TO, bool ATR, bool BTR>
+__global__ __launch_bounds__(NTHREADS) void gemm_t64_ring_kernel(const GemmK g) {
+  constexpr int D = 8;
+  __shared__ __attribute__((aligned(16))) char ebuf[2 * T64_BYTES + 64];
+  __shared__ __attribute__((aligned(16))) char ring[D * 2 * T64_BYTES];
+  int z, sp, tm, tn;
+  tile_coords(g, z, sp, tm, tn);
+  const int z1 = z / g.batch2, z2 = z % g.batch2;
+  const int m0 = tm * T64, n0 = tn * T64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  constexpr int BK = ROW_BYTES / (int)sizeof(T);
+  const int nk = (g.K + BK - 1) / BK;
+  const int k_tail = g.K % BK;
+
+  Stager64<T, ATR> sa;
+  Stager64<T, BTR> sb;
+  sa.init(g.A + (z1 * g.a_bs1 + z2 * g.a_bs2) * (long)sizeof(T), g.a_rs, g.a_ks, m0, g.M, 0, w, lane);
+  sb.init(g.B + (z1 * g.b_bs1 + z2 * g.b_bs2) * (long)sizeof(T), g.b_rs, g.b_ks, n0, g.N, 0, w, lane);
+  auto stage_in = [&](int kt) {
+    char* st = ring + (kt & (D - 1)) * 2 * T64_BYTES;
+    if (k_tail != 0 && kt == nk - 1) { sa.issue_tail(st, w, k_tail); sb.issue_tail(st + T64_BYTES, w, k_tail); }
+    else { sa.issue(st, w); sb.issue(st + T64_BYTES, w); }
+  };
+  for (int kt = 0; kt < D - 2 && kt < nk; ++kt) stage_in(kt);      // tiles 0..5
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned ring0 = (unsigned)(size_t)LDS_PTR(ring);
+  // two tiles per barrier: the second tile's fragment reads land under the first tile's MFMAs
+  for (int kt = 0; kt < nk; kt += 2) {
+    const bool two = kt + 1 < nk;
+    const int ahead = min(D - 4, nk - 1 - (two ? kt + 1 : kt));      // tiles issued beyond this pair (4 DMAs each per wave)
+    switch (ahead) {
+      case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + D - 2 < nk) stage_in(kt + D - 2);          // into the stages of the previous pair: every wave is past them
+    if (kt + D - 1 < nk) stage_in(kt + D - 1);
+    const unsigned t0 = ring0 + (unsigned)((kt & (D - 1)) * 2 * T64_BYTES);
+    const unsigned t1 = ring0 + (unsigned)(((kt + 1) & (D - 1)) * 2 * T64_BYTES);
+    FragRd<T, ATR> af[2][2][2];
+    FragRd<T, BTR> bf[2][2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[0][ks][i].issue(t0, wm * 32 + i * 16, ks, lane);
+        bf[0][ks][i].issue(t0 + T64_BYTES, wn * 32 + i * 16, ks, lane);
+      }
+    constexpr int PER_TILE = 4 * FragRd<T, ATR>::NREAD + 4 * FragRd<T, BTR>::NREAD;
+    if (two) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          af[1][ks][i].issue(t1, wm * 32 + i * 16, ks, lane);
+          bf[1][ks][i].issue(t1 + T64_BYTES, wn * 32 + i * 16, ks, lane);
+        }
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PER_TILE < 15 ? PER_TILE : 15) : "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      af[0][ks][0].tie(); af[0][ks][1].tie(); bf[0][ks][0].tie(); bf[0][ks][1].tie();
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) Mma<T>::step(af[0][ks][i].get(), bf[0][ks][j].get(), acc[i][j]);
+    }
+    if (two) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        af[1][ks][0].tie(); af[1][ks][1].tie(); bf[1][ks][0].tie(); bf[1][ks][1].tie();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) Mma<T>::step(af[1][ks][i].get(), bf[1][ks][j].get(), acc[i][j]);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    float* buf = reinterpret_cast<float*>(ebuf);
+    const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * 32 + i * 16 + lg * 4 + r, col = wn * 32 + j * 16 + lr;
+          const int pos = (col >> 2) ^ (((row >> 2) & 3) << 2);
+          buf[row * 64 + pos * 4 + (col & 3)] = acc[i][j][r];
+        }
+  }
+  __syncthreads();
+  stream_out<T, TO, false, 64>(g, ebuf, ebuf, z1, z2, 0, m0, n0, tid);
+}
+
 // sums the split-K slabs and applies the epilogue: one thread per output element
 template <typename T, typename TO>
 __global__ void splitk_reduce_kernel(const GemmK g, long total) {
@@ -1082,11 +1197,13 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
     const long nk64 = (g->K + bk64 - 1) / bk64;
     const bool pair = nk64 >= 12;                               // long K: halve the barrier chain (64 KiB of LDS)
     static const int no_pre = [] { const char* e = getenv("BIST_GEMM_NO_PRE"); return e ? atoi(e) : 0; }();      // tuning aid
-    const bool whole = g->K % bk64 == 0 && g64.x <= 256 && !no_pre;       // one workgroup per CU: NK x 16 KiB of LDS is free
+    const bool whole_cu = g64.x <= 256 && !no_pre;                        // one workgroup per CU: 128+ KiB of LDS is free
+    const bool whole = g->K % bk64 == 0 && whole_cu;
 #define GO64(ATR_, BTR_)                                                                                  \
   do {                                                                                                    \
     if (whole && nk64 == 8) hipLaunchKernelGGL((gemm_t64_pre_kernel<T, TO, ATR_, BTR_, 8>), g64, block, 0, st, k);      \
     else if (whole && nk64 == 5) hipLaunchKernelGGL((gemm_t64_pre_kernel<T, TO, ATR_, BTR_, 5>), g64, block, 0, st, k); \
+    else if (whole_cu && nk64 > 8) hipLaunchKernelGGL((gemm_t64_ring_kernel<T, TO, ATR_, BTR_>), g64, block, 0, st, k); \
     else if (pair) hipLaunchKernelGGL((gemm_t64_kernel<T, TO, ATR_, BTR_, true>), g64, block, 0, st, k);       \
     else hipLaunchKernelGGL((gemm_t64_kernel<T, TO, ATR_, BTR_, false>), g64, block, 0, st, k);           \
   } while (0)
