@@ -477,6 +477,7 @@ struct MhaBwdArgs {
 
 __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t qimg[32 * 64], kimg[64 * 64], vimg[64 * 64], gimg[32 * 64], pimg[32 * 64], simg[32 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char mimg[32 * 64];      // mask bytes of this (n): 0 = masked
   const int hh = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
   const int x = lane & 15, lg = lane >> 4;
   const int Lq = a.Lq, Lk = a.Lk;
@@ -485,15 +486,45 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
   const bf16_t* Vn = a.V + n * a.v_bs + hh * 64;
   const bf16_t* Gn = a.dO ? a.dO + n * a.o_bs + hh * 64 : nullptr;
   const uint4 z4 = make_uint4(0, 0, 0, 0);
-  for (int r = lane >> 3; r < 32; r += 8) {
-    const int c = (lane & 7) * 8;
-    *reinterpret_cast<uint4*>(qimg + r * 64 + c) = r < Lq ? *reinterpret_cast<const uint4*>(Qn + (long)r * a.ldq + c) : z4;
-    *reinterpret_cast<uint4*>(gimg + r * 64 + c) = (Gn && r < Lq) ? *reinterpret_cast<const uint4*>(Gn + (long)r * a.ldo + c) : z4;
-  }
-  for (int r = lane >> 3; r < 64; r += 8) {
-    const int c = (lane & 7) * 8;
-    *reinterpret_cast<uint4*>(kimg + r * 64 + c) = r < Lk ? *reinterpret_cast<const uint4*>(Kn + (long)r * a.ldk + c) : z4;
-    *reinterpret_cast<uint4*>(vimg + r * 64 + c) = r < Lk ? *reinterpret_cast<const uint4*>(Vn + (long)r * a.ldv + c) : z4;
+  {
+    // all 24 tile loads (and the mask bytes) are issued before the first LDS store: one memory latency, not 12
+    const int c = (lane & 7) * 8, rb = lane >> 3;
+    uint4 rq[4], rg[4], rk[8], rv[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = rb + 8 * t;
+      rq[t] = r < Lq ? *reinterpret_cast<const uint4*>(Qn + (long)r * a.ldq + c) : z4;
+      rg[t] = (Gn && r < Lq) ? *reinterpret_cast<const uint4*>(Gn + (long)r * a.ldo + c) : z4;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int r = rb + 8 * t;
+      rk[t] = r < Lk ? *reinterpret_cast<const uint4*>(Kn + (long)r * a.ldk + c) : z4;
+      rv[t] = r < Lk ? *reinterpret_cast<const uint4*>(Vn + (long)r * a.ldv + c) : z4;
+    }
+    unsigned char mb[4][8];
+    if (a.mask) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = rb + 8 * t;
+        const unsigned char* mrow = a.mask + n * a.mask_bs + (long)min(r, Lq - 1) * a.mask_qs;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mb[t][e] = (c + e < Lk) ? mrow[c + e] : (unsigned char)1;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = rb + 8 * t;
+      *reinterpret_cast<uint4*>(qimg + r * 64 + c) = rq[t];
+      *reinterpret_cast<uint4*>(gimg + r * 64 + c) = rg[t];
+      if (a.mask) *reinterpret_cast<uint2*>(mimg + r * 64 + c) = *reinterpret_cast<const uint2*>(mb[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int r = rb + 8 * t;
+      *reinterpret_cast<uint4*>(kimg + r * 64 + c) = rk[t];
+      *reinterpret_cast<uint4*>(vimg + r * 64 + c) = rv[t];
+    }
   }
   // S = Q K^T and dP = dO V^T   (rows i, cols j)
   f32x4 S[2][4], D[2][4];
@@ -520,7 +551,7 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int i = mi * 16 + lg * 4 + r;
       const bool row_ok = i < Lq;
-      const unsigned char* mrow = (a.mask && row_ok) ? a.mask + n * a.mask_bs + (long)i * a.mask_qs : nullptr;
+      const unsigned char* mrow = (a.mask && row_ok) ? mimg + i * 64 : nullptr;
       float sv[4], dv[4];
       bool msk[4];
       float mx = -INFINITY;

@@ -159,37 +159,52 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
 #pragma unroll
     for (int e = 0; e < E; ++e) { av[j * E + e] = to_f(qe[e]); pa[j * E + e] = 0.f; pb[j * E + e] = 0.f; }
   }
-  for (long row = r0; row < r1; ++row) {
-    float xv[NE], gv[NE];
-    float s = 0.f;
+  // two rows per trip: the loads of both rows (x, dy, residual gradient) are issued before either is reduced
+  for (long rowb = r0; rowb < r1; rowb += 2) {
+    uint4 qx[2][NV], qg[2][NV], qa[2][NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const uint4 qx = *reinterpret_cast<const uint4*>(x + row * ldx + (j * 64 + lane) * E);
-      const uint4 qg = *reinterpret_cast<const uint4*>(dy + row * lddy + (j * 64 + lane) * E);
-      const T* xe = reinterpret_cast<const T*>(&qx);
-      const T* ge = reinterpret_cast<const T*>(&qg);
+    for (int rr = 0; rr < 2; ++rr) {
+      const long row = min(rowb + rr, r1 - 1);
 #pragma unroll
-      for (int e = 0; e < E; ++e) { xv[j * E + e] = to_f(xe[e]); gv[j * E + e] = to_f(ge[e]); s += xv[j * E + e]; }
-    }
-    const float mean = wave_sum(s) / (float)d;
-    float q = 0.f, sg = 0.f, sgx = 0.f;
-#pragma unroll
-    for (int u = 0; u < NE; ++u) { xv[u] -= mean; const float g = gv[u] * av[u]; q += xv[u] * xv[u]; sg += g; sgx += g * xv[u]; }
-    q = wave_sum(q); sg = wave_sum(sg); sgx = wave_sum(sgx);
-    const float stdv = sqrtf(q / (float)(d - 1)), sden = stdv + eps;
-    const float inv = 1.f / sden, mg = sg / (float)d, k2 = sgx / ((float)(d - 1) * stdv * sden * sden);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      T o[E], ad[E];
-      if (dx_add) *reinterpret_cast<uint4*>(ad) = *reinterpret_cast<const uint4*>(dx_add + row * ldadd + (j * 64 + lane) * E);
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int u = j * E + e;
-        o[e] = from_f<T>((gv[u] * av[u] - mg) * inv - xv[u] * k2 + (dx_add ? to_f(ad[e]) : 0.f));
-        pa[u] += gv[u] * xv[u] * inv;
-        pb[u] += gv[u];
+      for (int j = 0; j < NV; ++j) {
+        qx[rr][j] = *reinterpret_cast<const uint4*>(x + row * ldx + (j * 64 + lane) * E);
+        qg[rr][j] = *reinterpret_cast<const uint4*>(dy + row * lddy + (j * 64 + lane) * E);
+        if (dx_add) qa[rr][j] = *reinterpret_cast<const uint4*>(dx_add + row * ldadd + (j * 64 + lane) * E);
       }
-      *reinterpret_cast<uint4*>(dx + row * lddx + (j * 64 + lane) * E) = *reinterpret_cast<const uint4*>(o);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const long row = rowb + rr;
+      if (row >= r1) break;
+      float xv[NE], gv[NE];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const T* xe = reinterpret_cast<const T*>(&qx[rr][j]);
+        const T* ge = reinterpret_cast<const T*>(&qg[rr][j]);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { xv[j * E + e] = to_f(xe[e]); gv[j * E + e] = to_f(ge[e]); s += xv[j * E + e]; }
+      }
+      const float mean = wave_sum(s) / (float)d;
+      float q = 0.f, sg = 0.f, sgx = 0.f;
+#pragma unroll
+      for (int u = 0; u < NE; ++u) { xv[u] -= mean; const float g = gv[u] * av[u]; q += xv[u] * xv[u]; sg += g; sgx += g * xv[u]; }
+      q = wave_sum(q); sg = wave_sum(sg); sgx = wave_sum(sgx);
+      const float stdv = sqrtf(q / (float)(d - 1)), sden = stdv + eps;
+      const float inv = 1.f / sden, mg = sg / (float)d, k2 = sgx / ((float)(d - 1) * stdv * sden * sden);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        T o[E];
+        const T* ad = reinterpret_cast<const T*>(&qa[rr][j]);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int u = j * E + e;
+          o[e] = from_f<T>((gv[u] * av[u] - mg) * inv - xv[u] * k2 + (dx_add ? to_f(ad[e]) : 0.f));
+          pa[u] += gv[u] * xv[u] * inv;
+          pb[u] += gv[u];
+        }
+        *reinterpret_cast<uint4*>(dx + row * lddx + (j * 64 + lane) * E) = *reinterpret_cast<const uint4*>(o);
+      }
     }
   }
 #pragma unroll
@@ -326,7 +341,7 @@ extern "C" int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t
       const BistColSum& q = jobs[base + i];
       BIST_REQUIRE(q.x && q.out && q.M > 0 && q.N > 0 && q.ldx >= q.N && q.M < (1L << 31) && q.ldx < (1L << 31), "bist_col_sum_multi: bad job %d", base + i);
       const long cb = blocks_for(q.N, 64);
-      long rpb = (q.M * cb + 255) / 256;               // ~256 workgroups per job
+      long rpb = (q.M * cb + 1023) / 1024;             // up to ~1024 workgroups per job, at least 16 rows each
       if (rpb < 16) rpb = 16;
       b.x[i] = q.x; b.out[i] = q.out; b.M[i] = (int)q.M; b.N[i] = q.N; b.ld[i] = (int)q.ldx; b.rpb[i] = (int)rpb; b.cb[i] = (int)cb;
       b.first[i] = total;
