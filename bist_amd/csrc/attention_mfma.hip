@@ -467,6 +467,13 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
 //   S = Q K^T, dP = dO V^T (+ dP_ext) -> softmax / softmax-backward in the accumulator layout
 //   dQ = scale dS K,  dK = scale dS^T Q,  dV = P^T dO
 // =====================================================================================================
+// v or zeros, component-wise (a ternary on the uint4 struct turns into an address select through scratch memory)
+__device__ __forceinline__ uint4 keep4(uint4 v, bool keep) {
+  const unsigned m = keep ? 0xffffffffu : 0u;
+  v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+  return v;
+}
+
 struct MhaBwdArgs {
   const bf16_t *Q, *K, *V, *dO; const unsigned char* mask; const float* dPext;
   bf16_t *dQ, *dK, *dV;
@@ -493,37 +500,44 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int r = rb + 8 * t;
-      rq[t] = r < Lq ? *reinterpret_cast<const uint4*>(Qn + (long)r * a.ldq + c) : z4;
-      rg[t] = (Gn && r < Lq) ? *reinterpret_cast<const uint4*>(Gn + (long)r * a.ldo + c) : z4;
+      // unconditional loads from a clamped row, zeroed afterwards: a conditional load becomes a pointer select
+      // against a zero in scratch memory and serialises on flat loads
+      const int rc = min(r, Lq - 1);
+      rq[t] = *reinterpret_cast<const uint4*>(Qn + (long)rc * a.ldq + c);
+      rg[t] = *reinterpret_cast<const uint4*>((Gn ? Gn : Qn) + (long)rc * (Gn ? a.ldo : a.ldq) + c);      // no dO: any valid address, zeroed below
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int r = rb + 8 * t;
-      rk[t] = r < Lk ? *reinterpret_cast<const uint4*>(Kn + (long)r * a.ldk + c) : z4;
-      rv[t] = r < Lk ? *reinterpret_cast<const uint4*>(Vn + (long)r * a.ldv + c) : z4;
+      const int rc = min(r, Lk - 1);
+      rk[t] = *reinterpret_cast<const uint4*>(Kn + (long)rc * a.ldk + c);
+      rv[t] = *reinterpret_cast<const uint4*>(Vn + (long)rc * a.ldv + c);
     }
-    unsigned char mb[4][8];
+    unsigned mlo[4], mhi[4];                 // 8 mask bytes per row piece, packed (a byte array would live in scratch)
     if (a.mask) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int r = rb + 8 * t;
         const unsigned char* mrow = a.mask + n * a.mask_bs + (long)min(r, Lq - 1) * a.mask_qs;
+        unsigned by[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mb[t][e] = (c + e < Lk) ? mrow[c + e] : (unsigned char)1;
+        for (int e = 0; e < 8; ++e) by[e] = (c + e < Lk) ? (unsigned)mrow[c + e] : 1u;
+        mlo[t] = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);
+        mhi[t] = by[4] | (by[5] << 8) | (by[6] << 16) | (by[7] << 24);
       }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int r = rb + 8 * t;
-      *reinterpret_cast<uint4*>(qimg + r * 64 + c) = rq[t];
-      *reinterpret_cast<uint4*>(gimg + r * 64 + c) = rg[t];
-      if (a.mask) *reinterpret_cast<uint2*>(mimg + r * 64 + c) = *reinterpret_cast<const uint2*>(mb[t]);
+      *reinterpret_cast<uint4*>(qimg + r * 64 + c) = keep4(rq[t], r < Lq);
+      *reinterpret_cast<uint4*>(gimg + r * 64 + c) = keep4(rg[t], r < Lq && Gn != nullptr);
+      if (a.mask) *reinterpret_cast<uint2*>(mimg + r * 64 + c) = make_uint2(mlo[t], mhi[t]);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int r = rb + 8 * t;
-      *reinterpret_cast<uint4*>(kimg + r * 64 + c) = rk[t];
-      *reinterpret_cast<uint4*>(vimg + r * 64 + c) = rv[t];
+      *reinterpret_cast<uint4*>(kimg + r * 64 + c) = keep4(rk[t], r < Lk);
+      *reinterpret_cast<uint4*>(vimg + r * 64 + c) = keep4(rv[t], r < Lk);
     }
   }
   // S = Q K^T and dP = dO V^T   (rows i, cols j)
