@@ -30,6 +30,10 @@ class BistGemm(C.Structure):
     ]
 
 
+class BistDrop(C.Structure):
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("ctr", C.c_void_p)]
+
+
 class BistColSum(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64), ("N", C.c_int32), ("ldx", C.c_int64)]
 
@@ -45,10 +49,12 @@ SIGNATURES = {
     "bist_gemm_is_fast": (C.c_int, [C.POINTER(BistGemm)]),
     "bist_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I64, _I64, _F, _I32, _P]),
     "bist_mha_core_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32,
-                                    _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
-    "bist_st_stage1_pv_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _P]),
-    "bist_st_stage2_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
-    "bist_embed_pe_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
+                                    _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.POINTER(BistDrop), _I32, _P]),
+    "bist_st_stage1_pv_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, C.POINTER(BistDrop), _I32, _I32, _P]),
+    "bist_st_stage2_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, C.POINTER(BistDrop), _I32, _P]),
+    "bist_scaled_bias_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
+    "bist_scaled_bias_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
+    "bist_embed_pe_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_temporal_mask": (C.c_int, [_P, _P, _I64, _I64, _I32, _P]),
     "bist_fuse_modalities": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _I64, _I32, _I32, _I32, _P]),
     "bist_add_bcast": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _P]),
@@ -62,11 +68,11 @@ SIGNATURES = {
     "bist_col_sum_acc": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
     "bist_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _I64, _I64, _F, _P, _I64, _I32, _P]),
     "bist_col_sum_multi": (C.c_int, [C.POINTER(BistColSum), _I32, _I32, _P]),
-    "bist_embed_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),
+    "bist_embed_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_fuse_modalities_bwd": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(C.c_void_p), _I64, _I32, _I32, _I32, _P]),
-    "bist_mha_core_bwd": (C.c_int, [_P] * 9 + [_I32] * 5 + [_I64] * 16 + [_F, _I32, _P]),
-    "bist_st_stage1_pv_bwd": (C.c_int, [_P] * 6 + [_I32] * 6 + [_I64, _I64, _I32, _I32, _P]),
-    "bist_st_stage2_bwd": (C.c_int, [_P] * 6 + [_I32] * 6 + [_P]),
+    "bist_mha_core_bwd": (C.c_int, [_P] * 9 + [_I32] * 5 + [_I64] * 16 + [_F, C.POINTER(BistDrop), _I32, _P]),
+    "bist_st_stage1_pv_bwd": (C.c_int, [_P] * 6 + [_I32] * 6 + [_I64, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),
+    "bist_st_stage2_bwd": (C.c_int, [_P] * 7 + [_I32] * 5 + [C.POINTER(BistDrop), _I32, _P]),
     "bist_pointer_mix_bwd": (C.c_int, [_P, _P, _I32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                        _P, _P, _P, _P, C.POINTER(C.c_void_p), _I64, _I32, _I32, _I32, _P]),
     "bist_log_softmax_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),

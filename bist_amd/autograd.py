@@ -172,8 +172,8 @@ class HeadUnfoldFn(Function):
     @staticmethod
     def forward(ctx, py, wv, bv, h):
         ctx.save_for_backward(py, wv)
-        ctx.cfg = (h, bv.dtype)
-        ctx.w_dst, ctx.b_dst = getattr(wv, "_grad_view", None), getattr(bv, "_acc32", None)
+        ctx.cfg = (h, bv.dtype if bv is not None else None)
+        ctx.w_dst, ctx.b_dst = getattr(wv, "_grad_view", None), (getattr(bv, "_acc32", None) if bv is not None else None)
         M = py.shape[0]
         d = wv.shape[1]
         dk = d // h
@@ -203,6 +203,8 @@ class HeadUnfoldFn(Function):
             dwv = torch.empty((d, d), device=py.device, dtype=wv.dtype)
             ops.gemm(do, py, dwv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=d, batch=(1, h),
                      a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * d))
+        if bdt is None:                      # no bias here: it is applied by ScaledBiasFn (attention dropout)
+            return dpy, dwv, None, None
         acc = ctx.b_dst if ctx.b_dst is not None else _f32_zeros((d,), do)
         check(lib.bist_col_sum_acc(do.data_ptr(), acc.data_ptr(), M, d, d, dtype_code(do.dtype), _stream()), "bist_col_sum_acc")
         return dpy, dwv, (None if ctx.b_dst is not None else _to_dtype_from_f32(acc, bdt)), None
@@ -328,11 +330,12 @@ class LayerNormResFn(Function):
 
 class EmbedFn(Function):
     @staticmethod
-    def forward(ctx, ids, lut, pe):
+    def forward(ctx, ids, lut, pe, drop=None):
         ctx.save_for_backward(ids)
         ctx.cfg = (tuple(lut.shape), lut.dtype)
+        ctx.drop = drop
         ctx.dst = getattr(lut, "_acc32", None)
-        return ops.embed_pe(ids, lut, pe)
+        return ops.embed_pe(ids, lut, pe, drop=drop)
 
     @staticmethod
     def backward(ctx, dy):
@@ -341,8 +344,8 @@ class EmbedFn(Function):
         dy = dy.contiguous()
         acc = ctx.dst if ctx.dst is not None else _f32_zeros(shape, dy)
         check(lib.bist_embed_bwd(ids.contiguous().data_ptr(), dy.data_ptr(), acc.data_ptr(), ids.numel(), shape[1],
-                                 dtype_code(dy.dtype), _stream()), "bist_embed_bwd")
-        return None, (None if ctx.dst is not None else _to_dtype_from_f32(acc, dt)), None
+                                 ops.drop_ref(ctx.drop), dtype_code(dy.dtype), _stream()), "bist_embed_bwd")
+        return None, (None if ctx.dst is not None else _to_dtype_from_f32(acc, dt)), None, None
 
 
 class FuseFn(Function):
@@ -399,12 +402,13 @@ class MhaCoreFn(Function):
     'q_k_v' (a, b, c).  Returns (O, P or None); a gradient arriving for P is honoured (pointer generator)."""
 
     @staticmethod
-    def forward(ctx, a, b, c, mode, mask, h, want_p):
+    def forward(ctx, a, b, c, mode, mask, h, want_p, drop=None):
         q, k, v = MhaCoreFn._views(a, b, c, mode)
         m8 = _mask_u8(mask)
-        o, p = ops.mha_core(q, k, v, m8, h, want_p=want_p)
+        o, p = ops.mha_core(q, k, v, m8, h, want_p=want_p, drop=drop)
         ctx.save_for_backward(a, b, c, m8)
         ctx.cfg = (mode, h)
+        ctx.drop = drop
         if p is None:
             ctx.mark_non_differentiable()
             return o, None
@@ -446,18 +450,20 @@ class MhaCoreFn(Function):
                                     dq.data_ptr(), dkk.data_ptr(), dv.data_ptr(), N, Lq, Lk, h, dk_,
                                     q.stride(1), k.stride(1), v.stride(1), d, q.stride(0), k.stride(0), v.stride(0), Lq * d,
                                     dq.stride(1), dkk.stride(1), dv.stride(1), dq.stride(0), dkk.stride(0), dv.stride(0),
-                                    mbs, mqs, 1.0 / math.sqrt(dk_), dtype_code(q.dtype), _stream()), "bist_mha_core_bwd")
-        return ga, gb, gc, None, None, None, None
+                                    mbs, mqs, 1.0 / math.sqrt(dk_), ops.drop_ref(ctx.drop), dtype_code(q.dtype), _stream()),
+              "bist_mha_core_bwd")
+        return ga, gb, gc, None, None, None, None, None
 
 
 class StStage1PvFn(Function):
     @staticmethod
-    def forward(ctx, scores, v, tmask, dims, direction):
+    def forward(ctx, scores, v, tmask, dims, direction, drop=None):
         B, T, S, Lq, h, dk = dims
         m8 = _mask_u8(tmask.reshape(B, T)) if tmask is not None else None
-        out = ops.st_stage1_pv(scores, v, m8, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
+        out = ops.st_stage1_pv(scores, v, m8, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction, drop=drop)
         ctx.save_for_backward(scores, v, m8)
         ctx.cfg = (dims, direction)
+        ctx.drop = drop
         return out
 
     @staticmethod
@@ -469,31 +475,63 @@ class StStage1PvFn(Function):
         dsc = torch.empty_like(scores)
         dv = torch.empty((B, T, S, d), device=v.device, dtype=v.dtype)
         check(lib.bist_st_stage1_pv_bwd(scores.data_ptr(), v.data_ptr(), _ptr(m8), do.data_ptr(), dsc.data_ptr(), dv.data_ptr(),
-                                        B, T, S, Lq, h, dk, v.stride(-2), d, direction, dtype_code(v.dtype), _stream()),
+                                        B, T, S, Lq, h, dk, v.stride(-2), d, direction, ops.drop_ref(ctx.drop), dtype_code(v.dtype),
+                                        _stream()),
               "bist_st_stage1_pv_bwd")
-        return dsc, dv, None, None, None
+        return dsc, dv, None, None, None, None
 
 
 class StStage2Fn(Function):
-    @staticmethod
-    def forward(ctx, q2f, y, gmask, h):
-        B, G = y.shape[0], y.shape[1]
-        m8 = _mask_u8(gmask.reshape(B, G)) if gmask is not None else None
-        out = ops.st_stage2(q2f, y, m8, h=h)
-        ctx.save_for_backward(q2f, y, m8)
-        ctx.h = h
-        return out
+    """(PY, rowsum): rowsum [B,Lq,h] f32 = sum_g P'[g] is only produced under dropout (None otherwise)."""
 
     @staticmethod
-    def backward(ctx, dpy):
+    def forward(ctx, q2f, y, gmask, h, drop=None):
+        B, G = y.shape[0], y.shape[1]
+        m8 = _mask_u8(gmask.reshape(B, G)) if gmask is not None else None
+        res = ops.st_stage2(q2f, y, m8, h=h, drop=drop)
+        ctx.save_for_backward(q2f, y, m8)
+        ctx.h, ctx.drop = h, drop
+        ctx.set_materialize_grads(False)
+        if isinstance(res, tuple):
+            return res
+        ctx.mark_non_differentiable()
+        return res, None
+
+    @staticmethod
+    def backward(ctx, dpy, drs):
         q2f, y, m8 = ctx.saved_tensors
         B, G, Lq, d = y.shape
-        dpy = dpy.contiguous()
+        dpy = torch.zeros((B, Lq, ctx.h, d), device=y.device, dtype=y.dtype) if dpy is None else dpy.contiguous()
+        if drs is not None:
+            drs = drs.contiguous().float()
         dq = torch.empty_like(q2f)
         dy = torch.empty_like(y)
-        check(lib.bist_st_stage2_bwd(q2f.data_ptr(), y.data_ptr(), _ptr(m8), dpy.data_ptr(), dq.data_ptr(), dy.data_ptr(),
-                                     B, G, Lq, ctx.h, d, dtype_code(y.dtype), _stream()), "bist_st_stage2_bwd")
-        return dq, dy, None, None
+        check(lib.bist_st_stage2_bwd(q2f.data_ptr(), y.data_ptr(), _ptr(m8), dpy.data_ptr(), _ptr(drs), dq.data_ptr(), dy.data_ptr(),
+                                     B, G, Lq, ctx.h, d, ops.drop_ref(ctx.drop), dtype_code(y.dtype), _stream()), "bist_st_stage2_bwd")
+        return dq, dy, None, None, None
+
+
+class ScaledBiasFn(Function):
+    """x + s[m, head] * bias   (the value bias of stage 2 when the probabilities were dropped)."""
+
+    @staticmethod
+    def forward(ctx, x, s, bias, h):
+        ctx.save_for_backward(s, bias)
+        ctx.h = h
+        ctx.b_dst = getattr(bias, "_acc32", None)
+        return ops.scaled_bias(x, s, bias, h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, bias = ctx.saved_tensors
+        h = ctx.h
+        d = dy.shape[-1]
+        dy2 = dy.reshape(-1, d).contiguous()
+        ds = torch.empty(s.shape, device=s.device, dtype=torch.float32)
+        acc = ctx.b_dst if ctx.b_dst is not None else _f32_zeros((d,), dy2)
+        check(lib.bist_scaled_bias_bwd(dy2.data_ptr(), s.data_ptr(), bias.data_ptr(), ds.data_ptr(), acc.data_ptr(), dy2.shape[0], h,
+                                       d // h, dtype_code(dy2.dtype), _stream()), "bist_scaled_bias_bwd")
+        return dy, ds, (None if ctx.b_dst is not None else _to_dtype_from_f32(acc, bias.dtype)), None
 
 
 # ----------------------------------------------------------------------------------------------

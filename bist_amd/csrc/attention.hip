@@ -23,7 +23,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void mha_core_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ V,
                                                        const unsigned char* __restrict__ mask, T* __restrict__ O, float* __restrict__ P,
                                                        int N, int Lq, int Lk, int h, int dk, long ldq, long ldk, long ldv, long ldo,
-                                                       long q_bs, long k_bs, long v_bs, long o_bs, long mask_bs, long mask_qs, float scale) {
+                                                       long q_bs, long k_bs, long v_bs, long o_bs, long mask_bs, long mask_qs, float scale,
+                                                       const DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long item = (long)blockIdx.x * 4 + w;
@@ -63,6 +64,12 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const T* __restrict__ Q, 
     float* pr = P + (((long)n * h + hh) * Lq + i) * Lk;
     for (int j = lane; j < Lk; j += 64) pr[j] = ps[j];
   }
+  if (drop.p > 0.f) {                                   // p_attn = dropout(p_attn), modules.py:62-63
+    const unsigned long long key = drop.key(), base = (unsigned long long)item * Lk;
+    const float ks = drop.keep_scale();
+    for (int j = lane; j < Lk; j += 64) ps[j] *= drop_mul(key, base + j, drop.p, ks);
+    __builtin_amdgcn_wave_barrier();
+  }
   T* o = O + n * o_bs + (long)i * ldo + hh * dk;
   for (int c = lane; c < dk; c += 64) {
     float acc = 0.f;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const T* __restrict__ Q, 
 template <typename T, typename TS>
 __global__ __launch_bounds__(256) void st1_pv_kernel(const TS* __restrict__ scores, const T* __restrict__ V,
                                                      const unsigned char* __restrict__ tmask, T* __restrict__ O,
-                                                     int T_, int S_, int Lq, int h, int dk, long ldv, int dir, int Gc) {
+                                                     int T_, int S_, int Lq, int h, int dk, long ldv, int dir, int Gc, const DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int G = dir == 0 ? S_ : T_, Kn = dir == 0 ? T_ : S_;
   const int KP = Kn + 1;                                  // padded row: conflict-free column walks
@@ -114,7 +121,15 @@ __global__ __launch_bounds__(256) void st1_pv_kernel(const TS* __restrict__ scor
     float den = 0.f;
     for (int k = 0; k < Kn; ++k) { const float e = expf(p[k] - mx); p[k] = e; den += e; }
     const float inv = 1.f / den;
-    for (int k = 0; k < Kn; ++k) p[k] *= inv;
+    if (drop.p > 0.f) {
+      const int i = r / gc, gl = r - i * gc;
+      const unsigned long long key = drop.key();
+      const unsigned long long base = ((((unsigned long long)b * G + (g0 + gl)) * h + hh) * Lq + i) * Kn;
+      const float ks = drop.keep_scale();
+      for (int k = 0; k < Kn; ++k) p[k] *= inv * drop_mul(key, base + k, drop.p, ks);
+    } else {
+      for (int k = 0; k < Kn; ++k) p[k] *= inv;
+    }
   }
   __syncthreads();
   // phase 3: P.V -- work item = (gl, c); 8 query rows at a time in registers
@@ -147,7 +162,7 @@ constexpr int ST2_MAXH = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void st2_kernel(const T* __restrict__ q2f, const T* __restrict__ Y,
                                                   const unsigned char* __restrict__ gmask, T* __restrict__ PY,
-                                                  int G, int Lq, int h, int d) {
+                                                  float* __restrict__ rowsum, int G, int Lq, int h, int d, const DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qf = smem;                 // [h][d]
   float* sc = smem + (long)h * d;   // [h][G]
@@ -191,7 +206,16 @@ __global__ __launch_bounds__(256) void st2_kernel(const T* __restrict__ q2f, con
     for (int g = lane; g < G; g += 64) { const float e = expf(p[g] - mx); p[g] = e; den += e; }
     den = wave_sum(den);
     const float inv = 1.f / den;
-    for (int g = lane; g < G; g += 64) p[g] *= inv;
+    float rs = 0.f;
+    if (drop.p > 0.f) {
+      const unsigned long long key = drop.key(), base = (((unsigned long long)b * Lq + i) * h + hh) * G;
+      const float ks = drop.keep_scale();
+      for (int g = lane; g < G; g += 64) { p[g] *= inv * drop_mul(key, base + g, drop.p, ks); rs += p[g]; }
+    } else {
+      for (int g = lane; g < G; g += 64) { p[g] *= inv; rs += p[g]; }
+    }
+    rs = wave_sum(rs);
+    if (rowsum && lane == 0) rowsum[((long)b * Lq + i) * h + hh] = rs;
   }
   __syncthreads();
   // phase 3: PY[hh][e] = sum_g P[hh][g] Y[g][e]
@@ -217,8 +241,10 @@ __global__ __launch_bounds__(256) void st2_kernel(const T* __restrict__ q2f, con
 extern "C" int bist_mha_core_fwd(const void* Q, const void* K, const void* V, const uint8_t* mask, void* O, float* p_attn,
                                  int32_t N, int32_t Lq, int32_t Lk, int32_t h, int32_t dk, int64_t ldq, int64_t ldk, int64_t ldv,
                                  int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs,
-                                 int64_t mask_qs, float scale, int32_t dtype, void* stream) {
+                                 int64_t mask_qs, float scale, const BistDrop* drop, int32_t dtype, void* stream) {
   BIST_REQUIRE(Q && K && V && O, "bist_mha_core_fwd: null pointer");
+  BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_mha_core_fwd: drop p out of range");
+  const DropArg dr = make_drop(drop);
   BIST_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && h > 0 && dk > 0, "bist_mha_core_fwd: bad shape");
   const size_t lds = (size_t)4 * (dk + Lk) * sizeof(float);
   BIST_REQUIRE(lds <= 64 * 1024, "bist_mha_core_fwd: dk+Lk=%d too large for the LDS row buffer", dk + Lk);
@@ -227,10 +253,10 @@ extern "C" int bist_mha_core_fwd(const void* Q, const void* K, const void* V, co
   const unsigned g = (unsigned)((items + 3) / 4);
   if (dtype == BIST_BF16)
     hipLaunchKernelGGL(mha_core_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, mask,
-                       (bf16_t*)O, p_attn, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale);
+                       (bf16_t*)O, p_attn, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, dr);
   else if (dtype == BIST_F32)
     hipLaunchKernelGGL(mha_core_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)Q, (const float*)K, (const float*)V, mask,
-                       (float*)O, p_attn, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale);
+                       (float*)O, p_attn, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, dr);
   else { bist_set_error("bist_mha_core_fwd: bad dtype %d", dtype); return BIST_EINVAL; }
   BIST_LAUNCH_CHECK("bist_mha_core_fwd");
   return BIST_OK;
@@ -238,15 +264,17 @@ extern "C" int bist_mha_core_fwd(const void* Q, const void* K, const void* V, co
 
 extern "C" int bist_st_stage1_pv_fwd(const void* scores, const void* V, const uint8_t* tmask, void* O, int32_t B, int32_t T,
                                      int32_t S, int32_t Lq, int32_t h, int32_t dk, int64_t ldv, int32_t direction,
-                                     int32_t sc_dtype, int32_t dtype, void* stream) {
+                                     const BistDrop* drop, int32_t sc_dtype, int32_t dtype, void* stream) {
   BIST_REQUIRE(scores && V && O, "bist_st_stage1_pv_fwd: null pointer");
+  BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_st_stage1_pv_fwd: drop p out of range");
+  const DropArg dr = make_drop(drop);
   BIST_REQUIRE(B > 0 && T > 0 && S > 0 && Lq > 0 && h > 0 && dk > 0, "bist_st_stage1_pv_fwd: bad shape");
   BIST_REQUIRE(direction == 0 || direction == 1, "bist_st_stage1_pv_fwd: direction must be 0 (t2s) or 1 (s2t)");
   BIST_REQUIRE(sc_dtype == BIST_F32 || sc_dtype == dtype, "bist_st_stage1_pv_fwd: scores must be f32 or the value dtype");
   BIST_REQUIRE(ldv >= (int64_t)h * dk, "bist_st_stage1_pv_fwd: ldv too small");
   if (dtype == BIST_BF16 && !getenv("BIST_ST1_VALU")) {          // matrix-core path (attention_mfma.hip)
     const int r = bist_st1_mfma(scores, sc_dtype == BIST_F32, V, tmask, O, nullptr, nullptr, nullptr, B, T, S, Lq, h, dk, ldv, 0,
-                                direction, 0, (hipStream_t)stream);
+                                direction, 0, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage1_pv_fwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
   }
@@ -261,7 +289,7 @@ extern "C" int bist_st_stage1_pv_fwd(const void* scores, const void* V, const ui
   dim3 grid((unsigned)((G + Gc - 1) / Gc), (unsigned)h, (unsigned)B);
 #define ST1_LAUNCH(TT, TSC)                                                                                             \
   hipLaunchKernelGGL((st1_pv_kernel<TT, TSC>), grid, dim3(256), lds, st, (const TSC*)scores, (const TT*)V, tmask, (TT*)O, \
-                     T, S, Lq, h, dk, ldv, direction, Gc)
+                     T, S, Lq, h, dk, ldv, direction, Gc, dr)
   if (dtype == BIST_BF16 && sc_dtype == BIST_BF16) ST1_LAUNCH(bf16_t, bf16_t);
   else if (dtype == BIST_BF16 && sc_dtype == BIST_F32) ST1_LAUNCH(bf16_t, float);
   else if (dtype == BIST_F32) ST1_LAUNCH(float, float);
@@ -271,13 +299,16 @@ extern "C" int bist_st_stage1_pv_fwd(const void* scores, const void* V, const ui
   return BIST_OK;
 }
 
-extern "C" int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t* gmask, void* PY, int32_t B, int32_t G,
-                                  int32_t Lq, int32_t h, int32_t d, int32_t dtype, void* stream) {
+extern "C" int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t* gmask, void* PY, float* rowsum, int32_t B, int32_t G,
+                                  int32_t Lq, int32_t h, int32_t d, const BistDrop* drop, int32_t dtype, void* stream) {
   BIST_REQUIRE(q2f && Y && PY, "bist_st_stage2_fwd: null pointer");
+  BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_st_stage2_fwd: drop p out of range");
+  const DropArg dr = make_drop(drop);
+  BIST_REQUIRE(dr.p == 0.f || rowsum, "bist_st_stage2_fwd: dropout needs the rowsum output (the value bias is scaled by it)");
   BIST_REQUIRE(B > 0 && G > 0 && Lq > 0 && h > 0 && d > 0, "bist_st_stage2_fwd: bad shape");
   BIST_REQUIRE(h <= ST2_MAXH, "bist_st_stage2_fwd: at most %d heads", ST2_MAXH);
   if (dtype == BIST_BF16 && !getenv("BIST_ST2_VALU")) {          // matrix-core path (attention_mfma.hip)
-    const int r = bist_st2_mfma(q2f, Y, gmask, PY, nullptr, nullptr, nullptr, B, G, Lq, h, d, 0, (hipStream_t)stream);
+    const int r = bist_st2_mfma(q2f, Y, gmask, PY, nullptr, nullptr, nullptr, rowsum, nullptr, B, G, Lq, h, d, 0, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage2_fwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
   }
@@ -286,9 +317,9 @@ extern "C" int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t*
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)Lq, (unsigned)B);
   if (dtype == BIST_BF16)
-    hipLaunchKernelGGL(st2_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)q2f, (const bf16_t*)Y, gmask, (bf16_t*)PY, G, Lq, h, d);
+    hipLaunchKernelGGL(st2_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)q2f, (const bf16_t*)Y, gmask, (bf16_t*)PY, rowsum, G, Lq, h, d, dr);
   else if (dtype == BIST_F32)
-    hipLaunchKernelGGL(st2_kernel<float>, grid, dim3(256), lds, st, (const float*)q2f, (const float*)Y, gmask, (float*)PY, G, Lq, h, d);
+    hipLaunchKernelGGL(st2_kernel<float>, grid, dim3(256), lds, st, (const float*)q2f, (const float*)Y, gmask, (float*)PY, rowsum, G, Lq, h, d, dr);
   else { bist_set_error("bist_st_stage2_fwd: bad dtype %d", dtype); return BIST_EINVAL; }
   BIST_LAUNCH_CHECK("bist_st_stage2_fwd");
   return BIST_OK;

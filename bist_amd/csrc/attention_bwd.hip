@@ -20,10 +20,12 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const T* __restrict__
                                                            T* __restrict__ dV, int Lq, int Lk, int h, int dk, long ldq, long ldk,
                                                            long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs,
                                                            long lddq, long lddk, long lddv, long dq_bs, long dk_bs, long dv_bs,
-                                                           long mask_bs, long mask_qs, float scale) {
+                                                           long mask_bs, long mask_qs, float scale, const DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* P = smem;
   float* dS = smem + (long)Lq * Lk;
+  const unsigned long long dkey = drop.p > 0.f ? drop.key() : 0ULL;
+  const float dks = drop.p > 0.f ? drop.keep_scale() : 1.f;
   const int hh = blockIdx.x, n = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const T* Qn = Q + n * q_bs + hh * dk;
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const T* __restrict__
       if (lane == 0) {
         s *= scale;
         if (mrow && mrow[j] == 0) s = MASK_FILL;
+        if (drop.p > 0.f) dp *= drop_mul(dkey, (((unsigned long long)n * h + hh) * Lq + i) * Lk + j, drop.p, dks);   // dP = mask/(1-p) dP'
         if (dPext) dp += dPext[(((long)n * h + hh) * Lq + i) * Lk + j];
         p[j] = s; ds[j] = dp;
       }
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const T* __restrict__
       float g = p[j] * (ds[j] - dot);
       if (mrow && mrow[j] == 0) g = 0.f;
       ds[j] = g * scale;
+      if (drop.p > 0.f) p[j] *= drop_mul(dkey, (((unsigned long long)n * h + hh) * Lq + i) * Lk + j, drop.p, dks);    // P' feeds dV
     }
   }
   __syncthreads();
@@ -117,10 +121,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void st1_pv_bwd_kernel(const float* __restrict__ scores, const T* __restrict__ V,
                                                          const unsigned char* __restrict__ tmask, const T* __restrict__ dO,
                                                          float* __restrict__ dscores, T* __restrict__ dV, int T_, int S_, int Lq,
-                                                         int h, int dk, long ldv, long lddv, int dir, int Gc) {
+                                                         int h, int dk, long ldv, long lddv, int dir, int Gc, const DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int G = dir == 0 ? S_ : T_, Kn = dir == 0 ? T_ : S_;
   const int KP = Kn + 1;
+  const unsigned long long dkey = drop.p > 0.f ? drop.key() : 0ULL;
+  const float dks = drop.p > 0.f ? drop.keep_scale() : 1.f;
   const int g0 = blockIdx.x * Gc, hh = blockIdx.y, b = blockIdx.z;
   const int gc = min(Gc, G - g0);
   const int tid = threadIdx.x;
@@ -183,11 +189,16 @@ __global__ __launch_bounds__(256) void st1_pv_bwd_kernel(const float* __restrict
     float* p = P + (long)r * KP;
     float* q = D + (long)r * KP;
     float dot = 0.f;
+    const int ri = r / gc, rgl = r - ri * gc;
+    const unsigned long long dbase = ((((unsigned long long)b * G + (g0 + rgl)) * h + hh) * Lq + ri) * Kn;
+    if (drop.p > 0.f)
+      for (int k = 0; k < Kn; ++k) q[k] *= drop_mul(dkey, dbase + k, drop.p, dks);          // dP = mask/(1-p) dP'
     for (int k = 0; k < Kn; ++k) dot += p[k] * q[k];
     for (int k = 0; k < Kn; ++k) {
       float gq = p[k] * (q[k] - dot);
       if (mk && mk[k] == 0) gq = 0.f;
       q[k] = gq;
+      if (drop.p > 0.f) p[k] *= drop_mul(dkey, dbase + k, drop.p, dks);                     // P' feeds dV
     }
   }
   __syncthreads();
@@ -215,8 +226,8 @@ __global__ __launch_bounds__(256) void st1_pv_bwd_kernel(const float* __restrict
 constexpr int ST2_MAXH = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void st2_bwd_kernel(const T* __restrict__ q2f, const T* __restrict__ Y, const unsigned char* __restrict__ gmask,
-                                                      const T* __restrict__ dPY, T* __restrict__ dq2f, T* __restrict__ dY,
-                                                      int G, int Lq, int h, int d) {
+                                                      const T* __restrict__ dPY, const float* __restrict__ d_rowsum, T* __restrict__ dq2f,
+                                                      T* __restrict__ dY, int G, int Lq, int h, int d, const DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qf = smem;
   float* gp = qf + (long)h * d;
@@ -264,12 +275,22 @@ __global__ __launch_bounds__(256) void st2_bwd_kernel(const T* __restrict__ q2f,
     den = wave_sum(den);
     const float inv = 1.f / den;
     float dot = 0.f;
-    for (int g = lane; g < G; g += 64) { p[g] *= inv; dot += p[g] * q[g]; }
+    const float drs = d_rowsum ? d_rowsum[((long)b * Lq + i) * h + hh] : 0.f;      // gradient of sum_g P'[g]
+    const unsigned long long dkey = drop.p > 0.f ? drop.key() : 0ULL;
+    const unsigned long long dbase = (((unsigned long long)b * Lq + i) * h + hh) * G;
+    const float dks = drop.p > 0.f ? drop.keep_scale() : 1.f;
+    for (int g = lane; g < G; g += 64) {
+      p[g] *= inv;
+      q[g] += drs;
+      if (drop.p > 0.f) q[g] *= drop_mul(dkey, dbase + g, drop.p, dks);             // dP = mask/(1-p) dP'
+      dot += p[g] * q[g];
+    }
     dot = wave_sum(dot);
     for (int g = lane; g < G; g += 64) {
       float gq = p[g] * (q[g] - dot);
       if (mk && mk[g] == 0) gq = 0.f;
       q[g] = gq;
+      if (drop.p > 0.f) p[g] *= drop_mul(dkey, dbase + g, drop.p, dks);             // P' feeds dY
     }
   }
   __syncthreads();
@@ -301,12 +322,14 @@ extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, co
                                  void* dQ, void* dK, void* dV, int32_t N, int32_t Lq, int32_t Lk, int32_t h, int32_t dk,
                                  int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                                  int64_t lddq, int64_t lddk, int64_t lddv, int64_t dq_bs, int64_t dk_bs, int64_t dv_bs,
-                                 int64_t mask_bs, int64_t mask_qs, float scale, int32_t dtype, void* stream) {
+                                 int64_t mask_bs, int64_t mask_qs, float scale, const BistDrop* drop, int32_t dtype, void* stream) {
   BIST_REQUIRE(Q && K && V && dQ && dK && dV && (dO || dP_ext), "bist_mha_core_bwd: null pointer");
+  BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_mha_core_bwd: drop p out of range");
+  const DropArg dr = make_drop(drop);
   BIST_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && h > 0 && dk > 0, "bist_mha_core_bwd: bad shape");
   if (dtype == BIST_BF16 && !getenv("BIST_MHA_VALU")) {          // matrix-core path (attention_mfma.hip)
     const int r = bist_mha_bwd_mfma(Q, K, V, mask, dO, dP_ext, dQ, dK, dV, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs,
-                                    lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, (hipStream_t)stream);
+                                    lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_mha_core_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
   }
@@ -317,7 +340,7 @@ extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, co
   dim3 grid((unsigned)h, (unsigned)N, (unsigned)cs);
 #define L(TT) hipLaunchKernelGGL(mha_core_bwd_kernel<TT>, grid, dim3(256), lds, st, (const TT*)Q, (const TT*)K, (const TT*)V, mask, (const TT*)dO, dP_ext, \
                                  (TT*)dQ, (TT*)dK, (TT*)dV, Lq, Lk, h, dk, (long)ldq, (long)ldk, (long)ldv, (long)ldo, (long)q_bs, (long)k_bs, (long)v_bs, (long)o_bs, \
-                                 (long)lddq, (long)lddk, (long)lddv, (long)dq_bs, (long)dk_bs, (long)dv_bs, (long)mask_bs, (long)mask_qs, scale)
+                                 (long)lddq, (long)lddk, (long)lddv, (long)dq_bs, (long)dk_bs, (long)dv_bs, (long)mask_bs, (long)mask_qs, scale, dr)
   if (dtype == BIST_BF16) L(bf16_t); else if (dtype == BIST_F32) L(float);
   else { bist_set_error("bist_mha_core_bwd: bad dtype %d", dtype); return BIST_EINVAL; }
 #undef L
@@ -327,12 +350,14 @@ extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, co
 
 extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const uint8_t* tmask, const void* dO, float* dscores, void* dV,
                                      int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk, int64_t ldv, int64_t lddv,
-                                     int32_t direction, int32_t dtype, void* stream) {
+                                     int32_t direction, const BistDrop* drop, int32_t dtype, void* stream) {
   BIST_REQUIRE(scores && V && dO && dscores && dV, "bist_st_stage1_pv_bwd: null pointer");
+  BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_st_stage1_pv_bwd: drop p out of range");
+  const DropArg dr = make_drop(drop);
   BIST_REQUIRE(B > 0 && T > 0 && S > 0 && Lq > 0 && h > 0 && dk > 0, "bist_st_stage1_pv_bwd: bad shape");
   BIST_REQUIRE(direction == 0 || direction == 1, "bist_st_stage1_pv_bwd: bad direction");
   if (dtype == BIST_BF16 && !getenv("BIST_ST1_VALU")) {          // matrix-core path (attention_mfma.hip)
-    const int r = bist_st1_mfma(scores, 1, V, tmask, nullptr, dO, dscores, dV, B, T, S, Lq, h, dk, ldv, lddv, direction, 1,
+    const int r = bist_st1_mfma(scores, 1, V, tmask, nullptr, dO, dscores, dV, B, T, S, Lq, h, dk, ldv, lddv, direction, 1, dr,
                                 (hipStream_t)stream);
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage1_pv_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
@@ -346,7 +371,7 @@ extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const u
   const size_t lds = (size_t)per_g * Gc;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((G + Gc - 1) / Gc), (unsigned)h, (unsigned)B);
-#define L(TT) hipLaunchKernelGGL(st1_pv_bwd_kernel<TT>, grid, dim3(256), lds, st, scores, (const TT*)V, tmask, (const TT*)dO, dscores, (TT*)dV, T, S, Lq, h, dk, (long)ldv, (long)lddv, direction, Gc)
+#define L(TT) hipLaunchKernelGGL(st1_pv_bwd_kernel<TT>, grid, dim3(256), lds, st, scores, (const TT*)V, tmask, (const TT*)dO, dscores, (TT*)dV, T, S, Lq, h, dk, (long)ldv, (long)lddv, direction, Gc, dr)
   if (dtype == BIST_BF16) L(bf16_t); else if (dtype == BIST_F32) L(float);
   else { bist_set_error("bist_st_stage1_pv_bwd: bad dtype %d", dtype); return BIST_EINVAL; }
 #undef L
@@ -354,12 +379,15 @@ extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const u
   return BIST_OK;
 }
 
-extern "C" int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t* gmask, const void* dPY, void* dq2f, void* dY,
-                                  int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, int32_t dtype, void* stream) {
+extern "C" int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t* gmask, const void* dPY, const float* d_rowsum,
+                                  void* dq2f, void* dY, int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, const BistDrop* drop,
+                                  int32_t dtype, void* stream) {
   BIST_REQUIRE(q2f && Y && dPY && dq2f && dY, "bist_st_stage2_bwd: null pointer");
+  BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_st_stage2_bwd: drop p out of range");
+  const DropArg dr = make_drop(drop);
   BIST_REQUIRE(B > 0 && G > 0 && Lq > 0 && h > 0 && h <= ST2_MAXH && d > 0, "bist_st_stage2_bwd: bad shape");
   if (dtype == BIST_BF16 && !getenv("BIST_ST2_VALU")) {          // matrix-core path (attention_mfma.hip)
-    const int r = bist_st2_mfma(q2f, Y, gmask, nullptr, dPY, dq2f, dY, B, G, Lq, h, d, 1, (hipStream_t)stream);
+    const int r = bist_st2_mfma(q2f, Y, gmask, nullptr, dPY, dq2f, dY, nullptr, d_rowsum, B, G, Lq, h, d, 1, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage2_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
   }
@@ -367,7 +395,7 @@ extern "C" int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t*
   BIST_REQUIRE(lds <= 64 * 1024, "bist_st_stage2_bwd: h*(d+G) too large for LDS");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)Lq, (unsigned)B);
-#define L(TT) hipLaunchKernelGGL(st2_bwd_kernel<TT>, grid, dim3(256), lds, st, (const TT*)q2f, (const TT*)Y, gmask, (const TT*)dPY, (TT*)dq2f, (TT*)dY, G, Lq, h, d)
+#define L(TT) hipLaunchKernelGGL(st2_bwd_kernel<TT>, grid, dim3(256), lds, st, (const TT*)q2f, (const TT*)Y, gmask, (const TT*)dPY, d_rowsum, (TT*)dq2f, (TT*)dY, G, Lq, h, d, dr)
   if (dtype == BIST_BF16) L(bf16_t); else if (dtype == BIST_F32) L(float);
   else { bist_set_error("bist_st_stage2_bwd: bad dtype %d", dtype); return BIST_EINVAL; }
 #undef L

@@ -46,6 +46,7 @@ struct St1Args {
   const bf16_t* dO; float* dscores; bf16_t* dV;   // backward
   int T, S, Lq, h; long ldv, lddv; int dir, Gc;
   int dbg;      // timing ablation only (BIST_ST1_DBG): bit0 skip slab gather, bit1 skip softmax, bit2 skip phase C
+  DropArg drop; // dropout of the probabilities: the slab keeps P, the bf16 image that feeds the MFMAs holds mask*P/(1-p)
 };
 
 template <typename TS, int KSTEPS, bool BWD>
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
   }
   __syncthreads();
   // ---- B: softmax rows -> slab (f32) and pimg (bf16); four lanes share a row, each keeps its slice in registers ----
+  const unsigned long long dkey = a.drop.p > 0.f ? a.drop.key() : 0ULL;
+  const float dks = a.drop.p > 0.f ? a.drop.keep_scale() : 1.f;
   {
     constexpr int PER = (KPAD + 3) / 4;              // keys per lane (k = part, part+4, ...)
     const int rows = (a.dbg & 2) ? 0 : Lq * gc;
@@ -173,10 +176,15 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
         const float inv = 1.f / den;
         const int i = r / gc, gl = r - i * gc;
         bf16_t* pi = pimg + ((long)gl * 32 + i) * KPAD;
+        const unsigned long long dbase = ((((unsigned long long)b * G + (g0 + gl)) * h + hh) * Lq + i) * Kn;
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
           const int k = part + 4 * u;
-          if (k < Kn) { const float q = v[u] * inv; p[k] = q; pi[k] = (bf16_t)q; }
+          if (k < Kn) {
+            const float q = v[u] * inv;
+            p[k] = q;
+            pi[k] = (bf16_t)(a.drop.p > 0.f ? q * drop_mul(dkey, dbase + k, a.drop.p, dks) : q);
+          }
         }
       }
     }
@@ -242,10 +250,12 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
         for (int r = 0; r < 4; ++r) {
           const int i = mi * 16 + lg * 4 + r;
           float pv[NKF], part = 0.f;
+          const unsigned long long dbase = ((((unsigned long long)b * G + g) * h + hh) * Lq + i) * Kn;
 #pragma unroll
           for (int ni = 0; ni < NKF; ++ni) {
             const int k = ni * 16 + x;
             pv[ni] = (i < Lq && k < Kn) ? slab[((long)i * gc + gl) * KP + k] : 0.f;
+            if (a.drop.p > 0.f) dp[mi][ni][r] *= drop_mul(dkey, dbase + k, a.drop.p, dks);      // dP = mask/(1-p) * dP'
             part += pv[ni] * dp[mi][ni][r];
           }
           part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
@@ -340,6 +350,8 @@ struct St2Args {
   bf16_t* PY;                                         // forward
   const bf16_t* dPY; bf16_t* dq2f; bf16_t* dY;        // backward
   int G, Lq, h, d;
+  float* rowsum; const float* d_rowsum;               // sum_g P'[b,i,hh,g] (forward, nullable) and its gradient (backward, nullable)
+  DropArg drop;
 };
 
 template <bool BWD>
@@ -406,15 +418,25 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
       const float e = lane < G ? expf(s - mx) : 0.f;
       const float p = e / wave_sum(e);
       scf[hh * 64 + lane] = p;
+      // dropout of the probabilities (modules.py:62-63): P' = mask * P / (1-p) feeds the weighted sums
+      float m = 1.f;
+      if (a.drop.p > 0.f && lane < G)
+        m = drop_mul(a.drop.key(), (((unsigned long long)b * Lq + i) * h + hh) * G + lane, a.drop.p, a.drop.keep_scale());
       if constexpr (!BWD) {
-        pimg[hh * 64 + lane] = (bf16_t)p;
+        pimg[hh * 64 + lane] = (bf16_t)(p * m);
+        if (a.rowsum) {
+          const float rs = wave_sum(p * m);
+          if (lane == 0) a.rowsum[((long)b * Lq + i) * h + hh] = rs;
+        }
       } else {
-        const float dp = lane < G ? dpf[hh * 64 + lane] : 0.f;
+        float dp = lane < G ? dpf[hh * 64 + lane] : 0.f;
+        if (a.d_rowsum && lane < G) dp += a.d_rowsum[((long)b * Lq + i) * h + hh];
+        dp *= m;                                            // dP = mask/(1-p) * dP'
         const float dot = wave_sum(p * dp);
         float ds = p * (dp - dot);
         if (lane >= G || (a.gmask && a.gmask[(long)b * G + lane] == 0)) ds = 0.f;
         pimg[hh * 64 + lane] = (bf16_t)ds;
-        pimg[(8 + hh) * 64 + lane] = (bf16_t)p;
+        pimg[(8 + hh) * 64 + lane] = (bf16_t)(p * m);
       }
     }
   }
@@ -480,6 +502,7 @@ struct MhaBwdArgs {
   int Lq, Lk, h;
   long ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs;
   float scale;
+  DropArg drop;
 };
 
 __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
@@ -559,6 +582,8 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
     }
   }
   // softmax and its backward in the accumulator layout: row i = mi*16 + lg*4 + r, col j = ni*16 + x
+  const unsigned long long dkey = a.drop.p > 0.f ? a.drop.key() : 0ULL;
+  const float dks = a.drop.p > 0.f ? a.drop.keep_scale() : 1.f;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -566,7 +591,7 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
       const int i = mi * 16 + lg * 4 + r;
       const bool row_ok = i < Lq;
       const unsigned char* mrow = (a.mask && row_ok) ? mimg + i * 64 : nullptr;
-      float sv[4], dv[4];
+      float sv[4], dv[4], dm[4];
       bool msk[4];
       float mx = -INFINITY;
 #pragma unroll
@@ -578,6 +603,11 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
         if (j >= Lk) sc = -INFINITY;
         sv[ni] = sc;
         dv[ni] = D[mi][ni][r];
+        dm[ni] = 1.f;
+        if (a.drop.p > 0.f && row_ok && j < Lk) {           // dP = mask/(1-p) * dP'   (modules.py:62-63)
+          dm[ni] = drop_mul(dkey, (((unsigned long long)n * a.h + hh) * Lq + i) * Lk + j, a.drop.p, dks);
+          dv[ni] *= dm[ni];
+        }
         if (a.dPext && row_ok && j < Lk) dv[ni] += a.dPext[(((long)n * a.h + hh) * Lq + i) * Lk + j];
         mx = fmaxf(mx, sc);
       }
@@ -597,7 +627,7 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
         const int j = ni * 16 + x;
         float ds = sv[ni] * (dv[ni] - dot) * a.scale;
         if (msk[ni] || !row_ok || j >= Lk) ds = 0.f;
-        pimg[i * 64 + j] = (bf16_t)(row_ok ? sv[ni] : 0.f);
+        pimg[i * 64 + j] = (bf16_t)(row_ok ? sv[ni] * dm[ni] : 0.f);        // P' = mask * P / (1-p) feeds dV
         simg[i * 64 + j] = (bf16_t)ds;
       }
     }
@@ -662,25 +692,26 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
 int bist_mha_bwd_mfma(const void* Q, const void* K, const void* V, const unsigned char* mask, const void* dO, const float* dPext,
                       void* dQ, void* dK, void* dV, int N, int Lq, int Lk, int h, int dk, long ldq, long ldk, long ldv, long ldo,
                       long q_bs, long k_bs, long v_bs, long o_bs, long lddq, long lddk, long lddv, long dq_bs, long dk_bs, long dv_bs,
-                      long mask_bs, long mask_qs, float scale, hipStream_t st) {
+                      long mask_bs, long mask_qs, float scale, const DropArg& drop, hipStream_t st) {
   if (dk != 64 || Lq > 32 || Lk > 64) return 0;
   auto al8 = [](long v) { return (v % 8) == 0; };
   if (!(al8(ldq) && al8(ldk) && al8(ldv) && al8(lddq) && al8(lddk) && al8(lddv) && al8(q_bs) && al8(k_bs) && al8(v_bs) && al8(dq_bs) &&
         al8(dk_bs) && al8(dv_bs) && (!dO || (al8(ldo) && al8(o_bs))))) return 0;
   if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV | (uintptr_t)dO) % 16) return 0;
   MhaBwdArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, mask, dPext, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV,
-               Lq, Lk, h, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale};
+               Lq, Lk, h, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, drop};
   hipLaunchKernelGGL(mha_bwd_mfma_kernel, dim3((unsigned)h, (unsigned)N), dim3(64), 0, st, a);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 
 // returns 1 if launched, 0 if outside the envelope, -1 on launch error
 int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, void* PY, const void* dPY, void* dq2f, void* dY,
-                  int B, int G, int Lq, int h, int d, int bwd, hipStream_t st) {
+                  float* rowsum, const float* d_rowsum, int B, int G, int Lq, int h, int d, int bwd, const DropArg& drop, hipStream_t st) {
   if (G > 64 || h > 8 || d > 512 || (d % 128) != 0) return 0;
   if (((uintptr_t)q2f | (uintptr_t)Y | (uintptr_t)(bwd ? dPY : q2f)) % 16) return 0;
   const size_t lds = (size_t)64 * d * 2 + (size_t)(bwd ? 32 : 8) * d * 2 + 2 * 8 * 64 * 4 + 32 * 64 * 2;
-  St2Args a{(const bf16_t*)q2f, (const bf16_t*)Y, gmask, (bf16_t*)PY, (const bf16_t*)dPY, (bf16_t*)dq2f, (bf16_t*)dY, G, Lq, h, d};
+  St2Args a{(const bf16_t*)q2f, (const bf16_t*)Y, gmask, (bf16_t*)PY, (const bf16_t*)dPY, (bf16_t*)dq2f, (bf16_t*)dY, G, Lq, h, d,
+            rowsum, d_rowsum, drop};
   static bool attr_f = false, attr_b = false;
   dim3 grid((unsigned)Lq, (unsigned)B);
   if (bwd) {
@@ -696,7 +727,7 @@ int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, vo
 // returns 1 if launched, 0 if the shape is outside this kernel's envelope (caller falls back), -1 on launch error
 int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsigned char* tmask, void* O, const void* dO,
                   float* dscores, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
-                  int bwd, hipStream_t st) {
+                  int bwd, const DropArg& drop, hipStream_t st) {
   const int G = dir == 0 ? S : T, Kn = dir == 0 ? T : S;
   if (dk != 64 || Lq > 32 || Kn > 128 || (ldv % 8) != 0 || ((uintptr_t)V % 16) != 0) return 0;
   if (bwd && ((lddv % 8) != 0 || ((long)h * dk) % 8 != 0 || !sc_is_f32)) return 0;
@@ -710,7 +741,7 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
   if (Gc > G) Gc = G;
   const size_t lds = (size_t)(((long)Lq * Gc * (Kn + 1) * 4 + 15) / 16 * 16) + (size_t)Gc * 32 * kpad * 2 + (size_t)fixed;
   static const int dbg = [] { const char* e = getenv("BIST_ST1_DBG"); return e ? atoi(e) : 0; }();
-  St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc, dbg};
+  St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc, dbg, drop};
 #define GO(TS_, KS_)                                                                   \
   return bwd ? launch_one<TS_, KS_, true>(a, B, lds, st) : launch_one<TS_, KS_, false>(a, B, lds, st)
   if (sc_is_f32) {

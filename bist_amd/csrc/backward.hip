@@ -220,11 +220,44 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
 
 // Embedding backward: dlut[ids[row], c] += dy[row, c] * sqrt(d)   (fp32 atomics)
 template <typename T>
-__global__ void embed_bwd_kernel(const long* __restrict__ ids, const T* __restrict__ dy, float* __restrict__ dlut, long rows, int d, float scale) {
+__global__ void embed_bwd_kernel(const long* __restrict__ ids, const T* __restrict__ dy, float* __restrict__ dlut, long rows, int d, float scale,
+                                 const DropArg drop) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * d) return;
   const long row = idx / d; const int c = (int)(idx % d);
-  atomicAdd(dlut + ids[row] * d + c, to_f(dy[idx]) * scale);
+  float g = to_f(dy[idx]) * scale;
+  if (drop.p > 0.f) g *= drop_mul(drop.key(), (unsigned long long)idx, drop.p, drop.keep_scale());
+  if (g != 0.f) atomicAdd(dlut + ids[row] * d + c, g);
+}
+
+// y = x + s[m, head] * bias  and its backward (the value bias of stage 2 under attention dropout, bist_hip.h)
+template <typename T>
+__global__ void scaled_bias_kernel(const T* __restrict__ x, const float* __restrict__ s, const T* __restrict__ bias, T* __restrict__ y,
+                                   long M, int h, int dk) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int d = h * dk;
+  if (idx >= M * d) return;
+  const long m = idx / d; const int c = (int)(idx % d);
+  y[idx] = from_f<T>(to_f(x[idx]) + s[m * h + c / dk] * to_f(bias[c]));
+}
+// one wave per (m, head): ds = <dy, bias>;  block = 4 waves; dbias through per-column atomics of s*dy
+template <typename T>
+__global__ __launch_bounds__(256) void scaled_bias_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ s, const T* __restrict__ bias,
+                                                              float* __restrict__ ds, float* __restrict__ dbias, long M, int h, int dk) {
+  const int lane = threadIdx.x & 63;
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= M * h) return;
+  const long m = item / h; const int hh = (int)(item % h);
+  const T* g = dy + (m * h + hh) * dk;
+  const float sv = s[item];
+  float acc = 0.f;
+  for (int c = lane; c < dk; c += 64) {
+    const float gv = to_f(g[c]);
+    acc += gv * to_f(bias[hh * dk + c]);
+    atomicAdd(dbias + hh * dk + c, sv * gv);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) ds[item] = acc;
 }
 
 // Modality fusion backward: out = sum_j w_j x_j, w = softmax(score)
@@ -388,11 +421,36 @@ extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, 
   return BIST_OK;
 }
 
-extern "C" int bist_embed_bwd(const int64_t* ids, const void* dy, float* dlut, int64_t rows, int32_t d, int32_t dtype, void* stream) {
+extern "C" int bist_scaled_bias_fwd(const void* x, const float* s, const void* bias, void* y, int64_t M, int32_t h, int32_t dk,
+                                    int32_t dtype, void* stream) {
+  BIST_REQUIRE(x && s && bias && y && M > 0 && h > 0 && dk > 0, "bist_scaled_bias_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+#define L(TT, ...) hipLaunchKernelGGL(scaled_bias_kernel<TT>, dim3(blocks_for(M * h * dk, 256)), dim3(256), 0, st, (const TT*)x, s, (const TT*)bias, (TT*)y, (long)M, h, dk)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_scaled_bias_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_scaled_bias_bwd(const void* dy, const float* s, const void* bias, float* ds, float* dbias, int64_t M, int32_t h,
+                                    int32_t dk, int32_t dtype, void* stream) {
+  BIST_REQUIRE(dy && s && bias && ds && dbias && M > 0 && h > 0 && dk > 0, "bist_scaled_bias_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+#define L(TT, ...) hipLaunchKernelGGL(scaled_bias_bwd_kernel<TT>, dim3(blocks_for(M * h, 4)), dim3(256), 0, st, (const TT*)dy, s, (const TT*)bias, ds, dbias, (long)M, h, dk)
+  DISPATCH_T(dtype, L, 0)
+#undef L
+  BIST_LAUNCH_CHECK("bist_scaled_bias_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_embed_bwd(const int64_t* ids, const void* dy, float* dlut, int64_t rows, int32_t d, const BistDrop* drop,
+                              int32_t dtype, void* stream) {
   BIST_REQUIRE(ids && dy && dlut && rows > 0 && d > 0, "bist_embed_bwd: bad argument");
+  BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_embed_bwd: drop p out of range");
+  const DropArg dr = make_drop(drop);
   hipStream_t st = (hipStream_t)stream;
   const float scale = sqrtf((float)d);
-#define L(TT, ...) hipLaunchKernelGGL(embed_bwd_kernel<TT>, dim3(blocks_for(rows * d, 256)), dim3(256), 0, st, (const long*)ids, (const TT*)dy, dlut, (long)rows, d, scale)
+#define L(TT, ...) hipLaunchKernelGGL(embed_bwd_kernel<TT>, dim3(blocks_for(rows * d, 256)), dim3(256), 0, st, (const long*)ids, (const TT*)dy, dlut, (long)rows, d, scale, dr)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_embed_bwd");

@@ -33,17 +33,18 @@ void bist_set_error(const char* fmt, ...);
   } while (0)
 
 // MFMA implementation of the stage-1 core (attention_mfma.hip): 1 = launched, 0 = shape outside its envelope, -1 = error
+struct DropArg;
 int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsigned char* tmask, void* O, const void* dO,
                   float* dscores, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
-                  int bwd, hipStream_t st);
+                  int bwd, const DropArg& drop, hipStream_t st);
 
 int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, void* PY, const void* dPY, void* dq2f, void* dY,
-                  int B, int G, int Lq, int h, int d, int bwd, hipStream_t st);
+                  float* rowsum, const float* d_rowsum, int B, int G, int Lq, int h, int d, int bwd, const DropArg& drop, hipStream_t st);
 
 int bist_mha_bwd_mfma(const void* Q, const void* K, const void* V, const unsigned char* mask, const void* dO, const float* dPext,
                       void* dQ, void* dK, void* dV, int N, int Lq, int Lk, int h, int dk, long ldq, long ldk, long ldv, long ldo,
                       long q_bs, long k_bs, long v_bs, long o_bs, long lddq, long lddk, long lddv, long dq_bs, long dk_bs, long dv_bs,
-                      long mask_bs, long mask_qs, float scale, hipStream_t st);
+                      long mask_bs, long mask_qs, float scale, const DropArg& drop, hipStream_t st);
 
 // ---- element conversion ----------------------------------------------------------------------
 __device__ __forceinline__ float to_f(float x) { return x; }
@@ -73,4 +74,20 @@ __device__ __forceinline__ uint32_t mix64(uint64_t x) {
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
   const uint32_t u = mix64(seed + idx * 0x9E3779B97F4A7C15ULL);
   return (float)(u >> 8) * (1.0f / 16777216.0f) >= p;
+}
+// Dropout of attention probabilities (reference modules.py:62-63) as the kernels carry it: p == 0 means off.
+// The mask of probability element `idx` (its linear index in the canonical [.., query, key] order documented at
+// each entry point) is drop_keep(seed + step counter, idx), the same in forward and backward.
+struct DropArg {
+  float p; unsigned long long seed; const unsigned long long* ctr;
+  __device__ __forceinline__ unsigned long long key() const { return seed + (ctr ? ctr[0] * 0xD1B54A32D192ED03ULL : 0ULL); }
+  __device__ __forceinline__ float keep_scale() const { return 1.f / (1.f - p); }
+};
+__device__ __forceinline__ float drop_mul(unsigned long long key, unsigned long long idx, float p, float keep_scale) {
+  return drop_keep(key, idx, p) ? keep_scale : 0.f;
+}
+inline DropArg make_drop(const BistDrop* d) {
+  DropArg r{0.f, 0ULL, nullptr};
+  if (d && d->p > 0.f) { r.p = d->p; r.seed = d->seed; r.ctr = (const unsigned long long*)d->ctr; }
+  return r;
 }

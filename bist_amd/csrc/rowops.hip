@@ -68,12 +68,14 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict_
 // Embeddings*sqrt(d) + PositionalEncoding (modules.py:121-123, 141-144); pe is the f32 table.
 template <typename T>
 __global__ void embed_pe_kernel(const long* __restrict__ ids, const T* __restrict__ lut, const float* __restrict__ pe,
-                                T* __restrict__ y, long rows, int L, int d, float scale) {
+                                T* __restrict__ y, long rows, int L, int d, float scale, const DropArg drop) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * d) return;
   const long row = idx / d; const int c = (int)(idx % d);
   const long id = ids[row];
-  y[idx] = from_f<T>(to_f(lut[id * d + c]) * scale + pe[(row % L) * (long)d + c]);
+  float v = to_f(lut[id * d + c]) * scale + pe[(row % L) * (long)d + c];
+  if (drop.p > 0.f) v *= drop_mul(drop.key(), (unsigned long long)idx, drop.p, drop.keep_scale());     // modules.py:144
+  y[idx] = from_f<T>(v);
 }
 
 // temporal_mask[row] = (sum of the row's S*C features != 0)  (data/dataset.py:79); one 256-thread block per row
@@ -157,16 +159,18 @@ extern "C" int bist_layernorm_fwd(const void* x, const void* a, const void* b, v
 }
 
 extern "C" int bist_embed_pe_fwd(const int64_t* ids, const void* lut, const float* pe, void* y, int64_t rows, int32_t L,
-                                 int32_t d, int32_t dtype, void* stream) {
+                                 int32_t d, const BistDrop* drop, int32_t dtype, void* stream) {
   BIST_REQUIRE(ids && lut && pe && y, "bist_embed_pe_fwd: null pointer");
+  BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_embed_pe_fwd: drop p out of range");
+  const DropArg dr = make_drop(drop);
   BIST_REQUIRE(rows > 0 && L > 0 && d > 0, "bist_embed_pe_fwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
   const float scale = sqrtf((float)d);
   const unsigned g = blocks_for(rows * d, 256);
   if (dtype == BIST_BF16)
-    hipLaunchKernelGGL(embed_pe_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const long*)ids, (const bf16_t*)lut, pe, (bf16_t*)y, rows, L, d, scale);
+    hipLaunchKernelGGL(embed_pe_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const long*)ids, (const bf16_t*)lut, pe, (bf16_t*)y, rows, L, d, scale, dr);
   else if (dtype == BIST_F32)
-    hipLaunchKernelGGL(embed_pe_kernel<float>, dim3(g), dim3(256), 0, st, (const long*)ids, (const float*)lut, pe, (float*)y, rows, L, d, scale);
+    hipLaunchKernelGGL(embed_pe_kernel<float>, dim3(g), dim3(256), 0, st, (const long*)ids, (const float*)lut, pe, (float*)y, rows, L, d, scale, dr);
   else { bist_set_error("bist_embed_pe_fwd: bad dtype %d", dtype); return BIST_EINVAL; }
   BIST_LAUNCH_CHECK("bist_embed_pe_fwd");
   return BIST_OK;

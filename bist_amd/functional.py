@@ -70,26 +70,44 @@ def bmm_nn(a: Tensor, b: Tensor) -> Tensor:
     return ag.BmmNNFn.forward(_NoCtx(), a, b)
 
 
-def mha_packed(a: Tensor, b: Optional[Tensor], c: Optional[Tensor], mode: str, mask: Optional[Tensor], h: int, want_p: bool = False):
-    """Attention core over packed projections (see autograd.MhaCoreFn); returns (ctx [N,Lq,d], P or None)."""
+def mha_packed(a: Tensor, b: Optional[Tensor], c: Optional[Tensor], mode: str, mask: Optional[Tensor], h: int, want_p: bool = False,
+               drop=None):
+    """Attention core over packed projections (see autograd.MhaCoreFn); returns (ctx [N,Lq,d], P or None).
+    drop = (p, seed): dropout of the probabilities (modules.py:62-63)."""
     if _grad():
-        return ag.MhaCoreFn.apply(a, b, c, mode, mask, h, want_p)
+        return ag.MhaCoreFn.apply(a, b, c, mode, mask, h, want_p, drop)
     q, k, v = ag.MhaCoreFn._views(a, b, c, mode)
-    return ops.mha_core(q, k, v, mask, h, want_p=want_p)
+    return ops.mha_core(q, k, v, mask, h, want_p=want_p, drop=drop)
 
 
-def st_stage1_pv(scores, v, tmask, *, B, T, S, Lq, h, dk, direction):
+def st_stage1_pv(scores, v, tmask, *, B, T, S, Lq, h, dk, direction, drop=None):
     if _grad():
-        return ag.StStage1PvFn.apply(scores, v, tmask, (B, T, S, Lq, h, dk), direction)
-    return ops.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
+        return ag.StStage1PvFn.apply(scores, v, tmask, (B, T, S, Lq, h, dk), direction, drop)
+    return ops.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction, drop=drop)
 
 
-def st_stage2(q2f, y, gmask, *, h):
-    return ag.StStage2Fn.apply(q2f, y, gmask, h) if _grad() else ops.st_stage2(q2f, y, gmask, h=h)
+def st_stage2(q2f, y, gmask, *, h, drop=None):
+    """(PY, rowsum or None); rowsum only under dropout -- scale the value bias with it (scaled_bias)."""
+    if _grad():
+        return ag.StStage2Fn.apply(q2f, y, gmask, h, drop)
+    res = ops.st_stage2(q2f, y, gmask, h=h, drop=drop)
+    return res if isinstance(res, tuple) else (res, None)
 
 
-def embed_pe(ids, lut, pe):
-    return ag.EmbedFn.apply(ids, lut, pe) if _grad() else ops.embed_pe(ids, lut, pe)
+def scaled_bias(x, s, bias, h):
+    return ag.ScaledBiasFn.apply(x, s, bias, h) if _grad() else ops.scaled_bias(x, s, bias, h)
+
+
+def attn_drop(module):
+    """(p, seed) for the dropout of attention probabilities held by a MultiHeadedAttention (modules.py:79,95)."""
+    p = float(getattr(getattr(module, "dropout", None), "p", 0.0))
+    if module.training and p > 0.0:
+        return (p, next_seed())
+    return None
+
+
+def embed_pe(ids, lut, pe, drop=None):
+    return ag.EmbedFn.apply(ids, lut, pe, drop) if _grad() else ops.embed_pe(ids, lut, pe, drop=drop)
 
 
 def fuse_modalities(score, xs: Sequence[Tensor]):

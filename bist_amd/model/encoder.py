@@ -133,7 +133,7 @@ class VidEncoderLayer4(nn.Module):
         v_ready = self.__dict__.get("_v_ready")
         if v_ready is not None:
             torch.cuda.current_stream().wait_stream(v_ready)      # V comes from the value-projection stream
-        o = Fn.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction)
+        o = Fn.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction, drop=Fn.attn_drop(attn))
         G = o.shape[1]
         y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=xr, res_map=(G * Lq, Lq), **Fn.drop_args(sub))
         return y.view(B, G, Lq, d)
@@ -147,8 +147,12 @@ class VidEncoderLayer4(nn.Module):
         xn, xr = sub.norm.with_residual(x)
         q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)
         q2f = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq, h, d)
-        py = Fn.st_stage2(q2f, y, gmask, h=h)
-        ctx = Fn.head_unfold(py.view(B * Lq, h * d), attn.linears[2].weight, attn.linears[2].bias, h)
+        py, rowsum = Fn.st_stage2(q2f, y, gmask, h=h, drop=Fn.attn_drop(attn))
+        if rowsum is None:
+            ctx = Fn.head_unfold(py.view(B * Lq, h * d), attn.linears[2].weight, attn.linears[2].bias, h)
+        else:       # dropped probabilities do not sum to one: P'(Y W^T + b) = (P'Y) W^T + rowsum(P') b
+            ctx = Fn.head_unfold(py.view(B * Lq, h * d), attn.linears[2].weight, None, h)
+            ctx = Fn.scaled_bias(ctx, rowsum, attn.linears[2].bias, h)
         return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, **Fn.drop_args(sub)).view(B, Lq, d)
 
     def value_projection(self, vft: Tensor):

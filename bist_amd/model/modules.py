@@ -104,24 +104,26 @@ class MultiHeadedAttention(nn.Module):
 
         The Q/K/V projections are as few GEMMs as the aliasing of the arguments allows (one packed
         [N,L,3d] output for self-attention, q + packed [N,Lk,2d] for cross-attention); the attention
-        core reads them in place as column views."""
+        core reads them in place as column views.  In training the probabilities are dropped inside the core
+        (modules.py:62-63; self.dropout holds p) -- ``self.attn`` keeps the probabilities BEFORE dropout, its only
+        readers being the pointer attentions, which are built with dropout=0 (mtn.py:89-92)."""
         d = self.h * self.d_k
         n, lq = query.shape[0], query.shape[1]
         if query is key and key is value:
             w, b = self._packed((0, 1, 2))
             qkv = Fn.linear(query, w, b).view(n, lq, 3 * d)
-            ctx, p = Fn.mha_packed(qkv, None, None, "qkv", mask, self.h, self.keep_attn)
+            ctx, p = Fn.mha_packed(qkv, None, None, "qkv", mask, self.h, self.keep_attn, Fn.attn_drop(self))
         else:
             q = Fn.linear(query, self.linears[0].weight, self.linears[0].bias).view(n, lq, d)
             lk = key.shape[1]
             if key is value:
                 w, b = self._packed((1, 2))
                 kv = Fn.linear(key, w, b).view(n, lk, 2 * d)
-                ctx, p = Fn.mha_packed(q, kv, None, "q_kv", mask, self.h, self.keep_attn)
+                ctx, p = Fn.mha_packed(q, kv, None, "q_kv", mask, self.h, self.keep_attn, Fn.attn_drop(self))
             else:
                 k = Fn.linear(key, self.linears[1].weight, self.linears[1].bias).view(n, lk, d)
                 v = Fn.linear(value, self.linears[2].weight, self.linears[2].bias).view(n, lk, d)
-                ctx, p = Fn.mha_packed(q, k, v, "q_k_v", mask, self.h, self.keep_attn)
+                ctx, p = Fn.mha_packed(q, k, v, "q_k_v", mask, self.h, self.keep_attn, Fn.attn_drop(self))
         self.attn = p
         return ctx
 
@@ -201,10 +203,15 @@ class PositionalEncoding(nn.Module):
         if x is None:
             return x
         L = x.shape[1]
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("stand-alone PositionalEncoding has no fused dropout; use embed_with_position")
         return Fn.add(x, self.table()[:L].to(x.dtype))
 
 
 def embed_with_position(seq: nn.Sequential, ids: Tensor) -> Tensor:
     """Fused ``nn.Sequential(Embeddings, PositionalEncoding)`` (mtn.py:79-82) in one kernel."""
     emb, pos = seq[0], seq[1]
-    return Fn.embed_pe(ids, emb.lut.weight, pos.table())
+    drop = None
+    if pos.training and pos.dropout.p > 0:                 # dropout after the position is added (modules.py:144)
+        drop = (float(pos.dropout.p), Fn.next_seed())
+    return Fn.embed_pe(ids, emb.lut.weight, pos.table(), drop)

@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, BF16, F32, BistColSum, BistGemm, check, lib
+from ._lib import ACT_NONE, ACT_RELU, BF16, F32, BistColSum, BistDrop, BistGemm, check, lib
 
 Tensor = torch.Tensor
 
@@ -176,8 +176,15 @@ def layernorm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6, out: Optional[
     return out
 
 
+def drop_ref(drop):
+    """(p, seed) or None -> BistDrop by reference (NULL when off); the device step counter rides along."""
+    if drop is None or drop[0] <= 0.0:
+        return None
+    return C.byref(BistDrop(float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, _ptr(DROP_CTR)))
+
+
 def mha_core(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], h: int, *, want_p: bool = False,
-             out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+             out: Optional[Tensor] = None, drop=None) -> Tuple[Tensor, Optional[Tensor]]:
     """softmax(QK^T/sqrt(dk), masked -1e9) V per head; q [N,Lq,d], k/v [N,Lk,d] (row-strided views ok).
 
     mask: bool/uint8 [N,1,Lk], [N,Lq,Lk], [1,Lq,Lk] or None (modules.py:59-60 semantics).
@@ -204,12 +211,12 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], h: int, *,
     check(lib.bist_mha_core_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), mptr, out.data_ptr(), _ptr(p),
                                 N, Lq, Lk, h, dk, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
                                 q.stride(0), k.stride(0), v.stride(0), out.stride(0), mbs, mqs,
-                                1.0 / math.sqrt(dk), dtype_code(q.dtype), _stream()), "bist_mha_core_fwd")
+                                1.0 / math.sqrt(dk), drop_ref(drop), dtype_code(q.dtype), _stream()), "bist_mha_core_fwd")
     return out, p
 
 
 def st_stage1_pv(scores: Tensor, v: Tensor, tmask: Optional[Tensor], *, B: int, T: int, S: int, Lq: int, h: int,
-                 dk: int, direction: int, out: Optional[Tensor] = None) -> Tensor:
+                 dk: int, direction: int, out: Optional[Tensor] = None, drop=None) -> Tensor:
     """Stage-1 softmax + P.V of t2s (direction 0) / s2t (direction 1); see include/bist_hip.h."""
     _dev(scores, v, tmask)
     d = h * dk
@@ -227,13 +234,15 @@ def st_stage1_pv(scores: Tensor, v: Tensor, tmask: Optional[Tensor], *, B: int, 
         tmask = (tmask.view(torch.uint8) if tmask.dtype == torch.bool else tmask.to(torch.uint8)).contiguous()
         mptr = tmask.data_ptr()
     check(lib.bist_st_stage1_pv_fwd(scores.data_ptr(), v.data_ptr(), mptr, out.data_ptr(), B, T, S, Lq, h, dk, ldv,
-                                    direction, dtype_code(scores.dtype), dtype_code(v.dtype), _stream()),
+                                    direction, drop_ref(drop), dtype_code(scores.dtype), dtype_code(v.dtype), _stream()),
           "bist_st_stage1_pv_fwd")
     return out
 
 
-def st_stage2(q2f: Tensor, y: Tensor, gmask: Optional[Tensor], *, h: int, out: Optional[Tensor] = None) -> Tensor:
-    """Stage-2 attention over the stage-1 outputs with K/V folded out; q2f [B,Lq,h,d], y [B,G,Lq,d]."""
+def st_stage2(q2f: Tensor, y: Tensor, gmask: Optional[Tensor], *, h: int, out: Optional[Tensor] = None, drop=None,
+              want_rowsum: bool = False):
+    """Stage-2 attention over the stage-1 outputs with K/V folded out; q2f [B,Lq,h,d], y [B,G,Lq,d].
+    With dropout (or want_rowsum) returns (PY, rowsum f32 [B,Lq,h]): the value bias must be scaled by rowsum."""
     _dev(q2f, y, gmask)
     B, G, Lq, d = y.shape
     if not (q2f.is_contiguous() and y.is_contiguous()):
@@ -245,12 +254,28 @@ def st_stage2(q2f: Tensor, y: Tensor, gmask: Optional[Tensor], *, h: int, out: O
         gmask = gmask.reshape(B, G)
         gmask = (gmask.view(torch.uint8) if gmask.dtype == torch.bool else gmask.to(torch.uint8)).contiguous()
         mptr = gmask.data_ptr()
-    check(lib.bist_st_stage2_fwd(q2f.data_ptr(), y.data_ptr(), mptr, out.data_ptr(), B, G, Lq, h, d,
+    dref = drop_ref(drop)
+    rs = torch.empty((B, Lq, h), device=y.device, dtype=torch.float32) if (dref is not None or want_rowsum) else None
+    check(lib.bist_st_stage2_fwd(q2f.data_ptr(), y.data_ptr(), mptr, out.data_ptr(), _ptr(rs), B, G, Lq, h, d, dref,
                                  dtype_code(y.dtype), _stream()), "bist_st_stage2_fwd")
-    return out
+    return out if rs is None else (out, rs)
 
 
-def embed_pe(ids: Tensor, lut: Tensor, pe: Tensor, out: Optional[Tensor] = None) -> Tensor:
+def scaled_bias(x: Tensor, s: Tensor, bias: Tensor, h: int, out: Optional[Tensor] = None) -> Tensor:
+    """x[m, hh*dk+c] + s[m, hh] * bias[hh*dk+c]: the value bias of stage 2 under attention dropout."""
+    _dev(x, s, bias)
+    d = x.shape[-1]
+    x2 = x.reshape(-1, d)
+    if not x2.is_contiguous() or not s.is_contiguous() or s.dtype != torch.float32 or s.numel() != x2.shape[0] * h:
+        raise ValueError("bist_amd.scaled_bias: bad operands")
+    if out is None:
+        out = torch.empty_like(x2)
+    check(lib.bist_scaled_bias_fwd(x2.data_ptr(), s.data_ptr(), bias.data_ptr(), out.data_ptr(), x2.shape[0], h, d // h,
+                                   dtype_code(x.dtype), _stream()), "bist_scaled_bias_fwd")
+    return out.view(x.shape)
+
+
+def embed_pe(ids: Tensor, lut: Tensor, pe: Tensor, out: Optional[Tensor] = None, drop=None) -> Tensor:
     """lut[ids]*sqrt(d) + pe[:L]  (modules.py:121-123,141-144); ids int64 [B,L], pe f32 [>=L,d]."""
     _dev(ids, lut, pe)
     B, L = ids.shape
@@ -260,7 +285,7 @@ def embed_pe(ids: Tensor, lut: Tensor, pe: Tensor, out: Optional[Tensor] = None)
     ids = ids.contiguous()
     if out is None:
         out = torch.empty((B, L, d), device=lut.device, dtype=lut.dtype)
-    check(lib.bist_embed_pe_fwd(ids.data_ptr(), lut.data_ptr(), pe.data_ptr(), out.data_ptr(), B * L, L, d,
+    check(lib.bist_embed_pe_fwd(ids.data_ptr(), lut.data_ptr(), pe.data_ptr(), out.data_ptr(), B * L, L, d, drop_ref(drop),
                                 dtype_code(lut.dtype), _stream()), "bist_embed_pe_fwd")
     return out
 

@@ -102,6 +102,19 @@ int bist_layernorm_fwd(const void* x, const void* a, const void* b, void* y, int
                        int64_t ldx, int64_t ldy, float eps, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dropout of attention probabilities in training (modules.py:62-63: p_attn = dropout(p_attn) after the
+ * softmax, before p_attn.V).  NULL or p == 0 turns it off.  The keep decision of probability element
+ * idx is a pure function of (seed, *ctr, idx) -- a counter-based mask regenerated by the backward
+ * kernels, never stored; ctr (nullable) is a device step counter so that a captured hipGraph draws
+ * fresh masks on every replay.  idx is the element's linear index in the order stated per entry point.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct BistDrop {
+  float p;                 /* drop probability, 0 <= p < 1 */
+  uint64_t seed;
+  const uint64_t* ctr;     /* device pointer or NULL */
+} BistDrop;
+
+/* ------------------------------------------------------------------------------------------
  * Small multi-head attention core (after the projections):
  *     O[n,i,hh*dk+c] = sum_j softmax_j( Q[n,i,hh,:].K[n,j,hh,:] * scale  masked -1e9 ) V[n,j,hh,c]
  * = attention() model/modules.py:54-64 for every head of MultiHeadedAttention (modules.py:94).
@@ -113,12 +126,13 @@ int bist_layernorm_fwd(const void* x, const void* a, const void* b, void* y, int
  * the pointer generator reads (model/generator.py:109-110).
  * Used for the query self-attentions A0/A3 (encoder.py:176,184), CapEncoderLayer
  * (encoder.py:214-215), MultimodalDecoderLayer12 (decoder.py:21-58) and the pointer attentions.
+ * drop: mask index ((n*h + hh)*Lq + i)*Lk + j; p_attn receives the probabilities BEFORE dropout.
  * ------------------------------------------------------------------------------------------ */
 int bist_mha_core_fwd(const void* Q, const void* K, const void* V, const uint8_t* mask, void* O, float* p_attn,
                       int32_t N, int32_t Lq, int32_t Lk, int32_t h, int32_t dk,
                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                       int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
-                      int64_t mask_bs, int64_t mask_qs, float scale, int32_t dtype, void* stream);
+                      int64_t mask_bs, int64_t mask_qs, float scale, const BistDrop* drop, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 1 of temporal->spatial (direction 0, encoder.py:110-123) and spatial->temporal
@@ -133,10 +147,11 @@ int bist_mha_core_fwd(const void* Q, const void* K, const void* V, const uint8_t
  *                O[b,t,i,hh*dk+c] = sum_s P[b,i,hh,t,s] V[b,t,s,hh*dk+c]        O: [B,T,Lq,d]
  * which is attention() (modules.py:54-64) of every (b,s) / (b,t) group without materialising
  * K, the permuted video tensor or the expanded query.
+ * drop: mask index ((((b*G + g)*h + hh)*Lq + i)*Kn + k), g the group (s or t), k the key (t or s).
  * ------------------------------------------------------------------------------------------ */
 int bist_st_stage1_pv_fwd(const void* scores, const void* V, const uint8_t* tmask, void* O,
                           int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk,
-                          int64_t ldv, int32_t direction, int32_t sc_dtype, int32_t dtype, void* stream);
+                          int64_t ldv, int32_t direction, const BistDrop* drop, int32_t sc_dtype, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 2 of both directions (encoder.py:125-134 / 152-165): query position (b,i) attends,
@@ -145,18 +160,29 @@ int bist_st_stage1_pv_fwd(const void* scores, const void* V, const uint8_t* tmas
  * applied after the weighted sum, the kernel needs only Y:
  *     sc[hh,g] = q2f[b,i,hh,:] . Y[b,g,i,:]   (masked -1e9 by gmask[b,g] if given)
  *     PY[b,i,hh,:] = sum_g softmax_g(sc)[hh,g] * Y[b,g,i,:]                    PY: [B,Lq,h,d]
+ * drop: mask index ((b*Lq + i)*h + hh)*G + g.  With dropout the kept probabilities no longer sum to one,
+ * and the value bias applied after the weighted sum must be scaled by their sum:
+ *     P'(Y W_v^T + b_v) = (P'Y) W_v^T + rowsum(P') b_v
+ * rowsum (f32 [B,Lq,h], nullable without dropout) receives sum_g P'[b,i,hh,g] (bist_scaled_bias_fwd).
  * ------------------------------------------------------------------------------------------ */
-int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t* gmask, void* PY,
-                       int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, int32_t dtype, void* stream);
+int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t* gmask, void* PY, float* rowsum,
+                       int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, const BistDrop* drop, int32_t dtype, void* stream);
+/* y[m, hh*dk + c] = x[m, hh*dk + c] + s[m, hh] * bias[hh*dk + c]   (in place allowed: y == x)            */
+int bist_scaled_bias_fwd(const void* x, const float* s, const void* bias, void* y, int64_t M, int32_t h, int32_t dk,
+                         int32_t dtype, void* stream);
+/* ds[m, hh] = sum_c dy[m, hh*dk+c] bias[hh*dk+c];  dbias[hh*dk+c] += sum_m s[m, hh] dy[m, hh*dk+c]  (f32 acc) */
+int bist_scaled_bias_bwd(const void* dy, const float* s, const void* bias, float* ds, float* dbias, int64_t M, int32_t h,
+                         int32_t dk, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise helpers on the path.
  * ------------------------------------------------------------------------------------------ */
 /* y[b,l,:] = lut[ids[b,l],:]*sqrt(d) + pe[l,:]   Embeddings + PositionalEncoding
  * (modules.py:121-123,141-144); y and lut in dtype, ids int64 [rows = B*L], pe the f32
- * sinusoid table [>=L, d] (the reference's registered buffer `pe`, modules.py:131-139).       */
+ * sinusoid table [>=L, d] (the reference's registered buffer `pe`, modules.py:131-139).
+ * drop: the dropout after the position is added (modules.py:144), mask index row*d + c.        */
 int bist_embed_pe_fwd(const int64_t* ids, const void* lut, const float* pe, void* y, int64_t rows, int32_t L,
-                      int32_t d, int32_t dtype, void* stream);
+                      int32_t d, const BistDrop* drop, int32_t dtype, void* stream);
 
 /* temporal_mask[b,t] = any(fts[b,t,:,:] != 0) computed as sum != 0 exactly like
  * data/dataset.py:79 ((fts.sum(2).sum(-1) != 0)); fts [B,T,S*C] in dtype, out uint8 [B,T].     */
@@ -226,7 +252,8 @@ int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, f
                        int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
                        int32_t dtype, void* stream);
 /* dlut[ids[row], :] += dy[row, :] * sqrt(d)  (fp32 accumulator [V, d]).                          */
-int bist_embed_bwd(const int64_t* ids, const void* dy, float* dlut, int64_t rows, int32_t d, int32_t dtype, void* stream);
+int bist_embed_bwd(const int64_t* ids, const void* dy, float* dlut, int64_t rows, int32_t d, const BistDrop* drop,
+                   int32_t dtype, void* stream);
 int bist_fuse_modalities_bwd(const void* score, const void* const* xs, const void* dout, void* dscore, void* const* dxs,
                              int64_t rows, int32_t n, int32_t d, int32_t dtype, void* stream);
 /* dQ/dK/dV of bist_mha_core_fwd; dO and/or dP_ext (gradient w.r.t. the returned probabilities,
@@ -236,14 +263,15 @@ int bist_mha_core_bwd(const void* Q, const void* K, const void* V, const uint8_t
                       void* dQ, void* dK, void* dV, int32_t N, int32_t Lq, int32_t Lk, int32_t h, int32_t dk,
                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                       int64_t lddq, int64_t lddk, int64_t lddv, int64_t dq_bs, int64_t dk_bs, int64_t dv_bs,
-                      int64_t mask_bs, int64_t mask_qs, float scale, int32_t dtype, void* stream);
+                      int64_t mask_bs, int64_t mask_qs, float scale, const BistDrop* drop, int32_t dtype, void* stream);
 /* dscores (f32 [B,Lq*h,T*S]) and dV ([B,T,S,*], row stride lddv) of bist_st_stage1_pv_fwd.        */
 int bist_st_stage1_pv_bwd(const float* scores, const void* V, const uint8_t* tmask, const void* dO, float* dscores, void* dV,
                           int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk, int64_t ldv, int64_t lddv,
-                          int32_t direction, int32_t dtype, void* stream);
-/* dq2f and dY of bist_st_stage2_fwd.                                                             */
-int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t* gmask, const void* dPY, void* dq2f, void* dY,
-                       int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, int32_t dtype, void* stream);
+                          int32_t direction, const BistDrop* drop, int32_t dtype, void* stream);
+/* dq2f and dY of bist_st_stage2_fwd; d_rowsum (f32 [B,Lq,h], nullable) is the gradient of `rowsum`.  */
+int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t* gmask, const void* dPY, const float* d_rowsum,
+                       void* dq2f, void* dY, int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, const BistDrop* drop,
+                       int32_t dtype, void* stream);
 int bist_pointer_mix_bwd(const float* logits, const float* switch_logits, int32_t n_ptr, const float* const* ptr_p,
                          const int64_t* const* ptr_text, const int32_t* ptr_len, const float* out, const float* dout,
                          float* dlogits, float* dswitch_logits, float* const* dptr_p, int64_t rows, int32_t Lt, int32_t V,

@@ -237,7 +237,7 @@ def test_stage2_backward(env):
     def ref(q2f, y):
         sc = torch.einsum("bihe,bgie->bihg", q2f, y).masked_fill(gm.view(B, 1, 1, G) == 0, -1e9)
         return torch.einsum("bihg,bgie->bihe", torch.softmax(sc, -1), y)
-    _check(lambda q, y: Fn.st_stage2(q, y, gm.cuda(), h=h), ref, [q2f, y], "stage2")
+    _check(lambda q, y: Fn.st_stage2(q, y, gm.cuda(), h=h)[0], ref, [q2f, y], "stage2")
 
 
 @pytest.mark.parametrize("B,G,Lq,h,d,masked", [(2, 49, 20, 8, 512, False), (2, 32, 20, 8, 512, True), (1, 64, 7, 4, 128, True)])
@@ -258,7 +258,7 @@ def test_stage2_bf16_matrix_core_path(env, B, G, Lq, h, d, masked):
     (ref * go).sum().backward()
     qd = q2f.to(torch.bfloat16).cuda().requires_grad_(True)
     yd = y.to(torch.bfloat16).cuda().requires_grad_(True)
-    out = Fn.st_stage2(qd, yd, None if gm is None else gm.cuda(), h=h)
+    out, _ = Fn.st_stage2(qd, yd, None if gm is None else gm.cuda(), h=h)
     (out.double() * go.cuda()).sum().backward()
     _close(out, ref.detach(), "st2 bf16 fwd", 1.5e-2)
     _close(qd.grad, qr.grad, "st2 bf16 dq2f", 2.5e-2)
@@ -453,3 +453,147 @@ def test_trainer_reduces_loss(env, dtype):
     assert all(math.isfinite(x) for x in losses)
     assert losses[-1] < 0.7 * losses[0], losses
     assert model.generator.vocab_gen.data_ptr() == model.query_embed[0].lut.weight.data_ptr()
+
+
+# ---- dropout of attention probabilities (reference modules.py:62-63) --------------------------------------------
+# The mask is a counter-based function of (seed, element index) regenerated by the backward kernels.  With an identity
+# value operand the kernel's output IS the dropped probability matrix, which recovers the mask; the torch reference
+# then uses that same mask, so forward and backward are compared exactly (fp32) / to bf16 accuracy.
+DROP = (0.3, 0x1234ABCD)
+
+
+def _mask_from(pd, p_ref, what):
+    """pd: dropped probabilities from the kernel, p_ref: softmax from torch -> the 0/1 mask; checks its statistics."""
+    keep = 1.0 - DROP[0]
+    m = (pd.abs() > 0.5 * p_ref.abs() / keep).double()
+    sel = p_ref.abs() > 1e-6                                  # elements where a drop is observable
+    rate = 1.0 - (m[sel].mean().item())
+    assert abs(rate - DROP[0]) < 0.06, f"{what}: drop rate {rate:.3f} (p = {DROP[0]})"
+    assert ((pd - m * p_ref / keep).abs().max().item()) < 2e-5 + 2e-2 * (pd.dtype != torch.float64), what
+    return m
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mha_core_probability_dropout(env, dtype):
+    ag, Fn, ops = env
+    N, Lq, Lk, h = 3, 20, 64, 8 if dtype == torch.bfloat16 else 2
+    dk = 64
+    d = h * dk
+    tol = 2e-5 if dtype == torch.float32 else 2.5e-2
+    q, k = _rand(N, Lq, d, seed=80, scale=0.3), _rand(N, Lk, d, seed=81, scale=0.3)
+    v = torch.eye(Lk, dtype=torch.float64).repeat(1, h)[None].repeat(N, 1, 1)         # [N, Lk, h*64]: V_h = I (Lk = dk = 64)
+    mask = torch.ones(N, 1, Lk, dtype=torch.bool); mask[1, 0, 50:] = False
+    qq, kk = q.to(dtype).double(), k.to(dtype).double()
+    qd, kd, vd = (t.to(dtype).cuda().requires_grad_(True) for t in (qq, kk, v))
+    out, _ = Fn.mha_packed(qd, kd, vd, "q_k_v", mask.cuda(), h, False, DROP)
+    out2, _ = Fn.mha_packed(qd, kd, vd, "q_k_v", mask.cuda(), h, False, DROP)
+    assert torch.equal(out, out2), "same seed, same mask"
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (qq, kk, v))
+    sc = torch.einsum("nihc,njhc->nhij", qr.view(N, Lq, h, dk), kr.view(N, Lk, h, dk)) / math.sqrt(dk)
+    p = torch.softmax(sc.masked_fill(mask.view(N, 1, 1, Lk) == 0, -1e9), -1)
+    pd = out.detach().double().cpu().view(N, Lq, h, Lk).permute(0, 2, 1, 3)            # O_h = P'_h I
+    m = _mask_from(pd.to(torch.float64 if dtype == torch.float32 else torch.float32), p.detach(), "mha mask")
+    ref = torch.einsum("nhij,njhc->nihc", p * m / (1 - DROP[0]), vr.view(N, Lk, h, dk)).reshape(N, Lq, d)
+    go = _rand(N, Lq, d, seed=82)
+    (ref * go).sum().backward()
+    (out.double() * go.cuda()).sum().backward()
+    _close(out, ref.detach(), "mha dropout fwd", tol)
+    _close(qd.grad, qr.grad, "mha dropout dQ", tol)
+    _close(kd.grad, kr.grad, "mha dropout dK", tol)
+    _close(vd.grad, vr.grad, "mha dropout dV", tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_stage1_probability_dropout(env, dtype, direction):
+    ag, Fn, ops = env
+    B, Lq, h, dk = 2, 7, 2, 64
+    T, S = (64, 5) if direction == 0 else (5, 64)           # keys = 64 = dk, so an identity V exposes the probabilities
+    d = h * dk
+    tol = 2e-5 if dtype == torch.float32 else 2.5e-2
+    G, Kn = (S, T) if direction == 0 else (T, S)
+    sc = _rand(B, Lq * h, T * S, seed=90)
+    tm = torch.ones(B, 1, T, dtype=torch.bool)
+    if direction == 0:
+        tm[0, 0, 40:] = False
+    eye = torch.eye(Kn, dtype=torch.float64).repeat(1, h)                                # [Kn, d]
+    v = (eye.view(T, 1, d).expand(T, S, d) if direction == 0 else eye.view(1, S, d).expand(T, S, d))[None].repeat(B, 1, 1, 1).contiguous()
+    scd = sc.float().cuda().requires_grad_(True)
+    vd = v.to(dtype).cuda().requires_grad_(True)
+    out = Fn.st_stage1_pv(scd, vd, tm.cuda(), B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction, drop=DROP)
+    scr, vr = sc.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    s5 = scr.view(B, Lq, h, T, S)
+    if direction == 0:
+        logits = s5.masked_fill(tm.view(B, 1, 1, T, 1) == 0, -1e9).permute(0, 4, 1, 2, 3)     # [B, S(g), Lq, h, T(k)]
+        vg = vr.permute(0, 2, 1, 3)                                                            # [B, S, T, d]
+    else:
+        logits = s5.permute(0, 3, 1, 2, 4)                                                    # [B, T(g), Lq, h, S(k)]
+        vg = vr
+    p = torch.softmax(logits, -1)
+    pd = out.detach().double().cpu().view(B, G, Lq, h, dk)                                     # O = P' I
+    m = _mask_from(pd.to(torch.float64 if dtype == torch.float32 else torch.float32), p.detach(), "st1 mask")
+    ref = torch.einsum("bgihk,bgkhc->bgihc", p * m / (1 - DROP[0]), vg.reshape(B, G, Kn, h, dk)).reshape(B, G, Lq, d)
+    go = _rand(B, G, Lq, d, seed=91)
+    (ref * go).sum().backward()
+    (out.double() * go.cuda()).sum().backward()
+    _close(out, ref.detach(), "st1 dropout fwd", tol)
+    _close(scd.grad, scr.grad, "st1 dropout dscores", tol)
+    _close(vd.grad, vr.grad, "st1 dropout dV", tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stage2_probability_dropout_and_scaled_bias(env, dtype):
+    """stage 2 under dropout: PY' = P'Y and rowsum(P') (the value bias is scaled by it, P'(YW^T+b) = (P'Y)W^T + rowsum b)."""
+    ag, Fn, ops = env
+    B, G, Lq, h, d = 2, 49, 6, 8, 128
+    dk = d // h
+    tol = 2e-5 if dtype == torch.float32 else 2.5e-2
+    q2f = _rand(B, Lq, h, d, seed=95, scale=d ** -0.5).to(dtype).double()
+    y = _rand(B, G, Lq, d, seed=96).to(dtype).double()
+    bias = _rand(d, seed=97).to(dtype).double()
+    gm = torch.ones(B, 1, G, dtype=torch.bool); gm[1, 0, 30:] = False
+    # pass 1: Y = [e_g ...] is impossible (d != G), so recover the mask from rowsum-free algebra: run with an indicator Y
+    yi = torch.zeros(B, G, Lq, d, dtype=torch.float64)
+    for g in range(G):
+        yi[:, g, :, g] = 1.0                                                             # Y[b,g,i,:] = e_g  (d >= G)
+    qd0 = q2f.to(dtype).cuda()
+    pd, rs0 = ops.st_stage2(qd0, yi.to(dtype).cuda(), gm.cuda(), h=h, drop=DROP)
+    sc_i = torch.einsum("bihe,bgie->bihg", q2f, yi).masked_fill(gm.view(B, 1, 1, G) == 0, -1e9)
+    p_i = torch.softmax(sc_i, -1)
+    m_i = _mask_from(pd.double().cpu()[..., :G].to(torch.float64 if dtype == torch.float32 else torch.float32), p_i, "st2 mask")
+    _close(rs0, (p_i * m_i / (1 - DROP[0])).sum(-1), "st2 rowsum", tol)
+    # pass 2: real Y, same seed -> same mask (the mask depends on (b,i,hh,g) only); forward + backward with the scaled bias
+    qd, yd, bd = (t.to(dtype).cuda().requires_grad_(True) for t in (q2f, y, bias))
+    py, rs = Fn.st_stage2(qd, yd, gm.cuda(), h=h, drop=DROP)
+    out = Fn.scaled_bias(py.view(B * Lq, h, d)[:, :, :dk].reshape(B * Lq, h * dk).contiguous(), rs, bd[:h * dk], h)
+    qr, yr, br = (t.clone().requires_grad_(True) for t in (q2f, y, bias))
+    sc = torch.einsum("bihe,bgie->bihg", qr, yr).masked_fill(gm.view(B, 1, 1, G) == 0, -1e9)
+    pp = torch.softmax(sc, -1) * m_i / (1 - DROP[0])
+    pyr = torch.einsum("bihg,bgie->bihe", pp, yr)
+    ref = (pyr[..., :dk] + pp.sum(-1, keepdim=True) * br[:h * dk].view(1, 1, h, dk)).reshape(B * Lq, h * dk)
+    go = _rand(B * Lq, h * dk, seed=98)
+    (ref * go).sum().backward()
+    (out.double() * go.cuda()).sum().backward()
+    _close(out, ref.detach(), "st2 dropout fwd", tol)
+    _close(qd.grad, qr.grad, "st2 dropout dq2f", tol)
+    _close(yd.grad, yr.grad, "st2 dropout dY", tol)
+    _close(bd.grad, br.grad, "st2 dropout dbias", tol)
+
+
+def test_embedding_position_dropout(env):
+    ag, Fn, ops = env
+    B, L, V, d = 3, 11, 50, 64
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(5))
+    lut = _rand(V, d, seed=99)
+    pe = _rand(L, d, seed=100).float()
+    ld = lut.float().cuda().requires_grad_(True)
+    out = Fn.embed_pe(ids.cuda(), ld, pe.cuda(), DROP)
+    full = lut[ids] * math.sqrt(d) + pe.double()
+    m = _mask_from(out.detach().double().cpu(), full, "embed mask")
+    lr = lut.clone().requires_grad_(True)
+    ref = (lr[ids] * math.sqrt(d) + pe.double()) * m / (1 - DROP[0])
+    go = _rand(B, L, d, seed=101)
+    (ref * go).sum().backward()
+    (out.double() * go.cuda()).sum().backward()
+    _close(out, ref.detach(), "embed dropout fwd", 2e-5)
+    _close(ld.grad, lr.grad, "embed dropout dlut", 2e-5)
