@@ -34,6 +34,22 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICRO
 CFG = dict(L=6, d=512, h=8, B=16, T=32, S=49, C=2048, Lq=20, Lh=60, Lc=25, Lt=20, V=3000)
 
 
+def p0_traffic(M, K, N):
+    """HBM bytes per P0 launch from the committed PMC passes (profiles/r01_p0_traffic_pmc.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this benchmark, FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md); None when the geometry differs from the profiled one.  Counters cannot be read from
+    inside a timed run, so this is the offline figure of the same kernel and shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_p0_traffic_pmc.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    if t.get("algorithmic_bytes_per_launch") != (M * K + N * K + M * N) * 2:
+        return None
+    return {"bytes_per_launch": t["traffic_bytes_per_launch"], "algorithmic_bytes": t["algorithmic_bytes_per_launch"],
+            "ratio": t["ratio"], "source": "profiles/r01_p0_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"}
+
+
 def model_args(L, d, h, dropout):
     return argparse.Namespace(d_model=d, att_h=h, nb_blocks=L, nb_venc_blocks=L, nb_cenc_blocks=L, nb_aenc_blocks=0,
                               t2s=1, s2t=1, ptr_gen=1, ptr_ft="query,cap", mask_unk=1, auto_encoder=1,
@@ -218,7 +234,7 @@ def main():
                    "global_batch": c["B"] * world, "tokens_per_step": ntok_all, "parallelism": f"dp{world}",
                    "clips_per_s": c["B"] * world * a.steps / dt},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": p0_traffic(M_p0, c["C"], c["d"]),
                      "kernel": f"gemm_fast_kernel<bf16> P0 [{M_p0}x{c['C']}]x[{c['C']}x{c['d']}]", "avg_launch_ms": p0_ms,
                      "launches_timed": len(p0)},
         "attn_fwd": {"what": "fused BiST attention forward F_P0+F_VL (SURVEY 8d), one layer, eval, hipGraph replay", "B": c["B"], "gflop_alg": (f_p0 + f_vl) / 1e9,
