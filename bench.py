@@ -234,7 +234,8 @@ def main():
                    "global_batch": c["B"] * world, "tokens_per_step": ntok_all, "parallelism": f"dp{world}",
                    "clips_per_s": c["B"] * world * a.steps / dt},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": p0_traffic(M_p0, c["C"], c["d"]),
+                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": (p0_traffic(M_p0, c["C"], c["d"]) or {}).get("bytes_per_launch"),
+                     "traffic_detail": p0_traffic(M_p0, c["C"], c["d"]),
                      "kernel": f"gemm_fast_kernel<bf16> P0 [{M_p0}x{c['C']}]x[{c['C']}x{c['d']}]", "avg_launch_ms": p0_ms,
                      "launches_timed": len(p0)},
         "attn_fwd": {"what": "fused BiST attention forward F_P0+F_VL (SURVEY 8d), one layer, eval, hipGraph replay", "B": c["B"], "gflop_alg": (f_p0 + f_vl) / 1e9,
