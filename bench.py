@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the beam-search turn timing (BASELINE configs[4])")
     ap.add_argument("--cpu-sample", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="launch the ~2.7k kernels of a step eagerly instead of replaying a hipGraph")
     a = ap.parse_args()
@@ -211,6 +212,29 @@ def main():
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / 20
 
+    def decode_turn_ms():
+        """BASELINE configs[4]: one dialogue turn of beam_search_decode (B=1, beam 5, maxlen 12) with and without the
+        per-turn reuse of the target-independent reasoning."""
+        from bist_amd.model.decode import beam_search_decode
+        from bist_amd.model.decoder import MultimodalDecoder8
+        b1 = synthetic_batch(1, T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"], seed=99, dtype=dtype)
+        res = {}
+        with torch.no_grad():
+            for name, flag in (("cached", True), ("recompute", False)):
+                MultimodalDecoder8.REASONING_CACHE = flag
+                try:
+                    ts = []
+                    for _ in range(3):
+                        torch.cuda.synchronize(); t0 = time.perf_counter()
+                        beam_search_decode(model, b1, 12, 2, 0, 3, 1, beam=5, penalty=1.0, nbest=5, train_args=args)
+                        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+                    res[name] = min(ts)
+                finally:
+                    MultimodalDecoder8.REASONING_CACHE = True
+        return {"what": "beam_search_decode turn, B=1 beam=5 maxlen=12 (BASELINE configs[4]), eager launches", "ms_per_turn": res["cached"],
+                "ms_per_turn_reasoning_recomputed": res["recompute"]}
+
+    decode = decode_turn_ms() if (rank == 0 and not a.no_decode) else None
     attn_ms = attn_forward_ms(batch)
     f_p0, f_vl = flops_alg(c["B"], c["T"], c["S"], c["C"], c["d"], c["Lq"], c["h"])
     attn_tflops = (f_p0 + f_vl) / (attn_ms * 1e-3) / 1e12
@@ -241,6 +265,7 @@ def main():
         "attn_fwd": {"what": "fused BiST attention forward F_P0+F_VL (SURVEY 8d), one layer, eval, hipGraph replay", "B": c["B"], "gflop_alg": (f_p0 + f_vl) / 1e9,
                      "ms": attn_ms, "tflops": attn_tflops, "frac_of_mfma_peak": attn_tflops / MFMA_BF16_PEAK_TFLOPS,
                      "at_B64": attn64},
+        "decode": decode,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_sample, 3, a.dropout)

@@ -120,7 +120,25 @@ class MultimodalDecoder8(nn.Module):
             return                                          # the reference defines no encoded_ft here (decoder.py:168-181)
         ft["encoded_ft"] = Fn.fuse_modalities(score.view(*parts[0].shape[:-1], -1), xs)
 
+    # Keys the reasoning layers write per decoder layer (decoder.py:126-181); everything else in ``ft`` is static.
+    _REASONING_KEYS = ("temporal_ft", "spatial_ft", "cap_ft", "encoded_ft")
+    REASONING_CACHE = True      # inference only; set False to recompute the reasoning on every decode() like the reference
+
     def forward(self, b, ft: Dict[str, Tensor], x: Tensor) -> Dict[str, Tensor]:
+        """decoder.py:107-186.  The visual / caption reasoning of every layer depends on the encoded inputs only,
+        not on the target prefix ``x`` -- yet the reference recomputes it in each of the ~60 ``model.decode`` calls
+        of a beam-search turn (decode.py:66; 88 % of the forward).  In inference (eval, no autograd) the
+        per-layer results are kept in ``ft`` (the dict ``model.encode`` returned for this turn, so the cache dies
+        with the turn) and later calls run only the decoder layers.  Same arithmetic, same results."""
+        use_cache = self.REASONING_CACHE and not self.training and not torch.is_grad_enabled()
+        cache = ft.get("_bist_reasoning") if use_cache else None
+        if cache is not None and len(cache) == len(self.layers):
+            for l, layer in enumerate(self.layers):
+                ft.update(cache[l])
+                x = layer(b, ft, x)
+            ft["decoded_text"] = self.norm(x)
+            return ft
+        cache = [] if use_cache else None
         q = ft["encoded_query"]
         in_ft = {"t2s": q, "s2t": q, "audio": q, "cap": q}
         for l, layer in enumerate(self.layers):
@@ -143,6 +161,10 @@ class MultimodalDecoder8(nn.Module):
                 in_ft = self.c_layers[l](in_ft, ft, b)
                 ft["cap_ft"] = self.cap_out_norm(in_ft["cap"])                               # :132
             self._fuse(ft)
+            if cache is not None:
+                cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})
             x = layer(b, ft, x)                                                              # :182
+        if cache is not None:
+            ft["_bist_reasoning"] = cache
         ft["decoded_text"] = self.norm(x)                                                    # :185
         return ft

@@ -149,6 +149,47 @@ def test_beam_search_matches_reference(hip, golden_dir, tag):
     assert abs(float(best) - float(g[f"{tag}_best"])) < 1e-3
 
 
+def test_decode_reuses_the_target_independent_reasoning(hip, golden_dir):
+    """across the model.decode calls of one turn (decode.py:66) the visual / caption reasoning is
+    computed once (kept in the turn's ``ft`` dict); results equal the recompute-every-call behaviour of the reference."""
+    M, Batch = hip
+    g = np.load(os.path.join(golden_dir, "g5_beam.npz"))
+    meta = json.loads(str(g["beam5_cfg"]))
+    cfg, dm = O.Cfg(**meta["cfg"]), meta["dims"]
+    ob = O.det_batch(1, dm["T"], dm["S"], dm["C"], dm["Lq"], dm["Lh"], dm["Lc"], dm["Lt"], dm["V"], seed=dm["seed"])
+    model, _ = build_model(M, cfg, dm["V"], dm["C"])
+    b = to_batch(Batch, ob)
+    dec = model.mutlimodal_decoder
+    calls = []
+    hook = dec.v_layers[0].register_forward_hook(lambda *a: calls.append(1))
+    try:
+        with torch.no_grad():
+            ft = model.encode(b)
+            outs = []
+            for _ in range(3):
+                ft = model.decode(b, ft)
+                outs.append(ft["decoded_text"].clone())
+            assert len(calls) == 1 and "_bist_reasoning" in ft, "the reasoning layers must run once per turn"
+            type(dec).REASONING_CACHE = False
+            try:
+                ft2 = model.decode(b, model.encode(b))
+            finally:
+                type(dec).REASONING_CACHE = True
+            assert len(calls) == 2
+    finally:
+        hook.remove()
+    for o in outs:
+        assert torch.equal(o, outs[0])
+    assert _err(ft2["decoded_text"], outs[0].cpu().float().numpy()) < 1e-6
+    for k in ("temporal_ft", "spatial_ft", "cap_ft", "encoded_ft"):
+        assert torch.equal(ft[k], ft2[k]), k
+    # training / autograd never uses the cache
+    with torch.enable_grad():
+        ft3 = model.encode(b)
+        model.decode(b, ft3)
+        assert "_bist_reasoning" not in ft3
+
+
 def test_generic_module_signatures(hip):
     """MultiHeadedAttention / PositionwiseFeedForward / LayerNorm keep the reference call signatures."""
     M, _ = hip
