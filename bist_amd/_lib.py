@@ -27,6 +27,7 @@ class BistGemm(C.Structure):
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_ctr", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("hint", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

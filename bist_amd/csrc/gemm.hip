@@ -915,6 +915,187 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_ring_kernel(const GemmK g) 
   stream_out<T, TO, false, 64>(g, ebuf, ebuf, z1, z2, 0, m0, n0, tid);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256-tile kernel for the big K-contiguous products (P0, the value projection, the output projections:
+// M = B*T*S rows).  The 128-tile kernel above sits at the LDS balance point of a 64x64 wave tile (32 FLOP per LDS
+// byte = the CU's MFMA:LDS ratio) and stalls on the vmcnt(0) of its barrier every K step (~800 TFLOP/s).  Here
+// (the deep-pipelined structure of cdna_hip_programming.md section 5, re-derived for a uniform schedule):
+//   * 8 waves (2 x 4), wave tile 128 x 64 (acc 8x4 fragments = 128 AGPRs): 43 FLOP per LDS byte;
+//   * one workgroup per CU, ALL LDS in one 128 KiB array: 2 K tiles x 4 "halves" of [128 rows][128 B]:
+//       Aq0 / Aq1 = the first / second 64 rows of each wave row's 128 A rows, Bq0 / Bq1 = the first / second 32
+//       rows of each wave column's 64 B rows -- so a half is exactly what one C quadrant of every wave needs;
+//   * a K tile is 4 phases, one C quadrant (64x32 per wave, 16 MFMAs) each, in the order (0,0) (0,1) (1,1) (1,0):
+//       phase 1 reads Aq0+Bq0 into registers, phase 2 Bq1, phase 3 Aq1, phase 4 nothing;
+//   * every phase stages ONE half by LDS-DMA (2 instructions per wave), 5+ phases before its first read and 2+
+//       phases after the last read of the half it overwrites:  p1: Bq1(kt+1)  p2: Aq1(kt+1)  p3: Aq0(kt+2)  p4: Bq0(kt+2);
+//       the DMA is issued between the MFMAs of the phase; the read segment of the next phase waits vmcnt(6), so
+//       three to four halves (64 KiB) stay in flight across the barriers;
+//   * the two wave rows run staggered by one barrier (one does MFMAs under s_setprio while the other reads LDS and
+//       issues DMA); a half is read one phase after the wait that retires it, i.e. two barriers later, which
+//       covers the other group's wait;
+//   * fragment reads are inline asm (the compiler adds no waits of its own), barriers are raw s_barrier.
+// ---------------------------------------------------------------------------------------------
+constexpr int BIG = 256;
+constexpr int HALF_BYTES = 128 * ROW_BYTES;          // 16 KiB
+constexpr int KT_BYTES = 4 * HALF_BYTES;             // one K tile: Aq0 | Bq0 | Bq1 | Aq1
+enum { H_AQ0 = 0, H_BQ0 = 1, H_BQ1 = 2, H_AQ1 = 3 };
+
+template <typename TO>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
+  using T = bf16_t;
+  __shared__ __attribute__((aligned(16))) char lds[2 * KT_BYTES];
+  int z, sp, tm, tn;
+  tile_coords(g, z, sp, tm, tn);
+  const int z1 = z / g.batch2, z2 = z % g.batch2;
+  const int m0 = tm * BIG, n0 = tn * BIG;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 2, wc = w & 3;
+  const int nk = g.K / 64;
+
+  // per-lane DMA sources: half hh, instruction j -> image rows (2w+j)*8 + lane/8, chunk swizzled on the source side
+  const char* src[4][2];
+  {
+    const char* Ab = g.A + (z1 * g.a_bs1 + z2 * g.a_bs2) * 2;
+    const char* Bb = g.B + (z1 * g.b_bs1 + z2 * g.b_bs2) * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int irow = (w * 2 + j) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ (((j & 1) << 2) | (lane >> 4));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int arow = min(m0 + (irow >> 6) * 128 + q * 64 + (irow & 63), g.M - 1);
+        const int brow = min(n0 + (irow >> 5) * 64 + q * 32 + (irow & 31), g.N - 1);
+        src[q ? H_AQ1 : H_AQ0][j] = Ab + (long)arow * g.a_rs * 2 + chunk * 16;
+        src[q ? H_BQ1 : H_BQ0][j] = Bb + (long)brow * g.b_rs * 2 + chunk * 16;
+      }
+    }
+  }
+  auto stage = [&](int hh, int kt) -> bool {           // half hh of K tile kt (pointers walk K tile by K tile)
+    if (kt >= nk) return false;
+    char* dst = lds + (kt & 1) * KT_BYTES + hh * HALF_BYTES + w * 2048;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src[hh][0]), LDS_PTR(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src[hh][1]), LDS_PTR(dst + 1024), 16, 0, 0);
+    src[hh][0] += ROW_BYTES; src[hh][1] += ROW_BYTES;
+    return true;
+  };
+  stage(H_AQ0, 0); stage(H_BQ0, 0); stage(H_BQ1, 0); stage(H_AQ1, 0);
+  const bool two = stage(H_AQ0, 1);
+  stage(H_BQ0, 1);
+  if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                         // Aq0(0), Bq0(0) have landed for every wave
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  FragRd<T, false> fa[2][4];          // [ks][i]: the A sub-tile of the current wave-row quadrant
+  FragRd<T, false> fb[2][2][2];       // [q][ks][j]: both B sub-tiles (Bq0 is reused by phase 4)
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(lds);
+
+  if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger the two wave rows by one barrier
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned cur = lds0 + (unsigned)((kt & 1) * KT_BYTES);
+#define BIG_PHASE(READ_B, BQ, READ_A, AH, STAGE_H, STAGE_KT, QM, QN, NEWER)                                       \
+    {                                                                                                            \
+      if (READ_B) {                                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+            fb[BQ][ks][j].issue(cur + (BQ ? H_BQ1 : H_BQ0) * HALF_BYTES, wc * 32 + j * 16, ks, lane);            \
+      }                                                                                                          \
+      if (READ_A) {                                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+            fa[ks][i].issue(cur + (AH) * HALF_BYTES, wr * 64 + i * 16, ks, lane);                                \
+      }                                                                                                          \
+      /* retire the half the NEXT phase reads: all but the NEWER most recent stagings (2 DMAs each) */          \
+      switch (NEWER) {                                                                                           \
+        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;                                          \
+        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;                                          \
+        case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;                                          \
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;                                         \
+      }                                                                                                          \
+      __builtin_amdgcn_s_barrier();                                                                              \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+      if (READ_B) { _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { fb[BQ][ks][0].tie(); fb[BQ][ks][1].tie(); } }   \
+      if (READ_A) { _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[ks][i].tie(); } \
+      __builtin_amdgcn_s_setprio(1);                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+          Mma<T>::step(fa[0][i].get(), fb[QN][0][j].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
+      stage(STAGE_H, STAGE_KT);             /* the DMA issue rides in the shadow of the MFMAs */                 \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+          Mma<T>::step(fa[1][i].get(), fb[QN][1][j].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
+      __builtin_amdgcn_s_setprio(0);                                                                             \
+      __builtin_amdgcn_s_barrier();                                                                              \
+    }
+    // NEWER = stagings issued after the half the NEXT phase reads (they may stay in flight).  In issue order the stagings
+    // are  ... Bq1(kt) Aq1(kt) Aq0(kt+1) Bq0(kt+1) | Bq1(kt+1) Aq1(kt+1) Aq0(kt+2) Bq0(kt+2) ...  (| = start of K tile kt),
+    // each issued in the MFMA segment of its phase, i.e. after that phase's wait; a staging past the last K tile is skipped.
+    const int i1 = kt + 1 < nk, i2 = kt + 2 < nk;
+    BIG_PHASE(true, 0, true, H_AQ0, H_BQ1, kt + 1, 0, 0, (1 + 2 * i1))        // next reads Bq1(kt)
+    BIG_PHASE(true, 1, false, H_AQ0, H_AQ1, kt + 1, 0, 1, (3 * i1))           // next reads Aq1(kt)
+    BIG_PHASE(false, 0, true, H_AQ1, H_AQ0, kt + 2, 1, 1, 3)                  // next reads nothing new
+    BIG_PHASE(false, 0, false, H_AQ1, H_BQ0, kt + 2, 1, 0, (2 * i1 + i2))     // next reads Aq0(kt+1), Bq0(kt+1)
+#undef BIG_PHASE
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();            // the extra barrier of the staggered group
+  __syncthreads();
+
+  // epilogue: each wave turns its 128x64 accumulators into rows through its own 16 KiB of LDS, 64 rows at a time
+  float* reg = reinterpret_cast<float*>(lds + w * 16384);
+  const int lr = lane & 15, lg = lane >> 4;
+  const long zlin = z1 * (long)g.batch2 + z2;
+  const unsigned long long zoff = (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N;
+  TO* C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
+  const T* bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
+  const TO* res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
+  const int cg = (lane & 7) * 8;                        // this lane's 8 columns inside the wave's 64
+  const int n = n0 + wc * 64 + cg;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = (bias && n + e < g.N) ? to_f(bias[n + e]) : 0.f;
+#pragma unroll
+  for (int qm = 0; qm < 2; ++qm) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i * 16 + lg * 4 + r, col = j * 16 + lr;
+          reg[row * 64 + (((col >> 2) ^ (((row >> 2) & 3) << 2)) << 2) + (col & 3)] = acc[qm * 4 + i][j][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const int m = m0 + wr * 128 + qm * 64 + row;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(reg + row * 64 + ((((cg >> 2) + q) ^ (((row >> 2) & 3) << 2)) << 2));
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      }
+      if (m < g.M && n < g.N) {
+        TO o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = from_f<TO>(epilogue_value<T, TO>(g, v[e], bv[e], res, m, min(n + e, g.N - 1), zoff));
+        TO* dst = C + (long)m * g.ldc + n;
+        if (n + 8 <= g.N && g.vec_c) {
+          if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+          else { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(o)[1]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (n + e < g.N) dst[e] = o[e];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // sums the split-K slabs and applies the epilogue: one thread per output element
 template <typename T, typename TO>
 __global__ void splitk_reduce_kernel(const GemmK g, long total) {
@@ -1190,6 +1371,18 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
     else if (p.stages == 22) hipLaunchKernelGGL((gemm_fast_kernel<T, TO, ATR_, BTR_, 22>), grid, block, 0, st, k); \
     else hipLaunchKernelGGL((gemm_fast_kernel<T, TO, ATR_, BTR_, 2>), grid, block, 0, st, k);                    \
   } while (0)
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    const long big_tiles = (long)((g->M + BIG - 1) / BIG) * ((g->N + BIG - 1) / BIG) * g->batch1 * g->batch2;
+    const bool legal = p.fast && !p.atr && !p.btr && g->K % 64 == 0 && g->K >= 128;
+    const bool wanted = g->hint == BIST_GEMM_TILE256 || (big_tiles >= 256 && g->N >= 2048 && g->K >= 2048 && p.split == 1);
+    if (legal && wanted) {
+      k.tiles_m = (g->M + BIG - 1) / BIG; k.tiles_n = (g->N + BIG - 1) / BIG;
+      k.split_k = 1; k.ws = nullptr;
+      hipLaunchKernelGGL((gemm_big_kernel<TO>), dim3((unsigned)big_tiles), dim3(512), 0, st, k);
+      BIST_LAUNCH_CHECK("bist_gemm(256-tile)");
+      return BIST_OK;
+    }
+  }
   if (p.fast && p.t64) {
     k.tiles_m = (g->M + T64 - 1) / T64; k.tiles_n = (g->N + T64 - 1) / T64;
     const dim3 g64((unsigned)((long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2));

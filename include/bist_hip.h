@@ -86,11 +86,19 @@ typedef struct BistGemm {
    * and a second kernel sums the slabs; NULL / 0 disables split-K.                              */
   void* workspace;
   int64_t workspace_bytes;
+  /* Kernel selection: 0 = automatic.  BIST_GEMM_TILE256 asks for the 256x256-tile deep-pipelined kernel
+   * (bf16, both operands K-contiguous, K a multiple of 64, unbatched or batched) wherever it is legal; it is
+   * chosen automatically only for products with >= 256 such tiles and N, K >= 2048 (it beats the 128-tile kernel
+   * by 15-20 % there, and loses on the short-K, N = 512 products of this model).  Tuning and test aid.            */
+  int32_t hint;
+  int32_t reserved;
 } BistGemm;
+#define BIST_GEMM_TILE256 2
 
 int bist_gemm(const BistGemm* g, void* stream);
-/* Which kernel bist_gemm would pick for this problem: 1 = LDS-DMA MFMA tile kernel, 2 = the same
- * with split-K, 0 = generic strided kernel (host-side query, used by tests and the bench report). */
+/* Which kernel bist_gemm would pick for this problem: 1 = LDS-DMA MFMA tile kernel (128-, 64- or 256-tile),
+ * 2 = the same with split-K, 3 = skinny (one side <= 8) VALU kernel, 0 = generic strided kernel
+ * (host-side query, used by tests and the bench report).                                          */
 int bist_gemm_is_fast(const BistGemm* g);
 
 /* ------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ def test_version_and_error_string_without_gpu():
 def test_gemm_struct_layout_matches_header():
     from bist_amd import _lib
     # values printed by a C program including include/bist_hip.h (sizeof, offsetof)
-    assert ctypes.sizeof(_lib.BistGemm) == 248
+    assert ctypes.sizeof(_lib.BistGemm) == 256
     assert _lib.BistGemm.a_rs.offset == 56 and _lib.BistGemm.alpha.offset == 184 and _lib.BistGemm.drop_seed.offset == 216
 
 

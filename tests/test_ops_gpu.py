@@ -66,6 +66,31 @@ def test_gemm_fast_linear(ops, dtype, tol, M, N, K):
          F32_TOL if dtype == torch.float32 else 2e-3, "linear f32 out")
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (1100, 300, 192), (256, 256, 128), (700, 1024, 832)])
+def test_gemm_tile256_kernel(ops, M, N, K):
+    """the 256x256-tile deep-pipelined kernel (hint BIST_GEMM_TILE256; automatic only for far larger products than
+    this model has): ragged row / column tiles, bias + ReLU, residual with accumulate, fp32 output."""
+    dtype, tol = torch.bfloat16, BF16_TOL
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    r = _rand(M, N, seed=4)
+    xd, wd, bd, rd = (t.to(dtype).cuda() for t in (x, w, b, r))
+    ref = _q(x, dtype) @ _q(w, dtype).t()
+
+    def run(out, **kw):
+        g = ops.gemm_desc(xd, wd, out, M=M, N=N, K=K, a_rs=K, b_rs=K, ldc=N, **kw)
+        g.hint = 2
+        from bist_amd import _lib
+        import ctypes
+        _lib.check(_lib.lib.bist_gemm(ctypes.byref(g), torch.cuda.current_stream().cuda_stream), "bist_gemm")
+        return out
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    _cmp(run(out, bias=bd), ref + _q(b, dtype), tol, "tile256 linear")
+    _cmp(run(out, bias=bd, act=ops.ACT_RELU), (ref + _q(b, dtype)).clamp_min(0), tol, "tile256 relu")
+    _cmp(run(out, bias=bd, residual=rd, ldr=N, alpha=0.5), 0.5 * ref + _q(b, dtype) + _q(r, dtype), tol, "tile256 residual")
+    o32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    _cmp(run(o32), ref, 2e-3, "tile256 f32 out")
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
 def test_gemm_generic_strides(ops, dtype, tol):
     # K tail (50), unaligned leading dims, transposed operands: all take the generic kernel
