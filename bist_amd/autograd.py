@@ -33,6 +33,31 @@ def _to_dtype_from_f32(acc: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+class _WeightGradStream:
+    """Weight-gradient GEMMs accumulate into the trainer's flat gradient and nothing downstream of the backward pass
+    reads them, so they leave the critical path: on ``ops.WGRAD_STREAM`` (one stream for ALL of them, which also
+    serialises accumulations into a shared weight) after a fork from the current stream.  The operands are kept alive
+    in ``ops.WGRAD_KEEP`` until the trainer joins the stream."""
+
+    def __init__(self, *keep):
+        self.keep = keep
+        self.cm = None
+
+    def __enter__(self):
+        st = ops.WGRAD_STREAM
+        if st is not None:
+            st.wait_stream(torch.cuda.current_stream())
+            ops.WGRAD_KEEP.append(self.keep)
+            self.cm = torch.cuda.stream(st)
+            self.cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.cm is not None:
+            self.cm.__exit__(*exc)
+        return False
+
+
 def _mask_u8(mask: Optional[Tensor]):
     if mask is None:
         return None
@@ -99,8 +124,9 @@ class LinearFn(Function):
         if ctx.needs_input_grad[1]:
             if ctx.w_dst is not None:            # dW accumulates in place: C = alpha * dz^T x + C
                 gv = ctx.w_dst
-                ops.gemm(dz, x2, gv, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=gv.stride(0), alpha=alpha,
-                         residual=gv, ldr=gv.stride(0))
+                with _WeightGradStream(dz, x2):
+                    ops.gemm(dz, x2, gv, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=gv.stride(0), alpha=alpha,
+                             residual=gv, ldr=gv.stride(0))
             else:
                 dw = torch.empty((N, K), device=dz.device, dtype=w.dtype)
                 ops.gemm(dz, x2, dw, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=K, alpha=alpha)
@@ -156,9 +182,10 @@ class HeadFoldFn(Function):
                  b_bs=(0, dk * wk.stride(0)), c_bs=(0, dk), alpha=alpha)
         gv = ctx.w_dst
         if gv is not None:
-            ops.gemm(q, dqf, gv, M=dk, N=d, K=M, a_rs=1, a_ks=q.stride(0), b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
-                     a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), alpha=alpha, residual=gv, ldr=gv.stride(0),
-                     r_bs=(0, dk * gv.stride(0)))
+            with _WeightGradStream(q, dqf):
+                ops.gemm(q, dqf, gv, M=dk, N=d, K=M, a_rs=1, a_ks=q.stride(0), b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
+                         a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), alpha=alpha, residual=gv, ldr=gv.stride(0),
+                         r_bs=(0, dk * gv.stride(0)))
             return dq, None, None, None
         dwk = torch.empty((d, d), device=q.device, dtype=wk.dtype)
         ops.gemm(q, dqf, dwk, M=dk, N=d, K=M, a_rs=1, a_ks=q.stride(0), b_rs=1, b_ks=h * d, ldc=d, batch=(1, h),
@@ -195,9 +222,10 @@ class HeadUnfoldFn(Function):
                  a_bs=(0, dk), b_bs=(0, dk * wv.stride(0)), c_bs=(0, d))
         gv = ctx.w_dst
         if gv is not None:
-            ops.gemm(do, py, gv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
-                     a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), residual=gv, ldr=gv.stride(0),
-                     r_bs=(0, dk * gv.stride(0)))
+            with _WeightGradStream(do, py):
+                ops.gemm(do, py, gv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
+                         a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), residual=gv, ldr=gv.stride(0),
+                         r_bs=(0, dk * gv.stride(0)))
             dwv = None
         else:
             dwv = torch.empty((d, d), device=py.device, dtype=wv.dtype)

@@ -109,6 +109,8 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
     return c
 
 
+WGRAD_STREAM = None       # trainer: side stream of the weight-gradient GEMMs (autograd._WeightGradStream); None = in line
+WGRAD_KEEP = []           # their operands, kept alive until the trainer joins that stream
 COLSUM_QUEUE = None       # trainer: list of (dz, acc32 view, M, N) bias-gradient jobs, flushed by col_sum_flush()
 
 

@@ -22,6 +22,7 @@ low-precision weights.  No per-parameter optimiser launches, no per-tensor colle
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -133,6 +134,10 @@ class Trainer:
             m._pk = pk
         self.params = order
         # device-side step counter mixed into every dropout seed, so that a captured graph draws new masks
+        # weight-gradient GEMMs on their own stream (autograd._WeightGradStream): measured SLOWER in a replayed hipGraph
+        # (21.2 vs 18.3 ms/step, round 1: ~300 extra cross-stream edges cost more than the overlap gains), so opt-in
+        self.wgrad_side_stream = os.environ.get("BIST_WGRAD_STREAM", "0") != "0"
+        self._wgrad_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.drop_ctr = torch.zeros(1, device=dev, dtype=torch.int64)
         ops.DROP_CTR = self.drop_ctr
         self.criterion = LabelSmoothing(vocab_size, pad, smoothing)
@@ -156,11 +161,17 @@ class Trainer:
         self.acc32.zero_()
         loss, terms = self.forward_loss(batch)
         ops.COLSUM_QUEUE = []                 # bias gradients: queued by LinearFn.backward, summed in a few launches below
+        wg = self._wgrad_stream if (self.wgrad_side_stream and loss.is_cuda) else None
+        ops.WGRAD_STREAM = wg                 # weight-gradient GEMMs: off the critical path, on their own stream
         try:
             loss.backward()
+            if wg is not None:
+                torch.cuda.current_stream().wait_stream(wg)
             ops.col_sum_flush()
         finally:
             ops.COLSUM_QUEUE = None
+            ops.WGRAD_STREAM = None
+            ops.WGRAD_KEEP.clear()
         for p in self.params:                # anything autograd still produced itself (views, fallbacks)
             if p.grad is not None:
                 p._grad_view.add_(p.grad)
