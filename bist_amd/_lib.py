@@ -35,6 +35,11 @@ class BistDrop(C.Structure):
     _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("ctr", C.c_void_p)]
 
 
+class BistLnGrad(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("a", C.c_void_p), ("da", C.c_void_p), ("db", C.c_void_p),
+                ("rows", C.c_int64), ("lddy", C.c_int64), ("ldx", C.c_int64), ("eps", C.c_float)]
+
+
 class BistColSum(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64), ("N", C.c_int32), ("ldx", C.c_int64)]
 
@@ -69,6 +74,7 @@ SIGNATURES = {
     "bist_col_sum_acc": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
     "bist_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _I64, _I64, _F, _P, _I64, _I32, _P]),
     "bist_col_sum_multi": (C.c_int, [C.POINTER(BistColSum), _I32, _I32, _P]),
+    "bist_layernorm_param_grad_multi": (C.c_int, [C.POINTER(BistLnGrad), _I32, _I32, _I32, _P]),
     "bist_embed_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_fuse_modalities_bwd": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(C.c_void_p), _I64, _I32, _I32, _I32, _P]),
     "bist_mha_core_bwd": (C.c_int, [_P] * 9 + [_I32] * 5 + [_I64] * 16 + [_F, C.POINTER(BistDrop), _I32, _P]),

@@ -315,11 +315,17 @@ def _ln_backward(ctx, dy, dres):
     dx = torch.empty(x2.shape, device=x.device, dtype=x.dtype)
     direct = ctx.a_dst is not None and ctx.b_dst is not None
     da, db = (ctx.a_dst, ctx.b_dst) if direct else (_f32_zeros((d,), x), _f32_zeros((d,), x))
-    check(lib.bist_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), a.data_ptr(), dx.data_ptr(), da.data_ptr(), db.data_ptr(),
+    # trainer: dx only on the critical path; the gain/offset gradients of every LayerNorm are summed in one batched launch
+    defer = (direct and ops.LNGRAD_QUEUE is not None and d * x.element_size() == 1024 and a.data_ptr() % 16 == 0
+             and all(t.data_ptr() % 16 == 0 and (t.stride(0) * t.element_size()) % 16 == 0 for t in (dy2, x2) + ((add2,) if add2 is not None else ())))
+    check(lib.bist_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), a.data_ptr(), dx.data_ptr(),
+                                 None if defer else da.data_ptr(), None if defer else db.data_ptr(),
                                  x2.shape[0], d, dy2.stride(0), x2.stride(0), d, eps,
                                  add2.data_ptr() if add2 is not None else None, add2.stride(0) if add2 is not None else 0,
                                  dtype_code(x.dtype), _stream()),
           "bist_layernorm_bwd")
+    if defer:
+        ops.LNGRAD_QUEUE.append((dy2, x2, a, da, db, eps))
     if direct:
         return dx.view(x.shape), None, None, None
     return dx.view(x.shape), _to_dtype_from_f32(da, a.dtype), _to_dtype_from_f32(db, bdt), None

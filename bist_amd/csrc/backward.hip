@@ -141,15 +141,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // Vectorised LayerNorm backward for rows that are a whole number of KiB: each lane owns NV 16-byte vectors of
 // the row (x and dy read once, kept in registers); the gain/offset gradients are summed over the block's rows in
 // registers, combined across the 4 waves through LDS, and leave as ONE atomic per column per block.
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
-                                                                T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
-                                                                long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
-                                                                const T* __restrict__ dx_add, long ldadd) {
+// DX: write the input gradient; PARAMS: accumulate the gain/offset gradients.  The trainer runs DX-only kernels on the
+// critical path and sums the parameter gradients of all LayerNorms of a backward pass in one batched launch.
+template <typename T, int NV, bool DX, bool PARAMS>
+__device__ __forceinline__ void layernorm_bwd_vec_body(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
+                                                       T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
+                                                       long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
+                                                       const T* __restrict__ dx_add, long ldadd, long blk, float (*red)[4][64 * NV * (16 / (int)sizeof(T))]) {
   constexpr int E = 16 / (int)sizeof(T), NE = NV * E;
-  __shared__ float red[2][4][64 * NE];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long wave = (long)blockIdx.x * 4 + w;
+  const long wave = blk * 4 + w;
   const long r0 = wave * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
   float av[NE], pa[NE], pb[NE];
 #pragma unroll
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
       for (int j = 0; j < NV; ++j) {
         qx[rr][j] = *reinterpret_cast<const uint4*>(x + row * ldx + (j * 64 + lane) * E);
         qg[rr][j] = *reinterpret_cast<const uint4*>(dy + row * lddy + (j * 64 + lane) * E);
-        if (dx_add) qa[rr][j] = *reinterpret_cast<const uint4*>(dx_add + row * ldadd + (j * 64 + lane) * E);
+        if (DX && dx_add) qa[rr][j] = *reinterpret_cast<const uint4*>(dx_add + row * ldadd + (j * 64 + lane) * E);
       }
     }
 #pragma unroll
@@ -199,23 +200,53 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const int u = j * E + e;
-          o[e] = from_f<T>((gv[u] * av[u] - mg) * inv - xv[u] * k2 + (dx_add ? to_f(ad[e]) : 0.f));
-          pa[u] += gv[u] * xv[u] * inv;
-          pb[u] += gv[u];
+          if (DX) o[e] = from_f<T>((gv[u] * av[u] - mg) * inv - xv[u] * k2 + (dx_add ? to_f(ad[e]) : 0.f));
+          if (PARAMS) { pa[u] += gv[u] * xv[u] * inv; pb[u] += gv[u]; }
         }
-        *reinterpret_cast<uint4*>(dx + row * lddx + (j * 64 + lane) * E) = *reinterpret_cast<const uint4*>(o);
+        if (DX) *reinterpret_cast<uint4*>(dx + row * lddx + (j * 64 + lane) * E) = *reinterpret_cast<const uint4*>(o);
       }
     }
   }
+  if constexpr (PARAMS) {
 #pragma unroll
-  for (int u = 0; u < NE; ++u) { red[0][w][u * 64 + lane] = pa[u]; red[1][w][u * 64 + lane] = pb[u]; }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < 64 * NE; idx += 256) {
-    const int u = idx >> 6, ln = idx & 63;
-    const int c = ((u / E) * 64 + ln) * E + (u % E);                    // column owned by (lane ln, register u)
-    atomicAdd(da + c, red[0][0][idx] + red[0][1][idx] + red[0][2][idx] + red[0][3][idx]);
-    atomicAdd(db + c, red[1][0][idx] + red[1][1][idx] + red[1][2][idx] + red[1][3][idx]);
+    for (int u = 0; u < NE; ++u) { red[0][w][u * 64 + lane] = pa[u]; red[1][w][u * 64 + lane] = pb[u]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * NE; idx += 256) {
+      const int u = idx >> 6, ln = idx & 63;
+      const int c = ((u / E) * 64 + ln) * E + (u % E);                    // column owned by (lane ln, register u)
+      atomicAdd(da + c, red[0][0][idx] + red[0][1][idx] + red[0][2][idx] + red[0][3][idx]);
+      atomicAdd(db + c, red[1][0][idx] + red[1][1][idx] + red[1][2][idx] + red[1][3][idx]);
+    }
   }
+}
+
+template <typename T, int NV, bool PARAMS>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
+                                                                T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
+                                                                long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
+                                                                const T* __restrict__ dx_add, long ldadd) {
+  __shared__ float red[PARAMS ? 2 : 1][4][64 * NV * (16 / (int)sizeof(T))];
+  layernorm_bwd_vec_body<T, NV, true, PARAMS>(dy, x, a, dx, da, db, rows, d, lddy, ldx, lddx, eps, rows_per_wave, dx_add, ldadd,
+                                              (long)blockIdx.x, red);
+}
+
+// gain/offset gradients of many LayerNorms (one row width) in one launch: block -> job through the prefix table
+constexpr int LNGRAD_JOBS = 40;
+struct LnGradBatch {
+  const void* dy[LNGRAD_JOBS]; const void* x[LNGRAD_JOBS]; const void* a[LNGRAD_JOBS]; float* da[LNGRAD_JOBS]; float* db[LNGRAD_JOBS];
+  int rows[LNGRAD_JOBS], lddy[LNGRAD_JOBS], ldx[LNGRAD_JOBS], rpw[LNGRAD_JOBS];
+  float eps[LNGRAD_JOBS];
+  int first[LNGRAD_JOBS + 1];
+  int n, d;
+};
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_param_grad_multi_kernel(const LnGradBatch b) {
+  __shared__ float red[2][4][64 * NV * (16 / (int)sizeof(T))];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.first[j + 1]) ++j;
+  layernorm_bwd_vec_body<T, NV, false, true>((const T*)b.dy[j], (const T*)b.x[j], (const T*)b.a[j], nullptr, b.da[j], b.db[j], (long)b.rows[j], b.d,
+                                             (long)b.lddy[j], (long)b.ldx[j], 0L, b.eps[j], b.rpw[j], nullptr, 0L,
+                                             (long)((int)blockIdx.x - b.first[j]), red);
 }
 
 // Embedding backward: dlut[ids[row], c] += dy[row, c] * sqrt(d)   (fp32 atomics)
@@ -391,7 +422,7 @@ extern "C" int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t
 extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
                                   int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
                                   int32_t dtype, void* stream) {
-  BIST_REQUIRE(dy && x && a && dx && da && db, "bist_layernorm_bwd: null pointer");
+  BIST_REQUIRE(dy && x && a && dx && ((da != nullptr) == (db != nullptr)), "bist_layernorm_bwd: null pointer");
   BIST_REQUIRE(rows > 0 && d > 1 && d <= 2048, "bist_layernorm_bwd: bad shape rows=%ld d=%d", (long)rows, d);
   hipStream_t st = (hipStream_t)stream;
   const long sz = dtype == BIST_BF16 ? 2 : 4;
@@ -402,15 +433,15 @@ extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, 
     int rpw2 = (int)((rows + 1023) / 1024);       // ~1024 waves: enough parallelism for dx, few atomics per column
     if (rpw2 < 2) rpw2 = 2;
     const unsigned g2 = blocks_for(blocks_for(rows, rpw2), 4);
-    if (dtype == BIST_BF16)
-      hipLaunchKernelGGL((layernorm_bwd_vec_kernel<bf16_t, 1>), dim3(g2), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)a,
-                         (bf16_t*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2, (const bf16_t*)dx_add, (long)ldadd);
-    else
-      hipLaunchKernelGGL((layernorm_bwd_vec_kernel<float, 1>), dim3(g2), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)a,
-                         (float*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2, (const float*)dx_add, (long)ldadd);
+#define LNV(TT, PP) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TT, 1, PP>), dim3(g2), dim3(256), 0, st, (const TT*)dy, (const TT*)x, (const TT*)a, \
+                                       (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2, (const TT*)dx_add, (long)ldadd)
+    if (dtype == BIST_BF16) { if (da) LNV(bf16_t, true); else LNV(bf16_t, false); }
+    else { if (da) LNV(float, true); else LNV(float, false); }
+#undef LNV
     BIST_LAUNCH_CHECK("bist_layernorm_bwd");
     return BIST_OK;
   }
+  BIST_REQUIRE(da != nullptr, "bist_layernorm_bwd: the dx-only form needs 1 KiB rows (d = 512 bf16 / 256 f32), 16-byte aligned");
   int rpw = (int)((rows + 4095) / 4096);          // <= 4096 waves flush their partial sums
   if (rpw < 1) rpw = 1;
   const unsigned g = blocks_for(blocks_for(rows, rpw), 4);
@@ -418,6 +449,37 @@ extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, 
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_layernorm_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_layernorm_param_grad_multi(const BistLnGrad* jobs, int32_t njobs, int32_t d, int32_t dtype, void* stream) {
+  BIST_REQUIRE(jobs && njobs > 0, "bist_layernorm_param_grad_multi: bad argument");
+  const long sz = dtype == BIST_BF16 ? 2 : 4;
+  BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && d * sz == 1024, "bist_layernorm_param_grad_multi: rows must be 1 KiB (d = 512 bf16 / 256 f32)");
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < njobs; base += LNGRAD_JOBS) {
+    LnGradBatch b;
+    b.n = njobs - base < LNGRAD_JOBS ? njobs - base : LNGRAD_JOBS;
+    b.d = d;
+    int total = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const BistLnGrad& q = jobs[base + i];
+      BIST_REQUIRE(q.dy && q.x && q.a && q.da && q.db && q.rows > 0 && q.rows < (1L << 31) && q.lddy >= d && q.ldx >= d,
+                   "bist_layernorm_param_grad_multi: bad job %d", base + i);
+      BIST_REQUIRE((((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.a) % 16 == 0) && (q.lddy * sz) % 16 == 0 && (q.ldx * sz) % 16 == 0,
+                   "bist_layernorm_param_grad_multi: job %d is not 16-byte aligned", base + i);
+      int rpw = (int)((q.rows + 255) / 256);           // ~256 waves per job: few atomics per column
+      if (rpw < 4) rpw = 4;
+      b.dy[i] = q.dy; b.x[i] = q.x; b.a[i] = q.a; b.da[i] = q.da; b.db[i] = q.db;
+      b.rows[i] = (int)q.rows; b.lddy[i] = (int)q.lddy; b.ldx[i] = (int)q.ldx; b.rpw[i] = rpw; b.eps[i] = q.eps;
+      b.first[i] = total;
+      total += (int)blocks_for(blocks_for(q.rows, rpw), 4);
+    }
+    b.first[b.n] = total;
+    if (dtype == BIST_BF16) hipLaunchKernelGGL((layernorm_param_grad_multi_kernel<bf16_t, 1>), dim3((unsigned)total), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((layernorm_param_grad_multi_kernel<float, 1>), dim3((unsigned)total), dim3(256), 0, st, b);
+    BIST_LAUNCH_CHECK("bist_layernorm_param_grad_multi");
+  }
   return BIST_OK;
 }
 

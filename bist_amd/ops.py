@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, BF16, F32, BistColSum, BistDrop, BistGemm, check, lib
+from ._lib import ACT_NONE, ACT_RELU, BF16, F32, BistColSum, BistDrop, BistGemm, BistLnGrad, check, lib
 
 Tensor = torch.Tensor
 
@@ -128,6 +128,26 @@ def col_sum_flush() -> None:
         for i, (dz, acc, M, N) in enumerate(jobs):
             arr[i].x, arr[i].out, arr[i].M, arr[i].N, arr[i].ldx = dz.data_ptr(), acc.data_ptr(), M, N, N
         check(lib.bist_col_sum_multi(arr, len(jobs), dtype_code(dt), _stream()), "bist_col_sum_multi")
+    q.clear()
+
+
+LNGRAD_QUEUE = None       # trainer: list of (dy, x, gain, da, db, eps) LayerNorm parameter-gradient jobs, see lngrad_flush()
+
+
+def lngrad_flush() -> None:
+    """Sum the queued LayerNorm gain/offset gradients (autograd._ln_backward) in batched launches."""
+    q = LNGRAD_QUEUE
+    if not q:
+        return
+    groups = {}
+    for job in q:
+        groups.setdefault((job[0].dtype, job[1].shape[1]), []).append(job)
+    for (dt, d), jobs in groups.items():
+        arr = (BistLnGrad * len(jobs))()
+        for i, (dy, x, a, da, db, eps) in enumerate(jobs):
+            arr[i].dy, arr[i].x, arr[i].a, arr[i].da, arr[i].db = dy.data_ptr(), x.data_ptr(), a.data_ptr(), da.data_ptr(), db.data_ptr()
+            arr[i].rows, arr[i].lddy, arr[i].ldx, arr[i].eps = x.shape[0], dy.stride(0), x.stride(0), eps
+        check(lib.bist_layernorm_param_grad_multi(arr, len(jobs), d, dtype_code(dt), _stream()), "bist_layernorm_param_grad_multi")
     q.clear()
 
 

@@ -161,6 +161,7 @@ class Trainer:
         self.acc32.zero_()
         loss, terms = self.forward_loss(batch)
         ops.COLSUM_QUEUE = []                 # bias gradients: queued by LinearFn.backward, summed in a few launches below
+        ops.LNGRAD_QUEUE = []                 # LayerNorm gain/offset gradients: likewise
         wg = self._wgrad_stream if (self.wgrad_side_stream and loss.is_cuda) else None
         ops.WGRAD_STREAM = wg                 # weight-gradient GEMMs: off the critical path, on their own stream
         try:
@@ -168,8 +169,10 @@ class Trainer:
             if wg is not None:
                 torch.cuda.current_stream().wait_stream(wg)
             ops.col_sum_flush()
+            ops.lngrad_flush()
         finally:
             ops.COLSUM_QUEUE = None
+            ops.LNGRAD_QUEUE = None
             ops.WGRAD_STREAM = None
             ops.WGRAD_KEEP.clear()
         for p in self.params:                # anything autograd still produced itself (views, fallbacks)

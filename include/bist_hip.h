@@ -259,6 +259,14 @@ int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t dtype, voi
 int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
                        int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
                        int32_t dtype, void* stream);
+/* da = db = NULL in bist_layernorm_bwd computes dx only (1 KiB rows: d = 512 bf16 / 256 f32); the gain / offset
+ * gradients of all such LayerNorms of a backward pass are then summed by ONE batched launch per 40 jobs:
+ *   da[c] += sum_r dy[r,c] (x[r,c] - mean_r) / (std_r + eps),   db[c] += sum_r dy[r,c]                      */
+typedef struct BistLnGrad {
+  const void* dy; const void* x; const void* a; float* da; float* db;
+  int64_t rows, lddy, ldx; float eps;
+} BistLnGrad;
+int bist_layernorm_param_grad_multi(const BistLnGrad* jobs, int32_t njobs, int32_t d, int32_t dtype, void* stream);
 /* dlut[ids[row], :] += dy[row, :] * sqrt(d)  (fp32 accumulator [V, d]).                          */
 int bist_embed_bwd(const int64_t* ids, const void* dy, float* dlut, int64_t rows, int32_t d, const BistDrop* drop,
                    int32_t dtype, void* stream);

@@ -105,6 +105,45 @@ def test_layernorm_backward(env):
         _check(hip, lambda x, a, b, w: (x + ref(x, a, b) @ w.t(), x * 2.0), [x, a, b, w], f"layernorm+residual d={d}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_parameter_gradients_batched(env, dtype):
+    """dx-only LayerNorm backward + bist_layernorm_param_grad_multi (the trainer's deferred gain/offset gradients)
+    against torch autograd, 45 jobs of ragged row counts (two launches)."""
+    ag, Fn, ops = env
+    d = 256 if dtype == torch.float32 else 512
+    tol = GT if dtype == torch.float32 else 2e-2
+    rows_list = [320, 7, 1, 1000, 33] * 9
+    jobs, refs = [], []
+    for i, rows in enumerate(rows_list):
+        x = (_rand(rows, d, seed=300 + i, scale=2.0) + 0.3).to(dtype).double()
+        a = (1 + 0.1 * _rand(d, seed=400 + i)).to(dtype).double()
+        dy = _rand(rows, d, seed=500 + i).to(dtype).double()
+        xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+        b = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+        y = ar * (xr - xr.mean(-1, keepdim=True)) / (xr.std(-1, keepdim=True) + 1e-6) + b
+        y.backward(dy)
+        refs.append((xr.grad, ar.grad, b.grad))
+        jobs.append((x.to(dtype).cuda(), a.to(dtype).cuda(), dy.to(dtype).cuda()))
+    from bist_amd._lib import check, lib
+    ops.LNGRAD_QUEUE = []
+    try:
+        outs = []
+        for x, a, dy in jobs:
+            dx = torch.empty_like(x)
+            da, db = torch.full((d,), 0.25, device="cuda"), torch.full((d,), -0.5, device="cuda")
+            check(lib.bist_layernorm_bwd(dy.data_ptr(), x.data_ptr(), a.data_ptr(), dx.data_ptr(), None, None, x.shape[0], d, d, d, d,
+                                         1e-6, None, 0, ops.dtype_code(dtype), torch.cuda.current_stream().cuda_stream), "ln bwd dx")
+            ops.LNGRAD_QUEUE.append((dy, x, a, da, db, 1e-6))
+            outs.append((dx, da, db))
+        ops.lngrad_flush()
+    finally:
+        ops.LNGRAD_QUEUE = None
+    for (dx, da, db), (rx, ra, rb) in zip(outs, refs):
+        _close(dx, rx, "ln dx-only", tol)
+        _close(da, 0.25 + ra, "ln dgain batched", tol)
+        _close(db, -0.5 + rb, "ln doffset batched", tol)
+
+
 def test_bias_gradients_batched(env):
     """bist_col_sum_multi: the queued bias gradients of a backward pass in one launch per 48 jobs."""
     ag, Fn, ops = env
