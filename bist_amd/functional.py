@@ -181,6 +181,17 @@ def side_stream(i: int):
     return st
 
 
+def column_block(w: Tensor, j: int, d: int) -> Tensor:
+    """w[:, j*d:(j+1)*d] of a concat-consuming weight (vc_combine_W, pointer_gen_W).  Under the trainer the block
+    carries its own view of the flat gradient, so the weight-gradient GEMM accumulates in place and autograd never
+    materialises a zero-padded full-size gradient per block (slice_backward: fill + copy + add)."""
+    blk = w[:, j * d:(j + 1) * d]
+    gv = getattr(w, "_grad_view", None)
+    if gv is not None:
+        blk._grad_view = gv[:, j * d:(j + 1) * d]
+    return blk
+
+
 def pack_rows(*ws: Tensor) -> Tensor:
     """Concatenate weight matrices / biases row-wise (device-side data movement only)."""
     return torch.cat(ws, dim=0)

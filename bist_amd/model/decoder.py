@@ -107,7 +107,7 @@ class MultimodalDecoder8(nn.Module):
             raise ValueError("vc_combine_W does not match the enabled modalities")
         score = None
         for j, p in enumerate(parts):                      # concat order: query, cap, spatial, temporal
-            score = Fn.linear(p, W[:, j * d:(j + 1) * d], bias if j == 0 else None, out=score, accumulate=j > 0)
+            score = Fn.linear(p, Fn.column_block(W, j, d), bias if j == 0 else None, out=score, accumulate=j > 0)
         # score column -> modality (decoder.py:156-165): 0 temporal, 1 spatial, 2 cap (both directions);
         # one direction: 0 that direction, 1 cap.  Without a caption layer: 0 temporal, 1 spatial.
         if args.t2s and args.s2t:

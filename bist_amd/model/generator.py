@@ -73,7 +73,7 @@ def _switch_logits(lin: nn.Linear, parts) -> Tensor:
     d = parts[0].shape[-1]
     out = None
     for j, p in enumerate(parts):
-        out = Fn.linear(p, lin.weight[:, j * d:(j + 1) * d], lin.bias if j == 0 else None, out=out, accumulate=j > 0,
+        out = Fn.linear(p, Fn.column_block(lin.weight, j, d), lin.bias if j == 0 else None, out=out, accumulate=j > 0,
                         out_dtype=torch.float32)
     return out
 

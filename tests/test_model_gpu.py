@@ -147,6 +147,17 @@ def test_beam_search_matches_reference(hip, golden_dir, tag):
         assert [int(t) for t in toks] == g[f"{tag}_hyp{i}"].tolist(), f"hyp {i}"
         assert abs(float(score) - float(g[f"{tag}_score{i}"])) < 1e-3
     assert abs(float(best) - float(g[f"{tag}_best"])) < 1e-3
+    # one model.decode per hypothesis (the reference's loop) gives the same n-best as the batched hypotheses
+    import bist_amd.model.decode as D
+    D.BATCH_HYPOTHESES = False
+    try:
+        with torch.no_grad():
+            hyps2, best2 = beam_search_decode(model, to_batch(Batch, ob), dm["maxlen"], O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID,
+                                              beam=meta["beam"], penalty=1.0, nbest=5, train_args=_args(cfg))
+    finally:
+        D.BATCH_HYPOTHESES = True
+    assert [[int(t) for t in h[0]] for h in hyps2] == [[int(t) for t in h[0]] for h in hyps]
+    assert all(abs(float(a[1]) - float(b[1])) < 1e-4 for a, b in zip(hyps, hyps2))
 
 
 def test_decode_reuses_the_target_independent_reasoning(hip, golden_dir):
