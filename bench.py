@@ -274,6 +274,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        barrier()                              # rank 0 also ran the decode / B=64 extras: leave together
         dist.destroy_process_group()
 
 
