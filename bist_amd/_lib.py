@@ -52,6 +52,7 @@ SIGNATURES = {
     "bist_last_error": (C.c_char_p, []),
     "bist_device_ok": (C.c_int, []),
     "bist_gemm": (C.c_int, [C.POINTER(BistGemm), _P]),
+    "bist_gemm_pair": (C.c_int, [C.POINTER(BistGemm), C.POINTER(BistGemm), _P]),
     "bist_gemm_is_fast": (C.c_int, [C.POINTER(BistGemm)]),
     "bist_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I64, _I64, _F, _I32, _P]),
     "bist_mha_core_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32,

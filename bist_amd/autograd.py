@@ -117,19 +117,28 @@ class LinearFn(Function):
                   "bist_epilogue_bwd")
             dz = dz2
         dx = dw = db = None
+        g_dx = g_dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), device=dz.device, dtype=x2.dtype)
-            ops.gemm(dz, w, dx, M=M, N=K, K=N, a_rs=N, a_ks=1, b_rs=1, b_ks=w.stride(0), ldc=K, alpha=alpha)
-            dx = dx.view(x_shape)
+            g_dx = ops.gemm_desc(dz, w, dx, M=M, N=K, K=N, a_rs=N, a_ks=1, b_rs=1, b_ks=w.stride(0), ldc=K, alpha=alpha)
         if ctx.needs_input_grad[1]:
             if ctx.w_dst is not None:            # dW accumulates in place: C = alpha * dz^T x + C
                 gv = ctx.w_dst
-                with _WeightGradStream(dz, x2):
-                    ops.gemm(dz, x2, gv, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=gv.stride(0), alpha=alpha,
-                             residual=gv, ldr=gv.stride(0))
+                g_dw = ops.gemm_desc(dz, x2, gv, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=gv.stride(0), alpha=alpha,
+                                     residual=gv, ldr=gv.stride(0))
             else:
                 dw = torch.empty((N, K), device=dz.device, dtype=w.dtype)
-                ops.gemm(dz, x2, dw, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=K, alpha=alpha)
+                g_dw = ops.gemm_desc(dz, x2, dw, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=K, alpha=alpha)
+        if g_dx is not None and g_dw is not None and ops.WGRAD_STREAM is None:
+            ops.gemm_pair(g_dx, g_dw)            # one launch when both are small (bist_gemm_pair)
+        else:
+            if g_dx is not None:
+                check(lib.bist_gemm(C.byref(g_dx), _stream()), "bist_gemm")
+            if g_dw is not None:
+                with _WeightGradStream(dz, x2):
+                    check(lib.bist_gemm(C.byref(g_dw), _stream()), "bist_gemm")
+        if dx is not None:
+            dx = dx.view(x_shape)
         if has_bias and ctx.needs_input_grad[2]:
             acc = ctx.b_dst if ctx.b_dst is not None else _f32_zeros((N,), dz)
             if ctx.b_dst is not None and ops.COLSUM_QUEUE is not None:

@@ -65,8 +65,8 @@ template <> struct Mma<float> {
 };
 
 // tile id -> (z, split, tm, tn) with the XCD-contiguous remap (bijective for any grid size)
-__device__ __forceinline__ void tile_coords(const GemmK& g, int& z, int& sp, int& tm, int& tn) {
-  const unsigned nwg = gridDim.x, bid = blockIdx.x;
+__device__ __forceinline__ void tile_coords(const GemmK& g, int& z, int& sp, int& tm, int& tn, unsigned bid = blockIdx.x,
+                                            unsigned nwg = gridDim.x) {
   const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
   unsigned lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   tn = lid % g.tiles_n; lid /= g.tiles_n;
@@ -805,13 +805,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_pre_kernel(const GemmK g) {
 // iteration waits for its own share of its tile pair (counted vmcnt), the barrier publishes the others' shares AND
 // proves that every wave is done with the previous pair, whose stages are then refilled with tiles t+6, t+7.  Fragment reads are inline asm (FragRd), so the
 // compiler sees no LDS read of the ring and adds no waits of its own.
+constexpr int RING_D = 8;
 template <typename T, typename TO, bool ATR, bool BTR>
-__global__ __launch_bounds__(NTHREADS) void gemm_t64_ring_kernel(const GemmK g) {
-  constexpr int D = 8;
-  __shared__ __attribute__((aligned(16))) char ebuf[2 * T64_BYTES + 64];
-  __shared__ __attribute__((aligned(16))) char ring[D * 2 * T64_BYTES];
+__device__ __forceinline__ void t64_ring_body(const GemmK& g, unsigned bid, unsigned nwg, char* ebuf, char* ring) {
+  constexpr int D = RING_D;
   int z, sp, tm, tn;
-  tile_coords(g, z, sp, tm, tn);
+  tile_coords(g, z, sp, tm, tn, bid, nwg);
   const int z1 = z / g.batch2, z2 = z % g.batch2;
   const int m0 = tm * T64, n0 = tn * T64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -913,6 +912,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_ring_kernel(const GemmK g) 
   }
   __syncthreads();
   stream_out<T, TO, false, 64>(g, ebuf, ebuf, z1, z2, 0, m0, n0, tid);
+}
+
+template <typename T, typename TO, bool ATR, bool BTR>
+__global__ __launch_bounds__(NTHREADS) void gemm_t64_ring_kernel(const GemmK g) {
+  __shared__ __attribute__((aligned(16))) char ebuf[2 * T64_BYTES + 64];
+  __shared__ __attribute__((aligned(16))) char ring[RING_D * 2 * T64_BYTES];
+  t64_ring_body<T, TO, ATR, BTR>(g, blockIdx.x, gridDim.x, ebuf, ring);
+}
+
+// The two backward products of one linear layer in ONE launch: dX = dZ.W (A K-contiguous, B row-contiguous) on the
+// first n1 workgroups, dW = dZ^T.X (both row-contiguous) on the rest.  Each alone is a 40-64 workgroup launch on 256
+// CUs; together they share the chip and one launch latency (bist_gemm_pair).
+template <typename T, typename TO1, typename TO2>
+__global__ __launch_bounds__(NTHREADS) void gemm_t64_pair_kernel(const GemmK g1, const GemmK g2, unsigned n1) {
+  __shared__ __attribute__((aligned(16))) char ebuf[2 * T64_BYTES + 64];
+  __shared__ __attribute__((aligned(16))) char ring[RING_D * 2 * T64_BYTES];
+  if (blockIdx.x < n1) t64_ring_body<T, TO1, false, true>(g1, blockIdx.x, n1, ebuf, ring);
+  else t64_ring_body<T, TO2, true, true>(g2, blockIdx.x - n1, gridDim.x - n1, ebuf, ring);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1437,7 +1454,9 @@ extern "C" int bist_gemm_is_fast(const BistGemm* g) {
   return p.fast ? (p.split > 1 ? 2 : 1) : 0;
 }
 
-extern "C" int bist_gemm(const BistGemm* g, void* stream) {
+namespace {
+int fill_gemmk(const BistGemm* g, GemmK& k) {
+
   BIST_REQUIRE(g != nullptr, "bist_gemm: null descriptor");
   BIST_REQUIRE(g->A && g->B && g->C, "bist_gemm: null operand");
   BIST_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0, "bist_gemm: bad shape M=%d N=%d K=%d", g->M, g->N, g->K);
@@ -1447,7 +1466,6 @@ extern "C" int bist_gemm(const BistGemm* g, void* stream) {
   BIST_REQUIRE(g->drop_p >= 0.f && g->drop_p < 1.f, "bist_gemm: drop_p out of range");
   BIST_REQUIRE((g->res_outer == 0) == (g->res_inner == 0) && g->res_outer >= 0, "bist_gemm: bad residual row map");
   BIST_REQUIRE(g->workspace_bytes >= 0 && (g->workspace || g->workspace_bytes == 0), "bist_gemm: bad workspace");
-  GemmK k;
   k.A = (const char*)g->A; k.B = (const char*)g->B; k.C = (char*)g->C;
   k.bias = (const char*)g->bias; k.residual = (const char*)g->residual;
   k.M = g->M; k.N = g->N; k.K = g->K;
@@ -1466,10 +1484,53 @@ extern "C" int bist_gemm(const BistGemm* g, void* stream) {
     k.vec_c = ((uintptr_t)g->C % 16 == 0) && al(g->ldc) && al(g->c_bs1) && al(g->c_bs2);
     k.vec_r = g->residual && ((uintptr_t)g->residual % 16 == 0) && al(g->ldr) && al(g->r_bs1) && al(g->r_bs2);
   }
+  return BIST_OK;
+}
+}  // namespace
+
+extern "C" int bist_gemm(const BistGemm* g, void* stream) {
+  GemmK k;
+  if (const int rc = fill_gemmk(g, k)) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (g->in_dtype == BIST_BF16) {
     if (g->out_dtype == BIST_BF16) return launch<bf16_t, bf16_t>(g, k, st);
     return launch<bf16_t, float>(g, k, st);
   }
   return launch<float, float>(g, k, st);
+}
+
+namespace {
+template <typename T, typename TO1, typename TO2>
+int launch_pair(const BistGemm* a, const BistGemm* b, GemmK& ka, GemmK& kb, hipStream_t st) {
+  ka.tiles_m = (a->M + T64 - 1) / T64; ka.tiles_n = (a->N + T64 - 1) / T64; ka.split_k = 1; ka.ws = nullptr;
+  kb.tiles_m = (b->M + T64 - 1) / T64; kb.tiles_n = (b->N + T64 - 1) / T64; kb.split_k = 1; kb.ws = nullptr;
+  const long n1 = (long)ka.tiles_m * ka.tiles_n * a->batch1 * a->batch2, n2 = (long)kb.tiles_m * kb.tiles_n * b->batch1 * b->batch2;
+  hipLaunchKernelGGL((gemm_t64_pair_kernel<T, TO1, TO2>), dim3((unsigned)(n1 + n2)), dim3(NTHREADS), 0, st, ka, kb, (unsigned)n1);
+  BIST_LAUNCH_CHECK("bist_gemm_pair");
+  return BIST_OK;
+}
+}  // namespace
+
+extern "C" int bist_gemm_pair(const BistGemm* a, const BistGemm* b, void* stream) {
+  BIST_REQUIRE(a && b, "bist_gemm_pair: null descriptor");
+  GemmK ka, kb;
+  if (const int rc = fill_gemmk(a, ka)) return rc;
+  if (const int rc = fill_gemmk(b, kb)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  static const int no_pair = [] { const char* e = getenv("BIST_GEMM_NO_PAIR"); return e ? atoi(e) : 0; }();      // tuning aid
+  const Plan pa = make_plan(a), pb = make_plan(b);
+  // one launch when both are small 64-tile products in the layouts of a linear layer's backward: (N,T) then (T,T)
+  const bool fused = !no_pair && a->in_dtype == b->in_dtype && !skinny_kind(a) && !skinny_kind(b) && pa.fast && pb.fast && pa.t64 && pb.t64 &&
+                     !pa.atr && pa.btr && pb.atr && pb.btr;
+  if (!fused) {
+    if (const int rc = bist_gemm(a, stream)) return rc;
+    return bist_gemm(b, stream);
+  }
+  const bool bf = a->in_dtype == BIST_BF16;
+  const bool o1 = a->out_dtype == BIST_F32 && bf, o2 = b->out_dtype == BIST_F32 && bf;      // f32 output from bf16 operands
+  if (!bf) return launch_pair<float, float, float>(a, b, ka, kb, st);
+  if (!o1 && !o2) return launch_pair<bf16_t, bf16_t, bf16_t>(a, b, ka, kb, st);
+  if (!o1 && o2) return launch_pair<bf16_t, bf16_t, float>(a, b, ka, kb, st);
+  if (o1 && !o2) return launch_pair<bf16_t, float, bf16_t>(a, b, ka, kb, st);
+  return launch_pair<bf16_t, float, float>(a, b, ka, kb, st);
 }

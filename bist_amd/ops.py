@@ -111,6 +111,12 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
 
 WGRAD_STREAM = None       # trainer: side stream of the weight-gradient GEMMs (autograd._WeightGradStream); None = in line
 WGRAD_KEEP = []           # their operands, kept alive until the trainer joins that stream
+def gemm_pair(ga: BistGemm, gb: BistGemm) -> None:
+    """Two independent products (descriptors from gemm_desc) in one call; one launch when they are the small dX / dW
+    pair of a linear layer's backward (bist_gemm_pair)."""
+    check(lib.bist_gemm_pair(C.byref(ga), C.byref(gb), _stream()), "bist_gemm_pair")
+
+
 COLSUM_QUEUE = None       # trainer: list of (dz, acc32 view, M, N) bias-gradient jobs, flushed by col_sum_flush()
 
 

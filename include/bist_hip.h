@@ -96,6 +96,11 @@ typedef struct BistGemm {
 #define BIST_GEMM_TILE256 2
 
 int bist_gemm(const BistGemm* g, void* stream);
+/* Two independent products in one call.  When they are the backward pair of a linear layer on few rows -- a: dX = dZ.W
+ * (A K-contiguous, B row-contiguous), b: dW = dZ^T.X (both row-contiguous), each too small to fill the chip on its own --
+ * they share ONE launch (the first workgroups work on a, the rest on b); otherwise this is bist_gemm(a) then
+ * bist_gemm(b).  Replaces the two addmm calls of nn.Linear's backward (modules.py:89-91,100 under autograd).      */
+int bist_gemm_pair(const BistGemm* a, const BistGemm* b, void* stream);
 /* Which kernel bist_gemm would pick for this problem: 1 = LDS-DMA MFMA tile kernel (128-, 64- or 256-tile),
  * 2 = the same with split-K, 3 = skinny (one side <= 8) VALU kernel, 0 = generic strided kernel
  * (host-side query, used by tests and the bench report).                                          */

@@ -66,6 +66,27 @@ def test_gemm_fast_linear(ops, dtype, tol, M, N, K):
          F32_TOL if dtype == torch.float32 else 2e-3, "linear f32 out")
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("rows,n_out,k_in", [(320, 512, 512), (320, 1536, 512), (400, 1024, 512), (72, 64, 200), (25088, 512, 512)])
+def test_gemm_pair_linear_backward(ops, dtype, tol, rows, n_out, k_in):
+    """bist_gemm_pair: dX = dZ.W and dW += dZ^T.X of one linear layer in ONE launch when both are small
+    (the last shape is too big for that and must fall back to two launches with the same results)."""
+    dz, w, x = _rand(rows, n_out, seed=70, scale=n_out ** -0.5), _rand(n_out, k_in, seed=71), _rand(rows, k_in, seed=72, scale=rows ** -0.5)
+    dzd, wd, xd = (t.to(dtype).cuda() for t in (dz, w, x))
+    dx = torch.empty(rows, k_in, device="cuda", dtype=dtype)
+    dw0 = _rand(n_out, k_in, seed=73)
+    dw = dw0.cuda()                                                    # fp32 accumulator, like the trainer's acc32 views
+    ga = ops.gemm_desc(dzd, wd, dx, M=rows, N=k_in, K=n_out, a_rs=n_out, a_ks=1, b_rs=1, b_ks=k_in, ldc=k_in, alpha=0.5)
+    gb = ops.gemm_desc(dzd, xd, dw, M=n_out, N=k_in, K=rows, a_rs=1, a_ks=n_out, b_rs=1, b_ks=k_in, ldc=k_in, residual=dw, ldr=k_in)
+    ops.gemm_pair(ga, gb)
+    _cmp(dx, 0.5 * (_q(dz, dtype) @ _q(w, dtype)), tol, "pair dX")
+    _cmp(dw, dw0 + _q(dz, dtype).t() @ _q(x, dtype), tol * 2, "pair dW (accumulated)")
+    dwb = torch.empty(n_out, k_in, device="cuda", dtype=dtype)
+    gb2 = ops.gemm_desc(dzd, xd, dwb, M=n_out, N=k_in, K=rows, a_rs=1, a_ks=n_out, b_rs=1, b_ks=k_in, ldc=k_in)
+    ops.gemm_pair(ga, gb2)
+    _cmp(dwb, _q(dz, dtype).t() @ _q(x, dtype), tol * 2, "pair dW (operand dtype)")
+
+
 @pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (1100, 300, 192), (256, 256, 128), (700, 1024, 832)])
 def test_gemm_tile256_kernel(ops, M, N, K):
     """the 256x256-tile deep-pipelined kernel (hint BIST_GEMM_TILE256; automatic only for far larger products than
