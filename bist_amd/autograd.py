@@ -116,37 +116,82 @@ class LinearFn(Function):
                                         _ptr(ops.DROP_CTR) if drop_p > 0 else None, dtype_code(dz.dtype), _stream()),
                   "bist_epilogue_bwd")
             dz = dz2
-        dx = dw = db = None
-        g_dx = g_dw = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), device=dz.device, dtype=x2.dtype)
-            g_dx = ops.gemm_desc(dz, w, dx, M=M, N=K, K=N, a_rs=N, a_ks=1, b_rs=1, b_ks=w.stride(0), ldc=K, alpha=alpha)
-        if ctx.needs_input_grad[1]:
-            if ctx.w_dst is not None:            # dW accumulates in place: C = alpha * dz^T x + C
-                gv = ctx.w_dst
-                g_dw = ops.gemm_desc(dz, x2, gv, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=gv.stride(0), alpha=alpha,
-                                     residual=gv, ldr=gv.stride(0))
-            else:
-                dw = torch.empty((N, K), device=dz.device, dtype=w.dtype)
-                g_dw = ops.gemm_desc(dz, x2, dw, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=K, alpha=alpha)
-        if g_dx is not None and g_dw is not None and ops.WGRAD_STREAM is None:
-            ops.gemm_pair(g_dx, g_dw)            # one launch when both are small (bist_gemm_pair)
-        else:
-            if g_dx is not None:
-                check(lib.bist_gemm(C.byref(g_dx), _stream()), "bist_gemm")
-            if g_dw is not None:
-                with _WeightGradStream(dz, x2):
-                    check(lib.bist_gemm(C.byref(g_dw), _stream()), "bist_gemm")
+        dx, dw, db = _linear_grads(x2, w, dz, alpha, ctx.w_dst, ctx.b_dst, bias_dtype if has_bias else None,
+                                   ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
         if dx is not None:
             dx = dx.view(x_shape)
-        if has_bias and ctx.needs_input_grad[2]:
-            acc = ctx.b_dst if ctx.b_dst is not None else _f32_zeros((N,), dz)
-            if ctx.b_dst is not None and ops.COLSUM_QUEUE is not None:
-                ops.COLSUM_QUEUE.append((dz, acc, M, N))     # the trainer sums all bias gradients in a few batched launches
-            else:
-                check(lib.bist_col_sum_acc(dz.data_ptr(), acc.data_ptr(), M, N, N, dtype_code(dz.dtype), _stream()), "bist_col_sum_acc")
-            db = None if ctx.b_dst is not None else _to_dtype_from_f32(acc, bias_dtype)
         return dx, dw, db, dres, None, None, None, None, None, None
+
+
+def _linear_grads(x2, w, dz, alpha, w_dst, b_dst, bias_dtype, need_dx, need_dw, need_db):
+    """dX = alpha dZ.W, dW = alpha dZ^T.X (accumulated into the trainer's gradient view when there is one), db = colsum(dZ)
+    of y = alpha x.W^T + b -- the two products as ONE launch when both are small (bist_gemm_pair)."""
+    M, K = x2.shape
+    N = w.shape[0]
+    dx = dw = db = None
+    g_dx = g_dw = None
+    if need_dx:
+        dx = torch.empty((M, K), device=dz.device, dtype=x2.dtype)
+        g_dx = ops.gemm_desc(dz, w, dx, M=M, N=K, K=N, a_rs=N, a_ks=1, b_rs=1, b_ks=w.stride(0), ldc=K, alpha=alpha)
+    if need_dw:
+        if w_dst is not None:                # dW accumulates in place: C = alpha * dz^T x + C
+            g_dw = ops.gemm_desc(dz, x2, w_dst, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=w_dst.stride(0), alpha=alpha,
+                                 residual=w_dst, ldr=w_dst.stride(0))
+        else:
+            dw = torch.empty((N, K), device=dz.device, dtype=w.dtype)
+            g_dw = ops.gemm_desc(dz, x2, dw, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=K, alpha=alpha)
+    if g_dx is not None and g_dw is not None and ops.WGRAD_STREAM is None:
+        ops.gemm_pair(g_dx, g_dw)
+    else:
+        if g_dx is not None:
+            check(lib.bist_gemm(C.byref(g_dx), _stream()), "bist_gemm")
+        if g_dw is not None:
+            with _WeightGradStream(dz, x2):
+                check(lib.bist_gemm(C.byref(g_dw), _stream()), "bist_gemm")
+    if need_db:
+        acc = b_dst if b_dst is not None else _f32_zeros((N,), dz)
+        if b_dst is not None and ops.COLSUM_QUEUE is not None:
+            ops.COLSUM_QUEUE.append((dz, acc, M, N))     # the trainer sums all bias gradients in a few batched launches
+        else:
+            check(lib.bist_col_sum_acc(dz.data_ptr(), acc.data_ptr(), M, N, N, dtype_code(dz.dtype), _stream()), "bist_col_sum_acc")
+        db = None if b_dst is not None else _to_dtype_from_f32(acc, bias_dtype)
+    return dx, dw, db
+
+
+class LinearPairFn(Function):
+    """(x1.W1^T + b1, x2.W2^T + b2): two independent plain projections (the query and the packed key/value projection of a
+    cross-attention, modules.py:89-91) in one launch forward, and one launch per projection backward."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, b1, x2, w2, b2):
+        xs = (x1.reshape(-1, x1.shape[-1]), x2.reshape(-1, x2.shape[-1]))
+        ys, descs = [], []
+        for x, w, b in ((xs[0], w1, b1), (xs[1], w2, b2)):
+            y = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=x.dtype)
+            descs.append(ops.gemm_desc(x, w, y, M=x.shape[0], N=w.shape[0], K=x.shape[1], a_rs=x.stride(0), b_rs=w.stride(0), ldc=y.stride(0), bias=b))
+            ys.append(y)
+        ops.gemm_pair(descs[0], descs[1])
+        ctx.save_for_backward(xs[0], w1, xs[1], w2)
+        ctx.cfg = [(getattr(w, "_grad_view", None), getattr(b, "_acc32", None) if b is not None else None,
+                    b.dtype if b is not None else None, tuple(x.shape)) for w, b, x in ((w1, b1, x1), (w2, b2, x2))]
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x1, w1, x2, w2 = ctx.saved_tensors
+        out = []
+        for i, (x, w, dy) in enumerate(((x1, w1, dy1), (x2, w2, dy2))):
+            w_dst, b_dst, bdt, x_shape = ctx.cfg[i]
+            if dy is None:
+                out += [None, None, None]
+                continue
+            dz = dy.reshape(x.shape[0], w.shape[0])
+            if not dz.is_contiguous():
+                dz = dz.contiguous()
+            dx, dw, db = _linear_grads(x, w, dz, 1.0, w_dst, b_dst, bdt, ctx.needs_input_grad[3 * i], ctx.needs_input_grad[3 * i + 1],
+                                       bdt is not None and ctx.needs_input_grad[3 * i + 2])
+            out += [dx.view(x_shape) if dx is not None else None, dw, db]
+        return tuple(out)
 
 
 def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, res_map=(0, 0), alpha=1.0, out=None, out_dtype=None,
@@ -187,15 +232,16 @@ class HeadFoldFn(Function):
         dk = d // h
         dqf = dqf.contiguous()
         dq = torch.empty((M, d), device=q.device, dtype=q.dtype)
-        ops.gemm(dqf, wk, dq, M=M, N=dk, K=d, a_rs=h * d, b_rs=wk.stride(0), ldc=d, batch=(1, h), a_bs=(0, d),
-                 b_bs=(0, dk * wk.stride(0)), c_bs=(0, dk), alpha=alpha)
+        g_dq = ops.gemm_desc(dqf, wk, dq, M=M, N=dk, K=d, a_rs=h * d, b_rs=wk.stride(0), ldc=d, batch=(1, h), a_bs=(0, d),
+                             b_bs=(0, dk * wk.stride(0)), c_bs=(0, dk), alpha=alpha)
         gv = ctx.w_dst
         if gv is not None:
-            with _WeightGradStream(q, dqf):
-                ops.gemm(q, dqf, gv, M=dk, N=d, K=M, a_rs=1, a_ks=q.stride(0), b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
-                         a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), alpha=alpha, residual=gv, ldr=gv.stride(0),
-                         r_bs=(0, dk * gv.stride(0)))
+            g_dw = ops.gemm_desc(q, dqf, gv, M=dk, N=d, K=M, a_rs=1, a_ks=q.stride(0), b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
+                                 a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), alpha=alpha, residual=gv, ldr=gv.stride(0),
+                                 r_bs=(0, dk * gv.stride(0)))
+            ops.gemm_pair(g_dq, g_dw)            # (N,N) + (T,T): one launch
             return dq, None, None, None
+        check(lib.bist_gemm(C.byref(g_dq), _stream()), "bist_gemm")
         dwk = torch.empty((d, d), device=q.device, dtype=wk.dtype)
         ops.gemm(q, dqf, dwk, M=dk, N=d, K=M, a_rs=1, a_ks=q.stride(0), b_rs=1, b_ks=h * d, ldc=d, batch=(1, h),
                  a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * d), alpha=alpha)
@@ -227,16 +273,17 @@ class HeadUnfoldFn(Function):
         dk = d // h
         do = do.contiguous()
         dpy = torch.empty((M, h * d), device=py.device, dtype=py.dtype)
-        ops.gemm(do, wv, dpy, M=M, N=d, K=dk, a_rs=d, a_ks=1, b_rs=1, b_ks=wv.stride(0), ldc=h * d, batch=(1, h),
-                 a_bs=(0, dk), b_bs=(0, dk * wv.stride(0)), c_bs=(0, d))
+        g_dpy = ops.gemm_desc(do, wv, dpy, M=M, N=d, K=dk, a_rs=d, a_ks=1, b_rs=1, b_ks=wv.stride(0), ldc=h * d, batch=(1, h),
+                              a_bs=(0, dk), b_bs=(0, dk * wv.stride(0)), c_bs=(0, d))
         gv = ctx.w_dst
         if gv is not None:
-            with _WeightGradStream(do, py):
-                ops.gemm(do, py, gv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
-                         a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), residual=gv, ldr=gv.stride(0),
-                         r_bs=(0, dk * gv.stride(0)))
+            g_dw = ops.gemm_desc(do, py, gv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=gv.stride(0), batch=(1, h),
+                                 a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * gv.stride(0)), residual=gv, ldr=gv.stride(0),
+                                 r_bs=(0, dk * gv.stride(0)))
+            ops.gemm_pair(g_dpy, g_dw)           # (N,T) + (T,T): one launch
             dwv = None
         else:
+            check(lib.bist_gemm(C.byref(g_dpy), _stream()), "bist_gemm")
             dwv = torch.empty((d, d), device=py.device, dtype=wv.dtype)
             ops.gemm(do, py, dwv, M=dk, N=d, K=M, a_rs=1, a_ks=d, b_rs=1, b_ks=h * d, ldc=d, batch=(1, h),
                      a_bs=(0, dk), b_bs=(0, d), c_bs=(0, dk * d))

@@ -924,12 +924,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_ring_kernel(const GemmK g) 
 // The two backward products of one linear layer in ONE launch: dX = dZ.W (A K-contiguous, B row-contiguous) on the
 // first n1 workgroups, dW = dZ^T.X (both row-contiguous) on the rest.  Each alone is a 40-64 workgroup launch on 256
 // CUs; together they share the chip and one launch latency (bist_gemm_pair).
-template <typename T, typename TO1, typename TO2>
+// Layout pairs built: PAIR_LIN  (N,T)+(T,T)  linear backward;  PAIR_FOLD (N,N)+(T,T)  per-head fold / un-fold backward;
+// PAIR_FWD (N,N)+(N,N)  two forward projections (query and packed key/value of a cross-attention).
+enum { PAIR_LIN = 0, PAIR_FOLD = 1, PAIR_FWD = 2 };
+template <typename T, typename TO1, typename TO2, int KIND>
 __global__ __launch_bounds__(NTHREADS) void gemm_t64_pair_kernel(const GemmK g1, const GemmK g2, unsigned n1) {
   __shared__ __attribute__((aligned(16))) char ebuf[2 * T64_BYTES + 64];
   __shared__ __attribute__((aligned(16))) char ring[RING_D * 2 * T64_BYTES];
-  if (blockIdx.x < n1) t64_ring_body<T, TO1, false, true>(g1, blockIdx.x, n1, ebuf, ring);
-  else t64_ring_body<T, TO2, true, true>(g2, blockIdx.x - n1, gridDim.x - n1, ebuf, ring);
+  if (blockIdx.x < n1) t64_ring_body<T, TO1, false, KIND == PAIR_LIN>(g1, blockIdx.x, n1, ebuf, ring);
+  else t64_ring_body<T, TO2, KIND != PAIR_FWD, KIND != PAIR_FWD>(g2, blockIdx.x - n1, gridDim.x - n1, ebuf, ring);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1501,11 +1504,14 @@ extern "C" int bist_gemm(const BistGemm* g, void* stream) {
 
 namespace {
 template <typename T, typename TO1, typename TO2>
-int launch_pair(const BistGemm* a, const BistGemm* b, GemmK& ka, GemmK& kb, hipStream_t st) {
+int launch_pair(const BistGemm* a, const BistGemm* b, GemmK& ka, GemmK& kb, int kind, hipStream_t st) {
   ka.tiles_m = (a->M + T64 - 1) / T64; ka.tiles_n = (a->N + T64 - 1) / T64; ka.split_k = 1; ka.ws = nullptr;
   kb.tiles_m = (b->M + T64 - 1) / T64; kb.tiles_n = (b->N + T64 - 1) / T64; kb.split_k = 1; kb.ws = nullptr;
   const long n1 = (long)ka.tiles_m * ka.tiles_n * a->batch1 * a->batch2, n2 = (long)kb.tiles_m * kb.tiles_n * b->batch1 * b->batch2;
-  hipLaunchKernelGGL((gemm_t64_pair_kernel<T, TO1, TO2>), dim3((unsigned)(n1 + n2)), dim3(NTHREADS), 0, st, ka, kb, (unsigned)n1);
+  const dim3 grid((unsigned)(n1 + n2));
+  if (kind == PAIR_LIN) hipLaunchKernelGGL((gemm_t64_pair_kernel<T, TO1, TO2, PAIR_LIN>), grid, dim3(NTHREADS), 0, st, ka, kb, (unsigned)n1);
+  else if (kind == PAIR_FOLD) hipLaunchKernelGGL((gemm_t64_pair_kernel<T, TO1, TO2, PAIR_FOLD>), grid, dim3(NTHREADS), 0, st, ka, kb, (unsigned)n1);
+  else hipLaunchKernelGGL((gemm_t64_pair_kernel<T, TO1, TO2, PAIR_FWD>), grid, dim3(NTHREADS), 0, st, ka, kb, (unsigned)n1);
   BIST_LAUNCH_CHECK("bist_gemm_pair");
   return BIST_OK;
 }
@@ -1519,18 +1525,22 @@ extern "C" int bist_gemm_pair(const BistGemm* a, const BistGemm* b, void* stream
   hipStream_t st = (hipStream_t)stream;
   static const int no_pair = [] { const char* e = getenv("BIST_GEMM_NO_PAIR"); return e ? atoi(e) : 0; }();      // tuning aid
   const Plan pa = make_plan(a), pb = make_plan(b);
-  // one launch when both are small 64-tile products in the layouts of a linear layer's backward: (N,T) then (T,T)
-  const bool fused = !no_pair && a->in_dtype == b->in_dtype && !skinny_kind(a) && !skinny_kind(b) && pa.fast && pb.fast && pa.t64 && pb.t64 &&
-                     !pa.atr && pa.btr && pb.atr && pb.btr;
+  // one launch when both are small 64-tile products in one of the built layout pairs
+  int kind = -1;
+  if (!pa.atr && pa.btr && pb.atr && pb.btr) kind = PAIR_LIN;
+  else if (!pa.atr && !pa.btr && pb.atr && pb.btr) kind = PAIR_FOLD;
+  else if (!pa.atr && !pa.btr && !pb.atr && !pb.btr) kind = PAIR_FWD;
+  const bool fused = !no_pair && kind >= 0 && a->in_dtype == b->in_dtype && !skinny_kind(a) && !skinny_kind(b) && pa.fast && pb.fast &&
+                     pa.t64 && pb.t64;
   if (!fused) {
     if (const int rc = bist_gemm(a, stream)) return rc;
     return bist_gemm(b, stream);
   }
   const bool bf = a->in_dtype == BIST_BF16;
   const bool o1 = a->out_dtype == BIST_F32 && bf, o2 = b->out_dtype == BIST_F32 && bf;      // f32 output from bf16 operands
-  if (!bf) return launch_pair<float, float, float>(a, b, ka, kb, st);
-  if (!o1 && !o2) return launch_pair<bf16_t, bf16_t, bf16_t>(a, b, ka, kb, st);
-  if (!o1 && o2) return launch_pair<bf16_t, bf16_t, float>(a, b, ka, kb, st);
-  if (o1 && !o2) return launch_pair<bf16_t, float, bf16_t>(a, b, ka, kb, st);
-  return launch_pair<bf16_t, float, float>(a, b, ka, kb, st);
+  if (!bf) return launch_pair<float, float, float>(a, b, ka, kb, kind, st);
+  if (!o1 && !o2) return launch_pair<bf16_t, bf16_t, bf16_t>(a, b, ka, kb, kind, st);
+  if (!o1 && o2) return launch_pair<bf16_t, bf16_t, float>(a, b, ka, kb, kind, st);
+  if (o1 && !o2) return launch_pair<bf16_t, float, bf16_t>(a, b, ka, kb, kind, st);
+  return launch_pair<bf16_t, float, float>(a, b, ka, kb, kind, st);
 }

@@ -29,6 +29,15 @@ def _grad() -> bool:
     return torch.is_grad_enabled()
 
 
+def linear_pair(x1: Tensor, w1: Tensor, b1: Optional[Tensor], x2: Tensor, w2: Tensor, b2: Optional[Tensor]):
+    """Two independent plain projections in one launch (see autograd.LinearPairFn / bist_gemm_pair)."""
+    if _grad():
+        y1, y2 = ag.LinearPairFn.apply(x1, w1, b1, x2, w2, b2)
+    else:
+        y1, y2 = ag.LinearPairFn.forward(_NoCtx(), x1, w1, b1, x2, w2, b2)
+    return y1.view(*x1.shape[:-1], -1), y2.view(*x2.shape[:-1], -1)
+
+
 def layernorm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
     return ag.LayerNormFn.apply(x, a, b, eps) if _grad() else ops.layernorm(x, a, b, eps)
 
@@ -201,4 +210,7 @@ class _NoCtx:
     """Stand-in for the autograd context when a Function's forward is called without autograd."""
 
     def save_for_backward(self, *a):
+        pass
+
+    def set_materialize_grads(self, *a):
         pass

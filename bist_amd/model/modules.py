@@ -114,13 +114,14 @@ class MultiHeadedAttention(nn.Module):
             qkv = Fn.linear(query, w, b).view(n, lq, 3 * d)
             ctx, p = Fn.mha_packed(qkv, None, None, "qkv", mask, self.h, self.keep_attn, Fn.attn_drop(self))
         else:
-            q = Fn.linear(query, self.linears[0].weight, self.linears[0].bias).view(n, lq, d)
             lk = key.shape[1]
             if key is value:
                 w, b = self._packed((1, 2))
-                kv = Fn.linear(key, w, b).view(n, lk, 2 * d)
+                q, kv = Fn.linear_pair(query, self.linears[0].weight, self.linears[0].bias, key, w, b)      # one launch
+                q, kv = q.view(n, lq, d), kv.view(n, lk, 2 * d)
                 ctx, p = Fn.mha_packed(q, kv, None, "q_kv", mask, self.h, self.keep_attn, Fn.attn_drop(self))
             else:
+                q = Fn.linear(query, self.linears[0].weight, self.linears[0].bias).view(n, lq, d)
                 k = Fn.linear(key, self.linears[1].weight, self.linears[1].bias).view(n, lk, d)
                 v = Fn.linear(value, self.linears[2].weight, self.linears[2].bias).view(n, lk, d)
                 ctx, p = Fn.mha_packed(q, k, v, "q_k_v", mask, self.h, self.keep_attn, Fn.attn_drop(self))

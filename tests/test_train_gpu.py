@@ -83,6 +83,15 @@ def test_linear_backward(env):
            lambda o, w, b, xr: ((o @ w.t() + b).view(B, G, Lq, N) + xr.view(B, 1, Lq, N)).reshape(-1, N), [o, w, b, xr], "linear+rowmap")
 
 
+def test_linear_pair_backward(env):
+    """two independent projections sharing launches (query + packed key/value of a cross-attention)."""
+    ag, Fn, ops = env
+    x1, w1, b1 = _rand(4, 20, 64, seed=30), _rand(64, 64, seed=31, scale=0.2), _rand(64, seed=32)
+    x2, w2, b2 = _rand(4, 25, 64, seed=33), _rand(128, 64, seed=34, scale=0.2), _rand(128, seed=35)
+    _check(lambda a, b, c, d, e, f: Fn.linear_pair(a, b, c, d, e, f),
+           lambda a, b, c, d, e, f: (a @ b.t() + c, d @ e.t() + f), [x1, w1, b1, x2, w2, b2], "linear_pair")
+
+
 def test_layernorm_backward(env):
     ag, Fn, ops = env
     x, a, b = _rand(37, 64, seed=7, scale=2.0) + 0.3, 1 + 0.1 * _rand(64, seed=8), 0.1 * _rand(64, seed=9)
