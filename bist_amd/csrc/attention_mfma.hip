@@ -503,6 +503,7 @@ struct MhaBwdArgs {
   long ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs;
   float scale;
   DropArg drop;
+  int nc;          // 64-column chunks per head (dk = 64 nc): the wave walks them, S and dP accumulate across chunks
 };
 
 __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
@@ -511,12 +512,17 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
   const int hh = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
   const int x = lane & 15, lg = lane >> 4;
   const int Lq = a.Lq, Lk = a.Lk;
-  const bf16_t* Qn = a.Q + n * a.q_bs + hh * 64;
-  const bf16_t* Kn = a.K + n * a.k_bs + hh * 64;
-  const bf16_t* Vn = a.V + n * a.v_bs + hh * 64;
-  const bf16_t* Gn = a.dO ? a.dO + n * a.o_bs + hh * 64 : nullptr;
-  const uint4 z4 = make_uint4(0, 0, 0, 0);
-  {
+  const int nc = a.nc;
+  const long hoff = (long)hh * nc * 64;
+  const bf16_t* Qh = a.Q + n * a.q_bs + hoff;
+  const bf16_t* Kh = a.K + n * a.k_bs + hoff;
+  const bf16_t* Vh = a.V + n * a.v_bs + hoff;
+  const bf16_t* Gh = a.dO ? a.dO + n * a.o_bs + hoff : nullptr;
+  auto stage = [&](int cc, bool with_mask) {
+    const bf16_t* Qn = Qh + cc * 64;
+    const bf16_t* Kn = Kh + cc * 64;
+    const bf16_t* Vn = Vh + cc * 64;
+    const bf16_t* Gn = Gh ? Gh + cc * 64 : nullptr;
     // all 24 tile loads (and the mask bytes) are issued before the first LDS store: one memory latency, not 12
     const int c = (lane & 7) * 8, rb = lane >> 3;
     uint4 rq[4], rg[4], rk[8], rv[8];
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
       rv[t] = *reinterpret_cast<const uint4*>(Vn + (long)rc * a.ldv + c);
     }
     unsigned mlo[4], mhi[4];                 // 8 mask bytes per row piece, packed (a byte array would live in scratch)
-    if (a.mask) {
+    if (a.mask && with_mask) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int r = rb + 8 * t;
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
       const int r = rb + 8 * t;
       *reinterpret_cast<uint4*>(qimg + r * 64 + c) = keep4(rq[t], r < Lq);
       *reinterpret_cast<uint4*>(gimg + r * 64 + c) = keep4(rg[t], r < Lq && Gn != nullptr);
-      if (a.mask) *reinterpret_cast<uint2*>(mimg + r * 64 + c) = make_uint2(mlo[t], mhi[t]);
+      if (a.mask && with_mask) *reinterpret_cast<uint2*>(mimg + r * 64 + c) = make_uint2(mlo[t], mhi[t]);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -562,13 +568,17 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
       *reinterpret_cast<uint4*>(kimg + r * 64 + c) = keep4(rk[t], r < Lk);
       *reinterpret_cast<uint4*>(vimg + r * 64 + c) = keep4(rv[t], r < Lk);
     }
-  }
-  // S = Q K^T and dP = dO V^T   (rows i, cols j)
+  };
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  (void)z4;
+  // S = Q K^T and dP = dO V^T   (rows i, cols j), summed over the head's 64-column chunks
   f32x4 S[2][4], D[2][4];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) { S[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; D[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int cc = 0; cc < nc; ++cc) {
+  stage(cc, cc == 0);
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     uint4 aq[2], ag[2];
@@ -581,6 +591,7 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
       for (int mi = 0; mi < 2; ++mi) { S[mi][ni] = mfma_bf16(aq[mi], bk, S[mi][ni]); D[mi][ni] = mfma_bf16(ag[mi], bv, D[mi][ni]); }
     }
   }
+  }   // chunks
   // softmax and its backward in the accumulator layout: row i = mi*16 + lg*4 + r, col j = ni*16 + x
   const unsigned long long dkey = a.drop.p > 0.f ? a.drop.key() : 0ULL;
   const float dks = a.drop.p > 0.f ? a.drop.keep_scale() : 1.f;
@@ -631,7 +642,9 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
         simg[i * 64 + j] = (bf16_t)ds;
       }
     }
-  // dQ = dS K  (M = i, N = c, K = j);  dK = dS^T Q, dV = P^T dO  (M = j, N = c, K = i)
+  // dQ = dS K  (M = i, N = c, K = j);  dK = dS^T Q, dV = P^T dO  (M = j, N = c, K = i), chunk by chunk of the head columns
+  for (int cc = 0; cc < nc; ++cc) {
+  if (nc > 1) stage(cc, false);          // one chunk: the tiles of phase 1 are still in place
   f32x4 dq[2][4], dkk[4][4], dvv[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -675,15 +688,16 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
         kimg[row * 64 + col] = (bf16_t)dkk[mi][ni][r];
         vimg[row * 64 + col] = (bf16_t)dvv[mi][ni][r];
       }
-  bf16_t* dQn = a.dQ + n * a.dq_bs + hh * 64;
-  bf16_t* dKn = a.dK + n * a.dk_bs + hh * 64;
-  bf16_t* dVn = a.dV + n * a.dv_bs + hh * 64;
+  bf16_t* dQn = a.dQ + n * a.dq_bs + hoff + cc * 64;
+  bf16_t* dKn = a.dK + n * a.dk_bs + hoff + cc * 64;
+  bf16_t* dVn = a.dV + n * a.dv_bs + hoff + cc * 64;
   for (int r = lane >> 3; r < Lq; r += 8)
     *reinterpret_cast<uint4*>(dQn + (long)r * a.lddq + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(qimg + r * 64 + (lane & 7) * 8);
   for (int r = lane >> 3; r < Lk; r += 8) {
     *reinterpret_cast<uint4*>(dKn + (long)r * a.lddk + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(kimg + r * 64 + (lane & 7) * 8);
     *reinterpret_cast<uint4*>(dVn + (long)r * a.lddv + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(vimg + r * 64 + (lane & 7) * 8);
   }
+  }   // chunks
 }
 
 }  // namespace
@@ -693,13 +707,13 @@ int bist_mha_bwd_mfma(const void* Q, const void* K, const void* V, const unsigne
                       void* dQ, void* dK, void* dV, int N, int Lq, int Lk, int h, int dk, long ldq, long ldk, long ldv, long ldo,
                       long q_bs, long k_bs, long v_bs, long o_bs, long lddq, long lddk, long lddv, long dq_bs, long dk_bs, long dv_bs,
                       long mask_bs, long mask_qs, float scale, const DropArg& drop, hipStream_t st) {
-  if (dk != 64 || Lq > 32 || Lk > 64) return 0;
+  if (dk % 64 != 0 || dk > 512 || Lq > 32 || Lk > 64) return 0;
   auto al8 = [](long v) { return (v % 8) == 0; };
   if (!(al8(ldq) && al8(ldk) && al8(ldv) && al8(lddq) && al8(lddk) && al8(lddv) && al8(q_bs) && al8(k_bs) && al8(v_bs) && al8(dq_bs) &&
         al8(dk_bs) && al8(dv_bs) && (!dO || (al8(ldo) && al8(o_bs))))) return 0;
   if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV | (uintptr_t)dO) % 16) return 0;
   MhaBwdArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, mask, dPext, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV,
-               Lq, Lk, h, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, drop};
+               Lq, Lk, h, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, drop, dk / 64};
   hipLaunchKernelGGL(mha_bwd_mfma_kernel, dim3((unsigned)h, (unsigned)N), dim3(64), 0, st, a);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }

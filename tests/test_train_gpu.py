@@ -200,13 +200,15 @@ def test_mha_core_backward_all_packings(env):
            lambda q, k, v: _ref_attn(q, k, v, causal, h), [q, k, v], "mha q_k_v + p_attn grad")
 
 
-@pytest.mark.parametrize("N,Lq,Lk,h,mk", [(3, 20, 20, 8, "key"), (2, 20, 60, 8, "key"), (2, 12, 12, 4, "causal"), (2, 32, 64, 2, None)])
-def test_mha_core_backward_bf16_matrix_core_path(env, N, Lq, Lk, h, mk):
-    """bf16 small-attention backward (one wave per head on the MFMA units, dk = 64) against fp64 on the rounded inputs,
-    including a gradient arriving through the probabilities (the pointer generator's use)."""
+@pytest.mark.parametrize("N,Lq,Lk,h,mk,dk", [(3, 20, 20, 8, "key", 64), (2, 20, 60, 8, "key", 64), (2, 12, 12, 4, "causal", 64),
+                                             (2, 32, 64, 2, None, 64), (4, 20, 25, 1, "key", 512), (2, 19, 60, 2, "key", 192)])
+def test_mha_core_backward_bf16_matrix_core_path(env, N, Lq, Lk, h, mk, dk):
+    """bf16 small-attention backward (one wave per head on the MFMA units, dk a multiple of 64 walked in 64-column chunks:
+    dk = 512, h = 1 is the pointer attention of the generator) against fp64 on the rounded inputs, including a gradient
+    arriving through the probabilities (the pointer generator's use)."""
     ag, Fn, ops = env
-    d = h * 64
-    q = _rand(N, Lq, d, seed=80).to(torch.bfloat16).double()
+    d = h * dk
+    q = _rand(N, Lq, d, seed=80, scale=(64.0 / dk) ** 0.5).to(torch.bfloat16).double()
     kv = _rand(N, Lk, 2 * d, seed=81).to(torch.bfloat16).double()
     mask = None
     if mk == "key":
