@@ -1216,20 +1216,18 @@ __global__ __launch_bounds__(256) void skinny_n_kernel(const GemmK g) {
       const uint4 qa = *reinterpret_cast<const uint4*>(A + k);
       const T* ae = reinterpret_cast<const T*>(&qa);
 #pragma unroll
-      for (int n = 0; n < SKINNY; ++n)
-        if (n < g.N) {
-          const uint4 qb = *reinterpret_cast<const uint4*>(B + n * g.b_rs + k);
-          const T* be = reinterpret_cast<const T*>(&qb);
+      for (int n = 0; n < SKINNY; ++n) {              // rows >= N re-read row N-1 (unconditional loads; never stored)
+        const uint4 qb = *reinterpret_cast<const uint4*>(B + (long)min(n, g.N - 1) * g.b_rs + k);
+        const T* be = reinterpret_cast<const T*>(&qb);
 #pragma unroll
-          for (int e = 0; e < E; ++e) acc[n] += to_f(ae[e]) * to_f(be[e]);
-        }
+        for (int e = 0; e < E; ++e) acc[n] += to_f(ae[e]) * to_f(be[e]);
+      }
     }
   } else {
     for (int k = lane; k < g.K; k += 64) {
       const float a = to_f(A[k]);
 #pragma unroll
-      for (int n = 0; n < SKINNY; ++n)
-        if (n < g.N) acc[n] += a * to_f(B[n * g.b_rs + k]);
+      for (int n = 0; n < SKINNY; ++n) acc[n] += a * to_f(B[(long)min(n, g.N - 1) * g.b_rs + k]);
     }
   }
   float mine = 0.f;
@@ -1254,8 +1252,11 @@ __global__ __launch_bounds__(256) void skinny_k_kernel(const GemmK g) {
   const T* B = reinterpret_cast<const T*>(g.B) + (long)n * g.b_rs;
   float acc = 0.f;
 #pragma unroll
-  for (int k = 0; k < SKINNY; ++k)
-    if (k < g.K) acc += to_f(A[k * g.a_ks]) * to_f(B[k * g.b_ks]);
+  for (int k = 0; k < SKINNY; ++k) {                  // unconditional loads from a clamped k, masked afterwards
+    const int kc = min(k, g.K - 1);
+    const float pr = to_f(A[kc * g.a_ks]) * to_f(B[kc * g.b_ks]);
+    acc += k < g.K ? pr : 0.f;
+  }
   const T* bias = reinterpret_cast<const T*>(g.bias);
   const TO* res = reinterpret_cast<const TO*>(g.residual);
   reinterpret_cast<TO*>(g.C)[(long)m * g.ldc + n] = from_f<TO>(epilogue_value<T, TO>(g, acc, bias ? to_f(bias[n]) : 0.f, res, m, n, 0ULL));
@@ -1276,14 +1277,17 @@ __global__ __launch_bounds__(1024) void skinny_tn_kernel(const GemmK g) {
   float acc[SKINNY];
 #pragma unroll
   for (int s = 0; s < SKINNY; ++s) acc[s] = 0.f;
-  if (gi < NB) {
-#pragma unroll 4
-    for (int k = kl; k < g.K; k += 16) {
-      const float p = to_f(P[(long)k * p_ks + gi]);
+  // unconditional loads (rows >= NS re-read row NS-1, wide indices past the end re-read the last one; their sums are
+  // never stored): a per-element condition would put a branch and a full wait around every load
+  const int gic = min(gi, NB - 1);
+  long qoff[SKINNY];
 #pragma unroll
-      for (int s = 0; s < SKINNY; ++s)
-        if (s < NS) acc[s] += p * to_f(Q[s * q_rs + (long)k * q_ks]);
-    }
+  for (int s = 0; s < SKINNY; ++s) qoff[s] = (long)min(s, NS - 1) * q_rs;
+#pragma unroll 4
+  for (int k = kl; k < g.K; k += 16) {
+    const float p = to_f(P[(long)k * p_ks + gic]);
+#pragma unroll
+    for (int s = 0; s < SKINNY; ++s) acc[s] += p * to_f(Q[qoff[s] + (long)k * q_ks]);
   }
 #pragma unroll
   for (int s = 0; s < SKINNY; ++s) red[kl][s][gl] = acc[s];
