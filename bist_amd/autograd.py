@@ -92,6 +92,7 @@ class LinearFn(Function):
         act, res_map, alpha, drop_p, drop_seed, has_bias, bias_dtype, has_res, res_shape, x_shape = ctx.cfg
         M, K = x2.shape
         N = w.shape[0]
+        pre = getattr(dy, "_bist_dz", None)            # (masked gradient, p, seed) left by _ln_backward on this very tensor
         dy = dy.reshape(M, N)
         if not dy.is_contiguous():
             dy = dy.contiguous()
@@ -107,7 +108,10 @@ class LinearFn(Function):
             else:
                 dres = dy.view(res_shape)
         dz = dy if dy.dtype == x2.dtype else ops.cast(dy, x2.dtype)
-        if act == ACT_RELU or drop_p > 0:
+        if pre is not None and act == ACT_NONE and pre[1:] == (float(drop_p), int(drop_seed)) and pre[0].numel() == M * N \
+                and pre[0].dtype == x2.dtype:
+            dz = pre[0].view(M, N)                     # already masked by the LayerNorm backward that produced dy
+        elif act == ACT_RELU or drop_p > 0:
             dz2 = torch.empty_like(dz)
             yy = y if y is not None else dz
             if y is not None and y.dtype != dz.dtype:
@@ -195,15 +199,22 @@ class LinearPairFn(Function):
 
 
 def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, res_map=(0, 0), alpha=1.0, out=None, out_dtype=None,
-           accumulate=False, drop_p=0.0, drop_seed=0):
+           accumulate=False, drop_p=0.0, drop_seed=0, out_shape=None):
     if not torch.is_grad_enabled():
-        return ops.linear(x, w, bias, act=act, residual=residual, res_map=res_map, alpha=alpha, out=out, out_dtype=out_dtype,
-                          accumulate=accumulate, drop_p=drop_p, drop_seed=drop_seed)
+        y = ops.linear(x, w, bias, act=act, residual=residual, res_map=res_map, alpha=alpha, out=out, out_dtype=out_dtype,
+                       accumulate=accumulate, drop_p=drop_p, drop_seed=drop_seed)
+        return y if out_shape is None else y.view(out_shape)
     if accumulate:                       # out-of-place under autograd: the running sum is the residual
         residual = out
     if residual is not None and residual.dim() != 2:
         residual = residual.reshape(-1, residual.shape[-1])
-    return LinearFn.apply(x, w, bias, residual, act, tuple(res_map), alpha, drop_p, drop_seed, out_dtype)
+    y = LinearFn.apply(x, w, bias, residual, act, tuple(res_map), alpha, drop_p, drop_seed, out_dtype)
+    if out_shape is not None:
+        y = y.view(out_shape)
+    if drop_p > 0 and act == ACT_NONE and res_map == (0, 0):
+        # y = drop(z) + res: a LayerNorm that consumes y can hand the masked gradient of z back (see _ln_backward)
+        y._bist_drop = (float(drop_p), int(drop_seed), w.shape[0])
+    return y
 
 
 # ----------------------------------------------------------------------------------------------
@@ -374,30 +385,37 @@ def _ln_backward(ctx, dy, dres):
     # trainer: dx only on the critical path; the gain/offset gradients of every LayerNorm are summed in one batched launch
     defer = (direct and ops.LNGRAD_QUEUE is not None and d * x.element_size() == 1024 and a.data_ptr() % 16 == 0
              and all(t.data_ptr() % 16 == 0 and (t.stride(0) * t.element_size()) % 16 == 0 for t in (dy2, x2) + ((add2,) if add2 is not None else ())))
+    up = getattr(ctx, "up_drop", None)          # x = drop(z) + res came out of a GEMM with this dropout epilogue
+    dz = torch.empty(x2.shape, device=x.device, dtype=x.dtype) if (up is not None and up[2] == d) else None
+    zdrop = C.byref(ops.BistDrop(up[0], up[1] & 0xFFFFFFFFFFFFFFFF, _ptr(ops.DROP_CTR))) if dz is not None else None
     check(lib.bist_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), a.data_ptr(), dx.data_ptr(),
                                  None if defer else da.data_ptr(), None if defer else db.data_ptr(),
                                  x2.shape[0], d, dy2.stride(0), x2.stride(0), d, eps,
                                  add2.data_ptr() if add2 is not None else None, add2.stride(0) if add2 is not None else 0,
-                                 dtype_code(x.dtype), _stream()),
+                                 _ptr(dz), zdrop, dtype_code(x.dtype), _stream()),
           "bist_layernorm_bwd")
     if defer:
         ops.LNGRAD_QUEUE.append((dy2, x2, a, da, db, eps))
+    gx = dx.view(x.shape)
+    if dz is not None:
+        gx._bist_dz = (dz, up[0], up[1])        # survives only if autograd hands THIS tensor to the producer's backward
     if direct:
-        return dx.view(x.shape), None, None, None
-    return dx.view(x.shape), _to_dtype_from_f32(da, a.dtype), _to_dtype_from_f32(db, bdt), None
+        return gx, None, None, None
+    return gx, _to_dtype_from_f32(da, a.dtype), _to_dtype_from_f32(db, bdt), None
 
 
 class LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, a, b, eps):
+    def forward(ctx, x, a, b, eps, up_drop=None):
         ctx.save_for_backward(x, a)
         ctx.cfg = (eps, b.dtype)
+        ctx.up_drop = up_drop
         ctx.a_dst, ctx.b_dst = getattr(a, "_acc32", None), getattr(b, "_acc32", None)
         return ops.layernorm(x, a, b, eps)
 
     @staticmethod
     def backward(ctx, dy):
-        return _ln_backward(ctx, dy, None)
+        return _ln_backward(ctx, dy, None) + (None,)
 
 
 class LayerNormResFn(Function):
@@ -406,16 +424,17 @@ class LayerNormResFn(Function):
     autograd never launches a separate add for the two uses of x."""
 
     @staticmethod
-    def forward(ctx, x, a, b, eps):
+    def forward(ctx, x, a, b, eps, up_drop=None):
         ctx.save_for_backward(x, a)
         ctx.cfg = (eps, b.dtype)
+        ctx.up_drop = up_drop
         ctx.a_dst, ctx.b_dst = getattr(a, "_acc32", None), getattr(b, "_acc32", None)
         ctx.set_materialize_grads(False)
         return ops.layernorm(x, a, b, eps), x
 
     @staticmethod
     def backward(ctx, dy, dres):
-        return _ln_backward(ctx, dy, dres)
+        return _ln_backward(ctx, dy, dres) + (None,)
 
 
 class EmbedFn(Function):

@@ -92,10 +92,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
                                                             T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
                                                             long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
-                                                            const T* __restrict__ dx_add, long ldadd) {
+                                                            const T* __restrict__ dx_add, long ldadd, T* __restrict__ dz, const DropArg zdrop) {
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long r0 = wave * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+  const unsigned long long zkey = dz ? zdrop.key() : 0ULL;
+  const float zks = dz ? zdrop.keep_scale() : 1.f;
   // per-lane partial sums of da/db over this wave's rows (columns lane, lane+64, ...), flushed once
   constexpr int MAXC = 32;                       // d <= 2048
   float pa[MAXC], pb[MAXC];
@@ -123,7 +125,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       if (c < d) {
         const float xc = to_f(xr[c]) - mean, gy = to_f(gr[c]);
         const float add = dx_add ? to_f(dx_add[row * ldadd + c]) : 0.f;
-        dxr[c] = from_f<T>((gy * to_f(a[c]) - mg) * inv - xc * k2 + add);
+        const T dxv = from_f<T>((gy * to_f(a[c]) - mg) * inv - xc * k2 + add);
+        dxr[c] = dxv;
+        if (dz) dz[row * (long)d + c] = from_f<T>(to_f(dxv) * drop_mul(zkey, (unsigned long long)row * d + c, zdrop.p, zks));
         pa[u] += gy * xc * inv;
         pb[u] += gy;
       }
@@ -147,8 +151,11 @@ template <typename T, int NV, bool DX, bool PARAMS>
 __device__ __forceinline__ void layernorm_bwd_vec_body(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
                                                        T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
                                                        long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
-                                                       const T* __restrict__ dx_add, long ldadd, long blk, float (*red)[4][64 * NV * (16 / (int)sizeof(T))]) {
+                                                       const T* __restrict__ dx_add, long ldadd, long blk, float (*red)[4][64 * NV * (16 / (int)sizeof(T))],
+                                                       T* __restrict__ dz = nullptr, const DropArg zdrop = DropArg{0.f, 0ULL, nullptr}) {
   constexpr int E = 16 / (int)sizeof(T), NE = NV * E;
+  const unsigned long long zkey = (DX && dz) ? zdrop.key() : 0ULL;
+  const float zks = (DX && dz) ? zdrop.keep_scale() : 1.f;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long wave = blk * 4 + w;
   const long r0 = wave * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
@@ -204,6 +211,13 @@ __device__ __forceinline__ void layernorm_bwd_vec_body(const T* __restrict__ dy,
           if (PARAMS) { pa[u] += gv[u] * xv[u] * inv; pb[u] += gv[u]; }
         }
         if (DX) *reinterpret_cast<uint4*>(dx + row * lddx + (j * 64 + lane) * E) = *reinterpret_cast<const uint4*>(o);
+        if (DX && dz) {          // the masked copy the producing GEMM's backward needs (its dropout epilogue): dz = mask/(1-p) * dx
+          T zo[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e)
+            zo[e] = from_f<T>(to_f(o[e]) * drop_mul(zkey, (unsigned long long)row * d + (j * 64 + lane) * E + e, zdrop.p, zks));
+          *reinterpret_cast<uint4*>(dz + row * (long)d + (j * 64 + lane) * E) = *reinterpret_cast<const uint4*>(zo);
+        }
       }
     }
   }
@@ -224,10 +238,10 @@ template <typename T, int NV, bool PARAMS>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
                                                                 T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
                                                                 long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
-                                                                const T* __restrict__ dx_add, long ldadd) {
+                                                                const T* __restrict__ dx_add, long ldadd, T* __restrict__ dz, const DropArg zdrop) {
   __shared__ float red[PARAMS ? 2 : 1][4][64 * NV * (16 / (int)sizeof(T))];
   layernorm_bwd_vec_body<T, NV, true, PARAMS>(dy, x, a, dx, da, db, rows, d, lddy, ldx, lddx, eps, rows_per_wave, dx_add, ldadd,
-                                              (long)blockIdx.x, red);
+                                              (long)blockIdx.x, red, dz, zdrop);
 }
 
 // gain/offset gradients of many LayerNorms (one row width) in one launch: block -> job through the prefix table
@@ -421,20 +435,22 @@ extern "C" int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t
 
 extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
                                   int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
-                                  int32_t dtype, void* stream) {
+                                  void* dz, const BistDrop* dz_drop, int32_t dtype, void* stream) {
   BIST_REQUIRE(dy && x && a && dx && ((da != nullptr) == (db != nullptr)), "bist_layernorm_bwd: null pointer");
   BIST_REQUIRE(rows > 0 && d > 1 && d <= 2048, "bist_layernorm_bwd: bad shape rows=%ld d=%d", (long)rows, d);
   hipStream_t st = (hipStream_t)stream;
   const long sz = dtype == BIST_BF16 ? 2 : 4;
   BIST_REQUIRE(!dx_add || ldadd >= d, "bist_layernorm_bwd: bad dx_add stride");
-  const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)a | (uintptr_t)dx | (uintptr_t)dx_add) % 16 == 0) && (lddy * sz) % 16 == 0 &&
+  BIST_REQUIRE(!dz || (dz_drop && dz_drop->p > 0.f && dz_drop->p < 1.f), "bist_layernorm_bwd: dz needs a dropout spec");
+  const DropArg zd = make_drop(dz ? dz_drop : nullptr);
+  const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)a | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)dz) % 16 == 0) && (lddy * sz) % 16 == 0 &&
                   (ldx * sz) % 16 == 0 && (lddx * sz) % 16 == 0 && (!dx_add || (ldadd * sz) % 16 == 0);
   if (al && (d * sz) == 1024) {                   // d = 512 bf16 / 256 f32: one 16-byte vector per lane
     int rpw2 = (int)((rows + 1023) / 1024);       // ~1024 waves: enough parallelism for dx, few atomics per column
     if (rpw2 < 2) rpw2 = 2;
     const unsigned g2 = blocks_for(blocks_for(rows, rpw2), 4);
 #define LNV(TT, PP) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TT, 1, PP>), dim3(g2), dim3(256), 0, st, (const TT*)dy, (const TT*)x, (const TT*)a, \
-                                       (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2, (const TT*)dx_add, (long)ldadd)
+                                       (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2, (const TT*)dx_add, (long)ldadd, (TT*)dz, zd)
     if (dtype == BIST_BF16) { if (da) LNV(bf16_t, true); else LNV(bf16_t, false); }
     else { if (da) LNV(float, true); else LNV(float, false); }
 #undef LNV
@@ -445,7 +461,7 @@ extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, 
   int rpw = (int)((rows + 4095) / 4096);          // <= 4096 waves flush their partial sums
   if (rpw < 1) rpw = 1;
   const unsigned g = blocks_for(blocks_for(rows, rpw), 4);
-#define L(TT, ...) hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3(g), dim3(256), 0, st, (const TT*)dy, (const TT*)x, (const TT*)a, (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw, (const TT*)dx_add, (long)ldadd)
+#define L(TT, ...) hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3(g), dim3(256), 0, st, (const TT*)dy, (const TT*)x, (const TT*)a, (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw, (const TT*)dx_add, (long)ldadd, (TT*)dz, zd)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_layernorm_bwd");

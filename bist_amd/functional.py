@@ -39,14 +39,14 @@ def linear_pair(x1: Tensor, w1: Tensor, b1: Optional[Tensor], x2: Tensor, w2: Te
 
 
 def layernorm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
-    return ag.LayerNormFn.apply(x, a, b, eps) if _grad() else ops.layernorm(x, a, b, eps)
+    return ag.LayerNormFn.apply(x, a, b, eps, getattr(x, "_bist_drop", None)) if _grad() else ops.layernorm(x, a, b, eps)
 
 
 def layernorm_res(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6):
     """(LN(x), x) for x + sublayer(LN(x)): hand the second value to the residual add, so that its gradient
     is folded into the LayerNorm backward kernel instead of a separate accumulation pass."""
     if _grad() and x.requires_grad:
-        return ag.LayerNormResFn.apply(x, a, b, eps)
+        return ag.LayerNormResFn.apply(x, a, b, eps, getattr(x, "_bist_drop", None))
     return layernorm(x, a, b, eps), x
 
 

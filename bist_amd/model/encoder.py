@@ -86,14 +86,14 @@ def _self_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Tens
     """x + MHA(LN(x), LN(x), LN(x), mask): A0/A3 and every other self-attention sublayer."""
     xn, xr = sub.norm.with_residual(x)
     ctx = attn.context(xn, xn, xn, mask)
-    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, **Fn.drop_args(sub)).view_as(x)
+    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, out_shape=x.shape, **Fn.drop_args(sub))
 
 
 def _cross_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Tensor, mem: Tensor, mask: Optional[Tensor]) -> Tensor:
     """x + MHA(LN(x), mem, mem, mask) -- only the query stream is normalised (modules.py:44)."""
     xn, xr = sub.norm.with_residual(x)
     ctx = attn.context(xn, mem, mem, mask)
-    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, **Fn.drop_args(sub)).view_as(x)
+    return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, out_shape=x.shape, **Fn.drop_args(sub))
 
 
 def _feed_forward(sub: SublayerConnection, ff: PositionwiseFeedForward, x: Tensor) -> Tensor:
@@ -153,7 +153,7 @@ class VidEncoderLayer4(nn.Module):
         else:       # dropped probabilities do not sum to one: P'(Y W^T + b) = (P'Y) W^T + rowsum(P') b
             ctx = Fn.head_unfold(py.view(B * Lq, h * d), attn.linears[2].weight, None, h)
             ctx = Fn.scaled_bias(ctx, rowsum, attn.linears[2].bias, h)
-        return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, **Fn.drop_args(sub)).view(B, Lq, d)
+        return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, out_shape=(B, Lq, d), **Fn.drop_args(sub))
 
     def value_projection(self, vft: Tensor):
         """V of A1 and A4 in one GEMM over the video tensor: returns (v_t2s, v_s2t) column views."""

@@ -150,8 +150,8 @@ class PositionwiseFeedForward(nn.Module):
         if self.training and self.dropout.p > 0:          # dropout(relu(w_1 x)), modules.py:113
             inner = {"drop_p": float(self.dropout.p), "drop_seed": Fn.next_seed()}
         hdn = Fn.linear(x, self.w_1.weight, self.w_1.bias, act=Fn.ACT_RELU, **inner)
-        out = Fn.linear(hdn, self.w_2.weight, self.w_2.bias, residual=residual, **(out_drop or {}))
-        return out.view(*x.shape[:-1], -1)
+        return Fn.linear(hdn, self.w_2.weight, self.w_2.bias, residual=residual, out_shape=(*x.shape[:-1], self.w_2.weight.shape[0]),
+                         **(out_drop or {}))
 
 
 class Embeddings(nn.Module):

@@ -263,7 +263,10 @@ int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t dtype, voi
  * two gradients of x are never summed by a separate pass.                                          */
 int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
                        int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
-                       int32_t dtype, void* stream);
+                       void* dz, const BistDrop* dz_drop, int32_t dtype, void* stream);
+/* dz (nullable, [rows, d] contiguous) additionally receives dropout-mask(dz_drop) * dx with mask index row*d + col:
+ * when x is the output of a GEMM with a dropout epilogue (x = drop(z) + res, modules.py:44), this is exactly the
+ * gradient of z, and the GEMM's backward needs no separate masking pass.                                        */
 /* da = db = NULL in bist_layernorm_bwd computes dx only (1 KiB rows: d = 512 bf16 / 256 f32); the gain / offset
  * gradients of all such LayerNorms of a backward pass are then summed by ONE batched launch per 40 jobs:
  *   da[c] += sum_r dy[r,c] (x[r,c] - mean_r) / (std_r + eps),   db[c] += sum_r dy[r,c]                      */

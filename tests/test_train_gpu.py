@@ -141,7 +141,7 @@ def test_layernorm_parameter_gradients_batched(env, dtype):
             dx = torch.empty_like(x)
             da, db = torch.full((d,), 0.25, device="cuda"), torch.full((d,), -0.5, device="cuda")
             check(lib.bist_layernorm_bwd(dy.data_ptr(), x.data_ptr(), a.data_ptr(), dx.data_ptr(), None, None, x.shape[0], d, d, d, d,
-                                         1e-6, None, 0, ops.dtype_code(dtype), torch.cuda.current_stream().cuda_stream), "ln bwd dx")
+                                         1e-6, None, 0, None, None, ops.dtype_code(dtype), torch.cuda.current_stream().cuda_stream), "ln bwd dx")
             ops.LNGRAD_QUEUE.append((dy, x, a, da, db, 1e-6))
             outs.append((dx, da, db))
         ops.lngrad_flush()
@@ -151,6 +151,37 @@ def test_layernorm_parameter_gradients_batched(env, dtype):
         _close(dx, rx, "ln dx-only", tol)
         _close(da, 0.25 + ra, "ln dgain batched", tol)
         _close(db, -0.5 + rb, "ln doffset batched", tol)
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.float32, 256), (torch.bfloat16, 512), (torch.float32, 64)])
+def test_dropout_gradient_masked_by_the_layernorm_backward(env, dtype, d):
+    """y = drop(x W^T + b) + r feeding a LayerNorm: the LayerNorm backward kernel also emits mask * dy, so the GEMM's
+    backward runs no masking pass -- gradients identical to the separate-pass path (same arithmetic on the same bits)."""
+    ag, Fn, ops = env
+    rows = 77
+    x, w, b, r = (_rand(rows, d, seed=600).to(dtype), _rand(d, d, seed=601, scale=d ** -0.5).to(dtype), _rand(d, seed=602).to(dtype),
+                  _rand(rows, d, seed=603).to(dtype))
+    a2, b2, w2 = (1 + 0.1 * _rand(d, seed=604)).to(dtype), (0.1 * _rand(d, seed=605)).to(dtype), _rand(d, d, seed=606, scale=d ** -0.5).to(dtype)
+    go = _rand(rows, d, seed=607).to(dtype).cuda()
+
+    def run(fused):
+        ts = [t.cuda().requires_grad_(True) for t in (x, w, b, r, a2, b2, w2)]
+        xd, wd, bd, rd, ad, b2d, w2d = ts
+        y = Fn.linear(xd, wd, bd, residual=rd, drop_p=0.3, drop_seed=777, out_shape=(rows, d))
+        assert getattr(y, "_bist_drop", None) == (0.3, 777, d)
+        if not fused:
+            del y._bist_drop
+        yn, yr = Fn.layernorm_res(y, ad, b2d)
+        out = Fn.linear(yn, w2d, None, residual=yr)
+        out.backward(go)
+        return [t.grad.clone() for t in ts]
+    g_fused = run(True)
+    g_plain = run(False)
+    for gf, gp, name in zip(g_fused, g_plain, "x w b r a2 b2 w2".split()):
+        if name in ("b", "a2", "b2"):          # fp32 atomics: the summation order differs from run to run
+            _close(gf, gp.double().cpu(), name, 1e-5 if dtype == torch.float32 else 1e-2)
+        else:
+            assert torch.equal(gf, gp), name
 
 
 def test_bias_gradients_batched(env):
