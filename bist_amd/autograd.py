@@ -72,7 +72,7 @@ class LinearFn(Function):
     """y = drop(act(alpha * x.W^T + bias)) + residual[row map]   (GEMM epilogue, include/bist_hip.h)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, act, res_map, alpha, drop_p, drop_seed, out_dtype):
+    def forward(ctx, x, w, bias, residual, act, res_map, alpha, drop_p, drop_seed, out_dtype, out_shape=None):
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         y = ops.linear(x2, w, bias, act=act, residual=residual, res_map=res_map, alpha=alpha, out_dtype=out_dtype,
@@ -84,7 +84,9 @@ class LinearFn(Function):
         # GEMM straight into the flat gradient buffer, bias gradients into the fp32 accumulator
         ctx.w_dst = getattr(w, "_grad_view", None)
         ctx.b_dst = getattr(bias, "_acc32", None) if bias is not None else None
-        return y
+        # the caller's shape is produced HERE (not by a view afterwards): a view node between this Function and its consumer
+        # would re-wrap the gradient tensor and drop the consumer's _bist_dz hand-off (see backward)
+        return y if out_shape is None else y.view(out_shape)
 
     @staticmethod
     def backward(ctx, dy):
@@ -124,7 +126,7 @@ class LinearFn(Function):
                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
         if dx is not None:
             dx = dx.view(x_shape)
-        return dx, dw, db, dres, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
 def _linear_grads(x2, w, dz, alpha, w_dst, b_dst, bias_dtype, need_dx, need_dw, need_db):
@@ -208,9 +210,8 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, res_map=(0, 0), alph
         residual = out
     if residual is not None and residual.dim() != 2:
         residual = residual.reshape(-1, residual.shape[-1])
-    y = LinearFn.apply(x, w, bias, residual, act, tuple(res_map), alpha, drop_p, drop_seed, out_dtype)
-    if out_shape is not None:
-        y = y.view(out_shape)
+    y = LinearFn.apply(x, w, bias, residual, act, tuple(res_map), alpha, drop_p, drop_seed, out_dtype,
+                       tuple(out_shape) if out_shape is not None else None)
     if drop_p > 0 and act == ACT_NONE and res_map == (0, 0):
         # y = drop(z) + res: a LayerNorm that consumes y can hand the masked gradient of z back (see _ln_backward)
         y._bist_drop = (float(drop_p), int(drop_seed), w.shape[0])

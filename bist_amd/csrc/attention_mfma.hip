@@ -700,157 +700,6 @@ __global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
   }   // chunks
 }
 
-// =====================================================================================================
-// Small multi-head attention FORWARD on the matrix cores (bf16, dk a multiple of 64, Lq <= 32, Lk <= 64): one wave per
-// (sequence n, head), the same tile geometry as the backward kernel above.
-//   S = Q K^T over the 64-column chunks -> softmax (mask fill -1e9, probabilities to p_attn before dropout) ->
-//   O_chunk = P' V_chunk with P' = dropout(P)
-// =====================================================================================================
-struct MhaFwdArgs {
-  const bf16_t *Q, *K, *V; const unsigned char* mask; bf16_t* O; float* P;
-  int Lq, Lk, h, nc;
-  long ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs;
-  float scale;
-  DropArg drop;
-};
-
-__global__ __launch_bounds__(64) void mha_fwd_mfma_kernel(const MhaFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t qimg[32 * 64], kimg[64 * 64], vimg[64 * 64], pimg[32 * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char mimg[32 * 64];
-  const int hh = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
-  const int x = lane & 15, lg = lane >> 4;
-  const int Lq = a.Lq, Lk = a.Lk, nc = a.nc;
-  const long hoff = (long)hh * nc * 64;
-  const bf16_t* Qh = a.Q + n * a.q_bs + hoff;
-  const bf16_t* Kh = a.K + n * a.k_bs + hoff;
-  const bf16_t* Vh = a.V + n * a.v_bs + hoff;
-  const int c = (lane & 7) * 8, rb = lane >> 3;
-  // stage Q, K chunk (and, first time, the mask bytes): all loads before the first LDS store
-  auto stage_qk = [&](int cc, bool with_mask) {
-    uint4 rq[4], rk[8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) rq[t] = *reinterpret_cast<const uint4*>(Qh + cc * 64 + (long)min(rb + 8 * t, Lq - 1) * a.ldq + c);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) rk[t] = *reinterpret_cast<const uint4*>(Kh + cc * 64 + (long)min(rb + 8 * t, Lk - 1) * a.ldk + c);
-    unsigned mlo[4], mhi[4];
-    if (a.mask && with_mask) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const unsigned char* mrow = a.mask + n * a.mask_bs + (long)min(rb + 8 * t, Lq - 1) * a.mask_qs;
-        unsigned by[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) by[e] = (c + e < Lk) ? (unsigned)mrow[c + e] : 1u;
-        mlo[t] = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);
-        mhi[t] = by[4] | (by[5] << 8) | (by[6] << 16) | (by[7] << 24);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int r = rb + 8 * t;
-      *reinterpret_cast<uint4*>(qimg + r * 64 + c) = keep4(rq[t], r < Lq);
-      if (a.mask && with_mask) *reinterpret_cast<uint2*>(mimg + r * 64 + c) = make_uint2(mlo[t], mhi[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int r = rb + 8 * t;
-      *reinterpret_cast<uint4*>(kimg + r * 64 + c) = keep4(rk[t], r < Lk);
-    }
-  };
-  f32x4 S[2][4];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) S[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int cc = 0; cc < nc; ++cc) {
-    stage_qk(cc, cc == 0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 aq[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) aq[mi] = frag_rows(qimg, 64, mi * 16, ks * 32, lane);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const uint4 bk = frag_rows(kimg, 64, ni * 16, ks * 32, lane);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) S[mi][ni] = mfma_bf16(aq[mi], bk, S[mi][ni]);
-      }
-    }
-  }
-  // softmax in the accumulator layout: row i = mi*16 + lg*4 + r, col j = ni*16 + x
-  const unsigned long long dkey = a.drop.p > 0.f ? a.drop.key() : 0ULL;
-  const float dks = a.drop.p > 0.f ? a.drop.keep_scale() : 1.f;
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = mi * 16 + lg * 4 + r;
-      const bool row_ok = i < Lq;
-      const unsigned char* mrow = (a.mask && row_ok) ? mimg + i * 64 : nullptr;
-      float sv[4];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int j = ni * 16 + x;
-        float sc = S[mi][ni][r] * a.scale;
-        if (mrow && j < Lk && mrow[j] == 0) sc = MASK_FILL;
-        if (j >= Lk) sc = -INFINITY;
-        sv[ni] = sc;
-        mx = fmaxf(mx, sc);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
-      float den = 0.f;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) { sv[ni] = (ni * 16 + x < Lk) ? expf(sv[ni] - mx) : 0.f; den += sv[ni]; }
-      den += __shfl_xor(den, 1, 64); den += __shfl_xor(den, 2, 64); den += __shfl_xor(den, 4, 64); den += __shfl_xor(den, 8, 64);
-      const float inv = 1.f / den;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int j = ni * 16 + x;
-        float pv = row_ok ? sv[ni] * inv : 0.f;
-        if (a.P && row_ok && j < Lk) a.P[(((long)n * a.h + hh) * Lq + i) * Lk + j] = pv;        // before dropout
-        if (a.drop.p > 0.f && row_ok && j < Lk) pv *= drop_mul(dkey, (((unsigned long long)n * a.h + hh) * Lq + i) * Lk + j, a.drop.p, dks);
-        pimg[i * 64 + j] = (bf16_t)pv;
-      }
-    }
-  // O_chunk = P' V_chunk   (M = i, N = c, K = j); qimg is dead and stages the output rows
-  bf16_t* Oh = a.O + n * a.o_bs + hoff;
-  for (int cc = 0; cc < nc; ++cc) {
-    {
-      uint4 rv[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) rv[t] = *reinterpret_cast<const uint4*>(Vh + cc * 64 + (long)min(rb + 8 * t, Lk - 1) * a.ldv + c);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) *reinterpret_cast<uint4*>(vimg + (rb + 8 * t) * 64 + c) = keep4(rv[t], rb + 8 * t < Lk);
-    }
-    f32x4 o[2][4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) o[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 ap[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) ap[mi] = frag_rows(pimg, 64, mi * 16, ks * 32, lane);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const uint4 bv = frag_cols(vimg, 64, ni * 16, ks * 32, lane);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) o[mi][ni] = mfma_bf16(ap[mi], bv, o[mi][ni]);
-      }
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) qimg[(mi * 16 + lg * 4 + r) * 64 + ni * 16 + x] = (bf16_t)o[mi][ni][r];
-    for (int r = lane >> 3; r < Lq; r += 8)
-      *reinterpret_cast<uint4*>(Oh + cc * 64 + (long)r * a.ldo + c) = *reinterpret_cast<const uint4*>(qimg + r * 64 + c);
-  }
-}
-
 }  // namespace
 
 // returns 1 if launched, 0 if outside the envelope, -1 on launch error
@@ -920,16 +769,3 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
 #undef GO
 }
 
-// returns 1 if launched, 0 if outside the envelope, -1 on launch error
-int bist_mha_fwd_mfma(const void* Q, const void* K, const void* V, const unsigned char* mask, void* O, float* P, int N, int Lq, int Lk,
-                      int h, int dk, long ldq, long ldk, long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs, long mask_bs,
-                      long mask_qs, float scale, const DropArg& drop, hipStream_t st) {
-  if (dk % 64 != 0 || dk > 512 || Lq > 32 || Lk > 64) return 0;
-  auto al8 = [](long v) { return (v % 8) == 0; };
-  if (!(al8(ldq) && al8(ldk) && al8(ldv) && al8(ldo) && al8(q_bs) && al8(k_bs) && al8(v_bs) && al8(o_bs))) return 0;
-  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) % 16) return 0;
-  MhaFwdArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, mask, (bf16_t*)O, P, Lq, Lk, h, dk / 64,
-               ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, drop};
-  hipLaunchKernelGGL(mha_fwd_mfma_kernel, dim3((unsigned)h, (unsigned)N), dim3(64), 0, st, a);
-  return hipGetLastError() == hipSuccess ? 1 : -1;
-}

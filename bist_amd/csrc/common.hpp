@@ -41,9 +41,6 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
 int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, void* PY, const void* dPY, void* dq2f, void* dY,
                   float* rowsum, const float* d_rowsum, int B, int G, int Lq, int h, int d, int bwd, const DropArg& drop, hipStream_t st);
 
-int bist_mha_fwd_mfma(const void* Q, const void* K, const void* V, const unsigned char* mask, void* O, float* P, int N, int Lq, int Lk,
-                      int h, int dk, long ldq, long ldk, long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs, long mask_bs,
-                      long mask_qs, float scale, const DropArg& drop, hipStream_t st);
 int bist_mha_bwd_mfma(const void* Q, const void* K, const void* V, const unsigned char* mask, const void* dO, const float* dPext,
                       void* dQ, void* dK, void* dV, int N, int Lq, int Lk, int h, int dk, long ldq, long ldk, long ldv, long ldo,
                       long q_bs, long k_bs, long v_bs, long o_bs, long lddq, long lddk, long lddv, long dq_bs, long dk_bs, long dv_bs,

@@ -167,7 +167,7 @@ def test_dropout_gradient_masked_by_the_layernorm_backward(env, dtype, d):
     def run(fused):
         ts = [t.cuda().requires_grad_(True) for t in (x, w, b, r, a2, b2, w2)]
         xd, wd, bd, rd, ad, b2d, w2d = ts
-        y = Fn.linear(xd, wd, bd, residual=rd, drop_p=0.3, drop_seed=777, out_shape=(rows, d))
+        y = Fn.linear(xd, wd, bd, residual=rd, drop_p=0.3, drop_seed=777, out_shape=(7, rows // 7, d))
         assert getattr(y, "_bist_drop", None) == (0.3, 777, d)
         if not fused:
             del y._bist_drop
@@ -175,8 +175,16 @@ def test_dropout_gradient_masked_by_the_layernorm_backward(env, dtype, d):
         out = Fn.linear(yn, w2d, None, residual=yr)
         out.backward(go)
         return [t.grad.clone() for t in ts]
-    g_fused = run(True)
-    g_plain = run(False)
+    calls = []
+    real = ag.lib.bist_epilogue_bwd
+    ag.lib.bist_epilogue_bwd = lambda *a: (calls.append(1), real(*a))[1]
+    try:
+        g_fused = run(True)
+        assert not calls, "the masked gradient must come from the LayerNorm backward, not from a separate pass"
+        g_plain = run(False)
+        assert len(calls) == 1
+    finally:
+        ag.lib.bist_epilogue_bwd = real
     for gf, gp, name in zip(g_fused, g_plain, "x w b r a2 b2 w2".split()):
         if name in ("b", "a2", "b2"):          # fp32 atomics: the summation order differs from run to run
             _close(gf, gp.double().cpu(), name, 1e-5 if dtype == torch.float32 else 1e-2)
