@@ -506,198 +506,188 @@ struct MhaBwdArgs {
   int nc;          // 64-column chunks per head (dk = 64 nc): the wave walks them, S and dP accumulate across chunks
 };
 
-__global__ __launch_bounds__(64) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
+// Four waves per (sequence, head): the one-wave version of this kernel was instruction-bound (~7 k instructions, 20 us).
+//   staging: 256 threads, one or two 16-byte rows pieces each;
+//   S / dP:  wave w owns the 16 keys [16w, 16w+16)  -> f32 [32][64] images in LDS;
+//   softmax and its backward: wave w owns 8 query rows, 8 lanes per row, 8 columns per lane (16-byte LDS traffic);
+//   dQ: wave w owns 16 of the chunk's 64 columns;  dK, dV: wave w owns 16 keys;
+//   outputs go back through the (dead) operand images and leave as 16-byte rows.
+__global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const MhaBwdArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t qimg[32 * 64], kimg[64 * 64], vimg[64 * 64], gimg[32 * 64], pimg[32 * 64], simg[32 * 64];
+  __shared__ __attribute__((aligned(16))) float sbuf[32 * 64], dbuf[32 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char mimg[32 * 64];      // mask bytes of this (n): 0 = masked
-  const int hh = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  const int hh = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int x = lane & 15, lg = lane >> 4;
-  const int Lq = a.Lq, Lk = a.Lk;
-  const int nc = a.nc;
+  const int Lq = a.Lq, Lk = a.Lk, nc = a.nc;
   const long hoff = (long)hh * nc * 64;
   const bf16_t* Qh = a.Q + n * a.q_bs + hoff;
   const bf16_t* Kh = a.K + n * a.k_bs + hoff;
   const bf16_t* Vh = a.V + n * a.v_bs + hoff;
   const bf16_t* Gh = a.dO ? a.dO + n * a.o_bs + hoff : nullptr;
-  auto stage = [&](int cc, bool with_mask) {
-    const bf16_t* Qn = Qh + cc * 64;
-    const bf16_t* Kn = Kh + cc * 64;
-    const bf16_t* Vn = Vh + cc * 64;
-    const bf16_t* Gn = Gh ? Gh + cc * 64 : nullptr;
-    // all 24 tile loads (and the mask bytes) are issued before the first LDS store: one memory latency, not 12
-    const int c = (lane & 7) * 8, rb = lane >> 3;
-    uint4 rq[4], rg[4], rk[8], rv[8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int r = rb + 8 * t;
-      // unconditional loads from a clamped row, zeroed afterwards: a conditional load becomes a pointer select
-      // against a zero in scratch memory and serialises on flat loads
-      const int rc = min(r, Lq - 1);
-      rq[t] = *reinterpret_cast<const uint4*>(Qn + (long)rc * a.ldq + c);
-      rg[t] = *reinterpret_cast<const uint4*>((Gn ? Gn : Qn) + (long)rc * (Gn ? a.ldo : a.ldq) + c);      // no dO: any valid address, zeroed below
+  const int sr = tid >> 3, sc = (tid & 7) * 8;          // staging: row sr (and sr + 32), columns sc .. sc+7
+  auto stage = [&](int cc, bool with_mask, bool with_v) {
+    // unconditional loads from clamped rows, zeroed afterwards (a conditional load would become a scratch pointer select)
+    const int rq = min(sr, Lq - 1), rk0 = min(sr, Lk - 1), rk1 = min(sr + 32, Lk - 1);
+    const uint4 q = *reinterpret_cast<const uint4*>(Qh + cc * 64 + (long)rq * a.ldq + sc);
+    const uint4 g = *reinterpret_cast<const uint4*>((Gh ? Gh + cc * 64 : Qh) + (long)rq * (Gh ? a.ldo : a.ldq) + sc);
+    const uint4 k0 = *reinterpret_cast<const uint4*>(Kh + cc * 64 + (long)rk0 * a.ldk + sc);
+    const uint4 k1 = *reinterpret_cast<const uint4*>(Kh + cc * 64 + (long)rk1 * a.ldk + sc);
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+    if (with_v) {
+      v0 = *reinterpret_cast<const uint4*>(Vh + cc * 64 + (long)rk0 * a.ldv + sc);
+      v1 = *reinterpret_cast<const uint4*>(Vh + cc * 64 + (long)rk1 * a.ldv + sc);
     }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int r = rb + 8 * t;
-      const int rc = min(r, Lk - 1);
-      rk[t] = *reinterpret_cast<const uint4*>(Kn + (long)rc * a.ldk + c);
-      rv[t] = *reinterpret_cast<const uint4*>(Vn + (long)rc * a.ldv + c);
-    }
-    unsigned mlo[4], mhi[4];                 // 8 mask bytes per row piece, packed (a byte array would live in scratch)
+    unsigned mlo = 0x01010101u, mhi = 0x01010101u;
     if (a.mask && with_mask) {
+      const unsigned char* mrow = a.mask + n * a.mask_bs + (long)rq * a.mask_qs;
+      unsigned by[8];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = rb + 8 * t;
-        const unsigned char* mrow = a.mask + n * a.mask_bs + (long)min(r, Lq - 1) * a.mask_qs;
-        unsigned by[8];
+      for (int e = 0; e < 8; ++e) by[e] = (sc + e < Lk) ? (unsigned)mrow[sc + e] : 1u;
+      mlo = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);
+      mhi = by[4] | (by[5] << 8) | (by[6] << 16) | (by[7] << 24);
+    }
+    *reinterpret_cast<uint4*>(qimg + sr * 64 + sc) = keep4(q, sr < Lq);
+    *reinterpret_cast<uint4*>(gimg + sr * 64 + sc) = keep4(g, sr < Lq && Gh != nullptr);
+    *reinterpret_cast<uint4*>(kimg + sr * 64 + sc) = keep4(k0, sr < Lk);
+    *reinterpret_cast<uint4*>(kimg + (sr + 32) * 64 + sc) = keep4(k1, sr + 32 < Lk);
+    if (with_v) {
+      *reinterpret_cast<uint4*>(vimg + sr * 64 + sc) = keep4(v0, sr < Lk);
+      *reinterpret_cast<uint4*>(vimg + (sr + 32) * 64 + sc) = keep4(v1, sr + 32 < Lk);
+    }
+    if (with_mask) *reinterpret_cast<uint2*>(mimg + sr * 64 + sc) = make_uint2(mlo, mhi);
+  };
+  // ---- S = Q K^T and dP = dO V^T for this wave's 16 keys, summed over the head's 64-column chunks ----
+  f32x4 S[2], D[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) by[e] = (c + e < Lk) ? (unsigned)mrow[c + e] : 1u;
-        mlo[t] = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);
-        mhi[t] = by[4] | (by[5] << 8) | (by[6] << 16) | (by[7] << 24);
+  for (int mi = 0; mi < 2; ++mi) { S[mi] = f32x4{0.f, 0.f, 0.f, 0.f}; D[mi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int cc = 0; cc < nc; ++cc) {
+    if (cc) __syncthreads();                              // the previous chunk's fragment reads are done
+    stage(cc, cc == 0, true);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 bk = frag_rows(kimg, 64, w * 16, ks * 32, lane), bv = frag_rows(vimg, 64, w * 16, ks * 32, lane);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        S[mi] = mfma_bf16(frag_rows(qimg, 64, mi * 16, ks * 32, lane), bk, S[mi]);
+        D[mi] = mfma_bf16(frag_rows(gimg, 64, mi * 16, ks * 32, lane), bv, D[mi]);
       }
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int r = rb + 8 * t;
-      *reinterpret_cast<uint4*>(qimg + r * 64 + c) = keep4(rq[t], r < Lq);
-      *reinterpret_cast<uint4*>(gimg + r * 64 + c) = keep4(rg[t], r < Lq && Gn != nullptr);
-      if (a.mask && with_mask) *reinterpret_cast<uint2*>(mimg + r * 64 + c) = make_uint2(mlo[t], mhi[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int r = rb + 8 * t;
-      *reinterpret_cast<uint4*>(kimg + r * 64 + c) = keep4(rk[t], r < Lk);
-      *reinterpret_cast<uint4*>(vimg + r * 64 + c) = keep4(rv[t], r < Lk);
-    }
-  };
-  const uint4 z4 = make_uint4(0, 0, 0, 0);
-  (void)z4;
-  // S = Q K^T and dP = dO V^T   (rows i, cols j), summed over the head's 64-column chunks
-  f32x4 S[2][4], D[2][4];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) { S[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; D[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int cc = 0; cc < nc; ++cc) {
-  stage(cc, cc == 0);
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    uint4 aq[2], ag[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) { aq[mi] = frag_rows(qimg, 64, mi * 16, ks * 32, lane); ag[mi] = frag_rows(gimg, 64, mi * 16, ks * 32, lane); }
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const uint4 bk = frag_rows(kimg, 64, ni * 16, ks * 32, lane), bv = frag_rows(vimg, 64, ni * 16, ks * 32, lane);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) { S[mi][ni] = mfma_bf16(aq[mi], bk, S[mi][ni]); D[mi][ni] = mfma_bf16(ag[mi], bv, D[mi][ni]); }
-    }
   }
-  }   // chunks
-  // softmax and its backward in the accumulator layout: row i = mi*16 + lg*4 + r, col j = ni*16 + x
-  const unsigned long long dkey = a.drop.p > 0.f ? a.drop.key() : 0ULL;
-  const float dks = a.drop.p > 0.f ? a.drop.keep_scale() : 1.f;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = mi * 16 + lg * 4 + r;
-      const bool row_ok = i < Lq;
-      const unsigned char* mrow = (a.mask && row_ok) ? mimg + i * 64 : nullptr;
-      float sv[4], dv[4], dm[4];
-      bool msk[4];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int j = ni * 16 + x;
-        msk[ni] = mrow && j < Lk && mrow[j] == 0;
-        float sc = S[mi][ni][r] * a.scale;
-        if (msk[ni]) sc = MASK_FILL;
-        if (j >= Lk) sc = -INFINITY;
-        sv[ni] = sc;
-        dv[ni] = D[mi][ni][r];
-        dm[ni] = 1.f;
-        if (a.drop.p > 0.f && row_ok && j < Lk) {           // dP = mask/(1-p) * dP'   (modules.py:62-63)
-          dm[ni] = drop_mul(dkey, (((unsigned long long)n * a.h + hh) * Lq + i) * Lk + j, a.drop.p, dks);
-          dv[ni] *= dm[ni];
-        }
-        if (a.dPext && row_ok && j < Lk) dv[ni] += a.dPext[(((long)n * a.h + hh) * Lq + i) * Lk + j];
-        mx = fmaxf(mx, sc);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
-      float den = 0.f;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) { sv[ni] = (ni * 16 + x < Lk) ? expf(sv[ni] - mx) : 0.f; den += sv[ni]; }
-      den += __shfl_xor(den, 1, 64); den += __shfl_xor(den, 2, 64); den += __shfl_xor(den, 4, 64); den += __shfl_xor(den, 8, 64);
-      const float inv = 1.f / den;
-      float dot = 0.f;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) { sv[ni] *= inv; dot += sv[ni] * dv[ni]; }
-      dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int j = ni * 16 + x;
-        float ds = sv[ni] * (dv[ni] - dot) * a.scale;
-        if (msk[ni] || !row_ok || j >= Lk) ds = 0.f;
-        pimg[i * 64 + j] = (bf16_t)(row_ok ? sv[ni] * dm[ni] : 0.f);        // P' = mask * P / (1-p) feeds dV
-        simg[i * 64 + j] = (bf16_t)ds;
-      }
+      const int i = mi * 16 + lg * 4 + r, j = w * 16 + x;
+      sbuf[i * 64 + j] = S[mi][r];
+      dbuf[i * 64 + j] = D[mi][r];
     }
-  // dQ = dS K  (M = i, N = c, K = j);  dK = dS^T Q, dV = P^T dO  (M = j, N = c, K = i), chunk by chunk of the head columns
-  for (int cc = 0; cc < nc; ++cc) {
-  if (nc > 1) stage(cc, false);          // one chunk: the tiles of phase 1 are still in place
-  f32x4 dq[2][4], dkk[4][4], dvv[4][4];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      if (mi < 2) dq[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dkk[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; dvv[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    uint4 as[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) as[mi] = frag_rows(simg, 64, mi * 16, ks * 32, lane);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const uint4 bk = frag_cols(kimg, 64, ni * 16, ks * 32, lane);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) dq[mi][ni] = mfma_bf16(as[mi], bk, dq[mi][ni]);
-    }
-  }
+  __syncthreads();
+  // ---- softmax and its backward: wave w owns rows 8w .. 8w+7, eight lanes per row, eight columns per lane ----
   {
-    uint4 bq[4], bg[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) { bq[ni] = frag_cols(qimg, 64, ni * 16, 0, lane); bg[ni] = frag_cols(gimg, 64, ni * 16, 0, lane); }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const uint4 as = frag_cols(simg, 64, mi * 16, 0, lane), ap = frag_cols(pimg, 64, mi * 16, 0, lane);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) { dkk[mi][ni] = mfma_bf16(as, bq[ni], dkk[mi][ni]); dvv[mi][ni] = mfma_bf16(ap, bg[ni], dvv[mi][ni]); }
+    const int i = w * 8 + (lane >> 3), j0 = (lane & 7) * 8;
+    const bool row_ok = i < Lq;
+    const unsigned long long dkey = a.drop.p > 0.f ? a.drop.key() : 0ULL;
+    const float dks = a.drop.p > 0.f ? a.drop.keep_scale() : 1.f;
+    float sv[8], dv[8], dm[8];
+    bool msk[8];
+    {
+      const float4 s0 = *reinterpret_cast<const float4*>(sbuf + i * 64 + j0), s1 = *reinterpret_cast<const float4*>(sbuf + i * 64 + j0 + 4);
+      const float4 d0 = *reinterpret_cast<const float4*>(dbuf + i * 64 + j0), d1 = *reinterpret_cast<const float4*>(dbuf + i * 64 + j0 + 4);
+      sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
+      dv[0] = d0.x; dv[1] = d0.y; dv[2] = d0.z; dv[3] = d0.w; dv[4] = d1.x; dv[5] = d1.y; dv[6] = d1.z; dv[7] = d1.w;
     }
+    const uint2 mb = *reinterpret_cast<const uint2*>(mimg + i * 64 + j0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = j0 + e;
+      const unsigned byte = ((e < 4 ? mb.x : mb.y) >> (8 * (e & 3))) & 0xffu;
+      msk[e] = a.mask && row_ok && j < Lk && byte == 0;
+      float sc2 = sv[e] * a.scale;
+      if (msk[e]) sc2 = MASK_FILL;
+      if (j >= Lk) sc2 = -INFINITY;
+      sv[e] = sc2;
+      dm[e] = 1.f;
+      if (a.drop.p > 0.f && row_ok && j < Lk) {           // dP = mask/(1-p) * dP'   (modules.py:62-63)
+        dm[e] = drop_mul(dkey, (((unsigned long long)n * a.h + hh) * Lq + i) * Lk + j, a.drop.p, dks);
+        dv[e] *= dm[e];
+      }
+      mx = fmaxf(mx, sc2);
+    }
+    if (a.dPext && row_ok) {
+      const float* pe = a.dPext + (((long)n * a.h + hh) * Lq + i) * Lk;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv[e] += pe[min(j0 + e, Lk - 1)] * (j0 + e < Lk ? 1.f : 0.f);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sv[e] = (j0 + e < Lk) ? expf(sv[e] - mx) : 0.f; den += sv[e]; }
+    den += __shfl_xor(den, 1, 64); den += __shfl_xor(den, 2, 64); den += __shfl_xor(den, 4, 64);
+    const float inv = 1.f / den;
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sv[e] *= inv; dot += sv[e] * dv[e]; }
+    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
+    bf16_t pe8[8], se8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float ds = sv[e] * (dv[e] - dot) * a.scale;
+      if (msk[e] || !row_ok || j0 + e >= Lk) ds = 0.f;
+      pe8[e] = (bf16_t)(row_ok ? sv[e] * dm[e] : 0.f);        // P' = mask * P / (1-p) feeds dV
+      se8[e] = (bf16_t)ds;
+    }
+    *reinterpret_cast<uint4*>(pimg + i * 64 + j0) = *reinterpret_cast<const uint4*>(pe8);
+    *reinterpret_cast<uint4*>(simg + i * 64 + j0) = *reinterpret_cast<const uint4*>(se8);
   }
-  // stores through LDS (the staged tiles are dead): dQ -> qimg, dK -> kimg, dV -> vimg, then 16-byte rows
+  __syncthreads();
+  // ---- dQ = dS K (wave w: 16 of the chunk's columns); dK = dS^T Q, dV = P^T dO (wave w: 16 keys), chunk by chunk ----
+  for (int cc = 0; cc < nc; ++cc) {
+    if (nc > 1) { stage(cc, false, false); __syncthreads(); }          // one chunk: the tiles of the first phase are still in place
+    f32x4 dq[2], dkk[4], dvv[4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+    for (int t = 0; t < 4; ++t) { if (t < 2) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dkk[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dvv[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 bk = frag_cols(kimg, 64, w * 16, ks * 32, lane);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) dq[mi] = mfma_bf16(frag_rows(simg, 64, mi * 16, ks * 32, lane), bk, dq[mi]);
+    }
+    {
+      const uint4 as = frag_cols(simg, 64, w * 16, 0, lane), ap = frag_cols(pimg, 64, w * 16, 0, lane);
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        const int row = mi * 16 + lg * 4 + r, col = ni * 16 + x;
-        if (mi < 2) qimg[row * 64 + col] = (bf16_t)dq[mi][ni][r];
-        kimg[row * 64 + col] = (bf16_t)dkk[mi][ni][r];
-        vimg[row * 64 + col] = (bf16_t)dvv[mi][ni][r];
+        dkk[ni] = mfma_bf16(as, frag_cols(qimg, 64, ni * 16, 0, lane), dkk[ni]);
+        dvv[ni] = mfma_bf16(ap, frag_cols(gimg, 64, ni * 16, 0, lane), dvv[ni]);
       }
-  bf16_t* dQn = a.dQ + n * a.dq_bs + hoff + cc * 64;
-  bf16_t* dKn = a.dK + n * a.dk_bs + hoff + cc * 64;
-  bf16_t* dVn = a.dV + n * a.dv_bs + hoff + cc * 64;
-  for (int r = lane >> 3; r < Lq; r += 8)
-    *reinterpret_cast<uint4*>(dQn + (long)r * a.lddq + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(qimg + r * 64 + (lane & 7) * 8);
-  for (int r = lane >> 3; r < Lk; r += 8) {
-    *reinterpret_cast<uint4*>(dKn + (long)r * a.lddk + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(kimg + r * 64 + (lane & 7) * 8);
-    *reinterpret_cast<uint4*>(dVn + (long)r * a.lddv + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(vimg + r * 64 + (lane & 7) * 8);
+    }
+    __syncthreads();                                      // every wave is done reading the operand images
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) qimg[(mi * 16 + lg * 4 + r) * 64 + w * 16 + x] = (bf16_t)dq[mi][r];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        kimg[(w * 16 + lg * 4 + r) * 64 + ni * 16 + x] = (bf16_t)dkk[ni][r];
+        vimg[(w * 16 + lg * 4 + r) * 64 + ni * 16 + x] = (bf16_t)dvv[ni][r];
+      }
+    }
+    __syncthreads();
+    bf16_t* dQn = a.dQ + n * a.dq_bs + hoff + cc * 64;
+    bf16_t* dKn = a.dK + n * a.dk_bs + hoff + cc * 64;
+    bf16_t* dVn = a.dV + n * a.dv_bs + hoff + cc * 64;
+    if (sr < Lq) *reinterpret_cast<uint4*>(dQn + (long)sr * a.lddq + sc) = *reinterpret_cast<const uint4*>(qimg + sr * 64 + sc);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r = sr + 32 * t;
+      if (r < Lk) {
+        *reinterpret_cast<uint4*>(dKn + (long)r * a.lddk + sc) = *reinterpret_cast<const uint4*>(kimg + r * 64 + sc);
+        *reinterpret_cast<uint4*>(dVn + (long)r * a.lddv + sc) = *reinterpret_cast<const uint4*>(vimg + r * 64 + sc);
+      }
+    }
+    if (cc + 1 < nc) __syncthreads();                     // the output rows have left before the next chunk is staged
   }
-  }   // chunks
 }
 
 }  // namespace
@@ -714,7 +704,7 @@ int bist_mha_bwd_mfma(const void* Q, const void* K, const void* V, const unsigne
   if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV | (uintptr_t)dO) % 16) return 0;
   MhaBwdArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, mask, dPext, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV,
                Lq, Lk, h, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, drop, dk / 64};
-  hipLaunchKernelGGL(mha_bwd_mfma_kernel, dim3((unsigned)h, (unsigned)N), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(mha_bwd_mfma_kernel, dim3((unsigned)h, (unsigned)N), dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 

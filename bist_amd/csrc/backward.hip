@@ -62,12 +62,14 @@ constexpr int COLSUM_JOBS = 48;
 struct ColSumBatch {
   const void* x[COLSUM_JOBS]; float* out[COLSUM_JOBS];
   int M[COLSUM_JOBS], N[COLSUM_JOBS], ld[COLSUM_JOBS], rpb[COLSUM_JOBS], cb[COLSUM_JOBS];
+  unsigned char vec[COLSUM_JOBS];    // 16-byte loads: N, ld whole pieces and an aligned base
   int first[COLSUM_JOBS + 1];        // first block of every job; first[n] = total
   int n;
 };
 template <typename T>
 __global__ __launch_bounds__(256) void col_sum_multi_kernel(const ColSumBatch b) {
-  __shared__ float part[4][64];
+  constexpr int E = 16 / (int)sizeof(T);          // columns per thread on the vector path
+  __shared__ float part[4][64 * E];
   int j = 0;
   while (j + 1 < b.n && (int)blockIdx.x >= b.first[j + 1]) ++j;
   const int lb = (int)blockIdx.x - b.first[j];
@@ -75,8 +77,32 @@ __global__ __launch_bounds__(256) void col_sum_multi_kernel(const ColSumBatch b)
   const T* x = reinterpret_cast<const T*>(b.x[j]);
   const int M = b.M[j], N = b.N[j], ld = b.ld[j], rpb = b.rpb[j];
   const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int n = bx * 64 + c;
   const int m0 = by * rpb, m1 = min(M, m0 + rpb);
+  if (b.vec[j]) {
+    // 16 bytes per thread per row: a block covers 64*E columns x 4 row lanes (rows are whole 16-byte pieces here)
+    const int n0 = (bx * 64 + c) * E;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    if (n0 < N) {
+#pragma unroll 4
+      for (int m = m0 + rl; m < m1; m += 4) {
+        const uint4 q = *reinterpret_cast<const uint4*>(x + (long)m * ld + n0);
+        const T* qe = reinterpret_cast<const T*>(&q);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += to_f(qe[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) part[rl][c * E + e] = acc[e];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * E; idx += 256) {
+      const int n = bx * 64 * E + idx;
+      if (n < N) atomicAdd(b.out[j] + n, part[0][idx] + part[1][idx] + part[2][idx] + part[3][idx]);
+    }
+    return;
+  }
+  const int n = bx * 64 + c;
   float acc = 0.f;
   if (n < N)
     for (int m = m0 + rl; m < m1; m += 4) acc += to_f(x[(long)m * ld + n]);
@@ -418,9 +444,12 @@ extern "C" int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t
     for (int i = 0; i < b.n; ++i) {
       const BistColSum& q = jobs[base + i];
       BIST_REQUIRE(q.x && q.out && q.M > 0 && q.N > 0 && q.ldx >= q.N && q.M < (1L << 31) && q.ldx < (1L << 31), "bist_col_sum_multi: bad job %d", base + i);
-      const long cb = blocks_for(q.N, 64);
+      const long esz = dtype == BIST_BF16 ? 2 : 4, piece = 16 / esz;
+      const bool vec = (q.N % piece == 0) && (q.ldx % piece == 0) && ((uintptr_t)q.x % 16 == 0);
+      const long cb = vec ? blocks_for(q.N, 64 * piece) : blocks_for(q.N, 64);
       long rpb = (q.M * cb + 1023) / 1024;             // up to ~1024 workgroups per job, at least 16 rows each
       if (rpb < 16) rpb = 16;
+      b.vec[i] = vec ? 1 : 0;
       b.x[i] = q.x; b.out[i] = q.out; b.M[i] = (int)q.M; b.N[i] = q.N; b.ld[i] = (int)q.ldx; b.rpb[i] = (int)rpb; b.cb[i] = (int)cb;
       b.first[i] = total;
       total += (int)(cb * blocks_for(q.M, (int)rpb));
