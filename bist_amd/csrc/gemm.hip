@@ -1534,8 +1534,11 @@ extern "C" int bist_gemm_pair(const BistGemm* a, const BistGemm* b, void* stream
   if (!pa.atr && pa.btr && pb.atr && pb.btr) kind = PAIR_LIN;
   else if (!pa.atr && !pa.btr && pb.atr && pb.btr) kind = PAIR_FOLD;
   else if (!pa.atr && !pa.btr && !pb.atr && !pb.btr) kind = PAIR_FWD;
+  // ... and together fit one round of workgroups (144 KiB of LDS each: one per CU); beyond that two launches are faster
+  const long wgs = (long)((a->M + T64 - 1) / T64) * ((a->N + T64 - 1) / T64) * a->batch1 * a->batch2 +
+                   (long)((b->M + T64 - 1) / T64) * ((b->N + T64 - 1) / T64) * b->batch1 * b->batch2;
   const bool fused = !no_pair && kind >= 0 && a->in_dtype == b->in_dtype && !skinny_kind(a) && !skinny_kind(b) && pa.fast && pb.fast &&
-                     pa.t64 && pb.t64;
+                     pa.t64 && pb.t64 && wgs <= 256;
   if (!fused) {
     if (const int rc = bist_gemm(a, stream)) return rc;
     return bist_gemm(b, stream);
