@@ -32,6 +32,7 @@ constexpr int BM = 128, BN = 128;
 constexpr int ROW_BYTES = 128;                 // K extent of an "N" tile in bytes
 constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand per stage
 constexpr int NTHREADS = 256;
+constexpr int WS_HEADER = 1024;                // floats at the head of the workspace: split-K ticket counters (kept zero between calls)
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -203,7 +204,7 @@ __device__ __forceinline__ void epilogue(const GemmK& g, f32x4 (&acc)[4][4], int
   const int lr = lane & 15, lg = lane >> 4;
   const long zlin = z1 * (long)g.batch2 + z2;
   if (g.split_k > 1) {            // raw partial sums; the reduce kernel applies the epilogue
-    float* W = g.ws + ((zlin * g.split_k + sp) * (long)g.M) * g.N;
+    float* W = g.ws + WS_HEADER + ((zlin * g.split_k + sp) * (long)g.M) * g.N;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + lr;
@@ -263,7 +264,7 @@ __device__ __forceinline__ void stream_out(const GemmK& g, const char* lds_lo, c
   long ld_out;
   bool vec_out;
   if constexpr (SPLIT) {
-    out_base = g.ws + ((zlin * g.split_k + sp) * (long)g.M) * g.N;
+    out_base = g.ws + WS_HEADER + ((zlin * g.split_k + sp) * (long)g.M) * g.N;
     ld_out = g.N; vec_out = (g.N & 3) == 0;
   } else {
     out_base = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
@@ -810,22 +811,33 @@ template <typename T, typename TO, bool ATR, bool BTR>
 __device__ __forceinline__ void t64_ring_body(const GemmK& g, unsigned bid, unsigned nwg, char* ebuf, char* ring) {
   constexpr int D = RING_D;
   int z, sp, tm, tn;
-  tile_coords(g, z, sp, tm, tn, bid, nwg);
+  const int S = g.split_k;
+  if (S > 1) {
+    // the K slices of one tile are neighbouring workgroups of one XCD (the last one to finish reads the others' slabs)
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    unsigned lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    sp = lid % S; lid /= S;
+    tn = lid % g.tiles_n; lid /= g.tiles_n;
+    tm = lid % g.tiles_m; z = lid / g.tiles_m;
+  } else {
+    tile_coords(g, z, sp, tm, tn, bid, nwg);
+  }
   const int z1 = z / g.batch2, z2 = z % g.batch2;
   const int m0 = tm * T64, n0 = tn * T64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
-  const int nk = (g.K + BK - 1) / BK;
+  const int nk_all = (g.K + BK - 1) / BK;
   const int k_tail = g.K % BK;
+  const int kt_lo = (int)((long)nk_all * sp / S), nk = (int)((long)nk_all * (sp + 1) / S) - kt_lo;      // this slice's K tiles
 
   Stager64<T, ATR> sa;
   Stager64<T, BTR> sb;
-  sa.init(g.A + (z1 * g.a_bs1 + z2 * g.a_bs2) * (long)sizeof(T), g.a_rs, g.a_ks, m0, g.M, 0, w, lane);
-  sb.init(g.B + (z1 * g.b_bs1 + z2 * g.b_bs2) * (long)sizeof(T), g.b_rs, g.b_ks, n0, g.N, 0, w, lane);
+  sa.init(g.A + (z1 * g.a_bs1 + z2 * g.a_bs2) * (long)sizeof(T), g.a_rs, g.a_ks, m0, g.M, kt_lo * BK, w, lane);
+  sb.init(g.B + (z1 * g.b_bs1 + z2 * g.b_bs2) * (long)sizeof(T), g.b_rs, g.b_ks, n0, g.N, kt_lo * BK, w, lane);
   auto stage_in = [&](int kt) {
     char* st = ring + (kt & (D - 1)) * 2 * T64_BYTES;
-    if (k_tail != 0 && kt == nk - 1) { sa.issue_tail(st, w, k_tail); sb.issue_tail(st + T64_BYTES, w, k_tail); }
+    if (k_tail != 0 && kt_lo + kt == nk_all - 1) { sa.issue_tail(st, w, k_tail); sb.issue_tail(st + T64_BYTES, w, k_tail); }
     else { sa.issue(st, w); sb.issue(st + T64_BYTES, w); }
   };
   for (int kt = 0; kt < D - 2 && kt < nk; ++kt) stage_in(kt);      // tiles 0..5
@@ -911,6 +923,50 @@ __device__ __forceinline__ void t64_ring_body(const GemmK& g, unsigned bid, unsi
         }
   }
   __syncthreads();
+  if (S > 1) {
+    // In-launch split-K combine (cdna_hip_programming.md section 5, "Projection GEMM at M = 256", item 2): every slice writes
+    // its fp32 tile image to a slab, releases at agent scope and takes a ticket; the slice that draws the last ticket acquires,
+    // adds the other slabs to its own image and runs the epilogue.  The counter returns to zero for the next launch.
+    const long tile = ((long)z * g.tiles_m + tm) * g.tiles_n + tn;
+    int* cnt = reinterpret_cast<int*>(g.ws) + tile;
+    float* slabs = g.ws + WS_HEADER + tile * S * (T64 * T64);
+    float* img = reinterpret_cast<float*>(ebuf);
+    int* flag = reinterpret_cast<int*>(ebuf + 2 * T64_BYTES);
+    float4* mine = reinterpret_cast<float4*>(slabs + (long)sp * (T64 * T64));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mine[q * NTHREADS + tid] = reinterpret_cast<const float4*>(img)[q * NTHREADS + tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == S - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    float4 sum[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum[q] = reinterpret_cast<const float4*>(img)[q * NTHREADS + tid];
+    for (int s2 = 0; s2 < S; ++s2) {
+      if (s2 == sp) continue;
+      const float4* other = reinterpret_cast<const float4*>(slabs + (long)s2 * (T64 * T64));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 o = other[q * NTHREADS + tid];
+        sum[q].x += o.x; sum[q].y += o.y; sum[q].z += o.z; sum[q].w += o.w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(img)[q * NTHREADS + tid] = sum[q];
+    __syncthreads();
+  }
   stream_out<T, TO, false, 64>(g, ebuf, ebuf, z1, z2, 0, m0, n0, tid);
 }
 
@@ -1125,7 +1181,7 @@ __global__ void splitk_reduce_kernel(const GemmK g, long total) {
   const long zlin = idx / mn, r = idx % mn;
   const int m = (int)(r / g.N), n = (int)(r % g.N);
   const int z1 = (int)(zlin / g.batch2), z2 = (int)(zlin % g.batch2);
-  const float* W = g.ws + zlin * g.split_k * mn + r;
+  const float* W = g.ws + WS_HEADER + zlin * g.split_k * mn + r;
   float acc = 0.f;
   for (int s = 0; s < g.split_k; ++s) acc += W[(long)s * mn];
   TO* C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
@@ -1337,6 +1393,7 @@ int launch_skinny(const BistGemm* g, const GemmK& k, int kind, hipStream_t st) {
 
 // ---- host side ------------------------------------------------------------------------------------
 struct Plan { bool fast; bool atr, btr; int split; size_t ws_bytes; int stages; bool t64; };
+constexpr size_t WS_HEADER_BYTES = WS_HEADER * sizeof(float);
 
 Plan make_plan(const BistGemm* g) {
   Plan p{false, false, false, 1, 0, 2, false};
@@ -1359,12 +1416,28 @@ Plan make_plan(const BistGemm* g) {
   const long tiles = (long)((g->M + BM - 1) / BM) * ((g->N + BN - 1) / BN) * g->batch1 * g->batch2;
   const long nk = (g->K + bk - 1) / bk;
   static const int no_t64 = [] { const char* e = getenv("BIST_GEMM_NO_T64"); return e ? atoi(e) : 0; }();      // tuning aid
-  if (!no_t64 && tiles < 128 && nk <= 64) { p.t64 = true; return p; }      // cannot fill half the chip: 64x64 tiles, no split
+  if (!no_t64 && tiles < 128 && nk <= 64) {      // cannot fill half the chip: 64x64 tiles
+    p.t64 = true;
+    // long K on few tiles (the K = 1536 / 2048 products at M = 320: 40 tiles): cut K over up to 4 workgroups per tile, combined
+    // inside the launch by the last one to finish; slices of >= 4 K tiles, at most one round of workgroups
+    // Measured (round 1): NOT a win at these sizes -- K = 2048 alone 10.9 us either way, inside a pair launch 15.2 vs 12.2 us,
+    // training step 16.06 vs 15.61 ms -- the release/acquire episode and the serial slab read cost what the extra
+    // workgroups save.  Kept behind BIST_GEMM_T64_SPLIT=1 / hint BIST_GEMM_SPLIT64 (tests) for larger K.
+    static const int want_sk = [] { const char* e = getenv("BIST_GEMM_T64_SPLIT"); return e ? atoi(e) : 0; }();
+    const bool no_sk = !(want_sk || (g->hint & BIST_GEMM_SPLIT64));
+    const long t64s = (long)((g->M + 63) / 64) * ((g->N + 63) / 64) * g->batch1 * g->batch2;
+    long s = nk / 4;
+    if (s > 4) s = 4;
+    if (s * t64s > 256) s = 256 / t64s;
+    const size_t need = WS_HEADER_BYTES + (size_t)t64s * s * 64 * 64 * sizeof(float);
+    if (!no_sk && nk >= 12 && s >= 2 && t64s <= WS_HEADER && g->workspace && need <= (size_t)g->workspace_bytes) { p.split = (int)s; p.ws_bytes = need; }
+    return p;
+  }
   if (g->workspace && tiles < 192 && nk >= 16) {
     long s = (512 + tiles - 1) / tiles;
     if (s > nk / 4) s = nk / 4;
     if (s > 64) s = 64;
-    const size_t need = (size_t)s * g->M * g->N * sizeof(float) * g->batch1 * g->batch2;
+    const size_t need = WS_HEADER_BYTES + (size_t)s * g->M * g->N * sizeof(float) * g->batch1 * g->batch2;
     if (s > 1 && need <= (size_t)g->workspace_bytes) { p.split = (int)s; p.ws_bytes = need; }
   }
   // The 4-stage ring (128 KiB LDS, one workgroup per CU) measured SLOWER than the 2-stage kernel at two
@@ -1416,9 +1489,11 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
     static const int no_pre = [] { const char* e = getenv("BIST_GEMM_NO_PRE"); return e ? atoi(e) : 0; }();      // tuning aid
     const bool whole_cu = g64.x <= 256 && !no_pre;                        // one workgroup per CU: 128+ KiB of LDS is free
     const bool whole = g->K % bk64 == 0 && whole_cu;
+    const dim3 g64s((unsigned)(g64.x * p.split));                 // in-launch split-K: `split` neighbouring workgroups per tile
 #define GO64(ATR_, BTR_)                                                                                  \
   do {                                                                                                    \
-    if (whole && nk64 == 8) hipLaunchKernelGGL((gemm_t64_pre_kernel<T, TO, ATR_, BTR_, 8>), g64, block, 0, st, k);      \
+    if (p.split > 1) hipLaunchKernelGGL((gemm_t64_ring_kernel<T, TO, ATR_, BTR_>), g64s, block, 0, st, k);             \
+    else if (whole && nk64 == 8) hipLaunchKernelGGL((gemm_t64_pre_kernel<T, TO, ATR_, BTR_, 8>), g64, block, 0, st, k);      \
     else if (whole && nk64 == 5) hipLaunchKernelGGL((gemm_t64_pre_kernel<T, TO, ATR_, BTR_, 5>), g64, block, 0, st, k); \
     else if (whole_cu && nk64 > 8) hipLaunchKernelGGL((gemm_t64_ring_kernel<T, TO, ATR_, BTR_>), g64, block, 0, st, k); \
     else if (pair) hipLaunchKernelGGL((gemm_t64_kernel<T, TO, ATR_, BTR_, true>), g64, block, 0, st, k);       \
@@ -1509,9 +1584,9 @@ extern "C" int bist_gemm(const BistGemm* g, void* stream) {
 namespace {
 template <typename T, typename TO1, typename TO2>
 int launch_pair(const BistGemm* a, const BistGemm* b, GemmK& ka, GemmK& kb, int kind, hipStream_t st) {
-  ka.tiles_m = (a->M + T64 - 1) / T64; ka.tiles_n = (a->N + T64 - 1) / T64; ka.split_k = 1; ka.ws = nullptr;
+  ka.tiles_m = (a->M + T64 - 1) / T64; ka.tiles_n = (a->N + T64 - 1) / T64;        // ka.split_k / ka.ws: set by the caller
   kb.tiles_m = (b->M + T64 - 1) / T64; kb.tiles_n = (b->N + T64 - 1) / T64; kb.split_k = 1; kb.ws = nullptr;
-  const long n1 = (long)ka.tiles_m * ka.tiles_n * a->batch1 * a->batch2, n2 = (long)kb.tiles_m * kb.tiles_n * b->batch1 * b->batch2;
+  const long n1 = (long)ka.tiles_m * ka.tiles_n * a->batch1 * a->batch2 * ka.split_k, n2 = (long)kb.tiles_m * kb.tiles_n * b->batch1 * b->batch2;
   const dim3 grid((unsigned)(n1 + n2));
   if (kind == PAIR_LIN) hipLaunchKernelGGL((gemm_t64_pair_kernel<T, TO1, TO2, PAIR_LIN>), grid, dim3(NTHREADS), 0, st, ka, kb, (unsigned)n1);
   else if (kind == PAIR_FOLD) hipLaunchKernelGGL((gemm_t64_pair_kernel<T, TO1, TO2, PAIR_FOLD>), grid, dim3(NTHREADS), 0, st, ka, kb, (unsigned)n1);
@@ -1535,10 +1610,12 @@ extern "C" int bist_gemm_pair(const BistGemm* a, const BistGemm* b, void* stream
   else if (!pa.atr && !pa.btr && pb.atr && pb.btr) kind = PAIR_FOLD;
   else if (!pa.atr && !pa.btr && !pb.atr && !pb.btr) kind = PAIR_FWD;
   // ... and together fit one round of workgroups (144 KiB of LDS each: one per CU); beyond that two launches are faster
-  const long wgs = (long)((a->M + T64 - 1) / T64) * ((a->N + T64 - 1) / T64) * a->batch1 * a->batch2 +
+  // the first product may be cut along K (make_plan: long K on few tiles); its slices count as workgroups
+  const long wgs = (long)((a->M + T64 - 1) / T64) * ((a->N + T64 - 1) / T64) * a->batch1 * a->batch2 * pa.split +
                    (long)((b->M + T64 - 1) / T64) * ((b->N + T64 - 1) / T64) * b->batch1 * b->batch2;
+  ka.split_k = pa.split; ka.ws = pa.split > 1 ? (float*)a->workspace : nullptr;
   const bool fused = !no_pair && kind >= 0 && a->in_dtype == b->in_dtype && !skinny_kind(a) && !skinny_kind(b) && pa.fast && pb.fast &&
-                     pa.t64 && pb.t64 && wgs <= 256;
+                     pa.t64 && pb.t64 && pb.split == 1 && wgs <= 256;
   if (!fused) {
     if (const int rc = bist_gemm(a, stream)) return rc;
     return bist_gemm(b, stream);

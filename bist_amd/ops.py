@@ -89,7 +89,7 @@ def _workspace(device) -> Tensor:
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
-        ws = torch.empty(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)
+        ws = torch.zeros(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)      # zeroed: its head holds split-K ticket counters
         _WS[key] = ws
     return ws
 

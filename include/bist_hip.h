@@ -83,7 +83,9 @@ typedef struct BistGemm {
   const uint64_t* drop_ctr;
   /* Optional split-K scratch (caller-owned device memory, fp32 partial tiles).  When given and the
    * problem has few output tiles and a long K (weight gradients), K is cut over several workgroups
-   * and a second kernel sums the slabs; NULL / 0 disables split-K.                              */
+   * and a second kernel sums the slabs; NULL / 0 disables split-K.  The first 4 KiB hold ticket counters
+   * of the in-launch combine: the buffer must be ZERO when first handed over (the library returns the
+   * counters to zero after every call) and must not be shared by launches that may run concurrently.   */
   void* workspace;
   int64_t workspace_bytes;
   /* Kernel selection: 0 = automatic.  BIST_GEMM_TILE256 asks for the 256x256-tile deep-pipelined kernel
@@ -94,6 +96,9 @@ typedef struct BistGemm {
   int32_t reserved;
 } BistGemm;
 #define BIST_GEMM_TILE256 2
+#define BIST_GEMM_SPLIT64 4   /* hint bit: cut a long K of a small 64-tile product over neighbouring workgroups and combine
+                               * them inside the launch (agent-scope release / ticket / acquire); measured slower than the
+                               * unsplit ring kernel on this model's shapes, so never chosen automatically              */
 
 int bist_gemm(const BistGemm* g, void* stream);
 /* Two independent products in one call.  When they are the backward pair of a linear layer on few rows -- a: dX = dZ.W

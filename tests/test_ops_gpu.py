@@ -45,6 +45,7 @@ def _q(x, dtype):
 CASES = [  # (M, N, K) -- K multiples of 8 take the LDS-DMA kernels for both dtypes
     (128, 128, 64), (300, 200, 128), (77, 513, 192), (1, 5, 64), (257, 129, 512), (320, 192, 1056), (1300, 1200, 96),
     (320, 192, 3000), (130, 70, 200), (64, 64, 8),     # K tails: the stager zero-fills the trailing partial tile
+    (320, 512, 1536), (320, 512, 2048), (100, 130, 1000),      # long K on few 64-tiles (ring kernel)
 ]
 
 
@@ -85,6 +86,29 @@ def test_gemm_pair_linear_backward(ops, dtype, tol, rows, n_out, k_in):
     gb2 = ops.gemm_desc(dzd, xd, dwb, M=n_out, N=k_in, K=rows, a_rs=1, a_ks=n_out, b_rs=1, b_ks=k_in, ldc=k_in)
     ops.gemm_pair(ga, gb2)
     _cmp(dwb, _q(dz, dtype).t() @ _q(x, dtype), tol * 2, "pair dW (operand dtype)")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("M,N,K,lay", [(320, 512, 1536, "NT"), (320, 512, 2048, "NN"), (100, 130, 1000, "NT"), (192, 264, 832, "TT")])
+def test_gemm_in_launch_split_k(ops, dtype, tol, M, N, K, lay):
+    """hint BIST_GEMM_SPLIT64: K cut over neighbouring workgroups of a 64-tile product, combined inside the launch by the
+    last slice to finish (release / ticket / acquire); repeated launches reuse the self-resetting ticket counters."""
+    import ctypes
+    from bist_amd import _lib
+    a, b = _rand(M, K, seed=90), _rand(N, K, seed=91, scale=K ** -0.5)
+    ref = _q(a, dtype) @ _q(b, dtype).t()
+    ad, bd = a.to(dtype).cuda(), b.to(dtype).cuda()
+    at, bt = a.t().contiguous().to(dtype).cuda(), b.t().contiguous().to(dtype).cuda()
+    A, ars, aks = (ad, K, 1) if lay[0] == "N" else (at, 1, M)
+    Bm, brs, bks = (bd, K, 1) if lay[1] == "T" and lay != "TT" else ((bt, 1, N) if lay in ("NN", "TT") else (bd, K, 1))
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    g = ops.gemm_desc(A, Bm, out, M=M, N=N, K=K, a_rs=ars, a_ks=aks, b_rs=brs, b_ks=bks, ldc=N)
+    g.hint = 4
+    assert _lib.lib.bist_gemm_is_fast(g) == 2
+    for rep in range(3):
+        out.zero_()
+        _lib.check(_lib.lib.bist_gemm(ctypes.byref(g), torch.cuda.current_stream().cuda_stream), "bist_gemm")
+        _cmp(out, ref, tol, f"in-launch split-K {lay} run {rep}")
 
 
 @pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (1100, 300, 192), (256, 256, 128), (700, 1024, 832)])
