@@ -121,11 +121,19 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # rehearsal aid (one-GPU box): BIST_BENCH_REHEARSAL=1 puts every rank on cuda:0 and exchanges through gloo, so the
+    # multi-rank control flow (barriers, gradient all-reduce, max-over-ranks timing) can be run without a second GPU
+    rehearsal = os.environ.get("BIST_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import bist_amd.model as M
     from bist_amd import functional as Fn, ops
