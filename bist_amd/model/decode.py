@@ -41,26 +41,155 @@ def _turn_for_rows(batch, ft, n, cache):
     return hit
 
 
+STEP_GRAPHS = True           # replay one hipGraph per (rows, prefix length) for the batched decode step
+
+
+class _TurnBuffers:
+    """Static device copies of a turn's inputs for `n` hypothesis rows (ids, masks, encoded text, per-layer reasoning).
+    Every step graph of this geometry reads THESE tensors, so a new turn costs one round of small copies, not a capture."""
+
+    def __init__(self, bn, fn):
+        self.b = types.SimpleNamespace(**vars(bn))
+        for name in ("query", "his", "cap", "query_mask", "his_mask", "cap_mask"):
+            v = getattr(bn, name, None)
+            setattr(self.b, name, v.clone() if v is not None else None)
+        self.f = {k: v.clone() for k, v in fn.items() if k != "_bist_reasoning"}
+        self.f["_bist_reasoning"] = [{k: v.clone() for k, v in layer.items()} for layer in fn["_bist_reasoning"]]
+        self.loaded = None               # the (bn, fn) pair currently held
+
+    def load(self, bn, fn):
+        if self.loaded is fn:
+            return
+        for name in ("query", "his", "cap", "query_mask", "his_mask", "cap_mask"):
+            v = getattr(bn, name, None)
+            if v is not None:
+                getattr(self.b, name).copy_(v)
+        for k, v in fn.items():
+            if k != "_bist_reasoning":
+                self.f[k].copy_(v)
+        for dst, src in zip(self.f["_bist_reasoning"], fn["_bist_reasoning"]):
+            for k, v in src.items():
+                dst[k].copy_(v)
+        self.loaded = fn
+
+
+def _graph_step(model, bn, fn, trg, train_args):
+    """decode + generator for the n hypothesis rows of one step, replayed from a hipGraph (captured once per geometry:
+    row count, prefix length, dialogue lengths, dtype); returns the log-probs [n, 1, V] as a numpy array."""
+    dev = trg.device
+    n, Lt = trg.shape
+    geom = (n, tuple(bn.query.shape), tuple(bn.his.shape), None if bn.cap is None else tuple(bn.cap.shape), fn["encoded_query"].dtype,
+            len(fn["_bist_reasoning"]))
+    store = model.__dict__.setdefault("_bist_step_graphs", {})
+    tb = store.get(("turn",) + geom)
+    if tb is None:
+        tb = store[("turn",) + geom] = _TurnBuffers(bn, fn)
+    tb.load(bn, fn)
+    g = store.get((Lt,) + geom)
+    if g is None:
+        strg = torch.zeros((n, Lt), dtype=torch.long, device=dev)
+        tb.b.trg = strg
+        tb.b.trg_mask = subsequent_mask(Lt, dev)
+
+        def run():
+            f2 = model.decode(tb.b, dict(tb.f))
+            step = dict(f2)
+            step["decoded_text"] = f2["decoded_text"][:, -1:].contiguous()
+            step["encoded_tgt"] = f2["encoded_tgt"][:, -1:].contiguous()
+            return model.generator(step, tb.b, train_args).float()
+        strg.copy_(trg)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = run()
+        g = store[(Lt,) + geom] = (graph, strg, tb.b.trg_mask, out)
+    graph, strg, _, out = g
+    strg.copy_(trg)
+    graph.replay()
+    return out.cpu().numpy()
+
+
+_TURN_FIELDS = ("query", "his", "cap", "fts", "query_mask", "his_mask", "cap_mask", "temporal_mask")
+
+
+def _graph_first_step(model, batch, start_symbol, train_args):
+    """model.encode + the first decode step (prefix = <sos>) of a turn, replayed from one hipGraph per dialogue geometry:
+    ~1000 launches of reasoning at B=1 are launch-bound when issued from Python.  Returns (ft, log-probs [1,1,V] numpy);
+    ft (encoded text, per-layer reasoning) lives in the graph's static outputs until the next turn of this geometry."""
+    dev = batch.query.device
+    geom = tuple((f, None if getattr(batch, f, None) is None else (tuple(getattr(batch, f).shape), getattr(batch, f).dtype)) for f in _TURN_FIELDS)
+    store = model.__dict__.setdefault("_bist_step_graphs", {})
+    g = store.get(("first",) + geom)
+    if g is None:
+        sb = types.SimpleNamespace(**vars(batch))
+        for f in _TURN_FIELDS:
+            v = getattr(batch, f, None)
+            setattr(sb, f, v.clone() if v is not None else None)
+        sb.trg = torch.full((1, 1), start_symbol, dtype=torch.long, device=dev)
+        sb.trg_mask = subsequent_mask(1, dev)
+
+        def run():
+            f2 = model.decode(sb, model.encode(sb))
+            step = dict(f2)
+            step["decoded_text"] = f2["decoded_text"][:, -1:].contiguous()
+            step["encoded_tgt"] = f2["encoded_tgt"][:, -1:].contiguous()
+            return f2, model.generator(step, sb, train_args).float()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            f2, out = run()
+        g = store[("first",) + geom] = (graph, sb, f2, out)
+    graph, sb, f2, out = g
+    for f in _TURN_FIELDS:
+        v = getattr(batch, f, None)
+        if v is not None:
+            getattr(sb, f).copy_(v)
+    graph.replay()
+    ft = {k: v for k, v in f2.items() if k != "_bist_reasoning"}
+    ft["_bist_reasoning"] = [dict(layer) for layer in f2["_bist_reasoning"]]
+    return ft, out.cpu().numpy()
+
+
 def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam=5, penalty=1.0,
                        nbest=5, min_len=1, train_args=None, dec_eos=False):
     dev = batch.query.device
-    ft = model.encode(batch)
+    use_graphs = (STEP_GRAPHS and BATCH_HYPOTHESES and batch.query.is_cuda and not torch.is_grad_enabled() and not model.training
+                  and getattr(type(model.mutlimodal_decoder), "REASONING_CACHE", False))
+    lp_first = None
+    if use_graphs:
+        ft, lp_first = _graph_first_step(model, batch, start_symbol, train_args)
+    else:
+        ft = model.encode(batch)
     hyplist = [([], 0.0, torch.full((1, 1), start_symbol, dtype=torch.long, device=dev))]
     best_state, comp_hyplist = None, []
     rows_cache = {}
     for l in range(max_len):
         new_hyplist, argmin = [], 0
-        lp_rows = None
-        if BATCH_HYPOTHESES and len(hyplist) > 1 and "_bist_reasoning" in ft:
+        lp_rows = lp_first if l == 0 else None
+        if lp_rows is not None:
+            pass
+        elif BATCH_HYPOTHESES and len(hyplist) > 1 and "_bist_reasoning" in ft:
             n = len(hyplist)
             bn, fn = _turn_for_rows(batch, ft, n, rows_cache)
-            bn.trg = torch.cat([st for _, _, st in hyplist], dim=0)
-            bn.trg_mask = subsequent_mask(bn.trg.size(1), dev)
-            fn = model.decode(bn, fn)
-            step = dict(fn)
-            step["decoded_text"] = fn["decoded_text"][:, -1:].contiguous()
-            step["encoded_tgt"] = fn["encoded_tgt"][:, -1:].contiguous()
-            lp_rows = model.generator(step, bn, train_args).float().cpu().numpy()        # [n, 1, V]
+            trg = torch.cat([st for _, _, st in hyplist], dim=0)
+            if use_graphs:
+                lp_rows = _graph_step(model, bn, fn, trg, train_args)                        # [n, 1, V]
+            else:
+                bn.trg = trg
+                bn.trg_mask = subsequent_mask(trg.size(1), dev)
+                f2 = model.decode(bn, dict(fn))
+                step = dict(f2)
+                step["decoded_text"] = f2["decoded_text"][:, -1:].contiguous()
+                step["encoded_tgt"] = f2["encoded_tgt"][:, -1:].contiguous()
+                lp_rows = model.generator(step, bn, train_args).float().cpu().numpy()    # [n, 1, V]
         for idx, (out, lp, st) in enumerate(hyplist):
             if lp_rows is not None:
                 lp_vec = np.squeeze(lp_rows[idx:idx + 1] + lp)
