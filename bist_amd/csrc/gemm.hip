@@ -128,7 +128,7 @@ __device__ __forceinline__ void compute_tile(const char* lds_a, const char* lds_
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Mma<T>::step(af[i], bf[j], acc[i][j]);
+      for (int j = 0; j < 4; ++j) Mma<T>::step(bf[j], af[i], acc[i][j]);
   }
 }
 
@@ -199,45 +199,169 @@ __device__ __forceinline__ float epilogue_value(const GemmK& g, float acc, float
   return v;
 }
 
+// v_permlane16_swap: lanes 16-31 / 48-63 of `a` trade places with lanes 0-15 / 32-47 of `b`.  Inline asm (with the two
+// wait states the instruction needs after a VALU write of an operand): the hipcc 7.2 builtin drops the second result.
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// Row-wise finish of VW consecutive output columns held by one lane (the layout an MFMA leaves when the B fragment
+// is its row operand): alpha, bias, ReLU, dropout, residual, then one or two 16-byte stores.  The per-launch switches are
+// wave-uniform and tested once per row piece, not once per element.
 template <typename T, typename TO>
-__device__ __forceinline__ void epilogue(const GemmK& g, f32x4 (&acc)[4][4], int z1, int z2, int sp, int m0, int n0, int wm, int wn, int lane) {
+struct RowOut {
+  const GemmK& g;
+  TO* C;
+  const T* bias;
+  const TO* res;
+  unsigned long long zoff, seed;
+  float keep_scale;
+  bool relu, dropping;
+  __device__ __forceinline__ RowOut(const GemmK& g_, int z1, int z2, unsigned long long zoff_) : g(g_), zoff(zoff_) {
+    C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
+    bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
+    res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
+    relu = g.act == BIST_ACT_RELU;
+    dropping = g.drop_p > 0.f;
+    seed = g.drop_seed + ((dropping && g.drop_ctr) ? g.drop_ctr[0] * 0xD1B54A32D192ED03ULL : 0ULL);
+    keep_scale = dropping ? 1.f / (1.f - g.drop_p) : 1.f;
+  }
+  template <int VW>
+  __device__ __forceinline__ void load_bias(float (&bv)[VW], int n) const {
+#pragma unroll
+    for (int e = 0; e < VW; ++e) bv[e] = 0.f;
+    if (!bias || n >= g.N) return;
+    if (n + VW <= g.N && (n & 7) == 0 && sizeof(T) == 2 && VW == 8 && (reinterpret_cast<size_t>(bias) & 15) == 0) {
+      T q[8];
+      *reinterpret_cast<uint4*>(q) = *reinterpret_cast<const uint4*>(bias + n);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) bv[e] = to_f(q[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) if (n + e < g.N) bv[e] = to_f(bias[n + e]);
+    }
+  }
+  template <int VW, int NB>
+  __device__ __forceinline__ void row(float (&v)[VW], const float (&bv)[NB], int m, int n) const {
+    static_assert(NB >= VW, "bias piece too short");
+    if (m >= g.M || n >= g.N) return;
+    const bool full = n + VW <= g.N;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) v[e] = v[e] * g.alpha + bv[e];
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (dropping) {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[e] = drop_keep(seed, zoff + (unsigned long long)m * g.N + n + e, g.drop_p) ? v[e] * keep_scale : 0.f;
+    }
+    if (res) {
+      const long rr = g.res_outer > 0 ? (long)(m / g.res_outer) * g.res_inner + (m % g.res_inner) : (long)m;
+      const TO* rp = res + rr * g.ldr + n;
+      if (full && g.vec_r) {
+        TO q[VW];
+#pragma unroll
+        for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(q)[c] = reinterpret_cast<const uint4*>(rp)[c];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) v[e] += to_f(q[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) if (n + e < g.N) v[e] += to_f(rp[e]);
+      }
+    }
+    TO o[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) o[e] = from_f<TO>(v[e]);
+    TO* dst = C + (long)m * g.ldc + n;
+    if (full && g.vec_c) {
+#pragma unroll
+      for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(dst)[c] = reinterpret_cast<const uint4*>(o)[c];
+    } else {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) if (n + e < g.N) dst[e] = o[e];
+    }
+  }
+};
+
+// Epilogue straight from the accumulators.  Every kernel below feeds the MFMA the B fragment as its ROW operand, so lane
+// (lr = lane & 15, lg = lane >> 4) of fragment (i, j) holds the 4 CONSECUTIVE COLUMNS C[row0 + i*16 + lr][col0 + j*16 + lg*4 .. +3]:
+// fp32 outputs are 16-byte stores as they stand; for 2-byte outputs one v_permlane16_swap per register between the
+// fragments j, j+1 leaves each lane 8 consecutive columns (16 bytes).  No LDS image, no barrier: a finished wave starts
+// storing while the others still compute, and at two workgroups per CU the stores run under the neighbour's K loop
+// (a CU stores ~10 B/clk, so the C tile is the longest serial piece of a short product).
+template <typename T, typename TO, int NI, int NJ>
+__device__ __forceinline__ void frag_out(const GemmK& g, f32x4 (&acc)[NI][NJ], int z1, int z2, int row0, int col0, int lane) {
   const int lr = lane & 15, lg = lane >> 4;
   const long zlin = z1 * (long)g.batch2 + z2;
-  if (g.split_k > 1) {            // raw partial sums; the reduce kernel applies the epilogue
-    float* W = g.ws + WS_HEADER + ((zlin * g.split_k + sp) * (long)g.M) * g.N;
+  RowOut<T, TO> out(g, z1, z2, (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N);
+  if constexpr (sizeof(TO) == 2) {
+    static_assert(NJ % 2 == 0, "fragment pairs");
+    const int cofs = (lg & 1) * 16 + (lg >> 1) * 8;
+    float bv[NJ / 2][8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + lr;
-      if (n >= g.N) continue;
+    for (int jp = 0; jp < NJ / 2; ++jp) out.load_bias(bv[jp], col0 + jp * 32 + cofs);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int jp = 0; jp < NJ / 2; ++jp) {
+        float v[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm * 64 + i * 16 + lg * 4 + r;
-          if (m < g.M) W[(long)m * g.N + n] = acc[i][j][r];
+          float a = acc[i][2 * jp][r], b = acc[i][2 * jp + 1][r];
+          swap16(a, b);
+          v[r] = a; v[4 + r] = b;
         }
-    }
-    return;
+        out.template row<8>(v, bv[jp], row0 + i * 16 + lr, col0 + jp * 32 + cofs);
+      }
+  } else {
+    float bv[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) out.load_bias(bv[j], col0 + j * 16 + lg * 4);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        out.template row<4>(v, bv[j], row0 + i * 16 + lr, col0 + j * 16 + lg * 4);
+      }
   }
-  TO* C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
-  const T* bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
-  const TO* res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
-  const unsigned long long zoff = (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N;
+}
+
+// raw fp32 partial sums of one split-K slice (the reduce kernel applies the epilogue); same fragment layout as frag_out
+template <int NI, int NJ>
+__device__ __forceinline__ void frag_out_partial(const GemmK& g, f32x4 (&acc)[NI][NJ], long zlin, int sp, int row0, int col0, int lane) {
+  const int lr = lane & 15, lg = lane >> 4;
+  float* W = g.ws + WS_HEADER + ((zlin * g.split_k + sp) * (long)g.M) * g.N;
+  const bool vec = (g.N & 3) == 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wn * 64 + j * 16 + lr;
-    if (n >= g.N) continue;
-    const float bv = bias ? to_f(bias[n]) : 0.f;
+  for (int i = 0; i < NI; ++i) {
+    const int m = row0 + i * 16 + lr;
+    if (m >= g.M) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < NJ; ++j) {
+      const int n = col0 + j * 16 + lg * 4;
+      float* dst = W + (long)m * g.N + n;
+      if (vec && n + 4 <= g.N) *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + lg * 4 + r;
-        if (m >= g.M) continue;
-        C[(long)m * g.ldc + n] = from_f<TO>(epilogue_value<T, TO>(g, acc[i][j][r], bv, res, m, n, zoff));
+        for (int r = 0; r < 4; ++r) if (n + r < g.N) dst[r] = acc[i][j][r];
       }
     }
   }
+}
+
+// the f32 [64][64] image of a 64-tile (16-byte chunk ^ 4*((row>>2)&3)) that stream_out<.., 64> reads: in-launch split-K only
+__device__ __forceinline__ void frag_to_image64(f32x4 (&acc)[2][2], float* buf, int wm, int wn, int lane) {
+  const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wm * 32 + i * 16 + lr, chunk = (wn * 32 + j * 16) / 4 + lg;
+      *reinterpret_cast<float4*>(buf + row * 64 + ((chunk ^ (((row >> 2) & 3) << 2)) << 2)) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
 }
 
 // Staged epilogue of the fast kernel.  The accumulators go to LDS as f32 (one [64 rows][128 cols] image per
@@ -339,26 +463,9 @@ __device__ __forceinline__ void stream_out(const GemmK& g, const char* lds_lo, c
 }
 
 template <typename T, typename TO>
-__device__ __forceinline__ void epilogue_staged(const GemmK& g, f32x4 (&acc)[4][4], char* lds_lo, char* lds_hi, int z1, int z2,
-                                                int sp, int m0, int n0, int wm, int wn, int lane, int tid) {
-  const int lr = lane & 15, lg = lane >> 4;
-  __syncthreads();                               // every wave is done reading the operand stages
-  {
-    float* buf = reinterpret_cast<float*>(wm == 0 ? lds_lo : lds_hi);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = i * 16 + lg * 4 + r, col = wn * 64 + j * 16 + lr;
-          const int pos = (col >> 2) ^ (((row >> 2) & 7) << 2);
-          buf[row * 128 + pos * 4 + (col & 3)] = acc[i][j][r];
-        }
-  }
-  __syncthreads();
-  if (g.split_k > 1) stream_out<T, TO, true>(g, lds_lo, lds_hi, z1, z2, sp, m0, n0, tid);
-  else stream_out<T, TO, false>(g, lds_lo, lds_hi, z1, z2, sp, m0, n0, tid);
+__device__ __forceinline__ void epilogue_direct(const GemmK& g, f32x4 (&acc)[4][4], int z1, int z2, int sp, int m0, int n0, int wm, int wn, int lane) {
+  if (g.split_k > 1) frag_out_partial<4, 4>(g, acc, z1 * (long)g.batch2 + z2, sp, m0 + wm * 64, n0 + wn * 64, lane);
+  else frag_out<T, TO, 4, 4>(g, acc, z1, z2, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -461,7 +568,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(const GemmK g) {
     }
   }
   if (g.dbg == 3) { if (acc[0][0][0] == 123.456f) g.C[0] = 1; return; }
-  epilogue_staged<T, TO>(g, acc, lds0, lds1, z1, z2, sp, m0, n0, wm, wn, lane, tid);
+  epilogue_direct<T, TO>(g, acc, z1, z2, sp, m0, n0, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -603,7 +710,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_kernel(const GemmK g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) Mma<T>::step(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) Mma<T>::step(bf[j], af[i], acc[i][j]);
     }
   };
   stage_in(lds0, 0);
@@ -635,24 +742,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_kernel(const GemmK g) {
       }
     }
   }
-  // epilogue: accumulators -> f32 [64][64] image in lds0 (16-byte chunk ^ 4*((row>>2)&3)), then 16-byte rows out
-  __syncthreads();
-  {
-    float* buf = reinterpret_cast<float*>(lds0);
-    const int lr = lane & 15, lg = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wm * 32 + i * 16 + lg * 4 + r, col = wn * 32 + j * 16 + lr;
-          const int pos = (col >> 2) ^ (((row >> 2) & 3) << 2);
-          buf[row * 64 + pos * 4 + (col & 3)] = acc[i][j][r];
-        }
-  }
-  __syncthreads();
-  stream_out<T, TO, false, 64>(g, lds0, lds0, z1, z2, 0, m0, n0, tid);
+  frag_out<T, TO, 2, 2>(g, acc, z1, z2, m0 + wm * 32, n0 + wn * 32, lane);
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -714,9 +804,6 @@ template <> struct FragRd<float, true> {                   // [32 K-rows][256 B]
 // the other waves' shares: the DRAM latency is paid once.
 template <typename T, typename TO, bool ATR, bool BTR, int NK>
 __global__ __launch_bounds__(NTHREADS) void gemm_t64_pre_kernel(const GemmK g) {
-  // the f32 epilogue image is its own (largest, hence first-placed) LDS object: the object at LDS address 0 loses
-  // its identity in the compiler's LDS-DMA tracking and would make the first fragment read wait for ALL DMAs
-  __shared__ __attribute__((aligned(16))) char ebuf[2 * T64_BYTES + 64];
   __shared__ __attribute__((aligned(16))) char l0[2 * T64_BYTES];
   __shared__ __attribute__((aligned(16))) char l1[2 * T64_BYTES];
   __shared__ __attribute__((aligned(16))) char l2[2 * T64_BYTES];
@@ -765,13 +852,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_pre_kernel(const GemmK g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) Mma<T>::step(af[0][i].get(), bf[0][j].get(), acc[i][j]);
+      for (int j = 0; j < 2; ++j) Mma<T>::step(bf[0][j].get(), af[0][i].get(), acc[i][j]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     af[1][0].tie(); af[1][1].tie(); bf[1][0].tie(); bf[1][1].tie();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) Mma<T>::step(af[1][i].get(), bf[1][j].get(), acc[i][j]);
+      for (int j = 0; j < 2; ++j) Mma<T>::step(bf[1][j].get(), af[1][i].get(), acc[i][j]);
   };
 #define PRE_USE(L_, t_)                                                              \
   if constexpr ((t_) < NK) {                                                         \
@@ -782,23 +869,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_pre_kernel(const GemmK g) {
   }
   PRE_USE(l0, 0) PRE_USE(l1, 1) PRE_USE(l2, 2) PRE_USE(l3, 3) PRE_USE(l4, 4) PRE_USE(l5, 5) PRE_USE(l6, 6) PRE_USE(l7, 7)
 #undef PRE_USE
-  __syncthreads();
-  {
-    float* buf = reinterpret_cast<float*>(ebuf);
-    const int lr = lane & 15, lg = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wm * 32 + i * 16 + lg * 4 + r, col = wn * 32 + j * 16 + lr;
-          const int pos = (col >> 2) ^ (((row >> 2) & 3) << 2);
-          buf[row * 64 + pos * 4 + (col & 3)] = acc[i][j][r];
-        }
-  }
-  __syncthreads();
-  stream_out<T, TO, false, 64>(g, ebuf, ebuf, z1, z2, 0, m0, n0, tid);
+  frag_out<T, TO, 2, 2>(g, acc, z1, z2, m0 + wm * 32, n0 + wn * 32, lane);
 }
 
 // Ring variant of the all-in-flight kernel for ANY number of K tiles (the K = 2048 products of the feed-forward
@@ -893,7 +964,7 @@ __device__ __forceinline__ void t64_ring_body(const GemmK& g, unsigned bid, unsi
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) Mma<T>::step(af[0][ks][i].get(), bf[0][ks][j].get(), acc[i][j]);
+        for (int j = 0; j < 2; ++j) Mma<T>::step(bf[0][ks][j].get(), af[0][ks][i].get(), acc[i][j]);
     }
     if (two) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -903,27 +974,18 @@ __device__ __forceinline__ void t64_ring_body(const GemmK& g, unsigned bid, unsi
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) Mma<T>::step(af[1][ks][i].get(), bf[1][ks][j].get(), acc[i][j]);
+          for (int j = 0; j < 2; ++j) Mma<T>::step(bf[1][ks][j].get(), af[1][ks][i].get(), acc[i][j]);
       }
     }
   }
-  __syncthreads();
-  {
-    float* buf = reinterpret_cast<float*>(ebuf);
-    const int lr = lane & 15, lg = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wm * 32 + i * 16 + lg * 4 + r, col = wn * 32 + j * 16 + lr;
-          const int pos = (col >> 2) ^ (((row >> 2) & 3) << 2);
-          buf[row * 64 + pos * 4 + (col & 3)] = acc[i][j][r];
-        }
+  if (S == 1) {
+    frag_out<T, TO, 2, 2>(g, acc, z1, z2, m0 + wm * 32, n0 + wn * 32, lane);
+    return;
   }
   __syncthreads();
-  if (S > 1) {
+  frag_to_image64(acc, reinterpret_cast<float*>(ebuf), wm, wn, lane);
+  __syncthreads();
+  {
     // In-launch split-K combine (cdna_hip_programming.md section 5, "Projection GEMM at M = 256", item 2): every slice writes
     // its fp32 tile image to a slab, releases at agent scope and takes a ticket; the slice that draws the last ticket acquires,
     // adds the other slabs to its own image and runs the epilogue.  The counter returns to zero for the next launch.
@@ -1016,7 +1078,7 @@ constexpr int HALF_BYTES = 128 * ROW_BYTES;          // 16 KiB
 constexpr int KT_BYTES = 4 * HALF_BYTES;             // one K tile: Aq0 | Bq0 | Bq1 | Aq1
 enum { H_AQ0 = 0, H_BQ0 = 1, H_BQ1 = 2, H_AQ1 = 3 };
 
-template <typename TO>
+template <typename TO, int V = 0>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
   using T = bf16_t;
   __shared__ __attribute__((aligned(16))) char lds[2 * KT_BYTES];
@@ -1048,17 +1110,21 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
   }
   auto stage = [&](int hh, int kt) -> bool {           // half hh of K tile kt (pointers walk K tile by K tile)
     if (kt >= nk) return false;
+    if constexpr (V == 2) { if (kt >= 2) return true; }
     char* dst = lds + (kt & 1) * KT_BYTES + hh * HALF_BYTES + w * 2048;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src[hh][0]), LDS_PTR(dst), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(GLB_PTR(src[hh][1]), LDS_PTR(dst + 1024), 16, 0, 0);
     src[hh][0] += ROW_BYTES; src[hh][1] += ROW_BYTES;
     return true;
   };
+  unsigned long long stamp[6];
+  if constexpr (V == 4) stamp[0] = wall_clock64();
   stage(H_AQ0, 0); stage(H_BQ0, 0); stage(H_BQ1, 0); stage(H_AQ1, 0);
   const bool two = stage(H_AQ0, 1);
   stage(H_BQ0, 1);
   if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();                         // Aq0(0), Bq0(0) have landed for every wave
+  if constexpr (V == 4) stamp[1] = wall_clock64();
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -1072,20 +1138,24 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
   if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger the two wave rows by one barrier
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned cur = lds0 + (unsigned)((kt & 1) * KT_BYTES);
-#define BIG_PHASE(READ_B, BQ, READ_A, AH, STAGE_H, STAGE_KT, QM, QN, NEWER)                                       \
+#define BIG_PHASE(READ_B, BQ, READ_A, AH, STAGE_H, STAGE_KT, QM, QN, NEWER0, NEWER1)                              \
     {                                                                                                            \
-      if (READ_B) {                                                                                              \
+      const int NEWER = V >= 1 ? (NEWER1) : (NEWER0);                                                            \
+      if (READ_B && V != 3) {                                                                                              \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
           _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
             fb[BQ][ks][j].issue(cur + (BQ ? H_BQ1 : H_BQ0) * HALF_BYTES, wc * 32 + j * 16, ks, lane);            \
       }                                                                                                          \
-      if (READ_A) {                                                                                              \
+      if (READ_A && V != 3) {                                                                                    \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
           _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
             fa[ks][i].issue(cur + (AH) * HALF_BYTES, wr * 64 + i * 16, ks, lane);                                \
       }                                                                                                          \
+      if constexpr (V >= 1) stage(STAGE_H, STAGE_KT);   /* DMA issue in the read segment: under the OTHER wave row's MFMAs */ \
       /* retire the half the NEXT phase reads: all but the NEWER most recent stagings (2 DMAs each) */          \
       switch (NEWER) {                                                                                           \
+        case -1: break;                                                                                          \
+        case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;                                          \
         case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;                                          \
         case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;                                          \
         case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;                                          \
@@ -1098,11 +1168,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
       __builtin_amdgcn_s_setprio(1);                                                                             \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-          Mma<T>::step(fa[0][i].get(), fb[QN][0][j].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
-      stage(STAGE_H, STAGE_KT);             /* the DMA issue rides in the shadow of the MFMAs */                 \
+          Mma<T>::step(fb[QN][0][j].get(), fa[0][i].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
+      if constexpr (V == 0) stage(STAGE_H, STAGE_KT);   /* the DMA issue rides in the shadow of the MFMAs */     \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-          Mma<T>::step(fa[1][i].get(), fb[QN][1][j].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
+          Mma<T>::step(fb[QN][1][j].get(), fa[1][i].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
       __builtin_amdgcn_s_setprio(0);                                                                             \
       __builtin_amdgcn_s_barrier();                                                                              \
     }
@@ -1110,65 +1180,64 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
     // are  ... Bq1(kt) Aq1(kt) Aq0(kt+1) Bq0(kt+1) | Bq1(kt+1) Aq1(kt+1) Aq0(kt+2) Bq0(kt+2) ...  (| = start of K tile kt),
     // each issued in the MFMA segment of its phase, i.e. after that phase's wait; a staging past the last K tile is skipped.
     const int i1 = kt + 1 < nk, i2 = kt + 2 < nk;
-    BIG_PHASE(true, 0, true, H_AQ0, H_BQ1, kt + 1, 0, 0, (1 + 2 * i1))        // next reads Bq1(kt)
-    BIG_PHASE(true, 1, false, H_AQ0, H_AQ1, kt + 1, 0, 1, (3 * i1))           // next reads Aq1(kt)
-    BIG_PHASE(false, 0, true, H_AQ1, H_AQ0, kt + 2, 1, 1, 3)                  // next reads nothing new
-    BIG_PHASE(false, 0, false, H_AQ1, H_BQ0, kt + 2, 1, 0, (2 * i1 + i2))     // next reads Aq0(kt+1), Bq0(kt+1)
+    // (NEWER1: the same count when the phase's own staging is issued BEFORE its wait, in the read segment.)
+    BIG_PHASE(true, 0, true, H_AQ0, H_BQ1, kt + 1, 0, 0, (1 + 2 * i1), (1 + 3 * i1))              // next reads Bq1(kt)
+    BIG_PHASE(true, 1, false, H_AQ0, H_AQ1, kt + 1, 0, 1, (3 * i1), (4 * i1))                     // next reads Aq1(kt)
+    BIG_PHASE(false, 0, true, H_AQ1, H_AQ0, kt + 2, 1, 1, 3, -1)                                  // next reads nothing new
+    BIG_PHASE(false, 0, false, H_AQ1, H_BQ0, kt + 2, 1, 0, (2 * i1 + i2), (2 * i1 + 2 * i2))      // next reads Aq0(kt+1), Bq0(kt+1)
 #undef BIG_PHASE
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();            // the extra barrier of the staggered group
   __syncthreads();
+  if constexpr (V == 4) stamp[2] = wall_clock64();
 
-  // epilogue: each wave turns its 128x64 accumulators into rows through its own 16 KiB of LDS, 64 rows at a time
-  float* reg = reinterpret_cast<float*>(lds + w * 16384);
-  const int lr = lane & 15, lg = lane >> 4;
-  const long zlin = z1 * (long)g.batch2 + z2;
-  const unsigned long long zoff = (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N;
-  TO* C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
-  const T* bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
-  const TO* res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
-  const int cg = (lane & 7) * 8;                        // this lane's 8 columns inside the wave's 64
-  const int n = n0 + wc * 64 + cg;
-  float bv[8];
+  // epilogue: the MFMAs above took the B fragment as the row operand, so lane (lr, lg) holds the 4 CONSECUTIVE COLUMNS
+  // C[i*16 + lr][j*16 + lg*4 .. +3] of fragment (i, j) -- no LDS transpose.  For 2-byte outputs one v_permlane16_swap per
+  // register between the fragments j, j+1 widens that to 8 consecutive columns (16 bytes) per lane.
+  {
+    const int lr = lane & 15, lg = lane >> 4;
+    const long zlin = z1 * (long)g.batch2 + z2;
+    RowOut<T, TO> out(g, z1, z2, (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N);
+    constexpr bool WIDE = sizeof(TO) == 2;
+    constexpr int VW = WIDE ? 8 : 4;
+    float bv[4][VW > 4 ? 8 : 4];          // [column group][e]
+    const int ncol = n0 + wc * 64;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = (bias && n + e < g.N) ? to_f(bias[n + e]) : 0.f;
+    for (int c = 0; c < (WIDE ? 2 : 4); ++c)
+      out.load_bias(bv[c], ncol + (WIDE ? c * 32 + (lg & 1) * 16 + (lg >> 1) * 8 : c * 16 + lg * 4));
+    if constexpr (V == 4) stamp[4] = wall_clock64();
 #pragma unroll
-  for (int qm = 0; qm < 2; ++qm) {
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + lr;
+      if constexpr (WIDE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int jp = 0; jp < 2; ++jp) {
+          float v[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = i * 16 + lg * 4 + r, col = j * 16 + lr;
-          reg[row * 64 + (((col >> 2) ^ (((row >> 2) & 3) << 2)) << 2) + (col & 3)] = acc[qm * 4 + i][j][r];
+          for (int r = 0; r < 4; ++r) {
+            float a = acc[i][2 * jp][r], b = acc[i][2 * jp + 1][r];
+            swap16(a, b);
+            v[r] = a; v[4 + r] = b;
+          }
+          out.template row<8>(v, bv[jp], m, ncol + jp * 32 + (lg & 1) * 16 + (lg >> 1) * 8);
         }
-    __builtin_amdgcn_wave_barrier();
+      } else {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 8 + (lane >> 3);
-      const int m = m0 + wr * 128 + qm * 64 + row;
-      float v[8];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(reg + row * 64 + ((((cg >> 2) + q) ^ (((row >> 2) & 3) << 2)) << 2));
-        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-      }
-      if (m < g.M && n < g.N) {
-        TO o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = from_f<TO>(epilogue_value<T, TO>(g, v[e], bv[e], res, m, min(n + e, g.N - 1), zoff));
-        TO* dst = C + (long)m * g.ldc + n;
-        if (n + 8 <= g.N && g.vec_c) {
-          if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
-          else { reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(o)[0]; reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(o)[1]; }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (n + e < g.N) dst[e] = o[e];
+        for (int j = 0; j < 4; ++j) {
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          out.template row<4>(v, bv[j], m, ncol + j * 16 + lg * 4);
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (V == 4) stamp[5] = wall_clock64();
+  }
+  if constexpr (V == 4) {
+    __syncthreads();
+    stamp[3] = wall_clock64();
+    if (tid == 0 && g.ws) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(g.ws) + (size_t)blockIdx.x * 6;
+      o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3]; o[4] = stamp[4]; o[5] = stamp[5];
+    }
   }
 }
 
@@ -1244,7 +1313,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_gen_kernel(const GemmK g) {
     __syncthreads();
     compute_tile<T, false, false>(lds, lds + TILE_BYTES, acc, wm, wn, lane);
   }
-  epilogue<T, TO>(g, acc, z1, z2, 0, m0, n0, wm, wn, lane);
+  epilogue_direct<T, TO>(g, acc, z1, z2, 0, m0, n0, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1471,11 +1540,17 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
   if constexpr (std::is_same<T, bf16_t>::value) {
     const long big_tiles = (long)((g->M + BIG - 1) / BIG) * ((g->N + BIG - 1) / BIG) * g->batch1 * g->batch2;
     const bool legal = p.fast && !p.atr && !p.btr && g->K % 64 == 0 && g->K >= 128;
-    const bool wanted = g->hint == BIST_GEMM_TILE256 || (big_tiles >= 256 && g->N >= 2048 && g->K >= 2048 && p.split == 1);
+    const bool wanted = (g->hint & 15) == BIST_GEMM_TILE256 || (big_tiles >= 256 && g->N >= 2048 && g->K >= 2048 && p.split == 1);
     if (legal && wanted) {
       k.tiles_m = (g->M + BIG - 1) / BIG; k.tiles_n = (g->N + BIG - 1) / BIG;
       k.split_k = 1; k.ws = nullptr;
-      hipLaunchKernelGGL((gemm_big_kernel<TO>), dim3((unsigned)big_tiles), dim3(512), 0, st, k);
+      switch (g->hint >> 4) {                                   // tuning aid: structure variants of the 256-tile kernel
+        case 1: hipLaunchKernelGGL((gemm_big_kernel<TO, 1>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
+        case 2: hipLaunchKernelGGL((gemm_big_kernel<TO, 2>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
+        case 3: hipLaunchKernelGGL((gemm_big_kernel<TO, 3>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
+        case 4: k.ws = (float*)g->workspace; hipLaunchKernelGGL((gemm_big_kernel<TO, 4>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
+        default: hipLaunchKernelGGL((gemm_big_kernel<TO, 0>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
+      }
       BIST_LAUNCH_CHECK("bist_gemm(256-tile)");
       return BIST_OK;
     }

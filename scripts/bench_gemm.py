@@ -26,6 +26,8 @@ SHAPES = [  # (name, M, N, K, layout)  layout: NT = x.W^T, NN = dy.W, TN = dy^T.
     ("dW small   M=512 N=512 K=320", 512, 512, 320, "TN"),
 ]
 dt = torch.bfloat16
+if os.environ.get('BIG'):
+    SHAPES = [x for x in SHAPES if 'small' not in x[0]]
 if os.environ.get('SMALL'):
     SHAPES = [x for x in SHAPES if 'small' in x[0]]
 for name, M, N, K, lay in SHAPES:
@@ -58,4 +60,14 @@ for name, M, N, K, lay in SHAPES:
     g.replay()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
-    print(f"{name:38s} plan={plan} {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s")
+    ref = ""
+    if os.environ.get("VS_BLAS"):       # yardstick only: hipBLASLt through torch on the same operands
+        fa = (lambda: torch.mm(a, b.t(), out=c)) if lay == "NT" else (lambda: torch.mm(a, b, out=c)) if lay == "NN" else (lambda: torch.mm(a.t(), b, out=c))
+        for _ in range(5): fa()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters): fa()
+        e1.record(); torch.cuda.synchronize()
+        ru = e0.elapsed_time(e1) / iters * 1e3
+        ref = f"   hipBLASLt {ru:8.1f} us {2.0*M*N*K/ru/1e6:8.1f} TFLOP/s"
+    print(f"{name:38s} plan={plan} {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s{ref}")
