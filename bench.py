@@ -183,7 +183,10 @@ def main():
 
     # dominant kernel: the P0 GEMM (M = B*T*S, N = d, K = C), forward launches only
     M_p0 = c["B"] * c["T"] * c["S"]
-    p0 = [e0.elapsed_time(e1) for (m, n, k, z), e0, e1 in timing if (m, n, k, z) == (M_p0, c["d"], c["C"], 1)]
+    p0 = [e0.elapsed_time(e1) for (m, n, k, z), e0, e1, _ in timing if (m, n, k, z) == (M_p0, c["d"], c["C"], 1)]
+    p0_plan = {plan for (m, n, k, z), _, _, plan in timing if (m, n, k, z) == (M_p0, c["d"], c["C"], 1)}
+    p0_kernel = {4: "gemm_big_kernel<bf16> (256x256 tiles)", 1: "gemm_fast_kernel<bf16> (128x128 tiles)"}.get(
+        next(iter(p0_plan)) if len(p0_plan) == 1 else -1, "bist_gemm")
     p0_ms = sum(p0) / max(1, len(p0))
     p0_flops = 2.0 * M_p0 * c["d"] * c["C"]
     achieved = p0_flops / (p0_ms * 1e-3) / 1e12 if p0_ms > 0 else 0.0
@@ -268,7 +271,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": (p0_traffic(M_p0, c["C"], c["d"]) or {}).get("bytes_per_launch"),
                      "traffic_detail": p0_traffic(M_p0, c["C"], c["d"]),
-                     "kernel": f"gemm_fast_kernel<bf16> P0 [{M_p0}x{c['C']}]x[{c['C']}x{c['d']}]", "avg_launch_ms": p0_ms,
+                     "kernel": f"{p0_kernel} P0 [{M_p0}x{c['C']}]x[{c['C']}x{c['d']}]", "avg_launch_ms": p0_ms,
                      "launches_timed": len(p0)},
         "attn_fwd": {"what": "fused BiST attention forward F_P0+F_VL (SURVEY 8d), one layer, eval, hipGraph replay", "B": c["B"], "gflop_alg": (f_p0 + f_vl) / 1e9,
                      "ms": attn_ms, "tflops": attn_tflops, "frac_of_mfma_peak": attn_tflops / MFMA_BF16_PEAK_TFLOPS,

@@ -67,13 +67,17 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- counter-based dropout mask ----------------------------------------------------------------
 // keep(idx) is a pure function of (seed, idx), so the backward pass regenerates the same mask.
-__device__ __forceinline__ uint32_t mix64(uint64_t x) {
+// One 64-bit hash serves the 4 consecutive elements 4*idx4 .. 4*idx4+3 (16 bits each; the drop probability is
+// floor(p * 65536) / 65536): kernels that walk 4 or 8 consecutive elements per lane hash once per group.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
-  return (uint32_t)x;
+  return x;
 }
+__device__ __forceinline__ uint32_t drop_threshold(float p) { return (uint32_t)(p * 65536.f); }
+__device__ __forceinline__ uint64_t drop_bits4(uint64_t seed, uint64_t idx4) { return mix64(seed + idx4 * 0x9E3779B97F4A7C15ULL); }
+__device__ __forceinline__ bool drop_keep_of(uint64_t bits4, int e, uint32_t thr) { return ((uint32_t)(bits4 >> (e * 16)) & 0xffffu) >= thr; }
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
-  const uint32_t u = mix64(seed + idx * 0x9E3779B97F4A7C15ULL);
-  return (float)(u >> 8) * (1.0f / 16777216.0f) >= p;
+  return drop_keep_of(drop_bits4(seed, idx >> 2), (int)(idx & 3), drop_threshold(p));
 }
 // Dropout of attention probabilities (reference modules.py:62-63) as the kernels carry it: p == 0 means off.
 // The mask of probability element `idx` (its linear index in the canonical [.., query, key] order documented at

@@ -241,6 +241,44 @@ struct RowOut {
       for (int e = 0; e < VW; ++e) if (n + e < g.N) bv[e] = to_f(bias[n + e]);
     }
   }
+  // Whole-tile fast path: every row and column of the wave's tile is inside the matrix, 16-byte rows everywhere, the
+  // residual (if any) maps row to row, N % 4 == 0.  Straight-line code, one instantiation per (dropout, residual) pair,
+  // so that a wave fetches only the instructions it runs (the generic row() below is ~10x the code).
+  __device__ __forceinline__ bool whole(int row0, int rows, int col0, int cols) const {
+    return row0 + rows <= g.M && col0 + cols <= g.N && g.vec_c && (g.N & 3) == 0 && (!res || (g.vec_r && g.res_outer <= 0));
+  }
+  template <int VW, bool DROP, bool RES, int NB>
+  __device__ __forceinline__ void row_whole(float (&v)[VW], const float (&bv)[NB], int m, int n, uint32_t thr) const {
+#pragma unroll
+    for (int e = 0; e < VW; ++e) v[e] = v[e] * g.alpha + bv[e];
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if constexpr (DROP) {
+      const unsigned long long i4 = (zoff + (unsigned long long)m * g.N + n) >> 2;
+#pragma unroll
+      for (int q = 0; q < VW / 4; ++q) {
+        const uint64_t bits = drop_bits4(seed, i4 + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = drop_keep_of(bits, e, thr) ? v[4 * q + e] * keep_scale : 0.f;
+      }
+    }
+    if constexpr (RES) {
+      TO q[VW];
+      const TO* rp = res + (long)m * g.ldr + n;
+#pragma unroll
+      for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(q)[c] = reinterpret_cast<const uint4*>(rp)[c];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[e] += to_f(q[e]);
+    }
+    TO o[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) o[e] = from_f<TO>(v[e]);
+    TO* dst = C + (long)m * g.ldc + n;
+#pragma unroll
+    for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(dst)[c] = reinterpret_cast<const uint4*>(o)[c];
+  }
   template <int VW, int NB>
   __device__ __forceinline__ void row(float (&v)[VW], const float (&bv)[NB], int m, int n) const {
     static_assert(NB >= VW, "bias piece too short");
@@ -290,11 +328,10 @@ struct RowOut {
 // fragments j, j+1 leaves each lane 8 consecutive columns (16 bytes).  No LDS image, no barrier: a finished wave starts
 // storing while the others still compute, and at two workgroups per CU the stores run under the neighbour's K loop
 // (a CU stores ~10 B/clk, so the C tile is the longest serial piece of a short product).
-template <typename T, typename TO, int NI, int NJ>
-__device__ __forceinline__ void frag_out(const GemmK& g, f32x4 (&acc)[NI][NJ], int z1, int z2, int row0, int col0, int lane) {
+template <typename T, typename TO, int NI, int NJ, int MODE>     // MODE: 0..3 = whole-tile fast path (bit 0 dropout, bit 1 residual), 4 = generic
+__device__ __forceinline__ void frag_rows(const RowOut<T, TO>& out, f32x4 (&acc)[NI][NJ], int row0, int col0, int lane) {
   const int lr = lane & 15, lg = lane >> 4;
-  const long zlin = z1 * (long)g.batch2 + z2;
-  RowOut<T, TO> out(g, z1, z2, (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N);
+  const uint32_t thr = drop_threshold(out.g.drop_p);
   if constexpr (sizeof(TO) == 2) {
     static_assert(NJ % 2 == 0, "fragment pairs");
     const int cofs = (lg & 1) * 16 + (lg >> 1) * 8;
@@ -312,7 +349,8 @@ __device__ __forceinline__ void frag_out(const GemmK& g, f32x4 (&acc)[NI][NJ], i
           swap16(a, b);
           v[r] = a; v[4 + r] = b;
         }
-        out.template row<8>(v, bv[jp], row0 + i * 16 + lr, col0 + jp * 32 + cofs);
+        if constexpr (MODE < 4) out.template row_whole<8, (MODE & 1) != 0, (MODE & 2) != 0>(v, bv[jp], row0 + i * 16 + lr, col0 + jp * 32 + cofs, thr);
+        else out.template row<8>(v, bv[jp], row0 + i * 16 + lr, col0 + jp * 32 + cofs);
       }
   } else {
     float bv[NJ][4];
@@ -323,8 +361,24 @@ __device__ __forceinline__ void frag_out(const GemmK& g, f32x4 (&acc)[NI][NJ], i
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        out.template row<4>(v, bv[j], row0 + i * 16 + lr, col0 + j * 16 + lg * 4);
+        if constexpr (MODE < 4) out.template row_whole<4, (MODE & 1) != 0, (MODE & 2) != 0>(v, bv[j], row0 + i * 16 + lr, col0 + j * 16 + lg * 4, thr);
+        else out.template row<4>(v, bv[j], row0 + i * 16 + lr, col0 + j * 16 + lg * 4);
       }
+  }
+}
+
+template <typename T, typename TO, int NI, int NJ>
+__device__ __forceinline__ void frag_out(const GemmK& g, f32x4 (&acc)[NI][NJ], int z1, int z2, int row0, int col0, int lane) {
+  const long zlin = z1 * (long)g.batch2 + z2;
+  const RowOut<T, TO> out(g, z1, z2, (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N);
+  if (out.whole(row0, NI * 16, col0, NJ * 16)) {
+    const int mode = (out.dropping ? 1 : 0) | (out.res ? 2 : 0);
+    if (mode == 0) frag_rows<T, TO, NI, NJ, 0>(out, acc, row0, col0, lane);
+    else if (mode == 1) frag_rows<T, TO, NI, NJ, 1>(out, acc, row0, col0, lane);
+    else if (mode == 2) frag_rows<T, TO, NI, NJ, 2>(out, acc, row0, col0, lane);
+    else frag_rows<T, TO, NI, NJ, 3>(out, acc, row0, col0, lane);
+  } else {
+    frag_rows<T, TO, NI, NJ, 4>(out, acc, row0, col0, lane);
   }
 }
 
@@ -1066,8 +1120,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_pair_kernel(const GemmK g1,
 //       phase 1 reads Aq0+Bq0 into registers, phase 2 Bq1, phase 3 Aq1, phase 4 nothing;
 //   * every phase stages ONE half by LDS-DMA (2 instructions per wave), 5+ phases before its first read and 2+
 //       phases after the last read of the half it overwrites:  p1: Bq1(kt+1)  p2: Aq1(kt+1)  p3: Aq0(kt+2)  p4: Bq0(kt+2);
-//       the DMA is issued between the MFMAs of the phase; the read segment of the next phase waits vmcnt(6), so
-//       three to four halves (64 KiB) stay in flight across the barriers;
+//       the DMA is issued in the phase's read segment (under the OTHER wave row's MFMAs: an LDS-DMA issue stalls its
+//       wave for ~60+ cycles), the waits are vmcnt(8) / none, so four halves (64 KiB) stay in flight across the barriers;
 //   * the two wave rows run staggered by one barrier (one does MFMAs under s_setprio while the other reads LDS and
 //       issues DMA); a half is read one phase after the wait that retires it, i.e. two barriers later, which
 //       covers the other group's wait;
@@ -1110,7 +1164,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
   }
   auto stage = [&](int hh, int kt) -> bool {           // half hh of K tile kt (pointers walk K tile by K tile)
     if (kt >= nk) return false;
-    if constexpr (V == 2) { if (kt >= 2) return true; }
     char* dst = lds + (kt & 1) * KT_BYTES + hh * HALF_BYTES + w * 2048;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src[hh][0]), LDS_PTR(dst), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(GLB_PTR(src[hh][1]), LDS_PTR(dst + 1024), 16, 0, 0);
@@ -1118,13 +1171,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
     return true;
   };
   unsigned long long stamp[6];
-  if constexpr (V == 4) stamp[0] = wall_clock64();
+  if constexpr (V == 1) stamp[0] = wall_clock64();
   stage(H_AQ0, 0); stage(H_BQ0, 0); stage(H_BQ1, 0); stage(H_AQ1, 0);
   const bool two = stage(H_AQ0, 1);
   stage(H_BQ0, 1);
   if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();                         // Aq0(0), Bq0(0) have landed for every wave
-  if constexpr (V == 4) stamp[1] = wall_clock64();
+  unsigned long long cyc0 = 0;
+  if constexpr (V == 1) { stamp[1] = wall_clock64(); cyc0 = clock64(); }
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -1138,20 +1192,19 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
   if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger the two wave rows by one barrier
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned cur = lds0 + (unsigned)((kt & 1) * KT_BYTES);
-#define BIG_PHASE(READ_B, BQ, READ_A, AH, STAGE_H, STAGE_KT, QM, QN, NEWER0, NEWER1)                              \
+#define BIG_PHASE(READ_B, BQ, READ_A, AH, STAGE_H, STAGE_KT, QM, QN, NEWER)                                       \
     {                                                                                                            \
-      const int NEWER = V >= 1 ? (NEWER1) : (NEWER0);                                                            \
-      if (READ_B && V != 3) {                                                                                              \
+      if (READ_B) {                                                                                              \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
           _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
             fb[BQ][ks][j].issue(cur + (BQ ? H_BQ1 : H_BQ0) * HALF_BYTES, wc * 32 + j * 16, ks, lane);            \
       }                                                                                                          \
-      if (READ_A && V != 3) {                                                                                    \
+      if (READ_A) {                                                                                              \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
           _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
             fa[ks][i].issue(cur + (AH) * HALF_BYTES, wr * 64 + i * 16, ks, lane);                                \
       }                                                                                                          \
-      if constexpr (V >= 1) stage(STAGE_H, STAGE_KT);   /* DMA issue in the read segment: under the OTHER wave row's MFMAs */ \
+      stage(STAGE_H, STAGE_KT);             /* DMA issue in the read segment: under the OTHER wave row's MFMAs */ \
       /* retire the half the NEXT phase reads: all but the NEWER most recent stagings (2 DMAs each) */          \
       switch (NEWER) {                                                                                           \
         case -1: break;                                                                                          \
@@ -1169,7 +1222,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
           Mma<T>::step(fb[QN][0][j].get(), fa[0][i].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
-      if constexpr (V == 0) stage(STAGE_H, STAGE_KT);   /* the DMA issue rides in the shadow of the MFMAs */     \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
           Mma<T>::step(fb[QN][1][j].get(), fa[1][i].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
@@ -1178,65 +1230,27 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
     }
     // NEWER = stagings issued after the half the NEXT phase reads (they may stay in flight).  In issue order the stagings
     // are  ... Bq1(kt) Aq1(kt) Aq0(kt+1) Bq0(kt+1) | Bq1(kt+1) Aq1(kt+1) Aq0(kt+2) Bq0(kt+2) ...  (| = start of K tile kt),
-    // each issued in the MFMA segment of its phase, i.e. after that phase's wait; a staging past the last K tile is skipped.
+    // each issued in the read segment of its phase, i.e. BEFORE that phase's wait; a staging past the last K tile is skipped.
     const int i1 = kt + 1 < nk, i2 = kt + 2 < nk;
-    // (NEWER1: the same count when the phase's own staging is issued BEFORE its wait, in the read segment.)
-    BIG_PHASE(true, 0, true, H_AQ0, H_BQ1, kt + 1, 0, 0, (1 + 2 * i1), (1 + 3 * i1))              // next reads Bq1(kt)
-    BIG_PHASE(true, 1, false, H_AQ0, H_AQ1, kt + 1, 0, 1, (3 * i1), (4 * i1))                     // next reads Aq1(kt)
-    BIG_PHASE(false, 0, true, H_AQ1, H_AQ0, kt + 2, 1, 1, 3, -1)                                  // next reads nothing new
-    BIG_PHASE(false, 0, false, H_AQ1, H_BQ0, kt + 2, 1, 0, (2 * i1 + i2), (2 * i1 + 2 * i2))      // next reads Aq0(kt+1), Bq0(kt+1)
+    BIG_PHASE(true, 0, true, H_AQ0, H_BQ1, kt + 1, 0, 0, (1 + 3 * i1))              // next reads Bq1(kt)
+    BIG_PHASE(true, 1, false, H_AQ0, H_AQ1, kt + 1, 0, 1, (4 * i1))                 // next reads Aq1(kt)
+    BIG_PHASE(false, 0, true, H_AQ1, H_AQ0, kt + 2, 1, 1, -1)                       // next reads nothing new
+    BIG_PHASE(false, 0, false, H_AQ1, H_BQ0, kt + 2, 1, 0, (2 * i1 + 2 * i2))       // next reads Aq0(kt+1), Bq0(kt+1)
 #undef BIG_PHASE
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();            // the extra barrier of the staggered group
   __syncthreads();
-  if constexpr (V == 4) stamp[2] = wall_clock64();
+  if constexpr (V == 1) { stamp[2] = wall_clock64(); cyc0 = clock64() - cyc0; }
 
-  // epilogue: the MFMAs above took the B fragment as the row operand, so lane (lr, lg) holds the 4 CONSECUTIVE COLUMNS
-  // C[i*16 + lr][j*16 + lg*4 .. +3] of fragment (i, j) -- no LDS transpose.  For 2-byte outputs one v_permlane16_swap per
-  // register between the fragments j, j+1 widens that to 8 consecutive columns (16 bytes) per lane.
-  {
-    const int lr = lane & 15, lg = lane >> 4;
-    const long zlin = z1 * (long)g.batch2 + z2;
-    RowOut<T, TO> out(g, z1, z2, (unsigned long long)zlin * (unsigned long long)g.M * (unsigned long long)g.N);
-    constexpr bool WIDE = sizeof(TO) == 2;
-    constexpr int VW = WIDE ? 8 : 4;
-    float bv[4][VW > 4 ? 8 : 4];          // [column group][e]
-    const int ncol = n0 + wc * 64;
-#pragma unroll
-    for (int c = 0; c < (WIDE ? 2 : 4); ++c)
-      out.load_bias(bv[c], ncol + (WIDE ? c * 32 + (lg & 1) * 16 + (lg >> 1) * 8 : c * 16 + lg * 4));
-    if constexpr (V == 4) stamp[4] = wall_clock64();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + i * 16 + lr;
-      if constexpr (WIDE) {
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          float v[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float a = acc[i][2 * jp][r], b = acc[i][2 * jp + 1][r];
-            swap16(a, b);
-            v[r] = a; v[4 + r] = b;
-          }
-          out.template row<8>(v, bv[jp], m, ncol + jp * 32 + (lg & 1) * 16 + (lg >> 1) * 8);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          out.template row<4>(v, bv[j], m, ncol + j * 16 + lg * 4);
-        }
-      }
-    }
-    if constexpr (V == 4) stamp[5] = wall_clock64();
-  }
-  if constexpr (V == 4) {
+  if constexpr (V == 1) stamp[4] = wall_clock64();
+  frag_out<T, TO, 8, 4>(g, acc, z1, z2, m0 + wr * 128, n0 + wc * 64, lane);
+  if constexpr (V == 1) stamp[5] = wall_clock64();
+  if constexpr (V == 1) {
     __syncthreads();
     stamp[3] = wall_clock64();
     if (tid == 0 && g.ws) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(g.ws) + (size_t)blockIdx.x * 6;
-      o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3]; o[4] = stamp[4]; o[5] = stamp[5];
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(g.ws) + (size_t)blockIdx.x * 8;
+      o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3]; o[4] = stamp[4]; o[5] = stamp[5]; o[6] = cyc0;
     }
   }
 }
@@ -1522,6 +1536,18 @@ Plan make_plan(const BistGemm* g) {
   return p;
 }
 
+// scripts/bench_gemm_big.py (SWEEP=1 COLD=1): from ~140 tiles of 256x256 the 256-tile kernel is ahead of the 128-tile
+// kernel on every K-contiguous bf16 product of the path (M = 25088: 23.5 vs 29.3 us at K = 512, 53 vs 78 us at K = 2048),
+// below that the finer tiles fill the chip better.
+bool use_tile256(const BistGemm* g, const Plan& p) {
+  if (g->in_dtype != BIST_BF16) return false;
+  const long big_tiles = (long)((g->M + BIG - 1) / BIG) * ((g->N + BIG - 1) / BIG) * g->batch1 * g->batch2;
+  const bool legal = p.fast && !p.atr && !p.btr && g->K % 64 == 0 && g->K >= 128;
+  static const int no_big = [] { const char* e = getenv("BIST_GEMM_NO_BIG"); return e ? atoi(e) : 0; }();    // tuning aid
+  const bool wanted = (g->hint & 15) == BIST_GEMM_TILE256 || (!no_big && big_tiles >= 140 && g->K >= 512 && p.split == 1);
+  return legal && wanted;
+}
+
 template <typename T, typename TO>
 int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
   if (const int sk = skinny_kind(g)) return launch_skinny<T, TO>(g, k, sk, st);
@@ -1539,17 +1565,14 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
   } while (0)
   if constexpr (std::is_same<T, bf16_t>::value) {
     const long big_tiles = (long)((g->M + BIG - 1) / BIG) * ((g->N + BIG - 1) / BIG) * g->batch1 * g->batch2;
-    const bool legal = p.fast && !p.atr && !p.btr && g->K % 64 == 0 && g->K >= 128;
-    const bool wanted = (g->hint & 15) == BIST_GEMM_TILE256 || (big_tiles >= 256 && g->N >= 2048 && g->K >= 2048 && p.split == 1);
-    if (legal && wanted) {
+    if (use_tile256(g, p)) {
       k.tiles_m = (g->M + BIG - 1) / BIG; k.tiles_n = (g->N + BIG - 1) / BIG;
       k.split_k = 1; k.ws = nullptr;
-      switch (g->hint >> 4) {                                   // tuning aid: structure variants of the 256-tile kernel
-        case 1: hipLaunchKernelGGL((gemm_big_kernel<TO, 1>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
-        case 2: hipLaunchKernelGGL((gemm_big_kernel<TO, 2>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
-        case 3: hipLaunchKernelGGL((gemm_big_kernel<TO, 3>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
-        case 4: k.ws = (float*)g->workspace; hipLaunchKernelGGL((gemm_big_kernel<TO, 4>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
-        default: hipLaunchKernelGGL((gemm_big_kernel<TO, 0>), dim3((unsigned)big_tiles), dim3(512), 0, st, k); break;
+      if ((g->hint & 15) == BIST_GEMM_TILE256 && (g->hint >> 4) == 1) {        // development aid: in-kernel stamps into the workspace
+        k.ws = (float*)g->workspace;
+        hipLaunchKernelGGL((gemm_big_kernel<TO, 1>), dim3((unsigned)big_tiles), dim3(512), 0, st, k);
+      } else {
+        hipLaunchKernelGGL((gemm_big_kernel<TO, 0>), dim3((unsigned)big_tiles), dim3(512), 0, st, k);
       }
       BIST_LAUNCH_CHECK("bist_gemm(256-tile)");
       return BIST_OK;
@@ -1608,6 +1631,7 @@ extern "C" int bist_gemm_is_fast(const BistGemm* g) {
   if (!g) return 0;
   if (skinny_kind(g)) return 3;
   const Plan p = make_plan(g);
+  if (use_tile256(g, p)) return 4;
   return p.fast ? (p.split > 1 ? 2 : 1) : 0;
 }
 

@@ -103,7 +103,7 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
         e0.record()
         check(lib.bist_gemm(C.byref(g), _stream()), "bist_gemm")
         e1.record()
-        GEMM_TIMING.append(((g.M, g.N, g.K, g.batch1 * g.batch2), e0, e1))
+        GEMM_TIMING.append(((g.M, g.N, g.K, g.batch1 * g.batch2), e0, e1, int(lib.bist_gemm_is_fast(C.byref(g)))))
         return c
     check(lib.bist_gemm(C.byref(g), _stream()), "bist_gemm")
     return c

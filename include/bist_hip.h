@@ -106,8 +106,9 @@ int bist_gemm(const BistGemm* g, void* stream);
  * they share ONE launch (the first workgroups work on a, the rest on b); otherwise this is bist_gemm(a) then
  * bist_gemm(b).  Replaces the two addmm calls of nn.Linear's backward (modules.py:89-91,100 under autograd).      */
 int bist_gemm_pair(const BistGemm* a, const BistGemm* b, void* stream);
-/* Which kernel bist_gemm would pick for this problem: 1 = LDS-DMA MFMA tile kernel (128-, 64- or 256-tile),
- * 2 = the same with split-K, 3 = skinny (one side <= 8) VALU kernel, 0 = generic strided kernel
+/* Which kernel bist_gemm would pick for this problem: 1 = LDS-DMA MFMA tile kernel (128- or 64-tile),
+ * 2 = the same with split-K, 3 = skinny (one side <= 8) VALU kernel, 4 = the 256x256-tile kernel (K-contiguous bf16
+ * products of 140+ such tiles, or hint BIST_GEMM_TILE256), 0 = generic strided kernel
  * (host-side query, used by tests and the bench report).                                          */
 int bist_gemm_is_fast(const BistGemm* g);
 

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bist_amd import ops, _lib
 dt = torch.bfloat16
 SH = [(25088, 512, 2048), (25088, 512, 512), (25088, 2048, 512), (15680, 512, 512), (4096, 4096, 4096), (100352, 512, 2048)]
+if os.environ.get("SWEEP"):
+    SH = [(m, 512, k) for k in (512, 2048) for m in (12544, 15680, 18816, 25088, 31360, 37632, 50176, 62720, 100352)] + [(25088, 1024, 512), (25088, 1536, 512), (15680, 2048, 512), (15680, 512, 2048)]
 cold = bool(os.environ.get("COLD"))
 for (M, N, K) in SH:
     nset = max(1, int(600e6 // (2 * (M * K + M * N)))) if cold else 1
@@ -19,8 +21,7 @@ for (M, N, K) in SH:
         torch.mm(A[i % nset], b.t(), out=Cs[i % nset])
     res = []
     ref = None
-    variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
-    cases = [("blas", blas), ("t128", lambda i: run(0, i))] + [(f"t256v{v}", (lambda v: lambda i: run(2 + 16 * v, i))(v)) for v in variants]
+    cases = [("blas", blas), ("auto", lambda i: run(0, i)), ("t256", lambda i: run(2, i))]
     for name, fn in cases:
         for i in range(3): fn(i)
         torch.cuda.synchronize()

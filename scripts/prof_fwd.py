@@ -42,7 +42,7 @@ with torch.no_grad():
         ft = model.forward(b); lp = model.generator(ft, b, args)
         torch.cuda.synchronize()
         agg = collections.OrderedDict()
-        for tag, e0, e1 in ops.GEMM_TIMING:
+        for tag, e0, e1, _plan in ops.GEMM_TIMING:
             agg.setdefault(tag, []).append(e0.elapsed_time(e1))
         tot = 0
         for tag, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):

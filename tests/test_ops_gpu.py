@@ -136,6 +136,36 @@ def test_gemm_tile256_kernel(ops, M, N, K):
     _cmp(run(o32), ref, 2e-3, "tile256 f32 out")
 
 
+def test_gemm_tile256_is_automatic_for_the_frame_grid_products(ops):
+    """K-contiguous bf16 products of 140+ tiles of 256x256 (the M = B*T*S products of the path at B >= 12) take the
+    256-tile kernel on their own; ragged last row tile, bias + ReLU + residual, and the dropout mask of its epilogue is
+    the one the generic kernels draw (same seed, same element index)."""
+    from bist_amd import _lib
+    M, N, K = 18100, 512, 512
+    dtype, tol = torch.bfloat16, BF16_TOL
+    x, w, b = _rand(M, K, seed=11), _rand(N, K, seed=12, scale=K ** -0.5), _rand(N, seed=13)
+    r = _rand(M, N, seed=14)
+    xd, wd, bd, rd = (t.to(dtype).cuda() for t in (x, w, b, r))
+    ref = _q(x, dtype) @ _q(w, dtype).t() + _q(b, dtype)
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    kw = dict(M=M, N=N, K=K, a_rs=K, b_rs=K, ldc=N)
+    assert _lib.lib.bist_gemm_is_fast(ops.gemm_desc(xd, wd, out, **kw)) == 4
+    _cmp(ops.gemm(xd, wd, out, bias=bd, act=ops.ACT_RELU, residual=rd, ldr=N, **kw), ref.clamp_min(0) + _q(r, dtype), tol, "auto tile256")
+    # dropout: kept elements are scaled by 1/(1-p), the rest are exactly the residual; the same call on a row slice that
+    # takes the 128-tile kernel draws the same mask for the same elements
+    p = 0.25
+    full = ops.gemm(xd, wd, out, bias=bd, drop_p=p, drop_seed=77, **kw).float().cpu()
+    kept = full != 0
+    assert abs(kept.float().mean().item() - (1 - p)) < 5e-3
+    _cmp(torch.where(kept, full * (1 - p), torch.zeros(())), torch.where(kept, ref.float(), torch.zeros(())), tol, "tile256 dropout")
+    Ms = 1024
+    small = torch.empty(Ms, N, device="cuda", dtype=dtype)
+    kws = dict(kw, M=Ms)
+    assert _lib.lib.bist_gemm_is_fast(ops.gemm_desc(xd[:Ms], wd, small, **kws)) == 1
+    ops.gemm(xd[:Ms], wd, small, bias=bd, drop_p=p, drop_seed=77, **kws)
+    assert torch.equal((small.float().cpu() != 0), kept[:Ms])
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
 def test_gemm_generic_strides(ops, dtype, tol):
     # K tail (50), unaligned leading dims, transposed operands: all take the generic kernel
