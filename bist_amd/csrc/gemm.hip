@@ -1108,38 +1108,52 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_pair_kernel(const GemmK g1,
 }
 
 // ---------------------------------------------------------------------------------------------
-// 256x256-tile kernel for the big K-contiguous products (P0, the value projection, the output projections:
+// 256-column-tile kernel for the big K-contiguous products (P0, the value projection, the output projections:
 // M = B*T*S rows).  The 128-tile kernel above sits at the LDS balance point of a 64x64 wave tile (32 FLOP per LDS
-// byte = the CU's MFMA:LDS ratio) and stalls on the vmcnt(0) of its barrier every K step (~800 TFLOP/s).  Here
-// (the deep-pipelined structure of cdna_hip_programming.md section 5, re-derived for a uniform schedule):
-//   * 8 waves (2 x 4), wave tile 128 x 64 (acc 8x4 fragments = 128 AGPRs): 43 FLOP per LDS byte;
+// byte = the CU's MFMA:LDS ratio) and stalls on the vmcnt(0) of its barrier every K step.  Here (the deep-pipelined
+// structure of cdna_hip_programming.md section 5, re-derived for two phases per K tile):
+//   * 8 waves (2 x 4), wave tile (FR*16) x 64 with FR row fragments: tile (FR*32) x 256 (FR = 8 is the one built);
 //   * one workgroup per CU, ALL LDS in one 128 KiB array: 2 K tiles x 4 "halves" of [128 rows][128 B]:
-//       Aq0 / Aq1 = the first / second 64 rows of each wave row's 128 A rows, Bq0 / Bq1 = the first / second 32
-//       rows of each wave column's 64 B rows -- so a half is exactly what one C quadrant of every wave needs;
-//   * a K tile is 4 phases, one C quadrant (64x32 per wave, 16 MFMAs) each, in the order (0,0) (0,1) (1,1) (1,0):
-//       phase 1 reads Aq0+Bq0 into registers, phase 2 Bq1, phase 3 Aq1, phase 4 nothing;
-//   * every phase stages ONE half by LDS-DMA (2 instructions per wave), 5+ phases before its first read and 2+
-//       phases after the last read of the half it overwrites:  p1: Bq1(kt+1)  p2: Aq1(kt+1)  p3: Aq0(kt+2)  p4: Bq0(kt+2);
-//       the DMA is issued in the phase's read segment (under the OTHER wave row's MFMAs: an LDS-DMA issue stalls its
-//       wave for ~60+ cycles), the waits are vmcnt(8) / none, so four halves (64 KiB) stay in flight across the barriers;
+//       Aq0 = row fragments 0-3 of both wave rows, Aq1 = fragments 4..FR-1, Bq0 / Bq1 = the first / second 32 rows of
+//       each wave column's 64 B rows;
+//   * a K tile is 2 phases: A = fragments 0-3 x all 4 column fragments (32 MFMAs; reads Aq0 and both B halves, 16
+//     ds_read_b128), B = fragments 4..FR-1 with the B registers kept (reads Aq1);
+//   * every phase stages TWO halves by LDS-DMA (4 instructions per wave) in its read segment, i.e. under the OTHER
+//     wave row's MFMAs (an LDS-DMA issue stalls its wave for ~60+ cycles):  A(kt): Bq1(kt+1) Aq1(kt+1),
+//     B(kt): Aq0(kt+2) Bq0(kt+2) -- each 2+ phases before its first read; the waits are vmcnt(8) / vmcnt(6), so three to
+//     four halves (48-64 KiB) stay in flight across the barriers;
 //   * the two wave rows run staggered by one barrier (one does MFMAs under s_setprio while the other reads LDS and
-//       issues DMA); a half is read one phase after the wait that retires it, i.e. two barriers later, which
-//       covers the other group's wait;
-//   * fragment reads are inline asm (the compiler adds no waits of its own), barriers are raw s_barrier.
+//     issues DMA): 4 barriers per K tile.  A read segment ends with lgkmcnt(0) BEFORE its barrier, so a half may be
+//     restaged from the next interval on; a half is read one interval after the wait + barrier that retire it.  A
+//     halves are staged and read by the same wave row, B halves by both (each wave stages 16 rows of every half);
+//   * fragment reads are inline asm (the compiler adds no waits of its own), barriers are raw s_barrier;
+//   * the epilogue stores straight from the accumulators (frag_out).
 // ---------------------------------------------------------------------------------------------
 constexpr int BIG = 256;
 constexpr int HALF_BYTES = 128 * ROW_BYTES;          // 16 KiB
 constexpr int KT_BYTES = 4 * HALF_BYTES;             // one K tile: Aq0 | Bq0 | Bq1 | Aq1
 enum { H_AQ0 = 0, H_BQ0 = 1, H_BQ1 = 2, H_AQ1 = 3 };
 
-template <typename TO, int V = 0>
+__device__ __forceinline__ void wait_dma_halves(int newer) {      // all but the `newer` most recent stagings (2 DMAs each) have landed
+  switch (newer) {
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <typename TO, int FR, int V>                 // V = 1: in-kernel stamps into the workspace (scripts/stamp_big.py)
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
   using T = bf16_t;
+  constexpr int BM = FR * 32, WROWS = FR * 16, NI1 = FR - 4;
+  static_assert(FR >= 5 && FR <= 8, "row fragments per wave");
   __shared__ __attribute__((aligned(16))) char lds[2 * KT_BYTES];
   int z, sp, tm, tn;
   tile_coords(g, z, sp, tm, tn);
   const int z1 = z / g.batch2, z2 = z % g.batch2;
-  const int m0 = tm * BIG, n0 = tn * BIG;
+  const int m0 = tm * BM, n0 = tn * BIG;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 2, wc = w & 3;
   const int nk = g.K / 64;
@@ -1155,97 +1169,103 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
       const int chunk = (lane & 7) ^ (((j & 1) << 2) | (lane >> 4));
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int arow = min(m0 + (irow >> 6) * 128 + q * 64 + (irow & 63), g.M - 1);
+        const int arow = min(m0 + (irow >> 6) * WROWS + q * 64 + (irow & 63), g.M - 1);
         const int brow = min(n0 + (irow >> 5) * 64 + q * 32 + (irow & 31), g.N - 1);
         src[q ? H_AQ1 : H_AQ0][j] = Ab + (long)arow * g.a_rs * 2 + chunk * 16;
         src[q ? H_BQ1 : H_BQ0][j] = Bb + (long)brow * g.b_rs * 2 + chunk * 16;
       }
     }
   }
-  auto stage = [&](int hh, int kt) -> bool {           // half hh of K tile kt (pointers walk K tile by K tile)
-    if (kt >= nk) return false;
+  auto stage = [&](int hh, int kt) {                   // half hh of K tile kt (pointers walk K tile by K tile)
+    if (kt >= nk) return;
     char* dst = lds + (kt & 1) * KT_BYTES + hh * HALF_BYTES + w * 2048;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src[hh][0]), LDS_PTR(dst), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(GLB_PTR(src[hh][1]), LDS_PTR(dst + 1024), 16, 0, 0);
     src[hh][0] += ROW_BYTES; src[hh][1] += ROW_BYTES;
-    return true;
   };
-  unsigned long long stamp[6];
+  unsigned long long stamp[6], cyc0 = 0;
   if constexpr (V == 1) stamp[0] = wall_clock64();
   stage(H_AQ0, 0); stage(H_BQ0, 0); stage(H_BQ1, 0); stage(H_AQ1, 0);
-  const bool two = stage(H_AQ0, 1);
-  stage(H_BQ0, 1);
-  if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                         // Aq0(0), Bq0(0) have landed for every wave
-  unsigned long long cyc0 = 0;
+  stage(H_AQ0, 1); stage(H_BQ0, 1);
+  wait_dma_halves(nk > 1 ? 3 : 1);                      // Aq0(0), Bq0(0), Bq1(0) have landed ...
+  __builtin_amdgcn_s_barrier();                         // ... for every wave
   if constexpr (V == 1) { stamp[1] = wall_clock64(); cyc0 = clock64(); }
 
-  f32x4 acc[8][4];
+  f32x4 acc[FR][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < FR; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  FragRd<T, false> fa[2][4];          // [ks][i]: the A sub-tile of the current wave-row quadrant
-  FragRd<T, false> fb[2][2][2];       // [q][ks][j]: both B sub-tiles (Bq0 is reused by phase 4)
+  FragRd<T, false> fa[2][4];          // [ks][i]: the A fragments of the current phase
+  FragRd<T, false> fb[2][2][2];       // [q][ks][j]: both B halves, read in phase A and kept for phase B
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(lds);
 
   if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger the two wave rows by one barrier
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned cur = lds0 + (unsigned)((kt & 1) * KT_BYTES);
-#define BIG_PHASE(READ_B, BQ, READ_A, AH, STAGE_H, STAGE_KT, QM, QN, NEWER)                                       \
-    {                                                                                                            \
-      if (READ_B) {                                                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-            fb[BQ][ks][j].issue(cur + (BQ ? H_BQ1 : H_BQ0) * HALF_BYTES, wc * 32 + j * 16, ks, lane);            \
-      }                                                                                                          \
-      if (READ_A) {                                                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-            fa[ks][i].issue(cur + (AH) * HALF_BYTES, wr * 64 + i * 16, ks, lane);                                \
-      }                                                                                                          \
-      stage(STAGE_H, STAGE_KT);             /* DMA issue in the read segment: under the OTHER wave row's MFMAs */ \
-      /* retire the half the NEXT phase reads: all but the NEWER most recent stagings (2 DMAs each) */          \
-      switch (NEWER) {                                                                                           \
-        case -1: break;                                                                                          \
-        case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;                                          \
-        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;                                          \
-        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;                                          \
-        case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;                                          \
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;                                         \
-      }                                                                                                          \
-      __builtin_amdgcn_s_barrier();                                                                              \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-      if (READ_B) { _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { fb[BQ][ks][0].tie(); fb[BQ][ks][1].tie(); } }   \
-      if (READ_A) { _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[ks][i].tie(); } \
-      __builtin_amdgcn_s_setprio(1);                                                                             \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-          Mma<T>::step(fb[QN][0][j].get(), fa[0][i].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-          Mma<T>::step(fb[QN][1][j].get(), fa[1][i].get(), acc[(QM) * 4 + i][(QN) * 2 + j]);                    \
-      __builtin_amdgcn_s_setprio(0);                                                                             \
-      __builtin_amdgcn_s_barrier();                                                                              \
-    }
-    // NEWER = stagings issued after the half the NEXT phase reads (they may stay in flight).  In issue order the stagings
-    // are  ... Bq1(kt) Aq1(kt) Aq0(kt+1) Bq0(kt+1) | Bq1(kt+1) Aq1(kt+1) Aq0(kt+2) Bq0(kt+2) ...  (| = start of K tile kt),
-    // each issued in the read segment of its phase, i.e. BEFORE that phase's wait; a staging past the last K tile is skipped.
     const int i1 = kt + 1 < nk, i2 = kt + 2 < nk;
-    BIG_PHASE(true, 0, true, H_AQ0, H_BQ1, kt + 1, 0, 0, (1 + 3 * i1))              // next reads Bq1(kt)
-    BIG_PHASE(true, 1, false, H_AQ0, H_AQ1, kt + 1, 0, 1, (4 * i1))                 // next reads Aq1(kt)
-    BIG_PHASE(false, 0, true, H_AQ1, H_AQ0, kt + 2, 1, 1, -1)                       // next reads nothing new
-    BIG_PHASE(false, 0, false, H_AQ1, H_BQ0, kt + 2, 1, 0, (2 * i1 + 2 * i2))       // next reads Aq0(kt+1), Bq0(kt+1)
-#undef BIG_PHASE
+    // ---- phase A: row fragments 0-3 ----
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[q][ks][j].issue(cur + (q ? H_BQ1 : H_BQ0) * HALF_BYTES, wc * 32 + j * 16, ks, lane);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[ks][i].issue(cur + H_AQ0 * HALF_BYTES, wr * 64 + i * 16, ks, lane);
+    stage(H_BQ1, kt + 1); stage(H_AQ1, kt + 1);
+    // stagings in issue order: .. Bq1(kt) Aq1(kt) | Aq0(kt+1) Bq0(kt+1) | Bq1(kt+1) Aq1(kt+1) | Aq0(kt+2) Bq0(kt+2) ..
+    wait_dma_halves(4 * i1);                            // Aq1(kt), read in phase B, has landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { fb[q][ks][0].tie(); fb[q][ks][1].tie(); }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[ks][i].tie();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<T>::step(fb[j >> 1][ks][j & 1].get(), fa[ks][i].get(), acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase B: row fragments 4 .. FR-1 ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < NI1; ++i) fa[ks][i].issue(cur + H_AQ1 * HALF_BYTES, wr * 64 + i * 16, ks, lane);
+    stage(H_AQ0, kt + 2); stage(H_BQ0, kt + 2);
+    if (i1) wait_dma_halves(1 + 2 * i2);                // Aq0, Bq0, Bq1 of K tile kt+1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < NI1; ++i) fa[ks][i].tie();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < NI1; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<T>::step(fb[j >> 1][ks][j & 1].get(), fa[ks][i].get(), acc[4 + i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();            // the extra barrier of the staggered group
-  __syncthreads();
-  if constexpr (V == 1) { stamp[2] = wall_clock64(); cyc0 = clock64() - cyc0; }
-
-  if constexpr (V == 1) stamp[4] = wall_clock64();
-  frag_out<T, TO, 8, 4>(g, acc, z1, z2, m0 + wr * 128, n0 + wc * 64, lane);
-  if constexpr (V == 1) stamp[5] = wall_clock64();
+  if constexpr (V == 1) { stamp[2] = wall_clock64(); cyc0 = clock64() - cyc0; stamp[4] = stamp[2]; }
+  frag_out<T, TO, FR, 4>(g, acc, z1, z2, m0 + wr * WROWS, n0 + wc * 64, lane);
   if constexpr (V == 1) {
+    stamp[5] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     stamp[3] = wall_clock64();
     if (tid == 0 && g.ws) {
@@ -1564,15 +1584,19 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_fast_kernel<T, TO, ATR_, BTR_, 2>), grid, block, 0, st, k);                    \
   } while (0)
   if constexpr (std::is_same<T, bf16_t>::value) {
-    const long big_tiles = (long)((g->M + BIG - 1) / BIG) * ((g->N + BIG - 1) / BIG) * g->batch1 * g->batch2;
     if (use_tile256(g, p)) {
-      k.tiles_m = (g->M + BIG - 1) / BIG; k.tiles_n = (g->N + BIG - 1) / BIG;
+      // Row fragments per wave: tile rows = 32 * FR.  FR = 7 puts M = 25088 on 224 instead of 196 CUs with 1/8 less work
+      // each, and measured no faster (51.9 vs 51.3 us in-kernel at K = 2048): the K loop is bound by the L2 -> LDS
+      // stream (64 KiB per K tile per CU, ~9 TB/s chip-wide), which more active CUs only load further.  Only FR = 8 is built.
+      constexpr int fr = 8;
+      k.tiles_m = (g->M + 32 * fr - 1) / (32 * fr); k.tiles_n = (g->N + BIG - 1) / BIG;
       k.split_k = 1; k.ws = nullptr;
+      const dim3 gb((unsigned)((long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2));
       if ((g->hint & 15) == BIST_GEMM_TILE256 && (g->hint >> 4) == 1) {        // development aid: in-kernel stamps into the workspace
         k.ws = (float*)g->workspace;
-        hipLaunchKernelGGL((gemm_big_kernel<TO, 1>), dim3((unsigned)big_tiles), dim3(512), 0, st, k);
+        hipLaunchKernelGGL((gemm_big_kernel<TO, fr, 1>), gb, dim3(512), 0, st, k);
       } else {
-        hipLaunchKernelGGL((gemm_big_kernel<TO, 0>), dim3((unsigned)big_tiles), dim3(512), 0, st, k);
+        hipLaunchKernelGGL((gemm_big_kernel<TO, fr, 0>), gb, dim3(512), 0, st, k);
       }
       BIST_LAUNCH_CHECK("bist_gemm(256-tile)");
       return BIST_OK;

@@ -12,8 +12,10 @@ for (M, N, K) in [(25088, 512, 512), (25088, 512, 2048), (4096, 4096, 4096)]:
     for _ in range(3):
         _lib.check(_lib.lib.bist_gemm(C.byref(g), ops._stream()), "gemm")
     torch.cuda.synchronize()
-    nt = ((M + 255) // 256) * ((N + 255) // 256)
+    nt = ((M + 191) // 192) * ((N + 255) // 256)
     st = ws.view(torch.int64)[: nt * 8].cpu().numpy().reshape(nt, 8).astype(np.float64) / 100.0    # us (100 MHz)
+    st = st[st[:, 0] > 0]
+    nt = len(st)
     t0 = st[:, 0].min()
     print(f"M={M} N={N} K={K} tiles={nt}: span {st[:,3].max()-t0:.1f} us; start spread {st[:,0].max()-t0:.1f};"
           f" prologue {np.mean(st[:,1]-st[:,0]):.2f} (max {np.max(st[:,1]-st[:,0]):.2f});"
