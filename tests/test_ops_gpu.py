@@ -166,6 +166,43 @@ def test_gemm_tile256_is_automatic_for_the_frame_grid_products(ops):
     assert torch.equal((small.float().cpu() != 0), kept[:Ms])
 
 
+def test_gemm_tile256_race_screen(ops):
+    """The 256-tile kernel orders its LDS-DMA stagings against the fragment reads by counted vmcnt waits and barriers only
+    (no data dependence the hardware could see): a misplaced wait shows as a rare wrong tile that comes and goes with
+    the memory system's timing.  Screen: the same product 40 times over operand sets larger than the 256 MiB MALL (so
+    the A stream arrives from HBM with varying latency), at 2, 3, 8 and 32 K tiles -- every result bit-identical to the
+    first, and the first equal to the 128-tile kernel's (different schedule, same accumulation order per output)."""
+    import ctypes
+    from bist_amd import _lib
+    dtype = torch.bfloat16
+    for (M, N, K) in [(25088, 512, 2048), (25088, 512, 512), (18100, 768, 192), (4096, 1024, 128)]:
+        nset = max(2, int(400e6 // (2 * M * K)))
+        g = torch.Generator(device="cuda").manual_seed(M + K)
+        A = [(torch.rand(M, K, device="cuda", generator=g) * 2 - 1).to(dtype) for _ in range(nset)]
+        w = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1).to(dtype)
+        kw = dict(M=M, N=N, K=K, a_rs=K, b_rs=K, ldc=N)
+
+        def run(a, hint):
+            out = torch.empty(M, N, device="cuda", dtype=dtype)
+            d = ops.gemm_desc(a, w, out, **kw)
+            d.hint = hint
+            if hint == 0:
+                d.M = M                          # the automatic choice may be the 256-tile kernel as well
+            _lib.check(_lib.lib.bist_gemm(ctypes.byref(d), torch.cuda.current_stream().cuda_stream), "bist_gemm")
+            return out
+        first = [run(a, 2) for a in A]
+        for rep in range(40):
+            i = rep % nset
+            assert torch.equal(run(A[i], 2), first[i]), f"{(M, N, K)}: run {rep} differs from the first"
+        # against the 128-tile kernel on a row slice small enough to take it
+        Ms = 1024
+        small = torch.empty(Ms, N, device="cuda", dtype=dtype)
+        d = ops.gemm_desc(A[0][:Ms], w, small, **dict(kw, M=Ms))
+        assert _lib.lib.bist_gemm_is_fast(d) == 1
+        _lib.check(_lib.lib.bist_gemm(ctypes.byref(d), torch.cuda.current_stream().cuda_stream), "bist_gemm")
+        assert (small.float() - first[0][:Ms].float()).abs().max().item() <= 2e-2 * max(1.0, first[0].float().abs().max().item())
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
 def test_gemm_generic_strides(ops, dtype, tol):
     # K tail (50), unaligned leading dims, transposed operands: all take the generic kernel
