@@ -1537,7 +1537,8 @@ Plan make_plan(const BistGemm* g) {
     return p;
   }
   if (g->workspace && tiles < 192 && nk >= 16) {
-    long s = (512 + tiles - 1) / tiles;
+    static const int target = [] { const char* e = getenv("BIST_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 512; }();   // tuning aid
+    long s = (target + tiles - 1) / tiles;
     if (s > nk / 4) s = nk / 4;
     if (s > 64) s = 64;
     const size_t need = WS_HEADER_BYTES + (size_t)s * g->M * g->N * sizeof(float) * g->batch1 * g->batch2;

@@ -4,7 +4,7 @@ clip with no data-path collective; the only exchange is one sum all-reduce of th
 folded into the Adam kernel's ``grad_scale``."""
 from __future__ import annotations
 
-from typing import Tuple
+from typing import List, Tuple
 
 import torch
 import torch.distributed as dist
@@ -35,6 +35,19 @@ def exchange_gradients(flat_grad: torch.Tensor, group=None, bucket_elems: int = 
         for w in works:
             w.wait()
     return 1.0 / world
+
+
+def chunk_bounds(n: int, chunks: int, align: int = 1) -> List[Tuple[int, int]]:
+    """[lo, hi) element ranges that cut n elements into at most `chunks` pieces whose starts are multiples of `align`."""
+    step = -(-n // max(1, chunks))
+    step = -(-step // align) * align
+    return [(lo, min(n, lo + step)) for lo in range(0, n, step)]
+
+
+def exchange_gradients_async(flat_grad: torch.Tensor, bounds: List[Tuple[int, int]], group=None):
+    """Issue one summing all-reduce per [lo, hi) piece of ``flat_grad`` (in place, in order) and return the work handles;
+    ``handle.wait()`` orders the caller's stream after that piece (RCCL) or blocks the host (gloo)."""
+    return [dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True) for lo, hi in bounds]
 
 
 def noam_rate(step: int, d_model: int, factor: float = 1.0, warmup: int = 4000) -> float:

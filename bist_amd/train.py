@@ -38,6 +38,9 @@ from .ops import _stream, dtype_code
 ALIGN = 64      # elements; keeps every parameter view 16-byte aligned for the LDS-DMA GEMM path
 
 
+EXCHANGE_CHUNKS = 8        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
+
+
 def _round(n: int) -> int:
     return (n + ALIGN - 1) // ALIGN * ALIGN
 
@@ -222,10 +225,25 @@ class Trainer:
         self._step += 1
         self.drop_ctr.fill_(self._step)
         terms = self._graph_backward(batch) if self.use_graph else self.backward(batch)
-        grad_scale = parallel.exchange_gradients(self.flat_grad, self.pg)      # one RCCL all-reduce of the flat buffer
+        # Gradient exchange + optimiser: the flat gradient goes over RCCL in EXCHANGE_CHUNKS large pieces issued back to
+        # back (xGMI is point-to-point: a few large messages keep all 7 links busy), and Adam runs on piece k as soon as its
+        # all-reduce has finished, i.e. under the all-reduce of piece k+1 (the compute stream waits on the collective's
+        # event, never the host).  One rank: a single Adam launch.
         work = None if self.compute_dtype == torch.float32 else self.flat_param
-        check(lib.bist_adam_step(self.master.data_ptr(), self.flat_grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                 work.data_ptr() if work is not None else None, self.numel, self.rate(), self.betas[0],
-                                 self.betas[1], self.eps, self._step, grad_scale, dtype_code(self.compute_dtype),
-                                 dtype_code(self.compute_dtype), _stream()), "bist_adam_step")
+        gsz = self.flat_grad.element_size()
+        rate = self.rate()
+
+        def adam(lo: int, hi: int, grad_scale: float):
+            check(lib.bist_adam_step(self.master.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + gsz * lo, self.m.data_ptr() + 4 * lo,
+                                     self.v.data_ptr() + 4 * lo, (work.data_ptr() + work.element_size() * lo) if work is not None else None,
+                                     hi - lo, rate, self.betas[0], self.betas[1], self.eps, self._step, grad_scale,
+                                     dtype_code(self.compute_dtype), dtype_code(self.compute_dtype), _stream()), "bist_adam_step")
+        if self.world > 1:
+            bounds = parallel.chunk_bounds(self.numel, EXCHANGE_CHUNKS, ALIGN)
+            works = parallel.exchange_gradients_async(self.flat_grad, bounds, self.pg)
+            for (lo, hi), wk in zip(bounds, works):
+                wk.wait()
+                adam(lo, hi, 1.0 / self.world)
+        else:
+            adam(0, self.numel, 1.0)
         return {k: v.detach() for k, v in terms.items()}

@@ -24,6 +24,16 @@ def _worker(rank, world, port, out):
         scale = parallel.exchange_gradients(g, bucket_elems=bucket)
         want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
         assert scale == 1.0 / world and torch.equal(g, want), (bucket, rank)
+    # the trainer's form: pieces issued back to back, each consumed as soon as its own all-reduce is done
+    g = local.clone()
+    bounds = parallel.chunk_bounds(n, 8, 64)
+    assert bounds[0][0] == 0 and bounds[-1][1] == n and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    assert all(lo % 64 == 0 for lo, _ in bounds) and len(bounds) <= 8
+    seen = torch.zeros(n)
+    for (lo, hi), wk in zip(bounds, parallel.exchange_gradients_async(g, bounds)):
+        wk.wait()
+        seen[lo:hi] = g[lo:hi]                                           # what an optimiser launched here would read
+    assert torch.equal(seen, want), rank
     # one SGD-like update with the exchanged gradient is identical on every rank
     w = torch.ones(n) - 0.1 * scale * g
     gathered = [torch.zeros(n) for _ in range(world)]
@@ -52,3 +62,4 @@ def test_single_process_is_identity():
     assert parallel.exchange_gradients(g) == 1.0 and torch.equal(g, torch.ones(5))
     assert abs(parallel.noam_rate(1, 512) - 512 ** -0.5 * 4000 ** -1.5) < 1e-12
     assert parallel.noam_rate(4000, 512) > parallel.noam_rate(8000, 512) > 0
+    assert parallel.chunk_bounds(10, 3) == [(0, 4), (4, 8), (8, 10)] and parallel.chunk_bounds(5, 8, 64) == [(0, 5)]
