@@ -299,8 +299,11 @@ struct RowOut {
       const TO* rp = res + rr * g.ldr + n;
       if (full && g.vec_r) {
         TO q[VW];
+        if constexpr (VW * sizeof(TO) == 8) *reinterpret_cast<uint2*>(q) = *reinterpret_cast<const uint2*>(rp);
+        else {
 #pragma unroll
-        for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(q)[c] = reinterpret_cast<const uint4*>(rp)[c];
+          for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(q)[c] = reinterpret_cast<const uint4*>(rp)[c];
+        }
 #pragma unroll
         for (int e = 0; e < VW; ++e) v[e] += to_f(q[e]);
       } else {
@@ -313,8 +316,11 @@ struct RowOut {
     for (int e = 0; e < VW; ++e) o[e] = from_f<TO>(v[e]);
     TO* dst = C + (long)m * g.ldc + n;
     if (full && g.vec_c) {
+      if constexpr (VW * sizeof(TO) == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(o);
+      else {
 #pragma unroll
-      for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(dst)[c] = reinterpret_cast<const uint4*>(o)[c];
+        for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(dst)[c] = reinterpret_cast<const uint4*>(o)[c];
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < VW; ++e) if (n + e < g.N) dst[e] = o[e];
@@ -1294,6 +1300,37 @@ __global__ void splitk_reduce_kernel(const GemmK g, long total) {
   C[(long)m * g.ldc + n] = from_f<TO>(epilogue_value<T, TO>(g, acc, bv, res, m, n, (unsigned long long)zlin * mn));
 }
 
+// The same for N % 4 == 0 (every product of the path): one thread per 4 consecutive columns, 16-byte slab reads with 8
+// slabs in flight per thread, the row-wise epilogue of the tile kernels (RowOut).
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmK g, long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const long mn = (long)g.M * g.N;
+  const long e0 = idx * 4;
+  const long zlin = e0 / mn, r = e0 % mn;
+  const int m = (int)(r / g.N), n = (int)(r % g.N);
+  const int z1 = (int)(zlin / g.batch2), z2 = (int)(zlin % g.batch2);
+  const float* W = g.ws + WS_HEADER + zlin * g.split_k * mn + r;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= g.split_k; s += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(W + (long)(s + u) * mn);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
+  }
+  for (; s < g.split_k; ++s) {
+    const float4 t = *reinterpret_cast<const float4*>(W + (long)s * mn);
+    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+  }
+  const RowOut<T, TO> out(g, z1, z2, (unsigned long long)zlin * (unsigned long long)mn);
+  float bv[4];
+  out.load_bias(bv, n);
+  out.template row<4>(v, bv, m, n);
+}
+
 // ---------------------------------------------------------------------------------------------
 // generic kernel: arbitrary element strides, any K; register staged, single buffer
 // ---------------------------------------------------------------------------------------------
@@ -1644,7 +1681,8 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
   BIST_LAUNCH_CHECK("bist_gemm");
   if (p.split > 1) {
     const long total = (long)g->M * g->N * g->batch1 * g->batch2;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T, TO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k, total);
+    if (g->N % 4 == 0) hipLaunchKernelGGL((splitk_reduce4_kernel<T, TO>), dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, k, total / 4);
+    else hipLaunchKernelGGL((splitk_reduce_kernel<T, TO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, k, total);
     BIST_LAUNCH_CHECK("bist_gemm(split-K reduce)");
   }
   return BIST_OK;
