@@ -28,6 +28,50 @@ __global__ void epilogue_bwd_kernel(const T* __restrict__ dy, const T* __restric
   dz[m * lddz + n] = from_f<T>(g);
 }
 
+// the same, 8 consecutive columns per thread (N % 8 == 0, 16-byte aligned rows): 16-byte loads / stores, two mask hashes
+template <typename T>
+__global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dz, long M, int N,
+                                                               long lddy, long ldy, long lddz, int act, float drop_p, unsigned long long seed0,
+                                                               const unsigned long long* __restrict__ ctr) {
+  static_assert(sizeof(T) == 2, "bf16 rows");
+  const long idx8 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n8 = N >> 3;
+  if (idx8 >= M * n8) return;
+  const long m = idx8 / n8; const int n = (int)(idx8 % n8) * 8;
+  T g8[8], y8[8];
+  *reinterpret_cast<uint4*>(g8) = *reinterpret_cast<const uint4*>(dy + m * lddy + n);
+  const bool relu = act == BIST_ACT_RELU;
+  if (relu) *reinterpret_cast<uint4*>(y8) = *reinterpret_cast<const uint4*>(y + m * ldy + n);
+  float g[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = to_f(g8[e]);
+  if (drop_p > 0.f) {
+    const float sc = 1.f / (1.f - drop_p);
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] *= sc;
+    } else {
+      const unsigned long long seed = seed0 + (ctr ? ctr[0] * 0xD1B54A32D192ED03ULL : 0ULL);
+      const uint32_t thr = drop_threshold(drop_p);
+      const unsigned long long i4 = (unsigned long long)(m * N + n) >> 2;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint64_t bits = drop_bits4(seed, i4 + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[4 * q + e] = drop_keep_of(bits, e, thr) ? g[4 * q + e] * sc : 0.f;
+      }
+    }
+  }
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (!(to_f(y8[e]) > 0.f)) g[e] = 0.f;
+  }
+  T o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = from_f<T>(g[e]);
+  *reinterpret_cast<uint4*>(dz + m * lddz + n) = *reinterpret_cast<const uint4*>(o);
+}
+
 // out[b, i, :] = sum_g x[b, g, i, :]   (gradient of the expanded-query residual of stage 1)
 template <typename T>
 __global__ void group_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int G, long inner, long total) {
@@ -401,6 +445,14 @@ extern "C" int bist_epilogue_bwd(const void* dy, const void* y, void* dz, int64_
   BIST_REQUIRE(dy && dz && M > 0 && N > 0, "bist_epilogue_bwd: bad argument");
   BIST_REQUIRE(act != BIST_ACT_RELU || y, "bist_epilogue_bwd: relu needs the forward output");
   hipStream_t st = (hipStream_t)stream;
+  auto al = [](const void* p, long ld) { return ((uintptr_t)p % 16 == 0) && (ld % 8 == 0); };
+  if (dtype == BIST_BF16 && N % 8 == 0 && al(dy, lddy) && al(dz, lddz) && (!y || al(y, ldy))) {
+    hipLaunchKernelGGL(epilogue_bwd_vec_kernel<bf16_t>, dim3(blocks_for(M * (N / 8), 256)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y,
+                       (bf16_t*)dz, (long)M, N, (long)lddy, (long)ldy, (long)lddz, act, drop_p, (unsigned long long)drop_seed,
+                       (const unsigned long long*)drop_ctr);
+    BIST_LAUNCH_CHECK("bist_epilogue_bwd");
+    return BIST_OK;
+  }
 #define L(TT, ...) hipLaunchKernelGGL(epilogue_bwd_kernel<TT>, dim3(blocks_for(M * N, 256)), dim3(256), 0, st, (const TT*)dy, (const TT*)y, (TT*)dz, (long)M, N, (long)lddy, (long)ldy, (long)lddz, act, drop_p, (unsigned long long)drop_seed, (const unsigned long long*)drop_ctr)
   DISPATCH_T(dtype, L, 0)
 #undef L
