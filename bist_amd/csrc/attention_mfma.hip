@@ -319,11 +319,11 @@ int launch_one(const St1Args& a, int B, size_t lds, hipStream_t st) {
 }
 
 // =====================================================================================================
-// Stage 2 on the matrix cores (bf16, d = 512-class widths: d % 128 == 0, d <= 512, h <= 8, G <= 64).
+// Stage 2 on the matrix cores (bf16, d = 512-class widths: d % 128 == 0, d <= 512, h <= 8, G <= 128).
 // One workgroup per (clip b, query position i).  LDS images (bf16, 16-byte chunks XOR-swizzled by row & 7 so
 // that both the row reads and the transposing reads are at most 2-way conflicted):
-//   yimg [64 rows g][d]   the G stage-1 outputs of this position (read ONCE from HBM, rows >= G zero)
-//   qg   [32 rows][d]     rows 0-7 folded query q2f, (backward) rows 8-15 dPY, rest zero
+//   yimg [64 or 128 rows g][d]   the G stage-1 outputs of this position (read ONCE from HBM, rows >= G zero)
+//   qg   [8 or 16 rows][d]       rows 0-7 folded query q2f, (backward) rows 8-15 dPY
 // forward :  sc[hh,g] = q2f[hh,:].Y[g,:]  -> softmax over g (mask -> -1e9)  -> PY[hh,:] = sum_g P[hh,g] Y[g,:]
 // backward:  sc, dP[hh,g] = dPY[hh,:].Y[g,:];  dS = P (dP - sum P dP);  dq2f[hh,:] = sum_g dS[hh,g] Y[g,:]
 //            dY[g,:] = sum_hh dS[hh,g] q2f[hh,:] + P[hh,g] dPY[hh,:]      (one K = 16 product against qg)
@@ -354,26 +354,35 @@ struct St2Args {
   DropArg drop;
 };
 
-template <bool BWD>
+// zero the K rows >= 16 of a transposing fragment read (lanes with lane >> 4 >= 2): lets the [dS; P] and [q2f; dPY]
+// images of the backward keep 16 rows instead of 32 zero-padded ones
+__device__ __forceinline__ uint4 k16_only(uint4 v, int lane) {
+  const unsigned m = (lane >> 4) < 2 ? 0xffffffffu : 0u;
+  v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+  return v;
+}
+
+template <bool BWD, int GB>                       // GB = 64-key blocks: G <= 64 GB (GB = 2: T = 128, BASELINE configs[3])
 __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int GP = 64 * GB;                                      // padded key count = pitch of the score / probability images
   const int G = a.G, Lq = a.Lq, h = a.h, d = a.d;
   const int i = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int x = lane & 15, lg = lane >> 4;
-  bf16_t* yimg = reinterpret_cast<bf16_t*>(smem);                  // [64][d]
-  constexpr int QROWS = BWD ? 32 : 8;                              // forward only needs the 8 query rows
-  bf16_t* qg = yimg + 64 * d;                                      // [QROWS][d]
-  float* scf = reinterpret_cast<float*>(qg + QROWS * d);           // [8][64] scores -> probabilities
-  float* dpf = scf + 8 * 64;                                       // [8][64] dP -> dS          (backward)
-  bf16_t* pimg = reinterpret_cast<bf16_t*>(dpf + 8 * 64);          // [32][64]: rows 0-7 A-operand of PY / dq2f (P or dS);
-                                                                   //           backward: rows 0-7 dS, 8-15 P, rest zero
+  bf16_t* yimg = reinterpret_cast<bf16_t*>(smem);                  // [GP][d]
+  constexpr int QROWS = BWD ? 16 : 8;                              // rows 0-7 q2f, (backward) 8-15 dPY
+  bf16_t* qg = yimg + GP * d;                                      // [QROWS][d]
+  float* scf = reinterpret_cast<float*>(qg + QROWS * d);           // [8][GP] scores -> probabilities
+  float* dpf = scf + 8 * GP;                                       // [8][GP] dP -> dS          (backward)
+  bf16_t* pimg = reinterpret_cast<bf16_t*>(dpf + (BWD ? 8 * GP : 0));   // [16][GP]: rows 0-7 A-operand of PY / dq2f (P or dS);
+                                                                   //           backward: rows 0-7 dS, 8-15 P
   const int cpr = d >> 3;                                          // 16-byte chunks per row
   const long qoff = ((long)b * Lq + i) * h * d;
   const long ystride = (long)Lq * d;
   const bf16_t* Yb = a.Y + ((long)b * G * Lq + i) * d;
   // ---- stage the images ---------------------------------------------------------------------------------
-  for (int idx = tid; idx < 64 * cpr; idx += 256) {
+  for (int idx = tid; idx < GP * cpr; idx += 256) {
     const int row = idx / cpr, c = idx - row * cpr;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < G) v = *reinterpret_cast<const uint4*>(Yb + row * ystride + c * 8);
@@ -386,17 +395,18 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
     else if (BWD && row >= 8 && row < 8 + h) v = *reinterpret_cast<const uint4*>(a.dPY + qoff + (long)(row - 8) * d + c * 8);
     *reinterpret_cast<uint4*>(qg + row * d + ((c ^ (row & 7)) << 3)) = v;
   }
-  for (int idx = tid; idx < 32 * 64 / 8; idx += 256) reinterpret_cast<uint4*>(pimg)[idx] = make_uint4(0, 0, 0, 0);
+  for (int idx = tid; idx < 16 * GP / 8; idx += 256) reinterpret_cast<uint4*>(pimg)[idx] = make_uint4(0, 0, 0, 0);
   __syncthreads();
-  // ---- scores (and dP): wave w owns keys g = 16w .. 16w+15 --------------------------------------------------
-  {
+  // ---- scores (and dP): wave w owns keys g = 64 kb + 16w .. +15 of every key block kb --------------------------
+#pragma unroll
+  for (int kb = 0; kb < GB; ++kb) {
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acd = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < d / 32; ++ks) {
-      const uint4 bfr = sfrag_rows(yimg, d, 16 * w + x, ks * 32, lane);
+      const uint4 bfr = sfrag_rows(yimg, d, 64 * kb + 16 * w + x, ks * 32, lane);
       acc = mfma_bf16(sfrag_rows(qg, d, x & 7, ks * 32, lane), bfr, acc);
       if constexpr (BWD) acd = mfma_bf16(sfrag_rows(qg, d, 8 + (x & 7), ks * 32, lane), bfr, acd);
     }
-    const int g = 16 * w + x;
+    const int g = 64 * kb + 16 * w + x;
     if (lg < 2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -404,39 +414,61 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
         float s = acc[r];
         if (g >= G) s = -INFINITY;
         else if (a.gmask && a.gmask[(long)b * G + g] == 0) s = MASK_FILL;
-        scf[hh * 64 + g] = s;
-        if constexpr (BWD) dpf[hh * 64 + g] = acd[r];
+        scf[hh * GP + g] = s;
+        if constexpr (BWD) dpf[hh * GP + g] = acd[r];
       }
     }
   }
   __syncthreads();
-  // ---- softmax over g (wave w: heads 2w, 2w+1; lanes = keys) ----------------------------------------------
+  // ---- softmax over g (wave w: heads 2w, 2w+1; lane = keys lane, lane + 64, ..) ------------------------------
   for (int hh = 2 * w; hh < 2 * w + 2; ++hh) {
     if (hh < h) {
-      const float s = scf[hh * 64 + lane];
-      const float mx = wave_max(s);
-      const float e = lane < G ? expf(s - mx) : 0.f;
-      const float p = e / wave_sum(e);
-      scf[hh * 64 + lane] = p;
-      // dropout of the probabilities (modules.py:62-63): P' = mask * P / (1-p) feeds the weighted sums
-      float m = 1.f;
-      if (a.drop.p > 0.f && lane < G)
-        m = drop_mul(a.drop.key(), (((unsigned long long)b * Lq + i) * h + hh) * G + lane, a.drop.p, a.drop.keep_scale());
+      float s[GB], e[GB], m[GB];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < GB; ++kb) { s[kb] = scf[hh * GP + 64 * kb + lane]; mx = fmaxf(mx, s[kb]); }
+      mx = wave_max(mx);
+      float den = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < GB; ++kb) { e[kb] = (64 * kb + lane < G) ? expf(s[kb] - mx) : 0.f; den += e[kb]; }
+      den = wave_sum(den);
+      const float inv = 1.f / den;
+      float rs = 0.f, dot = 0.f, dp[GB];
+#pragma unroll
+      for (int kb = 0; kb < GB; ++kb) {
+        const int g = 64 * kb + lane;
+        const float p = e[kb] * inv;
+        e[kb] = p;
+        scf[hh * GP + g] = p;
+        // dropout of the probabilities (modules.py:62-63): P' = mask * P / (1-p) feeds the weighted sums
+        m[kb] = 1.f;
+        if (a.drop.p > 0.f && g < G)
+          m[kb] = drop_mul(a.drop.key(), (((unsigned long long)b * Lq + i) * h + hh) * G + g, a.drop.p, a.drop.keep_scale());
+        if constexpr (!BWD) {
+          pimg[hh * GP + g] = (bf16_t)(p * m[kb]);
+          rs += p * m[kb];
+        } else {
+          dp[kb] = g < G ? dpf[hh * GP + g] : 0.f;
+          if (a.d_rowsum && g < G) dp[kb] += a.d_rowsum[((long)b * Lq + i) * h + hh];
+          dp[kb] *= m[kb];                                    // dP = mask/(1-p) * dP'
+          dot += p * dp[kb];
+        }
+      }
       if constexpr (!BWD) {
-        pimg[hh * 64 + lane] = (bf16_t)(p * m);
         if (a.rowsum) {
-          const float rs = wave_sum(p * m);
+          rs = wave_sum(rs);
           if (lane == 0) a.rowsum[((long)b * Lq + i) * h + hh] = rs;
         }
       } else {
-        float dp = lane < G ? dpf[hh * 64 + lane] : 0.f;
-        if (a.d_rowsum && lane < G) dp += a.d_rowsum[((long)b * Lq + i) * h + hh];
-        dp *= m;                                            // dP = mask/(1-p) * dP'
-        const float dot = wave_sum(p * dp);
-        float ds = p * (dp - dot);
-        if (lane >= G || (a.gmask && a.gmask[(long)b * G + lane] == 0)) ds = 0.f;
-        pimg[hh * 64 + lane] = (bf16_t)ds;
-        pimg[(8 + hh) * 64 + lane] = (bf16_t)(p * m);
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int kb = 0; kb < GB; ++kb) {
+          const int g = 64 * kb + lane;
+          float ds = e[kb] * (dp[kb] - dot);
+          if (g >= G || (a.gmask && a.gmask[(long)b * G + g] == 0)) ds = 0.f;
+          pimg[hh * GP + g] = (bf16_t)ds;
+          pimg[(8 + hh) * GP + g] = (bf16_t)(e[kb] * m[kb]);
+        }
       }
     }
   }
@@ -449,8 +481,8 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
       const int col0 = (w * nf + f) * 16;
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        acc = mfma_bf16(frag_rows(pimg, 64, 0, ks * 32, lane & ~8), sfrag_cols(yimg, d, col0, ks * 32, lane), acc);
+      for (int ks = 0; ks < 2 * GB; ++ks)
+        acc = mfma_bf16(frag_rows(pimg, GP, 0, ks * 32, lane & ~8), sfrag_cols(yimg, d, col0, ks * 32, lane), acc);
       if (lg < 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -461,16 +493,19 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
     }
   }
   if constexpr (BWD) {
-    // ---- dY[g, :] = [dS; P]^T (K = 16 heads') x [q2f; dPY]: wave w owns columns as above, all 4 key fragments ----
+    // ---- dY[g, :] = [dS; P]^T (K = 16 heads') x [q2f; dPY]: wave w owns columns as above, all key fragments.  Both
+    //      operands are transposing reads of 16-row images: the K rows 16-31 of the 16x16x32 product are zeroed in
+    //      registers (the read itself is clamped into the image) ----
     const int nf = d / 64;
+    const int lane16 = lane & 31;                    // same (x, kg & 1): rows kg*8 + q stay below 16
     bf16_t* dYb = a.dY + ((long)b * G * Lq + i) * d;
     for (int f = 0; f < nf; ++f) {
       const int col0 = (w * nf + f) * 16;
-      const uint4 bfr = sfrag_cols(qg, d, col0, 0, lane);
+      const uint4 bfr = k16_only(sfrag_cols(qg, d, col0, 0, lane16), lane);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
+      for (int mi = 0; mi < 4 * GB; ++mi) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc = mfma_bf16(frag_cols(pimg, 64, mi * 16, 0, lane), bfr, acc);
+        acc = mfma_bf16(k16_only(frag_cols(pimg, GP, mi * 16, 0, lane16), lane), bfr, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int g = mi * 16 + lg * 4 + r;
@@ -711,20 +746,22 @@ int bist_mha_bwd_mfma(const void* Q, const void* K, const void* V, const unsigne
 // returns 1 if launched, 0 if outside the envelope, -1 on launch error
 int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, void* PY, const void* dPY, void* dq2f, void* dY,
                   float* rowsum, const float* d_rowsum, int B, int G, int Lq, int h, int d, int bwd, const DropArg& drop, hipStream_t st) {
-  if (G > 64 || h > 8 || d > 512 || (d % 128) != 0) return 0;
+  if (G > 128 || h > 8 || d > 512 || (d % 128) != 0) return 0;
   if (((uintptr_t)q2f | (uintptr_t)Y | (uintptr_t)(bwd ? dPY : q2f)) % 16) return 0;
-  const size_t lds = (size_t)64 * d * 2 + (size_t)(bwd ? 32 : 8) * d * 2 + 2 * 8 * 64 * 4 + 32 * 64 * 2;
+  const int gb = G > 64 ? 2 : 1, gp = 64 * gb;
+  const size_t lds = (size_t)gp * d * 2 + (size_t)(bwd ? 16 : 8) * d * 2 + (size_t)(bwd ? 2 : 1) * 8 * gp * 4 + 16 * gp * 2;
   St2Args a{(const bf16_t*)q2f, (const bf16_t*)Y, gmask, (bf16_t*)PY, (const bf16_t*)dPY, (bf16_t*)dq2f, (bf16_t*)dY, G, Lq, h, d,
             rowsum, d_rowsum, drop};
-  static bool attr_f = false, attr_b = false;
   dim3 grid((unsigned)Lq, (unsigned)B);
-  if (bwd) {
-    if (!attr_b) { hipFuncSetAttribute(reinterpret_cast<const void*>(&st2_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_b = true; }
-    hipLaunchKernelGGL(st2_mfma_kernel<true>, grid, dim3(256), lds, st, a);
-  } else {
-    if (!attr_f) { hipFuncSetAttribute(reinterpret_cast<const void*>(&st2_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_f = true; }
-    hipLaunchKernelGGL(st2_mfma_kernel<false>, grid, dim3(256), lds, st, a);
-  }
+#define ST2_GO(BWD_, GB_)                                                                                                  \
+  do {                                                                                                                     \
+    static bool attr = false;                                                                                              \
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&st2_mfma_kernel<BWD_, GB_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    hipLaunchKernelGGL((st2_mfma_kernel<BWD_, GB_>), grid, dim3(256), lds, st, a);                                         \
+  } while (0)
+  if (bwd) { if (gb == 2) ST2_GO(true, 2); else ST2_GO(true, 1); }
+  else { if (gb == 2) ST2_GO(false, 2); else ST2_GO(false, 1); }
+#undef ST2_GO
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 

@@ -329,7 +329,8 @@ def test_stage2_backward(env):
     _check(lambda q, y: Fn.st_stage2(q, y, gm.cuda(), h=h)[0], ref, [q2f, y], "stage2")
 
 
-@pytest.mark.parametrize("B,G,Lq,h,d,masked", [(2, 49, 20, 8, 512, False), (2, 32, 20, 8, 512, True), (1, 64, 7, 4, 128, True)])
+@pytest.mark.parametrize("B,G,Lq,h,d,masked", [(2, 49, 20, 8, 512, False), (2, 32, 20, 8, 512, True), (1, 64, 7, 4, 128, True),
+                                               (2, 128, 20, 8, 512, True), (1, 100, 5, 8, 256, False), (1, 65, 3, 2, 128, True)])
 def test_stage2_bf16_matrix_core_path(env, B, G, Lq, h, d, masked):
     """bf16 stage-2 kernels (MFMA, swizzled LDS images) forward and backward against fp64 on the rounded inputs."""
     ag, Fn, ops = env
