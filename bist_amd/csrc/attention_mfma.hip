@@ -64,16 +64,18 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
   float* slab = reinterpret_cast<float*>(smem);                              // [Lq][Gc][KP]
   const int slab_bytes = ((Lq * Gc * KP * 4 + 15) / 16) * 16;
   bf16_t* pimg = reinterpret_cast<bf16_t*>(smem + slab_bytes);               // [Gc][32][KPAD]
-  bf16_t* vimg = pimg + Gc * 32 * KPAD;                                      // [4 waves][KPAD][64]
-  bf16_t* doimg = vimg + 4 * KPAD * DK;                                      // [4 waves][32][64]   (backward only)
+  bf16_t* vimg = pimg + Gc * 32 * KPAD;                                      // [Gc waves][KPAD][64]
+  bf16_t* doimg = vimg + Gc * KPAD * DK;                                     // [Gc waves][32][64]   (backward only)
   bf16_t* vt = vimg + w * KPAD * DK;
   bf16_t* dt = doimg + w * 32 * DK;
   {   // zero what the phases below do not overwrite: the P images, the key-padding rows of the V tiles, the query-padding
       // rows of the dO tiles (padding must be finite: it meets zero probabilities / zero rows in the MFMAs)
     for (int q = tid; q < Gc * 32 * KPAD / 8; q += 256) reinterpret_cast<uint4*>(pimg)[q] = make_uint4(0, 0, 0, 0);
-    for (int q = lane; q < (KPAD - Kn) * 8; q += 64) reinterpret_cast<uint4*>(vt + Kn * DK)[q] = make_uint4(0, 0, 0, 0);
-    if constexpr (BWD)
-      for (int q = lane; q < (32 - Lq) * 8; q += 64) reinterpret_cast<uint4*>(dt + Lq * DK)[q] = make_uint4(0, 0, 0, 0);
+    if (w < Gc) {
+      for (int q = lane; q < (KPAD - Kn) * 8; q += 64) reinterpret_cast<uint4*>(vt + Kn * DK)[q] = make_uint4(0, 0, 0, 0);
+      if constexpr (BWD)
+        for (int q = lane; q < (32 - Lq) * 8; q += 64) reinterpret_cast<uint4*>(dt + Lq * DK)[q] = make_uint4(0, 0, 0, 0);
+    }
   }
   // This wave's group (one per wave: Gc <= 4): start its V tile (and dO tile) now, so the HBM latency hides
   // behind the slab gather and the softmax.  LDS image as it lies in HBM: [k][64 channels].
@@ -774,13 +776,17 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
   if (bwd && ((lddv % 8) != 0 || ((long)h * dk) % 8 != 0 || !sc_is_f32)) return 0;
   const int ksteps = Kn <= 32 ? 1 : (Kn <= 64 ? 2 : 4);
   const int kpad = 32 * ksteps;
-  const long per_g = (long)Lq * (Kn + 1) * 4 + 32L * kpad * 2;
-  const long fixed = 4L * kpad * 64 * 2 + (bwd ? 4L * 32 * 64 * 2 : 0) + 16;
-  int Gc = (int)((150 * 1024 - fixed) / per_g);
+  // per group: slab rows + P image + V tile (+ dO tile); one group per wave, at most 4
+  const long per_g = (long)Lq * (Kn + 1) * 4 + 32L * kpad * 2 + (long)kpad * 64 * 2 + (bwd ? 32L * 64 * 2 : 0);
+  int Gc = (int)((150 * 1024 - 32) / per_g);
   if (Gc < 1) return 0;
-  if (Gc > 4) Gc = 4;                       // one group per wave: <= 80 KiB of LDS, two workgroups per CU
+  if (Gc > 4) Gc = 4;
+  static const int force_gc = [] { const char* e = getenv("BIST_ST1_GC"); return e ? atoi(e) : 0; }();      // tuning aid
+  if (kpad >= 128 && Gc > 2) Gc = 2;        // 128 keys: two groups per workgroup keep two workgroups on a CU (146 vs 168 us at T = 128)
+  if (force_gc >= 1 && force_gc < Gc) Gc = force_gc;
   if (Gc > G) Gc = G;
-  const size_t lds = (size_t)(((long)Lq * Gc * (Kn + 1) * 4 + 15) / 16 * 16) + (size_t)Gc * 32 * kpad * 2 + (size_t)fixed;
+  const size_t lds = (size_t)(((long)Lq * Gc * (Kn + 1) * 4 + 15) / 16 * 16) + (size_t)Gc * 32 * kpad * 2 + (size_t)Gc * kpad * 64 * 2 +
+                     (bwd ? (size_t)Gc * 32 * 64 * 2 : 0) + 16;
   static const int dbg = [] { const char* e = getenv("BIST_ST1_DBG"); return e ? atoi(e) : 0; }();
   St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc, dbg, drop};
 #define GO(TS_, KS_)                                                                   \

@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bist_amd import ops
 
-B = int(os.environ.get("B", 64)); T, S, Lq, h, dk = 32, 49, 20, 8, 64
+B = int(os.environ.get("B", 64)); T = int(os.environ.get("T", 32)); S, Lq, h, dk = 49, 20, 8, 64
 d = h * dk
 sc = torch.randn(B, Lq * h, T * S, device="cuda")
 v = torch.randn(B, T, S, 2 * d, device="cuda").bfloat16()
