@@ -98,8 +98,11 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
     """C = epilogue(alpha * A.B^T) with explicit element strides (see include/bist_hip.h)."""
     g = gemm_desc(a, b, c, **kw)
     if GEMM_TIMING is not None and (GEMM_TIMING_SHAPE is None or GEMM_TIMING_SHAPE == (g.M, g.N, g.K)):
-        # bench.py: HIP events around the launch, on the launch stream
+        # bench.py: HIP events around the launch, on the launch stream.  An eager pass is host-bound (~10 us of Python per
+        # launch), so the device would reach e0 long before the kernel is even submitted and the interval would include
+        # that host latency; a ~100 us spin queued first lets the host run ahead, and e0 / kernel / e1 execute back to back.
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(200_000)
         e0.record()
         check(lib.bist_gemm(C.byref(g), _stream()), "bist_gemm")
         e1.record()
