@@ -493,6 +493,28 @@ class AddFn(Function):
         return dy, dy
 
 
+class FanOutFn(Function):
+    """n aliases of one tensor for n consumers; backward sums their gradients in ONE pass (bist_add_n) where autograd's
+    own accumulation makes n-1 pairwise passes.  The video tensor of the reasoning layers has 3 L consumers, each with a
+    [B*T*S, d] gradient; the encoded texts feed every decoder layer."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        if len({g.dtype for g in gs}) > 1:
+            gs = [g.to(gs[0].dtype) for g in gs]
+        return ops.add_n(gs), None
+
+
 class CastFn(Function):
     @staticmethod
     def forward(ctx, x, dtype):

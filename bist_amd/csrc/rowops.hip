@@ -206,6 +206,56 @@ extern "C" int bist_fuse_modalities(const void* score, const void* const* xs, vo
   return BIST_OK;
 }
 
+namespace {
+struct AddNPtrs { const void* p[BIST_ADD_N_MAX]; };
+// 8 (bf16) or 4 (f32) elements per thread, 16-byte loads from every source, fp32 sums
+template <typename T>
+__global__ __launch_bounds__(256) void add_n_kernel(const AddNPtrs src, int n, T* __restrict__ out, long numel) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VW;
+  if (i0 >= numel) return;
+  float acc[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) acc[e] = 0.f;
+  if (i0 + VW <= numel) {
+    for (int j = 0; j < n; ++j) {
+      T v[VW];
+      *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(src.p[j]) + i0);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) acc[e] += to_f(v[e]);
+    }
+    T o[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) o[e] = from_f<T>(acc[e]);
+    *reinterpret_cast<uint4*>(out + i0) = *reinterpret_cast<const uint4*>(o);
+  } else {
+    for (int e = 0; i0 + e < numel; ++e) {
+      float a = 0.f;
+      for (int j = 0; j < n; ++j) a += to_f(reinterpret_cast<const T*>(src.p[j])[i0 + e]);
+      out[i0 + e] = from_f<T>(a);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int bist_add_n(const void* const* srcs, int32_t n, void* out, int64_t numel, int32_t dtype, void* stream) {
+  BIST_REQUIRE(srcs && out && n >= 1 && n <= BIST_ADD_N_MAX && numel > 0, "bist_add_n: bad argument (n = %d)", (int)n);
+  AddNPtrs p{};
+  for (int j = 0; j < n; ++j) {
+    BIST_REQUIRE(srcs[j] && ((uintptr_t)srcs[j] % 16) == 0, "bist_add_n: source %d null or not 16-byte aligned", j);
+    p.p[j] = srcs[j];
+  }
+  BIST_REQUIRE(((uintptr_t)out % 16) == 0, "bist_add_n: out not 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == BIST_BF16)
+    hipLaunchKernelGGL(add_n_kernel<bf16_t>, dim3(blocks_for((numel + 7) / 8, 256)), dim3(256), 0, st, p, n, (bf16_t*)out, (long)numel);
+  else if (dtype == BIST_F32)
+    hipLaunchKernelGGL(add_n_kernel<float>, dim3(blocks_for((numel + 3) / 4, 256)), dim3(256), 0, st, p, n, (float*)out, (long)numel);
+  else { bist_set_error("bist_add_n: bad dtype %d", dtype); return BIST_EINVAL; }
+  BIST_LAUNCH_CHECK("bist_add_n");
+  return BIST_OK;
+}
+
 extern "C" int bist_cast(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, void* stream) {
   BIST_REQUIRE(src && dst && n > 0, "bist_cast: bad argument");
   hipStream_t st = (hipStream_t)stream;

@@ -129,6 +129,17 @@ def add(a, b):
     return ops.add(a, b)
 
 
+class Fan:
+    """Hands out the aliases of FanOutFn one by one; once they are used up (or without autograd) the tensor itself."""
+
+    def __init__(self, x, n: int):
+        self.x = x
+        self._it = iter(ag.FanOutFn.apply(x, n)) if (n > 1 and _grad() and x.requires_grad and x.is_cuda) else iter(())
+
+    def take(self):
+        return next(self._it, self.x)
+
+
 def cast(x, dtype):
     if x.dtype == dtype:
         return x

@@ -28,9 +28,12 @@ class MultimodalDecoderLayer12(nn.Module):
 
     def forward(self, b, ft, x):
         a, s, args = self.attn, self.sublayer, self.args
+        fans = ft.get("_bist_mem_fan") or {}             # training: per-layer aliases of the encoded texts (one-pass gradient sum)
+        his = fans["encoded_his"].take() if "encoded_his" in fans else ft["encoded_his"]
+        qry = fans["encoded_query"].take() if "encoded_query" in fans else ft["encoded_query"]
         x = _self_attention(s[0], a[0], x, b.trg_mask)                                   # decoder.py:21
-        x = _cross_attention(s[1], a[1], x, ft["encoded_his"], b.his_mask)               # :22
-        x = _cross_attention(s[2], a[2], x, ft["encoded_query"], b.query_mask)           # :23
+        x = _cross_attention(s[1], a[1], x, his, b.his_mask)                             # :22
+        x = _cross_attention(s[2], a[2], x, qry, b.query_mask)                           # :23
         cnt = 3
         if args.nb_venc_blocks > 0 and args.nb_cenc_blocks > 0 and getattr(args, "enc_vc_combine", "none") != "none":
             x = _cross_attention(s[cnt], a[cnt], x, ft["encoded_ft"], b.query_mask); cnt += 1            # :27-29
@@ -141,6 +144,11 @@ class MultimodalDecoder8(nn.Module):
         cache = [] if use_cache else None
         q = ft["encoded_query"]
         in_ft = {"t2s": q, "s2t": q, "audio": q, "cap": q}
+        if self.v_N > 0 and "spatiotemporal_ft" in ft:
+            # training: the video tensor feeds 3 products per reasoning layer; their [B*T*S, d] gradients are summed in one pass
+            ft["_bist_vft_fan"] = Fn.Fan(ft["spatiotemporal_ft"], 3 * len(self.layers))
+        if torch.is_grad_enabled():
+            ft["_bist_mem_fan"] = {k: Fn.Fan(ft[k], len(self.layers)) for k in ("encoded_his", "encoded_query") if k in ft}
         for l, layer in enumerate(self.layers):
             fork_cap = self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda
             if fork_cap:                     # the caption reasoning layer is independent of the visual one
@@ -164,6 +172,8 @@ class MultimodalDecoder8(nn.Module):
             if cache is not None:
                 cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})
             x = layer(b, ft, x)                                                              # :182
+        ft.pop("_bist_vft_fan", None)
+        ft.pop("_bist_mem_fan", None)
         if cache is not None:
             ft["_bist_reasoning"] = cache
         ft["decoded_text"] = self.norm(x)                                                    # :185

@@ -182,6 +182,8 @@ class VidEncoderLayer4(nn.Module):
 
     def forward(self, in_ft: Dict[str, Tensor], ft: Dict[str, Tensor], b) -> Dict[str, Tensor]:
         vft = ft["spatiotemporal_ft"]
+        fan = ft.get("_bist_vft_fan")                      # aliases whose gradients are summed in one pass (training)
+        vft_v, vft_t2s, vft_s2t = (fan.take(), fan.take(), fan.take()) if fan is not None else (vft, vft, vft)
         t2s_on = (not hasattr(self.args, "t2s")) or self.args.t2s
         s2t_on = (not hasattr(self.args, "s2t")) or self.args.s2t
         concurrent = t2s_on and s2t_on and Fn.CONCURRENT and vft.is_cuda
@@ -196,20 +198,20 @@ class VidEncoderLayer4(nn.Module):
             v_stream = Fn.side_stream(2)
             v_stream.wait_stream(main)
             with torch.cuda.stream(v_stream):
-                v_t2s, v_s2t = self.value_projection(vft)
+                v_t2s, v_s2t = self.value_projection(vft_v)
         else:
-            v_t2s, v_s2t = self.value_projection(vft)
+            v_t2s, v_s2t = self.value_projection(vft_v)
         self._v_ready = v_stream
 
         def t2s_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
-            y = self._stage1(ai + 1, si + 1, x, vft, v_t2s, b.temporal_mask, 0)                   # A1
+            y = self._stage1(ai + 1, si + 1, x, vft_t2s, v_t2s, b.temporal_mask, 0)               # A1
             z = self._stage2(ai + 2, si + 2, x, y, None)                                          # A2
             in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
 
         def s2t_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
-            y = self._stage1(ai + 1, si + 1, x, vft, v_s2t, None, 1)                              # A4
+            y = self._stage1(ai + 1, si + 1, x, vft_s2t, v_s2t, None, 1)                          # A4
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
 

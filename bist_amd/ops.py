@@ -357,6 +357,24 @@ def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+ADD_N_MAX = 24
+
+
+def add_n(xs, out: Optional[Tensor] = None) -> Tensor:
+    """sum of same-shape contiguous tensors in one pass (bist_add_n); more than ADD_N_MAX terms go in rounds."""
+    xs = [x.contiguous() for x in xs]
+    _dev(*xs)
+    if out is None:
+        out = torch.empty_like(xs[0])
+    first = True
+    for o in range(0, len(xs), ADD_N_MAX - 1):
+        part = xs[o:o + ADD_N_MAX - 1] if first else [out] + xs[o:o + ADD_N_MAX - 1]
+        arr = (C.c_void_p * len(part))(*[t.data_ptr() for t in part])
+        check(lib.bist_add_n(arr, len(part), out.data_ptr(), out.numel(), dtype_code(out.dtype), _stream()), "bist_add_n")
+        first = False
+    return out
+
+
 def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """a + b (b broadcast over leading dims when smaller) -- SublayerConnection's residual add."""
     _dev(a, b)

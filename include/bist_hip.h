@@ -217,6 +217,13 @@ int bist_fuse_modalities(const void* score, const void* const* xs, void* out, in
  * not fused into a GEMM epilogue; nb < n broadcasts b.                                          */
 int bist_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t nb, int32_t dtype, void* stream);
 
+/* out[i] = sum_j srcs[j][i] for n <= BIST_ADD_N_MAX contiguous tensors of `numel` elements (fp32 accumulation): the
+ * gradient of a tensor with n consumers (the video tensor feeds 3 products in each of the L reasoning layers) in ONE
+ * pass, where autograd's AccumulateGrad chain (what train.py:32 `loss.backward()` does under PyTorch) makes n-1
+ * pairwise passes.  srcs = host array of device pointers; out may alias srcs[0].                                  */
+#define BIST_ADD_N_MAX 24
+int bist_add_n(const void* const* srcs, int32_t n, void* out, int64_t numel, int32_t dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Output heads ("next" row (f)-2 of SURVEY.md section 8; needed for the logits parity gate).
  * ------------------------------------------------------------------------------------------ */

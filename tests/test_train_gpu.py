@@ -687,3 +687,21 @@ def test_embedding_position_dropout(env):
     (out.double() * go.cuda()).sum().backward()
     _close(out, ref.detach(), "embed dropout fwd", 2e-5)
     _close(ld.grad, lr.grad, "embed dropout dlut", 2e-5)
+
+
+def test_fan_out_sums_consumer_gradients_in_one_pass(env):
+    """FanOutFn: n aliases, one n-ary gradient sum (bist_add_n) equal to autograd's pairwise accumulation; more terms than
+    one launch takes go in rounds; unused aliases contribute nothing."""
+    ag, Fn, ops = env
+    for dtype, n, shape in ((torch.float32, 5, (7, 33)), (torch.bfloat16, 30, (64, 40)), (torch.bfloat16, 3, (1000, 512))):
+        x = _rand(*shape, seed=90).to(dtype).cuda().requires_grad_(True)
+        ws = [_rand(*shape, seed=91 + j).to(dtype).cuda() for j in range(n)]
+        fan = Fn.Fan(x, n + 1)                                  # one alias is never used
+        ys = [fan.take() * w for w in ws]
+        torch.stack([y.float().sum() for y in ys]).sum().backward()
+        ref = torch.stack([w.double() for w in ws]).sum(0)
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        _close(x.grad, ref.cpu(), f"fan-out grad {dtype} n={n}", tol)
+    assert Fn.Fan(ws[0], 3).take() is ws[0]                     # no autograd: the tensor itself
+    out = ops.add_n([w.float() for w in ws[:3]])
+    assert torch.allclose(out, ws[0].float() + ws[1].float() + ws[2].float())
