@@ -201,6 +201,15 @@ def side_stream(i: int):
     return st
 
 
+def join_side_streams() -> None:
+    """Order the current stream after everything queued on the side streams (end of a backward pass: the weight-gradient
+    GEMMs of a side branch write the flat gradient directly, which autograd's own leaf-stream join does not see)."""
+    cur = torch.cuda.current_stream()
+    for (dev, _), st in _SIDE.items():
+        if dev == torch.cuda.current_device():
+            cur.wait_stream(st)
+
+
 def column_block(w: Tensor, j: int, d: int) -> Tensor:
     """w[:, j*d:(j+1)*d] of a concat-consuming weight (vc_combine_W, pointer_gen_W).  Under the trainer the block
     carries its own view of the flat gradient, so the weight-gradient GEMM accumulates in place and autograd never

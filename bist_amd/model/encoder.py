@@ -190,8 +190,9 @@ class VidEncoderLayer4(nn.Module):
         v_stream = None
         main = torch.cuda.current_stream() if concurrent else None
         if concurrent and not torch.is_grad_enabled():
-            # (inference only: with autograd the extra stream's backward work is not joined back before the end of a
-            # hipGraph capture -- capture_end crashes in the HIP runtime -- so training keeps V on the main stream)
+            # (inference only: under autograd a third forked stream makes hipGraph capture of the training step crash in
+            # the HIP runtime -- also with every side stream joined explicitly after backward -- so training keeps V on
+            # the main stream)
             # The value projections are the layer's big GEMMs and depend on the video tensor only: they run on
             # their own stream, under the query-side chains (self-attention, LayerNorm, Q projection, fold) of the
             # two directions, and are awaited just before the stage-1 cores.

@@ -32,6 +32,7 @@ from ._lib import check, lib
 from .model.label_smoothing import LabelSmoothing
 from .model.modules import MultiHeadedAttention
 from .model.optimize import SimpleLossCompute
+from . import functional as Fn
 from . import ops, parallel
 from .ops import _stream, dtype_code
 
@@ -169,6 +170,8 @@ class Trainer:
         ops.WGRAD_STREAM = wg                 # weight-gradient GEMMs: off the critical path, on their own stream
         try:
             loss.backward()
+            if loss.is_cuda:
+                Fn.join_side_streams()
             if wg is not None:
                 torch.cuda.current_stream().wait_stream(wg)
             ops.col_sum_flush()

@@ -21,5 +21,9 @@ with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
 torch.cuda.synchronize()
 rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::")]
 rows.sort(key=lambda e: -e.count)
-for e in rows[:40]:
+skip = ("aten::view", "aten::reshape", "aten::slice", "aten::as_strided", "aten::empty", "aten::empty_like", "aten::empty_strided",
+        "aten::view_as", "aten::transpose", "aten::permute", "aten::select", "aten::unsqueeze", "aten::squeeze", "aten::expand",
+        "aten::detach", "aten::alias", "aten::t", "aten::_unsafe_view", "aten::unflatten", "aten::stride", "aten::size", "aten::is_nonzero",
+        "aten::resize_", "aten::set_", "aten::result_type", "aten::to", "aten::lift_fresh", "aten::item", "aten::_local_scalar_dense")
+for e in [r for r in rows if r.key not in skip][:60]:
     print(f"{e.key:32s} n={e.count:4d}  shapes={str(e.input_shapes)[:110]}")
