@@ -145,8 +145,8 @@ class MultimodalDecoder8(nn.Module):
         q = ft["encoded_query"]
         in_ft = {"t2s": q, "s2t": q, "audio": q, "cap": q}
         if self.v_N > 0 and "spatiotemporal_ft" in ft:
-            # training: the video tensor feeds 3 products per reasoning layer; their [B*T*S, d] gradients are summed in one pass
-            ft["_bist_vft_fan"] = Fn.Fan(ft["spatiotemporal_ft"], 3 * len(self.layers))
+            # training: the video tensor feeds 4 products per reasoning layer (2 score products, 2 value projections); their [B*T*S, d] gradients are summed in one pass
+            ft["_bist_vft_fan"] = Fn.Fan(ft["spatiotemporal_ft"], 4 * len(self.layers))
         if torch.is_grad_enabled():
             ft["_bist_mem_fan"] = {k: Fn.Fan(ft[k], len(self.layers)) for k in ("encoded_his", "encoded_query") if k in ft}
         for l, layer in enumerate(self.layers):

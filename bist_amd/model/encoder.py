@@ -183,36 +183,50 @@ class VidEncoderLayer4(nn.Module):
     def forward(self, in_ft: Dict[str, Tensor], ft: Dict[str, Tensor], b) -> Dict[str, Tensor]:
         vft = ft["spatiotemporal_ft"]
         fan = ft.get("_bist_vft_fan")                      # aliases whose gradients are summed in one pass (training)
-        vft_v, vft_t2s, vft_s2t = (fan.take(), fan.take(), fan.take()) if fan is not None else (vft, vft, vft)
+        take = fan.take if fan is not None else (lambda: vft)
+        vft_t2s, vft_s2t = take(), take()
         t2s_on = (not hasattr(self.args, "t2s")) or self.args.t2s
         s2t_on = (not hasattr(self.args, "s2t")) or self.args.s2t
         concurrent = t2s_on and s2t_on and Fn.CONCURRENT and vft.is_cuda
         v_stream = None
         main = torch.cuda.current_stream() if concurrent else None
-        if concurrent and not torch.is_grad_enabled():
+
+        def branch_v(ai):
+            a = self.attn[ai]
+            B, T, S, d = vft.shape
+            return Fn.linear(take().view(B * T * S, d), a.linears[2].weight, a.linears[2].bias).view(B, T, S, d)
+
+        per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V
+        v_t2s = v_s2t = None
+        if per_branch_v:
+            # training: one value GEMM per direction (each dV is a whole tensor), issued INSIDE its branch, so that the
+            # projection and its two backward products run on that branch's stream
+            pass
+        elif torch.is_grad_enabled() and t2s_on and s2t_on:
+            v_t2s, v_s2t = branch_v(1), branch_v(4)
+        elif concurrent:
             # (inference only: under autograd a third forked stream makes hipGraph capture of the training step crash in
-            # the HIP runtime -- also with every side stream joined explicitly after backward -- so training keeps V on
-            # the main stream)
+            # the HIP runtime -- also with every side stream joined explicitly after backward)
             # The value projections are the layer's big GEMMs and depend on the video tensor only: they run on
             # their own stream, under the query-side chains (self-attention, LayerNorm, Q projection, fold) of the
             # two directions, and are awaited just before the stage-1 cores.
             v_stream = Fn.side_stream(2)
             v_stream.wait_stream(main)
             with torch.cuda.stream(v_stream):
-                v_t2s, v_s2t = self.value_projection(vft_v)
+                v_t2s, v_s2t = self.value_projection(take())
         else:
-            v_t2s, v_s2t = self.value_projection(vft_v)
+            v_t2s, v_s2t = self.value_projection(take())
         self._v_ready = v_stream
 
         def t2s_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
-            y = self._stage1(ai + 1, si + 1, x, vft_t2s, v_t2s, b.temporal_mask, 0)               # A1
+            y = self._stage1(ai + 1, si + 1, x, vft_t2s, branch_v(ai + 1) if per_branch_v else v_t2s, b.temporal_mask, 0)   # A1
             z = self._stage2(ai + 2, si + 2, x, y, None)                                          # A2
             in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
 
         def s2t_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
-            y = self._stage1(ai + 1, si + 1, x, vft_s2t, v_s2t, None, 1)                          # A4
+            y = self._stage1(ai + 1, si + 1, x, vft_s2t, branch_v(ai + 1) if per_branch_v else v_s2t, None, 1)              # A4
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
 
