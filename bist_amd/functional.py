@@ -204,6 +204,9 @@ def side_stream(i: int):
 BRANCH_V = os.environ.get("BIST_BRANCH_V", "0") != "0"      # tuning aid: value projection of a direction inside its branch (training); measured slower (14.5 vs 13.0 ms)
 
 
+PIPELINE_DECODER = os.environ.get("BIST_PIPELINE_DECODER", "1") != "0"      # tuning aid: decoder layer l under reasoning layer l+1
+
+
 def join_side_streams() -> None:
     """Order the current stream after everything queued on the side streams (end of a backward pass: the weight-gradient
     GEMMs of a side branch write the flat gradient directly, which autograd's own leaf-stream join does not see)."""

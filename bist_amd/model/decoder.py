@@ -149,6 +149,7 @@ class MultimodalDecoder8(nn.Module):
             ft["_bist_vft_fan"] = Fn.Fan(ft["spatiotemporal_ft"], 4 * len(self.layers))
         if torch.is_grad_enabled():
             ft["_bist_mem_fan"] = {k: Fn.Fan(ft[k], len(self.layers)) for k in ("encoded_his", "encoded_query") if k in ft}
+        dec_pending = None
         for l, layer in enumerate(self.layers):
             fork_cap = self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda
             if fork_cap:                     # the caption reasoning layer is independent of the visual one
@@ -171,7 +172,18 @@ class MultimodalDecoder8(nn.Module):
             self._fuse(ft)
             if cache is not None:
                 cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})
-            x = layer(b, ft, x)                                                              # :182
+            if fork_cap and Fn.PIPELINE_DECODER:
+                # The decoder layer needs this layer's fused memory, the NEXT reasoning layer does not need the decoder
+                # layer: it goes to the caption stream (ahead of the next caption layer) and runs under the next
+                # layer's visual reasoning; the join at the end of that layer (or below) waits for it.
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    x = layer(b, ft, x)                                                      # :182
+                dec_pending = side
+            else:
+                x = layer(b, ft, x)                                                          # :182
+        if dec_pending is not None:
+            torch.cuda.current_stream().wait_stream(dec_pending)
         ft.pop("_bist_vft_fan", None)
         ft.pop("_bist_mem_fan", None)
         if cache is not None:
