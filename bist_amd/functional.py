@@ -207,6 +207,9 @@ BRANCH_V = os.environ.get("BIST_BRANCH_V", "0") != "0"      # tuning aid: value 
 PIPELINE_DECODER = os.environ.get("BIST_PIPELINE_DECODER", "1") != "0"      # tuning aid: decoder layer l under reasoning layer l+1
 
 
+VALUES_AHEAD = os.environ.get("BIST_VALUES_AHEAD", "1") != "0"      # tuning aid: value projections of layer l+1 on the caption stream
+
+
 def join_side_streams() -> None:
     """Order the current stream after everything queued on the side streams (end of a backward pass: the weight-gradient
     GEMMs of a side branch write the flat gradient directly, which autograd's own leaf-stream join does not see)."""

@@ -150,6 +150,24 @@ class MultimodalDecoder8(nn.Module):
         if torch.is_grad_enabled():
             ft["_bist_mem_fan"] = {k: Fn.Fan(ft[k], len(self.layers)) for k in ("encoded_his", "encoded_query") if k in ft}
         dec_pending = None
+        # Training: the value projections of layer l+1 (two big GEMMs that depend on the video tensor only) are issued on the
+        # caption stream ahead of decoder layer l, and awaited through an event just before the stage-1 cores; their
+        # backward products then run on that stream under the small-kernel chains of the two directions.
+        values_ahead = (torch.is_grad_enabled() and self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda and Fn.VALUES_AHEAD
+                        and getattr(self.args, "t2s", 1) and getattr(self.args, "s2t", 1) and "_bist_vft_fan" in ft)
+
+        def issue_values(l):
+            main_, side_ = torch.cuda.current_stream(), Fn.side_stream(1)
+            fan = ft["_bist_vft_fan"]
+            va = fan.take()
+            side_.wait_stream(main_)
+            with torch.cuda.stream(side_):
+                v1 = self.v_layers[l].train_value(va, 1)          # t2s only: its consumer (and its gradient) live on the main stream;
+                ev = torch.cuda.Event()                           # an edge between two side streams crashes hipGraph capture
+                ev.record(side_)
+            ft["_bist_v_pre"] = (v1, None, ev)
+        if values_ahead:
+            issue_values(0)
         for l, layer in enumerate(self.layers):
             fork_cap = self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda
             if fork_cap:                     # the caption reasoning layer is independent of the visual one
@@ -172,6 +190,8 @@ class MultimodalDecoder8(nn.Module):
             self._fuse(ft)
             if cache is not None:
                 cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})
+            if values_ahead and l + 1 < len(self.layers):
+                issue_values(l + 1)
             if fork_cap and Fn.PIPELINE_DECODER:
                 # The decoder layer needs this layer's fused memory, the NEXT reasoning layer does not need the decoder
                 # layer: it goes to the caption stream (ahead of the next caption layer) and runs under the next
@@ -186,6 +206,7 @@ class MultimodalDecoder8(nn.Module):
             torch.cuda.current_stream().wait_stream(dec_pending)
         ft.pop("_bist_vft_fan", None)
         ft.pop("_bist_mem_fan", None)
+        ft.pop("_bist_v_pre", None)
         if cache is not None:
             ft["_bist_reasoning"] = cache
         ft["decoded_text"] = self.norm(x)                                                    # :185

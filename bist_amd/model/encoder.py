@@ -133,6 +133,9 @@ class VidEncoderLayer4(nn.Module):
         v_ready = self.__dict__.get("_v_ready")
         if v_ready is not None:
             torch.cuda.current_stream().wait_stream(v_ready)      # V comes from the value-projection stream
+        v_event = self.__dict__.get("_v_event")
+        if v_event is not None:
+            torch.cuda.current_stream().wait_event(v_event)       # V was projected ahead of this layer on another stream
         o = Fn.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction, drop=Fn.attn_drop(attn))
         G = o.shape[1]
         y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=xr, res_map=(G * Lq, Lq), **Fn.drop_args(sub))
@@ -180,6 +183,18 @@ class VidEncoderLayer4(nn.Module):
         v = Fn.linear(vft.view(B * T * S, d), a.linears[2].weight, a.linears[2].bias).view(B, T, S, d)
         return (v, None) if self.args.t2s else (None, v)
 
+    def train_value(self, vft_a: Tensor, ai: int):
+        B, T, S, d = vft_a.shape
+        a = self.attn[ai]
+        return Fn.linear(vft_a.view(B * T * S, d), a.linears[2].weight, a.linears[2].bias).view(B, T, S, d)
+
+    def train_values(self, vft_a: Tensor, vft_b: Tensor):
+        """Training: one value GEMM per direction (each dV is a whole tensor) -> (v_t2s, v_s2t)."""
+        B, T, S, d = vft_a.shape
+        a1, a4 = self.attn[1], self.attn[4]
+        return (Fn.linear(vft_a.view(B * T * S, d), a1.linears[2].weight, a1.linears[2].bias).view(B, T, S, d),
+                Fn.linear(vft_b.view(B * T * S, d), a4.linears[2].weight, a4.linears[2].bias).view(B, T, S, d))
+
     def forward(self, in_ft: Dict[str, Tensor], ft: Dict[str, Tensor], b) -> Dict[str, Tensor]:
         vft = ft["spatiotemporal_ft"]
         fan = ft.get("_bist_vft_fan")                      # aliases whose gradients are summed in one pass (training)
@@ -196,14 +211,21 @@ class VidEncoderLayer4(nn.Module):
             B, T, S, d = vft.shape
             return Fn.linear(take().view(B * T * S, d), a.linears[2].weight, a.linears[2].bias).view(B, T, S, d)
 
-        per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V
+        per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V and "_bist_v_pre" not in ft
         v_t2s = v_s2t = None
-        if per_branch_v:
+        pre = ft.pop("_bist_v_pre", None)                  # (v_t2s, v_s2t, event): projected ahead by the layer loop (decoder.py)
+        self._v_event = None
+        if pre is not None:
+            v_t2s, v_s2t, ev = pre
+            main.wait_event(ev) if main is not None else torch.cuda.current_stream().wait_event(ev)
+            if v_s2t is None:
+                v_s2t = self.train_value(take(), 4)
+        elif per_branch_v:
             # training: one value GEMM per direction (each dV is a whole tensor), issued INSIDE its branch, so that the
             # projection and its two backward products run on that branch's stream
             pass
         elif torch.is_grad_enabled() and t2s_on and s2t_on:
-            v_t2s, v_s2t = branch_v(1), branch_v(4)
+            v_t2s, v_s2t = self.train_values(take(), take())
         elif concurrent:
             # (inference only: under autograd a third forked stream makes hipGraph capture of the training step crash in
             # the HIP runtime -- also with every side stream joined explicitly after backward)
@@ -240,6 +262,7 @@ class VidEncoderLayer4(nn.Module):
             if v_stream is not None:
                 main.wait_stream(v_stream)
             self._v_ready = None
+            self._v_event = None
         else:
             ai = si = fi = 0
             if t2s_on:
