@@ -1,0 +1,25 @@
+"""Busy time per hardware queue / stream over ONE replayed training step of a rocprofv3 kernel trace (development aid)."""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+# the last occurrence of adam_kernel marks step ends; take the window between the last two adam launches of the replayed steps
+adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+lo, hi = adam[k - 1] + 1, adam[k] + 1
+win = rows[lo:hi]
+t0 = min(int(r["Start_Timestamp"]) for r in win); t1 = max(int(r["End_Timestamp"]) for r in win)
+print(f"step window: {len(win)} launches, span {(t1 - t0) / 1e6:.2f} ms")
+for key in ("Queue_Id", "Stream_Id"):
+    busy = collections.Counter(); n = collections.Counter()
+    for r in win:
+        busy[r[key]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6; n[r[key]] += 1
+    print(key, {q: (n[q], round(b, 2)) for q, b in sorted(busy.items())})
+# concurrency profile: fraction of the span with 1, 2, 3+ kernels running
+ev = []
+for r in win:
+    ev.append((int(r["Start_Timestamp"]), 1)); ev.append((int(r["End_Timestamp"]), -1))
+ev.sort()
+cur, last, hist = 0, t0, collections.Counter()
+for t, d in ev:
+    hist[min(cur, 4)] += t - last; last = t; cur += d
+tot = sum(hist.values())
+print("time with k kernels in flight:", {k: f"{v / tot * 100:.1f}%" for k, v in sorted(hist.items())})
