@@ -2,6 +2,7 @@
 // Reductions over rows (bias, LayerNorm gain/offset, embedding rows) accumulate into fp32 buffers
 // with global float atomics shaped as contiguous row segments (one dword per lane).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -499,7 +500,10 @@ extern "C" int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t
       const long esz = dtype == BIST_BF16 ? 2 : 4, piece = 16 / esz;
       const bool vec = (q.N % piece == 0) && (q.ldx % piece == 0) && ((uintptr_t)q.x % 16 == 0);
       const long cb = vec ? blocks_for(q.N, 64 * piece) : blocks_for(q.N, 64);
-      long rpb = (q.M * cb + 1023) / 1024;             // up to ~1024 workgroups per job, at least 16 rows each
+      static const long target = [] { const char* e = getenv("BIST_COLSUM_TARGET"); return e ? atol(e) : 128L; }();   // tuning aid
+      // ~128 workgroups per job (at least 16 rows each): every workgroup ends in N atomics on the SAME N accumulators, and with
+      // 1024 workgroups per [25088 x 512] job the step spent 0.4 ms more in these reductions (12.38 vs 11.97 ms)
+      long rpb = (q.M * cb + target - 1) / target;
       if (rpb < 16) rpb = 16;
       b.vec[i] = vec ? 1 : 0;
       b.x[i] = q.x; b.out[i] = q.out; b.M[i] = (int)q.M; b.N[i] = q.N; b.ld[i] = (int)q.ldx; b.rpb[i] = (int)rpb; b.cb[i] = (int)cb;
@@ -565,7 +569,8 @@ extern "C" int bist_layernorm_param_grad_multi(const BistLnGrad* jobs, int32_t n
                    "bist_layernorm_param_grad_multi: bad job %d", base + i);
       BIST_REQUIRE((((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.a) % 16 == 0) && (q.lddy * sz) % 16 == 0 && (q.ldx * sz) % 16 == 0,
                    "bist_layernorm_param_grad_multi: job %d is not 16-byte aligned", base + i);
-      int rpw = (int)((q.rows + 255) / 256);           // ~256 waves per job: few atomics per column
+      static const long wtarget = [] { const char* e = getenv("BIST_LNGRAD_TARGET"); return e ? atol(e) : 4096L; }();    // tuning aid
+      int rpw = (int)((q.rows + wtarget - 1) / wtarget);           // up to ~4096 waves per job (the [25088 x 512] LayerNorm of P0: 7 rows per wave; 11.80 vs 11.98 ms per step at 256 waves)
       if (rpw < 4) rpw = 4;
       b.dy[i] = q.dy; b.x[i] = q.x; b.a[i] = q.a; b.da[i] = q.da; b.db[i] = q.db;
       b.rows[i] = (int)q.rows; b.lddy[i] = (int)q.lddy; b.ldx[i] = (int)q.ldx; b.rpw[i] = rpw; b.eps[i] = q.eps;
