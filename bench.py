@@ -211,7 +211,7 @@ def main():
                     run()
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 run()
             for _ in range(3):
                 g.replay()

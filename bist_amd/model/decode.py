@@ -104,7 +104,7 @@ def _graph_step(model, bn, fn, trg, train_args):
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
             out = run()
         g = store[(Lt,) + geom] = (graph, strg, tb.b.trg_mask, out)
     graph, strg, _, out = g
@@ -144,7 +144,7 @@ def _graph_first_step(model, batch, start_symbol, train_args):
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
             f2, out = run()
         g = store[("first",) + geom] = (graph, sb, f2, out)
     graph, sb, f2, out = g

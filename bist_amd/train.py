@@ -207,7 +207,7 @@ class Trainer:
                 self.backward(batch)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
             terms = self.backward(batch)
         self._graph, self._graph_key, self._static_batch, self._static_terms = graph, key, batch, terms
 
