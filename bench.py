@@ -134,6 +134,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif os.environ.get("BIST_BENCH_REHEARSAL") == "rccl1":
+        # rehearsal aid (one-GPU box): a ONE-rank RCCL process group with the multi-rank exchange path forced on, so that RCCL
+        # initialisation, the asynchronous bf16 all-reduces of the gradient pieces and their stream ordering run next to
+        # the hipGraph capture / replay of the step in one process
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["BIST_FORCE_EXCHANGE"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
 
     import bist_amd.model as M
     from bist_amd import functional as Fn, ops
@@ -287,6 +295,9 @@ def main():
     if world > 1:
         barrier()                              # rank 0 also ran the decode / B=64 extras: leave together
         dist.destroy_process_group()
+    elif os.environ.get("BIST_BENCH_REHEARSAL") == "rccl1":
+        import torch.distributed as dist1
+        dist1.destroy_process_group()
 
 
 if __name__ == "__main__":

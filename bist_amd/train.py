@@ -241,7 +241,7 @@ class Trainer:
                                      self.v.data_ptr() + 4 * lo, (work.data_ptr() + work.element_size() * lo) if work is not None else None,
                                      hi - lo, rate, self.betas[0], self.betas[1], self.eps, self._step, grad_scale,
                                      dtype_code(self.compute_dtype), dtype_code(self.compute_dtype), _stream()), "bist_adam_step")
-        if self.world > 1:
+        if self.world > 1 or (os.environ.get("BIST_FORCE_EXCHANGE") == "1" and dist.is_initialized()):      # (rehearsal aid, bench.py)
             bounds = parallel.chunk_bounds(self.numel, EXCHANGE_CHUNKS, ALIGN)
             works = parallel.exchange_gradients_async(self.flat_grad, bounds, self.pg)
             for (lo, hi), wk in zip(bounds, works):
