@@ -39,7 +39,7 @@ from .ops import _stream, dtype_code
 ALIGN = 64      # elements; keeps every parameter view 16-byte aligned for the LDS-DMA GEMM path
 
 
-EXCHANGE_CHUNKS = 8        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
+EXCHANGE_CHUNKS = int(os.environ.get("BIST_EXCHANGE_CHUNKS", "4"))        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
 
 
 def _round(n: int) -> int:
