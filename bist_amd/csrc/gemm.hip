@@ -1623,18 +1623,23 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
   } while (0)
   if constexpr (std::is_same<T, bf16_t>::value) {
     if (use_tile256(g, p)) {
-      // Row fragments per wave: tile rows = 32 * FR.  FR = 7 puts M = 25088 on 224 instead of 196 CUs with 1/8 less work
-      // each, and measured no faster (51.9 vs 51.3 us in-kernel at K = 2048): the K loop is bound by the L2 -> LDS
-      // stream (64 KiB per K tile per CU, ~9 TB/s chip-wide), which more active CUs only load further.  Only FR = 8 is built.
-      constexpr int fr = 8;
+      // Row fragments per wave: tile rows = 32 * FR.  Built: FR = 8 (256 rows) and FR = 5 (160 rows: the batched score
+      // products have M = Lq*h = 160 rows per clip, 62 % of a 256-row tile); the one with fewer padded rows is used, FR = 8 on a
+      // tie.  (FR = 7 puts M = 25088 on 224 instead of 196 CUs with 1/8 less work each and measured no faster -- 51.9 vs
+      // 51.3 us in-kernel at K = 2048: the K loop is bound by the L2 -> LDS stream, which more active CUs only load further.)
+      const long pad8 = (long)((g->M + 255) / 256) * 256, pad5 = (long)((g->M + 159) / 160) * 160;
+      const bool stamps = (g->hint & 15) == BIST_GEMM_TILE256 && (g->hint >> 4) == 1;       // development aid (FR = 8 only)
+      const int fr = (!stamps && pad5 < pad8) ? 5 : 8;
       k.tiles_m = (g->M + 32 * fr - 1) / (32 * fr); k.tiles_n = (g->N + BIG - 1) / BIG;
       k.split_k = 1; k.ws = nullptr;
       const dim3 gb((unsigned)((long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2));
-      if ((g->hint & 15) == BIST_GEMM_TILE256 && (g->hint >> 4) == 1) {        // development aid: in-kernel stamps into the workspace
+      if (stamps) {                                  // in-kernel stamps into the workspace
         k.ws = (float*)g->workspace;
-        hipLaunchKernelGGL((gemm_big_kernel<TO, fr, 1>), gb, dim3(512), 0, st, k);
+        hipLaunchKernelGGL((gemm_big_kernel<TO, 8, 1>), gb, dim3(512), 0, st, k);
+      } else if (fr == 5) {
+        hipLaunchKernelGGL((gemm_big_kernel<TO, 5, 0>), gb, dim3(512), 0, st, k);
       } else {
-        hipLaunchKernelGGL((gemm_big_kernel<TO, fr, 0>), gb, dim3(512), 0, st, k);
+        hipLaunchKernelGGL((gemm_big_kernel<TO, 8, 0>), gb, dim3(512), 0, st, k);
       }
       BIST_LAUNCH_CHECK("bist_gemm(256-tile)");
       return BIST_OK;

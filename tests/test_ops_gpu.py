@@ -111,7 +111,7 @@ def test_gemm_in_launch_split_k(ops, dtype, tol, M, N, K, lay):
         _cmp(out, ref, tol, f"in-launch split-K {lay} run {rep}")
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (1100, 300, 192), (256, 256, 128), (700, 1024, 832)])
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (1100, 300, 192), (256, 256, 128), (700, 1024, 832), (160, 1568, 512), (470, 300, 128)])
 def test_gemm_tile256_kernel(ops, M, N, K):
     """the 256x256-tile deep-pipelined kernel (hint BIST_GEMM_TILE256; automatic only for far larger products than
     this model has): ragged row / column tiles, bias + ReLU, residual with accumulate, fp32 output."""
