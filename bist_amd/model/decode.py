@@ -73,10 +73,25 @@ class _TurnBuffers:
         self.loaded = fn
 
 
+def _descending(lp_vec, k):
+    """Token ids in the order ``np.argsort(lp_vec)[::-1]`` visits them (decode.py:88), as far as the beam loop can look: it takes
+    at most ``beam`` candidates per hypothesis and skips at most two symbols (<unk>, <eos>), so the k = beam + 2 largest are
+    enough.  A partial selection orders equal values differently from a full sort, so whenever the k+1 largest values are not
+    all distinct the full sort is used -- the visiting order is then the reference's in every case."""
+    n = lp_vec.shape[0]
+    if n <= 4 * k:
+        return np.argsort(lp_vec)[::-1]
+    top = np.argpartition(lp_vec, n - (k + 1))[n - (k + 1):]
+    vals = lp_vec[top]
+    if np.unique(vals).size != vals.size:
+        return np.argsort(lp_vec)[::-1]
+    return top[np.argsort(vals)[::-1]][:k]
+
+
 def _graph_step(model, bn, fn, trg, train_args):
     """decode + generator for the n hypothesis rows of one step, replayed from a hipGraph (captured once per geometry:
     row count, prefix length, dialogue lengths, dtype); returns the log-probs [n, 1, V] as a numpy array."""
-    dev = trg.device
+    dev = bn.query.device
     n, Lt = trg.shape
     geom = (n, tuple(bn.query.shape), tuple(bn.his.shape), None if bn.cap is None else tuple(bn.cap.shape), fn["encoded_query"].dtype,
             len(fn["_bist_reasoning"]))
@@ -168,7 +183,9 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
         ft, lp_first = _graph_first_step(model, batch, start_symbol, train_args)
     else:
         ft = model.encode(batch)
-    hyplist = [([], 0.0, torch.full((1, 1), start_symbol, dtype=torch.long, device=dev))]
+    # the hypotheses' token prefixes live on the HOST (the reference keeps them as device tensors and pays two tiny device
+    # launches per candidate: decode.py:88-99); one [n, Lt] copy per step carries them to the device
+    hyplist = [([], 0.0, torch.full((1, 1), start_symbol, dtype=torch.long))]
     best_state, comp_hyplist = None, []
     rows_cache = {}
     for l in range(max_len):
@@ -183,6 +200,7 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
             if use_graphs:
                 lp_rows = _graph_step(model, bn, fn, trg, train_args)                        # [n, 1, V]
             else:
+                trg = trg.to(dev)
                 bn.trg = trg
                 bn.trg_mask = subsequent_mask(trg.size(1), dev)
                 f2 = model.decode(bn, dict(fn))
@@ -194,7 +212,7 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
             if lp_rows is not None:
                 lp_vec = np.squeeze(lp_rows[idx:idx + 1] + lp)
             else:
-                batch.trg = st
+                batch.trg = st.to(dev)
                 batch.trg_mask = subsequent_mask(st.size(1), dev)
                 ft = model.decode(batch, ft)
                 step = dict(ft)
@@ -207,19 +225,19 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
                 comp_hyplist.append((out, new_lp))
                 if best_state is None or best_state < new_lp:
                     best_state = new_lp
-            for o in np.argsort(lp_vec)[::-1]:
+            for o in _descending(lp_vec, beam + 2):
                 if o == unk_symbol or (not dec_eos and o == end_symbol):
                     continue
                 new_lp = lp_vec[o]
                 if len(new_hyplist) == beam:
                     if new_hyplist[argmin][1] < new_lp:
-                        new_st = torch.cat([st, torch.full((1, 1), int(o), dtype=torch.long, device=dev)], dim=1)
+                        new_st = torch.cat([st, torch.full((1, 1), int(o), dtype=torch.long)], dim=1)
                         new_hyplist[argmin] = (out + [o], new_lp, new_st)
                         argmin = min(enumerate(new_hyplist), key=lambda e: e[1][1])[0]
                     else:
                         break
                 else:
-                    new_st = torch.cat([st, torch.full((1, 1), int(o), dtype=torch.long, device=dev)], dim=1)
+                    new_st = torch.cat([st, torch.full((1, 1), int(o), dtype=torch.long)], dim=1)
                     new_hyplist.append((out + [o], new_lp, new_st))
                     if len(new_hyplist) == beam:
                         argmin = min(enumerate(new_hyplist), key=lambda e: e[1][1])[0]
