@@ -85,6 +85,30 @@ __global__ void group_sum_kernel(const T* __restrict__ x, T* __restrict__ out, i
   out[idx] = from_f<T>(acc);
 }
 
+// the same with 16 bytes per thread (inner % E == 0, aligned): G independent 16-byte loads per thread
+template <typename T>
+__global__ __launch_bounds__(256) void group_sum_vec_kernel(const T* __restrict__ x, T* __restrict__ out, int G, long inner, long total) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * E;
+  if (idx >= total) return;
+  const long b = idx / inner, r = idx % inner;
+  const T* p = x + b * G * inner + r;
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll 4
+  for (int g = 0; g < G; ++g) {
+    T v[E];
+    *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(p + (long)g * inner);
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] += to_f(v[e]);
+  }
+  T o[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) o[e] = from_f<T>(acc[e]);
+  *reinterpret_cast<uint4*>(out + idx) = *reinterpret_cast<const uint4*>(o);
+}
+
 // out[n] += sum_m x[m, n]   (bias gradient).  Block = 64 columns x 4 row lanes; grid = (column blocks, row chunks);
 // the four row lanes are combined through LDS, then one atomic per column per block.
 template <typename T>
@@ -356,31 +380,43 @@ __global__ void scaled_bias_kernel(const T* __restrict__ x, const float* __restr
   const long m = idx / d; const int c = (int)(idx % d);
   y[idx] = from_f<T>(to_f(x[idx]) + s[m * h + c / dk] * to_f(bias[c]));
 }
-// one wave per (m, head): ds = <dy, bias>;  block = 4 waves; dbias through per-column atomics of s*dy
+// ds[m, head] = <dy[m, head, :], bias[head, :]>  and  dbias[head, c] += sum_m s[m, head] dy[m, head, c].
+// One wave per head per block of RPB rows: the wave walks its rows, keeps the dbias partial sums of its head in
+// registers (dk <= 256: up to 4 columns per lane) and issues ONE atomic per column per block (it was one per element).
 template <typename T>
 __global__ __launch_bounds__(256) void scaled_bias_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ s, const T* __restrict__ bias,
-                                                              float* __restrict__ ds, float* __restrict__ dbias, long M, int h, int dk) {
-  const int lane = threadIdx.x & 63;
-  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= M * h) return;
-  const long m = item / h; const int hh = (int)(item % h);
-  const T* g = dy + (m * h + hh) * dk;
-  const float sv = s[item];
-  float acc = 0.f;
-  for (int c = lane; c < dk; c += 64) {
-    const float gv = to_f(g[c]);
-    acc += gv * to_f(bias[hh * dk + c]);
-    atomicAdd(dbias + hh * dk + c, sv * gv);
+                                                              float* __restrict__ ds, float* __restrict__ dbias, long M, int h, int dk, int rpb) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long m0 = (long)blockIdx.x * rpb, m1 = min(M, m0 + rpb);
+  for (int hh = w; hh < h; hh += 4) {
+    float bv[4], part[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; bv[u] = c < dk ? to_f(bias[hh * dk + c]) : 0.f; part[u] = 0.f; }
+    for (long m = m0; m < m1; ++m) {
+      const T* g = dy + (m * h + hh) * dk;
+      const float sv = s[m * h + hh];
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = lane + 64 * u;
+        const float gv = c < dk ? to_f(g[c]) : 0.f;
+        acc += gv * bv[u];
+        part[u] += sv * gv;
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) ds[m * h + hh] = acc;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; if (c < dk) atomicAdd(dbias + hh * dk + c, part[u]); }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) ds[item] = acc;
 }
 
 // Modality fusion backward: out = sum_j w_j x_j, w = softmax(score)
 struct FusePtrs { const void* x[4]; void* dx[4]; };
 template <typename T>
 __global__ __launch_bounds__(256) void fuse_bwd_kernel(const T* __restrict__ score, FusePtrs p, const T* __restrict__ dout,
-                                                       T* __restrict__ dscore, long rows, int n, int d) {
+                                                       T* __restrict__ dscore, long rows, int n, int d, int vec) {
+  constexpr int E = 16 / (int)sizeof(T);
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -388,11 +424,29 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const T* __restrict__ sco
   for (int j = 0; j < n; ++j) { w[j] = to_f(score[row * n + j]); mx = fmaxf(mx, w[j]); }
   for (int j = 0; j < n; ++j) { w[j] = expf(w[j] - mx); den += w[j]; }
   for (int j = 0; j < n; ++j) { w[j] /= den; dw[j] = 0.f; }
-  for (int c = lane; c < d; c += 64) {
-    const float g = to_f(dout[row * d + c]);
-    for (int j = 0; j < n; ++j) {
-      dw[j] += g * to_f(reinterpret_cast<const T*>(p.x[j])[row * d + c]);
-      reinterpret_cast<T*>(p.dx[j])[row * d + c] = from_f<T>(w[j] * g);
+  if (vec) {                               // 16-byte pieces: d % E == 0 and every row 16-byte aligned
+    for (int c = lane * E; c < d; c += 64 * E) {
+      T g8[E];
+      *reinterpret_cast<uint4*>(g8) = *reinterpret_cast<const uint4*>(dout + row * d + c);
+      for (int j = 0; j < n; ++j) {
+        T x8[E], o8[E];
+        *reinterpret_cast<uint4*>(x8) = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.x[j]) + row * d + c);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float g = to_f(g8[e]);
+          dw[j] += g * to_f(x8[e]);
+          o8[e] = from_f<T>(w[j] * g);
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dx[j]) + row * d + c) = *reinterpret_cast<const uint4*>(o8);
+      }
+    }
+  } else {
+    for (int c = lane; c < d; c += 64) {
+      const float g = to_f(dout[row * d + c]);
+      for (int j = 0; j < n; ++j) {
+        dw[j] += g * to_f(reinterpret_cast<const T*>(p.x[j])[row * d + c]);
+        reinterpret_cast<T*>(p.dx[j])[row * d + c] = from_f<T>(w[j] * g);
+      }
     }
   }
   float dot = 0.f;
@@ -465,6 +519,13 @@ extern "C" int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, in
   BIST_REQUIRE(x && out && B > 0 && G > 0 && inner > 0, "bist_group_sum: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const long total = B * inner;
+  const long gsz = dtype == BIST_BF16 ? 2 : 4, ge = 16 / gsz;
+  if ((dtype == BIST_BF16 || dtype == BIST_F32) && inner % ge == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+    if (dtype == BIST_BF16) hipLaunchKernelGGL(group_sum_vec_kernel<bf16_t>, dim3(blocks_for(total / ge, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, G, (long)inner, total);
+    else hipLaunchKernelGGL(group_sum_vec_kernel<float>, dim3(blocks_for(total / ge, 256)), dim3(256), 0, st, (const float*)x, (float*)out, G, (long)inner, total);
+    BIST_LAUNCH_CHECK("bist_group_sum");
+    return BIST_OK;
+  }
 #define L(TT, ...) hipLaunchKernelGGL(group_sum_kernel<TT>, dim3(blocks_for(total, 256)), dim3(256), 0, st, (const TT*)x, (TT*)out, G, (long)inner, total)
   DISPATCH_T(dtype, L, 0)
 #undef L
@@ -600,7 +661,9 @@ extern "C" int bist_scaled_bias_bwd(const void* dy, const float* s, const void* 
                                     int32_t dk, int32_t dtype, void* stream) {
   BIST_REQUIRE(dy && s && bias && ds && dbias && M > 0 && h > 0 && dk > 0, "bist_scaled_bias_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
-#define L(TT, ...) hipLaunchKernelGGL(scaled_bias_bwd_kernel<TT>, dim3(blocks_for(M * h, 4)), dim3(256), 0, st, (const TT*)dy, s, (const TT*)bias, ds, dbias, (long)M, h, dk)
+  BIST_REQUIRE(dk <= 256, "bist_scaled_bias_bwd: head width %d > 256", dk);
+  const int rpb = 4;                             // rows per block: M / 4 blocks, 4 atomics per column per 16 rows ... (M = 320: 80 blocks)
+#define L(TT, ...) hipLaunchKernelGGL(scaled_bias_bwd_kernel<TT>, dim3(blocks_for(M, rpb)), dim3(256), 0, st, (const TT*)dy, s, (const TT*)bias, ds, dbias, (long)M, h, dk, rpb)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_scaled_bias_bwd");
@@ -627,7 +690,10 @@ extern "C" int bist_fuse_modalities_bwd(const void* score, const void* const* xs
   FusePtrs p;
   for (int j = 0; j < 4; ++j) { p.x[j] = j < n ? xs[j] : nullptr; p.dx[j] = j < n ? dxs[j] : nullptr; }
   hipStream_t st = (hipStream_t)stream;
-#define L(TT, ...) hipLaunchKernelGGL(fuse_bwd_kernel<TT>, dim3(blocks_for(rows, 4)), dim3(256), 0, st, (const TT*)score, p, (const TT*)dout, (TT*)dscore, (long)rows, n, d)
+  const long esz = dtype == BIST_BF16 ? 2 : 4;
+  int vec = (d % (16 / esz)) == 0 && ((uintptr_t)dout % 16) == 0;
+  for (int j = 0; j < n; ++j) vec = vec && ((uintptr_t)xs[j] % 16) == 0 && ((uintptr_t)dxs[j] % 16) == 0;
+#define L(TT, ...) hipLaunchKernelGGL(fuse_bwd_kernel<TT>, dim3(blocks_for(rows, 4)), dim3(256), 0, st, (const TT*)score, p, (const TT*)dout, (TT*)dscore, (long)rows, n, d, vec)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_fuse_modalities_bwd");
