@@ -80,7 +80,7 @@ SIGNATURES = {
     "bist_embed_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_fuse_modalities_bwd": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(C.c_void_p), _I64, _I32, _I32, _I32, _P]),
     "bist_mha_core_bwd": (C.c_int, [_P] * 9 + [_I32] * 5 + [_I64] * 16 + [_F, C.POINTER(BistDrop), _I32, _P]),
-    "bist_st_stage1_pv_bwd": (C.c_int, [_P] * 6 + [_I32] * 6 + [_I64, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),
+    "bist_st_stage1_pv_bwd": (C.c_int, [_P] * 5 + [_I32, _P] + [_I32] * 6 + [_I64, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_st_stage2_bwd": (C.c_int, [_P] * 7 + [_I32] * 5 + [C.POINTER(BistDrop), _I32, _P]),
     "bist_pointer_mix_bwd": (C.c_int, [_P, _P, _I32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                        _P, _P, _P, _P, C.POINTER(C.c_void_p), _I64, _I32, _I32, _I32, _P]),

@@ -324,7 +324,9 @@ class StScoresFn(Function):
         qf, vft = ctx.saved_tensors
         B, R, d = qf.shape
         TS = vft.shape[1]
-        g = ops.cast(dsc.contiguous(), qf.dtype)
+        g = getattr(dsc, "_bist_dsc", None)        # bf16 gradient handed over by StStage1PvFn.backward (dsc is then a placeholder)
+        if g is None or g.dtype != qf.dtype:
+            g = ops.cast(dsc.contiguous(), qf.dtype)
         dqf = torch.empty((B, R, d), device=qf.device, dtype=qf.dtype)
         ops.gemm(g, vft, dqf, M=R, N=d, K=TS, a_rs=TS, a_ks=1, b_rs=1, b_ks=vft.stride(1), ldc=d, batch=(B, 1),
                  a_bs=(R * TS, 0), b_bs=(vft.stride(0), 0), c_bs=(R * d, 0))
@@ -596,6 +598,7 @@ class StStage1PvFn(Function):
         ctx.save_for_backward(scores, v, m8)
         ctx.cfg = (dims, direction)
         ctx.drop = drop
+        ctx.to_scores_fn = type(getattr(scores, "grad_fn", None)).__name__ == "StScoresFnBackward"
         return out
 
     @staticmethod
@@ -604,12 +607,20 @@ class StStage1PvFn(Function):
         (B, T, S, Lq, h, dk), direction = ctx.cfg
         d = h * dk
         do = do.contiguous()
-        dsc = torch.empty_like(scores)
+        # When the scores come from StScoresFn, its backward takes the gradient as a bf16 GEMM operand: the kernel writes
+        # dscores in bf16 and the tensor travels as an attribute of an (uninitialised, never read) f32 placeholder --
+        # autograd would cast a bf16 gradient of an f32 tensor back to f32.  Saves the f32 -> bf16 pass per direction.
+        direct16 = ctx.to_scores_fn and v.dtype == torch.bfloat16
+        dsc = torch.empty(scores.shape, device=scores.device, dtype=torch.bfloat16 if direct16 else scores.dtype)
         dv = torch.empty((B, T, S, d), device=v.device, dtype=v.dtype)
-        check(lib.bist_st_stage1_pv_bwd(scores.data_ptr(), v.data_ptr(), _ptr(m8), do.data_ptr(), dsc.data_ptr(), dv.data_ptr(),
+        check(lib.bist_st_stage1_pv_bwd(scores.data_ptr(), v.data_ptr(), _ptr(m8), do.data_ptr(), dsc.data_ptr(), dtype_code(dsc.dtype), dv.data_ptr(),
                                         B, T, S, Lq, h, dk, v.stride(-2), d, direction, ops.drop_ref(ctx.drop), dtype_code(v.dtype),
                                         _stream()),
               "bist_st_stage1_pv_bwd")
+        if direct16:
+            holder = torch.empty_like(scores)
+            holder._bist_dsc = dsc
+            dsc = holder
         return dsc, dv, None, None, None, None
 
 

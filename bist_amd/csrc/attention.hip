@@ -273,7 +273,7 @@ extern "C" int bist_st_stage1_pv_fwd(const void* scores, const void* V, const ui
   BIST_REQUIRE(sc_dtype == BIST_F32 || sc_dtype == dtype, "bist_st_stage1_pv_fwd: scores must be f32 or the value dtype");
   BIST_REQUIRE(ldv >= (int64_t)h * dk, "bist_st_stage1_pv_fwd: ldv too small");
   if (dtype == BIST_BF16 && !getenv("BIST_ST1_VALU")) {          // matrix-core path (attention_mfma.hip)
-    const int r = bist_st1_mfma(scores, sc_dtype == BIST_F32, V, tmask, O, nullptr, nullptr, nullptr, B, T, S, Lq, h, dk, ldv, 0,
+    const int r = bist_st1_mfma(scores, sc_dtype == BIST_F32, V, tmask, O, nullptr, nullptr, 0, nullptr, B, T, S, Lq, h, dk, ldv, 0,
                                 direction, 0, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage1_pv_fwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void st1_pv_bwd_kernel(const float* __restrict__ scores, const T* __restrict__ V,
                                                          const unsigned char* __restrict__ tmask, const T* __restrict__ dO,
-                                                         float* __restrict__ dscores, T* __restrict__ dV, int T_, int S_, int Lq,
+                                                         void* __restrict__ dscores, int dsc_bf16, T* __restrict__ dV, int T_, int S_, int Lq,
                                                          int h, int dk, long ldv, long lddv, int dir, int Gc, const DropArg drop) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int G = dir == 0 ? S_ : T_, Kn = dir == 0 ? T_ : S_;
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void st1_pv_bwd_kernel(const float* __restrict
   float* D = smem + (long)Lq * Gc * KP;
   float* dOs = D + (long)Lq * Gc * KP;
   const float* sc = scores + (long)b * Lq * h * TS_;
-  float* dsc = dscores + (long)b * Lq * h * TS_;
+  float* dsc = reinterpret_cast<float*>(dscores) + (long)b * Lq * h * TS_;
+  bf16_t* dsc16 = reinterpret_cast<bf16_t*>(dscores) + (long)b * Lq * h * TS_;
   const unsigned char* mk = (dir == 0 && tmask) ? tmask + (long)b * T_ : nullptr;
   const int total = Lq * gc * Kn;
   for (int idx = tid; idx < total; idx += 256) {
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(256) void st1_pv_bwd_kernel(const float* __restrict
     else          { k = idx % Kn; const int t2 = idx / Kn; gl = t2 % gc; i = t2 / gc; }
     const int g = g0 + gl;
     const long col = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
-    dsc[((long)i * h + hh) * TS_ + col] = D[((long)i * gc + gl) * KP + k];
+    if (dsc_bf16) dsc16[((long)i * h + hh) * TS_ + col] = (bf16_t)D[((long)i * gc + gl) * KP + k];
+    else dsc[((long)i * h + hh) * TS_ + col] = D[((long)i * gc + gl) * KP + k];
   }
   for (int item = tid; item < gc * Kn * dk; item += 256) {   // dV[(g,k), c] = sum_i P[i][gl][k] dO[g,i,c]
     const int c = item % dk; const int t2 = item / dk; const int k = t2 % Kn, gl = t2 / Kn;
@@ -348,7 +350,7 @@ extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, co
   return BIST_OK;
 }
 
-extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const uint8_t* tmask, const void* dO, float* dscores, void* dV,
+extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const uint8_t* tmask, const void* dO, void* dscores, int32_t dscores_dtype, void* dV,
                                      int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk, int64_t ldv, int64_t lddv,
                                      int32_t direction, const BistDrop* drop, int32_t dtype, void* stream) {
   BIST_REQUIRE(scores && V && dO && dscores && dV, "bist_st_stage1_pv_bwd: null pointer");
@@ -356,8 +358,10 @@ extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const u
   const DropArg dr = make_drop(drop);
   BIST_REQUIRE(B > 0 && T > 0 && S > 0 && Lq > 0 && h > 0 && dk > 0, "bist_st_stage1_pv_bwd: bad shape");
   BIST_REQUIRE(direction == 0 || direction == 1, "bist_st_stage1_pv_bwd: bad direction");
+  BIST_REQUIRE(dscores_dtype == BIST_F32 || dscores_dtype == BIST_BF16, "bist_st_stage1_pv_bwd: bad dscores dtype %d", (int)dscores_dtype);
+  const int dsc_bf16 = dscores_dtype == BIST_BF16;
   if (dtype == BIST_BF16 && !getenv("BIST_ST1_VALU")) {          // matrix-core path (attention_mfma.hip)
-    const int r = bist_st1_mfma(scores, 1, V, tmask, nullptr, dO, dscores, dV, B, T, S, Lq, h, dk, ldv, lddv, direction, 1, dr,
+    const int r = bist_st1_mfma(scores, 1, V, tmask, nullptr, dO, dscores, dsc_bf16, dV, B, T, S, Lq, h, dk, ldv, lddv, direction, 1, dr,
                                 (hipStream_t)stream);
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage1_pv_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
@@ -371,7 +375,7 @@ extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const u
   const size_t lds = (size_t)per_g * Gc;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((G + Gc - 1) / Gc), (unsigned)h, (unsigned)B);
-#define L(TT) hipLaunchKernelGGL(st1_pv_bwd_kernel<TT>, grid, dim3(256), lds, st, scores, (const TT*)V, tmask, (const TT*)dO, dscores, (TT*)dV, T, S, Lq, h, dk, (long)ldv, (long)lddv, direction, Gc, dr)
+#define L(TT) hipLaunchKernelGGL(st1_pv_bwd_kernel<TT>, grid, dim3(256), lds, st, scores, (const TT*)V, tmask, (const TT*)dO, dscores, dsc_bf16, (TT*)dV, T, S, Lq, h, dk, (long)ldv, (long)lddv, direction, Gc, dr)
   if (dtype == BIST_BF16) L(bf16_t); else if (dtype == BIST_F32) L(float);
   else { bist_set_error("bist_st_stage1_pv_bwd: bad dtype %d", dtype); return BIST_EINVAL; }
 #undef L

@@ -43,8 +43,9 @@ __device__ __forceinline__ uint4 frag_cols(const bf16_t* img, int pitch, int col
 struct St1Args {
   const void* scores; const bf16_t* V; const unsigned char* tmask;
   bf16_t* O;                      // forward output
-  const bf16_t* dO; float* dscores; bf16_t* dV;   // backward
+  const bf16_t* dO; void* dscores; bf16_t* dV;   // backward (dscores f32, or bf16 when dsc_bf16)
   int T, S, Lq, h; long ldv, lddv; int dir, Gc;
+  int dsc_bf16;
   int dbg;      // timing ablation only (BIST_ST1_DBG): bit0 skip slab gather, bit1 skip softmax, bit2 skip phase C
   DropArg drop; // dropout of the probabilities: the slab keeps P, the bf16 image that feeds the MFMAs holds mask*P/(1-p)
 };
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
         }
       }
       // dS = P (dP - sum_k P dP), 0 where masked; C layout: k = ni*16 + x, i = mi*16 + lg*4 + r
-      float* dsc = a.dscores + (long)b * Lq * h * TS_;
+      float* dsc = reinterpret_cast<float*>(a.dscores) + (long)b * Lq * h * TS_;
+      bf16_t* dsc16 = reinterpret_cast<bf16_t*>(a.dscores) + (long)b * Lq * h * TS_;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -270,7 +272,8 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
                 float gq = pv[ni] * (dp[mi][ni][r] - part);
                 if (mk && mk[k] == 0) gq = 0.f;
                 const long col = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
-                dsc[((long)i * h + hh) * TS_ + col] = gq;
+                if (a.dsc_bf16) dsc16[((long)i * h + hh) * TS_ + col] = (bf16_t)gq;
+                else dsc[((long)i * h + hh) * TS_ + col] = gq;
               }
             }
           }
@@ -769,7 +772,7 @@ int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, vo
 
 // returns 1 if launched, 0 if the shape is outside this kernel's envelope (caller falls back), -1 on launch error
 int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsigned char* tmask, void* O, const void* dO,
-                  float* dscores, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
+                  void* dscores, int dsc_bf16, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
                   int bwd, const DropArg& drop, hipStream_t st) {
   const int G = dir == 0 ? S : T, Kn = dir == 0 ? T : S;
   if (dk != 64 || Lq > 32 || Kn > 128 || (ldv % 8) != 0 || ((uintptr_t)V % 16) != 0) return 0;
@@ -788,7 +791,7 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
   const size_t lds = (size_t)(((long)Lq * Gc * (Kn + 1) * 4 + 15) / 16 * 16) + (size_t)Gc * 32 * kpad * 2 + (size_t)Gc * kpad * 64 * 2 +
                      (bwd ? (size_t)Gc * 32 * 64 * 2 : 0) + 16;
   static const int dbg = [] { const char* e = getenv("BIST_ST1_DBG"); return e ? atoi(e) : 0; }();
-  St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc, dbg, drop};
+  St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc, dsc_bf16, dbg, drop};
 #define GO(TS_, KS_)                                                                   \
   return bwd ? launch_one<TS_, KS_, true>(a, B, lds, st) : launch_one<TS_, KS_, false>(a, B, lds, st)
   if (sc_is_f32) {

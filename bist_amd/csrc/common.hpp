@@ -35,7 +35,7 @@ void bist_set_error(const char* fmt, ...);
 // MFMA implementation of the stage-1 core (attention_mfma.hip): 1 = launched, 0 = shape outside its envelope, -1 = error
 struct DropArg;
 int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsigned char* tmask, void* O, const void* dO,
-                  float* dscores, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
+                  void* dscores, int dsc_bf16, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
                   int bwd, const DropArg& drop, hipStream_t st);
 
 int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, void* PY, const void* dPY, void* dq2f, void* dY,

@@ -301,8 +301,9 @@ int bist_mha_core_bwd(const void* Q, const void* K, const void* V, const uint8_t
                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                       int64_t lddq, int64_t lddk, int64_t lddv, int64_t dq_bs, int64_t dk_bs, int64_t dv_bs,
                       int64_t mask_bs, int64_t mask_qs, float scale, const BistDrop* drop, int32_t dtype, void* stream);
-/* dscores (f32 [B,Lq*h,T*S]) and dV ([B,T,S,*], row stride lddv) of bist_st_stage1_pv_fwd.        */
-int bist_st_stage1_pv_bwd(const float* scores, const void* V, const uint8_t* tmask, const void* dO, float* dscores, void* dV,
+/* dscores ([B,Lq*h,T*S] in dscores_dtype: BIST_F32, or BIST_BF16 when the score products' backward takes bf16 operands --
+ * saves the f32 -> bf16 pass over 4*B*Lq*h*T*S bytes) and dV ([B,T,S,*], row stride lddv) of bist_st_stage1_pv_fwd.        */
+int bist_st_stage1_pv_bwd(const float* scores, const void* V, const uint8_t* tmask, const void* dO, void* dscores, int32_t dscores_dtype, void* dV,
                           int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk, int64_t ldv, int64_t lddv,
                           int32_t direction, const BistDrop* drop, int32_t dtype, void* stream);
 /* dq2f and dY of bist_st_stage2_fwd; d_rowsum (f32 [B,Lq,h], nullable) is the gradient of `rowsum`.  */
