@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const T* __restrict__ Q, 
                                                        const unsigned char* __restrict__ mask, T* __restrict__ O, float* __restrict__ P,
                                                        int N, int Lq, int Lk, int h, int dk, long ldq, long ldk, long ldv, long ldo,
                                                        long q_bs, long k_bs, long v_bs, long o_bs, long mask_bs, long mask_qs, float scale,
-                                                       const DropArg drop) {
+                                                       const DropArg drop, int kvec) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long item = (long)blockIdx.x * 4 + w;
@@ -47,7 +47,17 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const T* __restrict__ Q, 
   for (int j = lane; j < Lk; j += 64) {
     const T* kr = Kn + (long)j * ldk;
     float s = 0.f;
-    for (int c = 0; c < dk; ++c) s += qs[c] * to_f(kr[c]);
+    if (kvec) {                                           // 16-byte pieces of the key row (was one 2-byte load per element)
+      constexpr int E = 16 / (int)sizeof(T);
+      for (int c = 0; c < dk; c += E) {
+        T k8[E];
+        *reinterpret_cast<uint4*>(k8) = *reinterpret_cast<const uint4*>(kr + c);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s += qs[c + e] * to_f(k8[e]);
+      }
+    } else {
+      for (int c = 0; c < dk; ++c) s += qs[c] * to_f(kr[c]);
+    }
     s *= scale;
     if (mrow && mrow[j] == 0) s = MASK_FILL;
     ps[j] = s;
@@ -251,12 +261,14 @@ extern "C" int bist_mha_core_fwd(const void* Q, const void* K, const void* V, co
   hipStream_t st = (hipStream_t)stream;
   const long items = (long)N * h * Lq;
   const unsigned g = (unsigned)((items + 3) / 4);
+  const long esz = dtype == BIST_BF16 ? 2 : 4, piece = 16 / esz;
+  const int kvec = ((uintptr_t)K % 16 == 0) && ldk % piece == 0 && k_bs % piece == 0 && dk % piece == 0;
   if (dtype == BIST_BF16)
     hipLaunchKernelGGL(mha_core_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, mask,
-                       (bf16_t*)O, p_attn, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, dr);
+                       (bf16_t*)O, p_attn, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, dr, kvec);
   else if (dtype == BIST_F32)
     hipLaunchKernelGGL(mha_core_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)Q, (const float*)K, (const float*)V, mask,
-                       (float*)O, p_attn, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, dr);
+                       (float*)O, p_attn, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, dr, kvec);
   else { bist_set_error("bist_mha_core_fwd: bad dtype %d", dtype); return BIST_EINVAL; }
   BIST_LAUNCH_CHECK("bist_mha_core_fwd");
   return BIST_OK;
