@@ -633,6 +633,10 @@ extern "C" int bist_layernorm_param_grad_multi(const BistLnGrad* jobs, int32_t n
       static const long wtarget = [] { const char* e = getenv("BIST_LNGRAD_TARGET"); return e ? atol(e) : 4096L; }();    // tuning aid
       int rpw = (int)((q.rows + wtarget - 1) / wtarget);           // up to ~4096 waves per job (the [25088 x 512] LayerNorm of P0: 7 rows per wave; 11.80 vs 11.98 ms per step at 256 waves)
       if (rpw < 4) rpw = 4;
+      // few-row jobs (the ~120 LayerNorms on B*Lq = 320 rows): every block ends in 2*d atomics on the job's OWN accumulators, so
+      // 20 blocks per job were 2.4 M atomics per step; 4 blocks per job instead (12.08 -> 11.89 ms per step; 1 block: 12.16)
+      static const long small_blocks = [] { const char* e = getenv("BIST_LNGRAD_SMALL_BLOCKS"); return e ? atol(e) : 4L; }();    // tuning aid
+      if (q.rows <= 2048) { const long r2 = (q.rows + 4 * small_blocks - 1) / (4 * small_blocks); if (r2 > rpw) rpw = (int)r2; }
       b.dy[i] = q.dy; b.x[i] = q.x; b.a[i] = q.a; b.da[i] = q.da; b.db[i] = q.db;
       b.rows[i] = (int)q.rows; b.lddy[i] = (int)q.lddy; b.ldx[i] = (int)q.ldx; b.rpw[i] = rpw; b.eps[i] = q.eps;
       b.first[i] = total;
