@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbist_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_GATE = 0, 1, 2
 
 
 class BistGemm(C.Structure):

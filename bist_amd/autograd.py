@@ -9,13 +9,14 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
 from torch.autograd import Function
 
 from . import ops
-from ._lib import ACT_NONE, ACT_RELU, check, lib
+from ._lib import ACT_GATE, ACT_NONE, ACT_RELU, check, lib
 from .ops import _ptr, _stream, dtype_code
 
 Tensor = torch.Tensor
@@ -84,6 +85,8 @@ class LinearFn(Function):
         # GEMM straight into the flat gradient buffer, bias gradients into the fp32 accumulator
         ctx.w_dst = getattr(w, "_grad_view", None)
         ctx.b_dst = getattr(bias, "_acc32", None) if bias is not None else None
+        gate = getattr(x, "_bist_gate", None)             # x = drop(relu(.)) of the producing linear layer, 2-D and saved here as x2
+        ctx.gate = gate if (gate is not None and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)) else None
         # the caller's shape is produced HERE (not by a view afterwards): a view node between this Function and its consumer
         # would re-wrap the gradient tensor and drop the consumer's _bist_dz hand-off (see backward)
         return y if out_shape is None else y.view(out_shape)
@@ -110,7 +113,10 @@ class LinearFn(Function):
             else:
                 dres = dy.view(res_shape)
         dz = dy if dy.dtype == x2.dtype else ops.cast(dy, x2.dtype)
-        if pre is not None and act == ACT_NONE and pre[1:] == (float(drop_p), int(drop_seed)) and pre[0].numel() == M * N \
+        if pre is not None and len(pre) == 4 and act == ACT_RELU and pre[1:3] == (float(drop_p), int(drop_seed)) \
+                and pre[0].numel() == M * N and pre[0].dtype == x2.dtype:
+            dz = pre[0].view(M, N)                     # already gated (y > 0, 1/(1-p)) by the consumer's dX product
+        elif pre is not None and len(pre) == 3 and act == ACT_NONE and pre[1:] == (float(drop_p), int(drop_seed)) and pre[0].numel() == M * N \
                 and pre[0].dtype == x2.dtype:
             dz = pre[0].view(M, N)                     # already masked by the LayerNorm backward that produced dy
         elif act == ACT_RELU or drop_p > 0:
@@ -123,13 +129,15 @@ class LinearFn(Function):
                   "bist_epilogue_bwd")
             dz = dz2
         dx, dw, db = _linear_grads(x2, w, dz, alpha, ctx.w_dst, ctx.b_dst, bias_dtype if has_bias else None,
-                                   ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
+                                   ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2], gate=ctx.gate)
         if dx is not None:
             dx = dx.view(x_shape)
+            if ctx.gate is not None:
+                dx._bist_dz = (dx, ctx.gate[0], ctx.gate[1], "gate")      # survives only if autograd hands THIS tensor to the producer
         return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
-def _linear_grads(x2, w, dz, alpha, w_dst, b_dst, bias_dtype, need_dx, need_dw, need_db):
+def _linear_grads(x2, w, dz, alpha, w_dst, b_dst, bias_dtype, need_dx, need_dw, need_db, gate=None):
     """dX = alpha dZ.W, dW = alpha dZ^T.X (accumulated into the trainer's gradient view when there is one), db = colsum(dZ)
     of y = alpha x.W^T + b -- the two products as ONE launch when both are small (bist_gemm_pair)."""
     M, K = x2.shape
@@ -138,7 +146,11 @@ def _linear_grads(x2, w, dz, alpha, w_dst, b_dst, bias_dtype, need_dx, need_dw, 
     g_dx = g_dw = None
     if need_dx:
         dx = torch.empty((M, K), device=dz.device, dtype=x2.dtype)
-        g_dx = ops.gemm_desc(dz, w, dx, M=M, N=K, K=N, a_rs=N, a_ks=1, b_rs=1, b_ks=w.stride(0), ldc=K, alpha=alpha)
+        if gate is not None:      # x2 = drop(relu(z)) of the producing layer: dX gated by x2 > 0 and scaled by 1/(1-p) = the gradient of z
+            g_dx = ops.gemm_desc(dz, w, dx, M=M, N=K, K=N, a_rs=N, a_ks=1, b_rs=1, b_ks=w.stride(0), ldc=K,
+                                 alpha=alpha / (1.0 - gate[0]), act=ACT_GATE, residual=x2, ldr=x2.stride(0))
+        else:
+            g_dx = ops.gemm_desc(dz, w, dx, M=M, N=K, K=N, a_rs=N, a_ks=1, b_rs=1, b_ks=w.stride(0), ldc=K, alpha=alpha)
     if need_dw:
         if w_dst is not None:                # dW accumulates in place: C = alpha * dz^T x + C
             g_dw = ops.gemm_desc(dz, x2, w_dst, M=N, N=K, K=M, a_rs=1, a_ks=N, b_rs=1, b_ks=x2.stride(0), ldc=w_dst.stride(0), alpha=alpha,
@@ -200,6 +212,9 @@ class LinearPairFn(Function):
         return tuple(out)
 
 
+GATE_HANDOFF = os.environ.get("BIST_GATE_HANDOFF", "1") != "0"      # tuning aid
+
+
 def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, res_map=(0, 0), alpha=1.0, out=None, out_dtype=None,
            accumulate=False, drop_p=0.0, drop_seed=0, out_shape=None):
     if not torch.is_grad_enabled():
@@ -215,6 +230,10 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, res_map=(0, 0), alph
     if drop_p > 0 and act == ACT_NONE and res_map == (0, 0):
         # y = drop(z) + res: a LayerNorm that consumes y can hand the masked gradient of z back (see _ln_backward)
         y._bist_drop = (float(drop_p), int(drop_seed), w.shape[0])
+    if act == ACT_RELU and residual is None and out_shape is None and GATE_HANDOFF:
+        # y = drop(relu(z)): a linear layer that consumes y gates its dX product with y > 0 and hands the result back as the
+        # gradient of z (LinearFn.backward), so no separate masking pass runs between the two backward products
+        y._bist_gate = (float(drop_p), int(drop_seed))
     return y
 
 

@@ -194,7 +194,8 @@ __device__ __forceinline__ float epilogue_value(const GemmK& g, float acc, float
   }
   if (res) {
     const long rr = g.res_outer > 0 ? (long)(m / g.res_outer) * g.res_inner + (m % g.res_inner) : (long)m;
-    v += to_f(res[rr * g.ldr + n]);
+    const float r = to_f(res[rr * g.ldr + n]);
+    v = g.act == BIST_ACT_GATE ? (r > 0.f ? v : 0.f) : v + r;
   }
   return v;
 }
@@ -216,12 +217,13 @@ struct RowOut {
   const TO* res;
   unsigned long long zoff, seed;
   float keep_scale;
-  bool relu, dropping;
+  bool relu, dropping, gate;
   __device__ __forceinline__ RowOut(const GemmK& g_, int z1, int z2, unsigned long long zoff_) : g(g_), zoff(zoff_) {
     C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
     bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
     res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
     relu = g.act == BIST_ACT_RELU;
+    gate = g.act == BIST_ACT_GATE;
     dropping = g.drop_p > 0.f;
     seed = g.drop_seed + ((dropping && g.drop_ctr) ? g.drop_ctr[0] * 0xD1B54A32D192ED03ULL : 0ULL);
     keep_scale = dropping ? 1.f / (1.f - g.drop_p) : 1.f;
@@ -269,8 +271,13 @@ struct RowOut {
       const TO* rp = res + (long)m * g.ldr + n;
 #pragma unroll
       for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(q)[c] = reinterpret_cast<const uint4*>(rp)[c];
+      if (gate) {
 #pragma unroll
-      for (int e = 0; e < VW; ++e) v[e] += to_f(q[e]);
+        for (int e = 0; e < VW; ++e) v[e] = to_f(q[e]) > 0.f ? v[e] : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) v[e] += to_f(q[e]);
+      }
     }
     TO o[VW];
 #pragma unroll
@@ -305,10 +312,10 @@ struct RowOut {
           for (int c = 0; c < (int)(VW * sizeof(TO) / 16); ++c) reinterpret_cast<uint4*>(q)[c] = reinterpret_cast<const uint4*>(rp)[c];
         }
 #pragma unroll
-        for (int e = 0; e < VW; ++e) v[e] += to_f(q[e]);
+        for (int e = 0; e < VW; ++e) v[e] = gate ? (to_f(q[e]) > 0.f ? v[e] : 0.f) : v[e] + to_f(q[e]);
       } else {
 #pragma unroll
-        for (int e = 0; e < VW; ++e) if (n + e < g.N) v[e] += to_f(rp[e]);
+        for (int e = 0; e < VW; ++e) if (n + e < g.N) v[e] = gate ? (to_f(rp[e]) > 0.f ? v[e] : 0.f) : v[e] + to_f(rp[e]);
       }
     }
     TO o[VW];
@@ -509,7 +516,7 @@ __device__ __forceinline__ void stream_out(const GemmK& g, const char* lds_lo, c
         float x = v[e] * g.alpha + bv[e];
         if (g.act == BIST_ACT_RELU) x = fmaxf(x, 0.f);
         if (g.drop_p > 0.f) x = drop_keep(seed, zoff + (unsigned long long)m * g.N + n + e, g.drop_p) ? x * keep_scale : 0.f;
-        o[e] = from_f<TO>(x + rv[e]);
+        o[e] = from_f<TO>(g.act == BIST_ACT_GATE ? (rv[e] > 0.f ? x : 0.f) : x + rv[e]);
       }
     }
     TS* dst = out_base + (long)m * ld_out + n;
@@ -1714,6 +1721,8 @@ int fill_gemmk(const BistGemm* g, GemmK& k) {
   BIST_REQUIRE(g->out_dtype == BIST_F32 || g->out_dtype == g->in_dtype, "bist_gemm: out_dtype must be f32 or equal in_dtype");
   BIST_REQUIRE(g->drop_p >= 0.f && g->drop_p < 1.f, "bist_gemm: drop_p out of range");
   BIST_REQUIRE((g->res_outer == 0) == (g->res_inner == 0) && g->res_outer >= 0, "bist_gemm: bad residual row map");
+  BIST_REQUIRE(g->act == BIST_ACT_NONE || g->act == BIST_ACT_RELU || (g->act == BIST_ACT_GATE && g->residual && g->drop_p == 0.f),
+               "bist_gemm: bad act %d (the gate needs a residual operand and no dropout)", (int)g->act);
   BIST_REQUIRE(g->workspace_bytes >= 0 && (g->workspace || g->workspace_bytes == 0), "bist_gemm: bad workspace");
   k.A = (const char*)g->A; k.B = (const char*)g->B; k.C = (char*)g->C;
   k.bias = (const char*)g->bias; k.residual = (const char*)g->residual;

@@ -36,6 +36,9 @@ extern "C" {
 
 #define BIST_ACT_NONE 0
 #define BIST_ACT_RELU 1
+#define BIST_ACT_GATE 2   /* y = residual[m,n] > 0 ? alpha*acc + bias : 0 -- the residual operand is a GATE, not an addend: the
+                           * backward of y1 = dropout(relu(z)) fused into the product that computes dy1 (dh = dy.W2 of the
+                           * feed-forward block, modules.py:112-113), with 1/(1-p) folded into alpha                          */
 
 int bist_version(void);
 const char* bist_last_error(void);

@@ -166,6 +166,22 @@ def test_gemm_tile256_is_automatic_for_the_frame_grid_products(ops):
     assert torch.equal((small.float().cpu() != 0), kept[:Ms])
 
 
+@pytest.mark.parametrize("M,N,K", [(320, 2048, 512), (77, 130, 96), (18100, 512, 512)])
+def test_gemm_gate_epilogue(ops, M, N, K):
+    """BIST_ACT_GATE: y = gate > 0 ? alpha * x.W^T : 0 -- the backward of dropout(relu(z)) fused into the product that
+    computes its output gradient (64-tile, generic and 256-tile kernels)."""
+    from bist_amd._lib import ACT_GATE
+    dtype, tol = torch.bfloat16, BF16_TOL
+    x, w = _rand(M, K, seed=31), _rand(N, K, seed=32, scale=K ** -0.5)
+    gate = _rand(M, N, seed=33).clamp_min(0)                   # ~half zeros, like a ReLU output
+    xd, wd, gd = (t.to(dtype).cuda() for t in (x, w, gate))
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(xd, wd, out, M=M, N=N, K=K, a_rs=K, b_rs=K, ldc=N, alpha=1.25, act=ACT_GATE, residual=gd, ldr=N)
+    ref = torch.where(_q(gate, dtype) > 0, 1.25 * (_q(x, dtype) @ _q(w, dtype).t()), torch.zeros(()))
+    _cmp(out, ref, tol, "gate epilogue")
+    assert torch.equal(out.float().cpu() == 0, ref == 0) or (out.float().cpu()[ref == 0] == 0).all()
+
+
 def test_gemm_tile256_race_screen(ops):
     """The 256-tile kernel orders its LDS-DMA stagings against the fragment reads by counted vmcnt waits and barriers only
     (no data dependence the hardware could see): a misplaced wait shows as a rare wrong tile that comes and goes with
