@@ -92,9 +92,9 @@ typedef struct BistGemm {
   void* workspace;
   int64_t workspace_bytes;
   /* Kernel selection: 0 = automatic.  BIST_GEMM_TILE256 asks for the 256x256-tile deep-pipelined kernel
-   * (bf16, both operands K-contiguous, K a multiple of 64, unbatched or batched) wherever it is legal; it is
-   * chosen automatically only for products with >= 256 such tiles and N, K >= 2048 (it beats the 128-tile kernel
-   * by 15-20 % there, and loses on the short-K, N = 512 products of this model).  Tuning and test aid.            */
+   * (bf16, both operands K-contiguous, K a multiple of 64 and >= 128, unbatched or batched) wherever it is legal; it is
+   * chosen automatically for such products of >= 140 tiles and K >= 512 (the M = B*T*S products of the path from B = 12:
+   * P0 56 vs 78 us against the 128-tile kernel), with 160-row tiles when M pads better to 160 than to 256.            */
   int32_t hint;
   int32_t reserved;
 } BistGemm;
