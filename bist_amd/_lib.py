@@ -89,6 +89,7 @@ SIGNATURES = {
     "bist_cast_from_f32": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "bist_add_f32_into": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "bist_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _I32, _F, _I32, _I32, _P]),
+    "bist_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _P]),
     "bist_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _P]),
 }
 

@@ -472,11 +472,15 @@ __global__ void add_f32_into_kernel(const float* __restrict__ s, T* __restrict__
 // Adam step on fp32 master weights with an optional low-precision working copy:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
 // (torch.optim.Adam semantics, the optimiser the reference wraps in NoamOpt, train.py:129-130)
+// hyper (nullable, device): {lr, 1 - beta1^t, 1 - beta2^t, grad_scale} of THIS step -- lets the launch live inside a captured
+// hipGraph, whose kernel arguments are frozen at capture time
 template <typename TG, typename TW>
 __global__ void adam_kernel(float* __restrict__ p, const TG* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            TW* __restrict__ work, long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float gscale) {
+                            TW* __restrict__ work, long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float gscale,
+                            const float* __restrict__ hyper) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; gscale = hyper[3]; }
   const float gi = to_f(g[i]) * gscale;
   const float mi = b1 * m[i] + (1.f - b1) * gi;
   const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -730,7 +734,7 @@ extern "C" int bist_adam_step(float* p, const void* g, float* m, float* v, void*
   hipStream_t st = (hipStream_t)stream;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   const unsigned grid = blocks_for(n, 256);
-#define ADAM(TG, TW) hipLaunchKernelGGL((adam_kernel<TG, TW>), dim3(grid), dim3(256), 0, st, p, (const TG*)g, m, v, (TW*)work, (long)n, lr, beta1, beta2, eps, bc1, bc2, grad_scale)
+#define ADAM(TG, TW) hipLaunchKernelGGL((adam_kernel<TG, TW>), dim3(grid), dim3(256), 0, st, p, (const TG*)g, m, v, (TW*)work, (long)n, lr, beta1, beta2, eps, bc1, bc2, grad_scale, (const float*)nullptr)
   if (grad_dtype == BIST_F32 && (work == nullptr || work_dtype == BIST_F32)) ADAM(float, float);
   else if (grad_dtype == BIST_F32 && work_dtype == BIST_BF16) ADAM(float, bf16_t);
   else if (grad_dtype == BIST_BF16 && (work == nullptr || work_dtype == BIST_BF16)) ADAM(bf16_t, bf16_t);
@@ -738,5 +742,21 @@ extern "C" int bist_adam_step(float* p, const void* g, float* m, float* v, void*
   else { bist_set_error("bist_adam_step: bad dtype combination"); return BIST_EINVAL; }
 #undef ADAM
   BIST_LAUNCH_CHECK("bist_adam_step");
+  return BIST_OK;
+}
+
+extern "C" int bist_adam_step_dev(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
+                                  float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream) {
+  BIST_REQUIRE(p && g && m && v && hyper && n > 0, "bist_adam_step_dev: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = blocks_for(n, 256);
+#define ADAM(TG, TW) hipLaunchKernelGGL((adam_kernel<TG, TW>), dim3(grid), dim3(256), 0, st, p, (const TG*)g, m, v, (TW*)work, (long)n, 0.f, beta1, beta2, eps, 1.f, 1.f, 1.f, hyper)
+  if (grad_dtype == BIST_F32 && (work == nullptr || work_dtype == BIST_F32)) ADAM(float, float);
+  else if (grad_dtype == BIST_F32 && work_dtype == BIST_BF16) ADAM(float, bf16_t);
+  else if (grad_dtype == BIST_BF16 && (work == nullptr || work_dtype == BIST_BF16)) ADAM(bf16_t, bf16_t);
+  else if (grad_dtype == BIST_BF16 && work_dtype == BIST_F32) ADAM(bf16_t, float);
+  else { bist_set_error("bist_adam_step_dev: bad dtype combination"); return BIST_EINVAL; }
+#undef ADAM
+  BIST_LAUNCH_CHECK("bist_adam_step_dev");
   return BIST_OK;
 }

@@ -58,6 +58,10 @@ class Trainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self._step = 0
+        # one rank: the optimiser is part of backward() (and of its captured hipGraph); several ranks: the gradient exchange
+        # comes first, Adam stays an eager launch per exchanged piece (step())
+        self.adam_in_step = (self.world == 1 and os.environ.get("BIST_ADAM_IN_STEP", "1") != "0"
+                             and not (os.environ.get("BIST_FORCE_EXCHANGE") == "1" and dist.is_available() and dist.is_initialized()))
 
         params: List[torch.nn.Parameter] = []
         seen = set()
@@ -116,6 +120,8 @@ class Trainer:
         self.acc32 = torch.zeros(self.n32, device=dev, dtype=torch.float32)
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)          # {lr, 1 - beta1^t, 1 - beta2^t, grad_scale} of the current step
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
 
         for p in order:
             o, k = offs[id(p)], p.numel()
@@ -159,8 +165,22 @@ class Trainer:
             loss = t if loss is None else loss + t
         return loss, terms
 
-    def backward(self, batch):
-        """forward + backward; leaves the complete gradient in ``flat_grad`` (no optimiser step)."""
+    def _adam_dev(self, lo: int, hi: int) -> None:
+        """Adam on flat elements [lo, hi) with this step's scalars read from ``self.hyper`` (device): capturable."""
+        if hi <= lo:
+            return
+        work = None if self.compute_dtype == torch.float32 else self.flat_param
+        gsz = self.flat_grad.element_size()
+        check(lib.bist_adam_step_dev(self.master.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + gsz * lo, self.m.data_ptr() + 4 * lo,
+                                     self.v.data_ptr() + 4 * lo, (work.data_ptr() + work.element_size() * lo) if work is not None else None,
+                                     hi - lo, self.hyper.data_ptr(), self.betas[0], self.betas[1], self.eps,
+                                     dtype_code(self.compute_dtype), dtype_code(self.compute_dtype), _stream()), "bist_adam_step_dev")
+
+    def backward(self, batch, optimizer: bool = False):
+        """forward + backward; leaves the complete gradient in ``flat_grad``.  optimizer=True (single rank) also applies
+        Adam with the scalars in ``self.hyper``: the big matrices -- everything behind the fp32-accumulated prefix of
+        biases / LayerNorm parameters, 98 % of the elements -- on a side stream BESIDE the deferred bias / LayerNorm
+        reductions that close the backward pass, the prefix after them."""
         self.flat_grad.zero_()
         self.acc32.zero_()
         loss, terms = self.forward_loss(batch)
@@ -174,6 +194,16 @@ class Trainer:
                 Fn.join_side_streams()
             if wg is not None:
                 torch.cuda.current_stream().wait_stream(wg)
+            for p in self.params:                # anything autograd still produced itself (views, fallbacks)
+                if p.grad is not None:
+                    p._grad_view.add_(p.grad)
+                    p.grad = None
+            side = None
+            if optimizer and loss.is_cuda:       # every gradient behind the prefix is final: its Adam runs beside the reductions below
+                main, side = torch.cuda.current_stream(), Fn.side_stream(0)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._adam_dev(self.n32, self.numel)
             ops.col_sum_flush()
             ops.lngrad_flush()
         finally:
@@ -181,12 +211,14 @@ class Trainer:
             ops.LNGRAD_QUEUE = None
             ops.WGRAD_STREAM = None
             ops.WGRAD_KEEP.clear()
-        for p in self.params:                # anything autograd still produced itself (views, fallbacks)
-            if p.grad is not None:
-                p._grad_view.add_(p.grad)
-                p.grad = None
         check(lib.bist_add_f32_into(self.acc32.data_ptr(), self.flat_grad.data_ptr(), self.n32, dtype_code(self.compute_dtype),
                                     _stream()), "bist_add_f32_into")
+        if optimizer:
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+                self._adam_dev(0, self.n32)
+            else:
+                self._adam_dev(0, self.numel)
         return terms
 
     # ---- hipGraph path: forward + backward + gradient fold captured once per batch geometry ----------------
@@ -204,11 +236,11 @@ class Trainer:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                self.backward(batch)
+                self.backward(batch)              # warm-up passes leave the weights alone
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
-            terms = self.backward(batch)
+            terms = self.backward(batch, optimizer=self.adam_in_step)
         self._graph, self._graph_key, self._static_batch, self._static_terms = graph, key, batch, terms
 
     def _graph_backward(self, batch):
@@ -227,7 +259,15 @@ class Trainer:
         """One optimiser step; returns the (detached, device-side) loss terms."""
         self._step += 1
         self.drop_ctr.fill_(self._step)
-        terms = self._graph_backward(batch) if self.use_graph else self.backward(batch)
+        if self.adam_in_step:                # this step's optimiser scalars, read by the Adam launches inside backward()
+            self._hyper_host[0] = self.rate()
+            self._hyper_host[1] = 1.0 - self.betas[0] ** self._step
+            self._hyper_host[2] = 1.0 - self.betas[1] ** self._step
+            self._hyper_host[3] = 1.0
+            self.hyper.copy_(self._hyper_host, non_blocking=True)
+        terms = self._graph_backward(batch) if self.use_graph else self.backward(batch, optimizer=self.adam_in_step)
+        if self.adam_in_step:
+            return {k: v.detach() for k, v in terms.items()}
         # Gradient exchange + optimiser: the flat gradient goes over RCCL in EXCHANGE_CHUNKS large pieces issued back to
         # back (xGMI is point-to-point: a few large messages keep all 7 links busy), and Adam runs on piece k as soon as its
         # all-reduce has finished, i.e. under the all-reduce of piece k+1 (the compute stream waits on the collective's

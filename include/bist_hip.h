@@ -330,6 +330,11 @@ int bist_add_f32_into(const float* src, void* dst, int64_t n, int32_t dtype, voi
  * (nullable) receives the updated weights in work_dtype (the bf16 copy the kernels read).        */
 int bist_adam_step(float* p, const void* g, float* m, float* v, void* work, int64_t n, float lr, float beta1, float beta2,
                    float eps, int32_t step, float grad_scale, int32_t grad_dtype, int32_t work_dtype, void* stream);
+/* The same step with the per-step scalars read from device memory: hyper = {lr, 1 - beta1^t, 1 - beta2^t, grad_scale} (f32).
+ * A launch inside a captured hipGraph freezes its kernel arguments; with this form the optimiser is part of the replayed
+ * step (the host refreshes `hyper` before each replay) and can run beside the tail of the backward pass.                */
+int bist_adam_step_dev(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
+                       float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream);
 
 /* dst = cast(src) between f32 and bf16 (n elements). */
 int bist_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, void* stream);
