@@ -52,7 +52,7 @@ class Trainer:
                  betas=(0.9, 0.98), eps: float = 1e-9, process_group=None, use_graph: bool = False):
         self.model, self.args = model, args
         self.use_graph = use_graph
-        self._graph = self._graph_key = self._static_batch = self._static_terms = None
+        self._graph = self._graph2 = self._graph_key = self._static_batch = self._static_terms = None
         self.compute_dtype = compute_dtype
         self.warmup, self.factor, self.betas, self.eps = warmup, factor, betas, eps
         self.pg = process_group
@@ -60,8 +60,9 @@ class Trainer:
         self._step = 0
         # one rank: the optimiser is part of backward() (and of its captured hipGraph); several ranks: the gradient exchange
         # comes first, Adam stays an eager launch per exchanged piece (step())
-        self.adam_in_step = (self.world == 1 and os.environ.get("BIST_ADAM_IN_STEP", "1") != "0"
-                             and not (os.environ.get("BIST_FORCE_EXCHANGE") == "1" and dist.is_available() and dist.is_initialized()))
+        self.exchanging = self.world > 1 or (os.environ.get("BIST_FORCE_EXCHANGE") == "1" and dist.is_available()
+                                             and dist.is_initialized())          # (one-rank rehearsal aid, bench.py)
+        self.adam_in_step = not self.exchanging and os.environ.get("BIST_ADAM_IN_STEP", "1") != "0"
 
         params: List[torch.nn.Parameter] = []
         seen = set()
@@ -176,15 +177,13 @@ class Trainer:
                                      hi - lo, self.hyper.data_ptr(), self.betas[0], self.betas[1], self.eps,
                                      dtype_code(self.compute_dtype), dtype_code(self.compute_dtype), _stream()), "bist_adam_step_dev")
 
-    def backward(self, batch, optimizer: bool = False):
-        """forward + backward; leaves the complete gradient in ``flat_grad``.  optimizer=True (single rank) also applies
-        Adam with the scalars in ``self.hyper``: the big matrices -- everything behind the fp32-accumulated prefix of
-        biases / LayerNorm parameters, 98 % of the elements -- on a side stream BESIDE the deferred bias / LayerNorm
-        reductions that close the backward pass, the prefix after them."""
+    def _backward_open(self, batch):
+        """forward + backward up to the point where every gradient BEHIND the fp32-accumulated prefix (the big matrices, 98 %
+        of the elements) is final; the bias / LayerNorm-parameter reductions stay queued for _backward_close()."""
         self.flat_grad.zero_()
         self.acc32.zero_()
         loss, terms = self.forward_loss(batch)
-        ops.COLSUM_QUEUE = []                 # bias gradients: queued by LinearFn.backward, summed in a few launches below
+        ops.COLSUM_QUEUE = []                 # bias gradients: queued by LinearFn.backward, summed in a few launches by _backward_close
         ops.LNGRAD_QUEUE = []                 # LayerNorm gain/offset gradients: likewise
         wg = self._wgrad_stream if (self.wgrad_side_stream and loss.is_cuda) else None
         ops.WGRAD_STREAM = wg                 # weight-gradient GEMMs: off the critical path, on their own stream
@@ -198,21 +197,37 @@ class Trainer:
                 if p.grad is not None:
                     p._grad_view.add_(p.grad)
                     p.grad = None
-            side = None
-            if optimizer and loss.is_cuda:       # every gradient behind the prefix is final: its Adam runs beside the reductions below
-                main, side = torch.cuda.current_stream(), Fn.side_stream(0)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._adam_dev(self.n32, self.numel)
+        except BaseException:
+            ops.COLSUM_QUEUE = ops.LNGRAD_QUEUE = None
+            raise
+        finally:
+            ops.WGRAD_STREAM = None
+            ops.WGRAD_KEEP.clear()
+        return terms
+
+    def _backward_close(self) -> None:
+        """The deferred bias / LayerNorm-parameter reductions and the fold of the fp32 prefix into the gradient buffer."""
+        try:
             ops.col_sum_flush()
             ops.lngrad_flush()
         finally:
             ops.COLSUM_QUEUE = None
             ops.LNGRAD_QUEUE = None
-            ops.WGRAD_STREAM = None
-            ops.WGRAD_KEEP.clear()
         check(lib.bist_add_f32_into(self.acc32.data_ptr(), self.flat_grad.data_ptr(), self.n32, dtype_code(self.compute_dtype),
                                     _stream()), "bist_add_f32_into")
+
+    def backward(self, batch, optimizer: bool = False):
+        """forward + backward; leaves the complete gradient in ``flat_grad``.  optimizer=True (single rank) also applies
+        Adam with the scalars in ``self.hyper``: the big matrices on a side stream BESIDE the closing reductions, the
+        prefix of biases / LayerNorm parameters after them."""
+        terms = self._backward_open(batch)
+        side = None
+        if optimizer and self.flat_grad.is_cuda:
+            main, side = torch.cuda.current_stream(), Fn.side_stream(0)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._adam_dev(self.n32, self.numel)
+        self._backward_close()
         if optimizer:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
@@ -230,20 +245,28 @@ class Trainer:
                      if getattr(batch, f, None) is not None)
 
     def _capture(self, batch, key):
-        """Record the ~2.7k launches of forward+backward into one hipGraph (the batch tensors become the graph's
-        static inputs).  Warm-up runs on a side stream first, as graph capture requires."""
+        """Record the launches of forward+backward (+ Adam on one rank) into hipGraphs (the batch tensors become the graphs'
+        static inputs).  Warm-up runs on a side stream first, as graph capture requires.  Several ranks: TWO graphs, the
+        cut where the big matrices' gradients are final, so that their all-reduce starts under the closing reductions."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
                 self.backward(batch)              # warm-up passes leave the weights alone
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
-            terms = self.backward(batch, optimizer=self.adam_in_step)
-        self._graph, self._graph_key, self._static_batch, self._static_terms = graph, key, batch, terms
+        graph, graph2 = torch.cuda.CUDAGraph(), None
+        if self.exchanging:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
+                terms = self._backward_open(batch)
+            graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph2, capture_error_mode="thread_local"):
+                self._backward_close()
+        else:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                terms = self.backward(batch, optimizer=self.adam_in_step)
+        self._graph, self._graph2, self._graph_key, self._static_batch, self._static_terms = graph, graph2, key, batch, terms
 
-    def _graph_backward(self, batch):
+    def _graph_open(self, batch):
         key = self._shape_key(batch)
         if self._graph is None or key != self._graph_key:
             self._capture(batch, key)
@@ -265,13 +288,8 @@ class Trainer:
             self._hyper_host[2] = 1.0 - self.betas[1] ** self._step
             self._hyper_host[3] = 1.0
             self.hyper.copy_(self._hyper_host, non_blocking=True)
-        terms = self._graph_backward(batch) if self.use_graph else self.backward(batch, optimizer=self.adam_in_step)
-        if self.adam_in_step:
+            terms = self._graph_open(batch) if self.use_graph else self.backward(batch, optimizer=True)
             return {k: v.detach() for k, v in terms.items()}
-        # Gradient exchange + optimiser: the flat gradient goes over RCCL in EXCHANGE_CHUNKS large pieces issued back to
-        # back (xGMI is point-to-point: a few large messages keep all 7 links busy), and Adam runs on piece k as soon as its
-        # all-reduce has finished, i.e. under the all-reduce of piece k+1 (the compute stream waits on the collective's
-        # event, never the host).  One rank: a single Adam launch.
         work = None if self.compute_dtype == torch.float32 else self.flat_param
         gsz = self.flat_grad.element_size()
         rate = self.rate()
@@ -281,12 +299,25 @@ class Trainer:
                                      self.v.data_ptr() + 4 * lo, (work.data_ptr() + work.element_size() * lo) if work is not None else None,
                                      hi - lo, rate, self.betas[0], self.betas[1], self.eps, self._step, grad_scale,
                                      dtype_code(self.compute_dtype), dtype_code(self.compute_dtype), _stream()), "bist_adam_step")
-        if self.world > 1 or (os.environ.get("BIST_FORCE_EXCHANGE") == "1" and dist.is_initialized()):      # (rehearsal aid, bench.py)
-            bounds = parallel.chunk_bounds(self.numel, EXCHANGE_CHUNKS, ALIGN)
-            works = parallel.exchange_gradients_async(self.flat_grad, bounds, self.pg)
-            for (lo, hi), wk in zip(bounds, works):
-                wk.wait()
-                adam(lo, hi, 1.0 / self.world)
-        else:
+        if not self.exchanging:              # one rank, optimiser outside the step (BIST_ADAM_IN_STEP=0)
+            terms = self._graph_open(batch) if self.use_graph else self.backward(batch)
             adam(0, self.numel, 1.0)
+            return {k: v.detach() for k, v in terms.items()}
+        # Several ranks.  The gradients behind the fp32-accumulated prefix (the big matrices) are final before the closing
+        # bias / LayerNorm reductions: their all-reduce -- EXCHANGE_CHUNKS large pieces issued back to back (xGMI is
+        # point-to-point: a few large messages keep all 7 links busy) -- starts under those reductions, the prefix follows,
+        # and Adam runs on a piece as soon as its own all-reduce has finished, i.e. under the next piece's (the compute
+        # stream waits on the collective's event, never the host).
+        terms = self._graph_open(batch) if self.use_graph else self._backward_open(batch)
+        big = [(self.n32 + lo, self.n32 + hi) for lo, hi in parallel.chunk_bounds(self.numel - self.n32, EXCHANGE_CHUNKS, ALIGN)]
+        works = parallel.exchange_gradients_async(self.flat_grad, big, self.pg)
+        if self.use_graph:
+            self._graph2.replay()
+        else:
+            self._backward_close()
+        bounds = big + [(0, self.n32)]
+        works += parallel.exchange_gradients_async(self.flat_grad, [(0, self.n32)], self.pg)
+        for (lo, hi), wk in zip(bounds, works):
+            wk.wait()
+            adam(lo, hi, 1.0 / self.world)
         return {k: v.detach() for k, v in terms.items()}

@@ -708,3 +708,35 @@ def test_fan_out_sums_consumer_gradients_in_one_pass(env):
     assert Fn.Fan(ws[0], 3).take() is ws[0]                     # no autograd: the tensor itself
     out = ops.add_n([w.float() for w in ws[:3]])
     assert torch.allclose(out, ws[0].float() + ws[1].float() + ws[2].float())
+
+
+def test_exchange_path_matches_single_rank_step(env):
+    """The several-rank form of the step -- two hipGraphs with the big matrices' all-reduce issued between them, Adam per
+    exchanged piece -- run with a ONE-rank RCCL group (the all-reduce is then the identity): same losses, step for step,
+    as the one-rank form with the optimiser inside the captured step."""
+    import copy, os, socket
+    import torch.distributed as dist
+    import bist_amd.model as M
+    from bist_amd.data.synthetic import synthetic_batch
+    from bist_amd.train import Trainer
+    cfg = O.Cfg(d_model=64, att_h=4, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    args = _args(cfg)
+    torch.manual_seed(0)
+    m1 = M.make_model(80, 80, args, ft_sizes=[64]).cuda().eval()
+    m2 = copy.deepcopy(m1)
+    b = synthetic_batch(4, T=6, S=9, C=64, Lq=7, Lh=9, Lc=6, Lt=6, vocab=80, dtype=torch.float32)
+    t1 = Trainer(m1, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=True)
+    assert t1.adam_in_step and not t1.exchanging
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}", device_id=torch.device("cuda", 0))
+    os.environ["BIST_FORCE_EXCHANGE"] = "1"
+    try:
+        t2 = Trainer(m2, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=True)
+        assert t2.exchanging and not t2.adam_in_step
+        l1 = [t1.step(b)["out"].item() for _ in range(4)]
+        l2 = [t2.step(b)["out"].item() for _ in range(4)]
+        assert t2._graph2 is not None
+    finally:
+        os.environ.pop("BIST_FORCE_EXCHANGE", None)
+        dist.destroy_process_group()
+    assert all(abs(a - c) <= 2e-3 * (1 + i) * abs(a) for i, (a, c) in enumerate(zip(l1, l2))), (l1, l2)
