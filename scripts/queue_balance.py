@@ -2,7 +2,11 @@
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 # the last occurrence of adam_kernel marks step ends; take the window between the last two adam launches of the replayed steps
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+if len({int(rows[i]["Grid_Size_X"]) for i in adam}) > 1:          # two Adam launches per step: the small (prefix) one ends it
+    gmin = min(int(rows[i]["Grid_Size_X"]) for i in adam)
+    adam = [i for i in adam if int(rows[i]["Grid_Size_X"]) == gmin]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 lo, hi = adam[k - 1] + 1, adam[k] + 1
 win = rows[lo:hi]

@@ -8,7 +8,10 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ad = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
-seg = rows[ad[-2] + 1:ad[-1] + 1]
+# a step ends with its LAST Adam launch: one launch per step, or two (big matrices beside the closing reductions, then the prefix)
+gmin = min(int(rows[i]["Grid_Size_X"]) for i in ad)
+ends = [i for i in ad if int(rows[i]["Grid_Size_X"]) == gmin] if len({int(rows[i]["Grid_Size_X"]) for i in ad}) > 1 else ad
+seg = rows[ends[-2] + 1:ends[-1] + 1]
 agg = collections.defaultdict(list)
 for r in seg:
     n = r["Kernel_Name"]
