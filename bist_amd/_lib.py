@@ -66,6 +66,7 @@ SIGNATURES = {
     "bist_fuse_modalities": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _I64, _I32, _I32, _I32, _P]),
     "bist_add_bcast": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _P]),
     "bist_add_n": (C.c_int, [_P, _I32, _P, _I64, _I32, _P]),
+    "bist_permute_ts": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "bist_pointer_mix_fwd": (C.c_int, [_P, _P, _I32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                        _P, _I64, _I32, _I32, _I32, _P]),
     "bist_log_softmax_fwd": (C.c_int, [_P, _P, _I64, _I32, _P]),

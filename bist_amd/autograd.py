@@ -514,6 +514,18 @@ class AddFn(Function):
         return dy, dy
 
 
+class PermuteTSFn(Function):
+    """[B,T,S,d] -> [B,S,T,d]; the gradient takes the same kernel back."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.permute_ts(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.permute_ts(dy)
+
+
 class FanOutFn(Function):
     """n aliases of one tensor for n consumers; backward sums their gradients in ONE pass (bist_add_n) where autograd's
     own accumulation makes n-1 pairwise passes.  The video tensor of the reasoning layers has 3 L consumers, each with a
@@ -612,7 +624,7 @@ class StStage1PvFn(Function):
     @staticmethod
     def forward(ctx, scores, v, tmask, dims, direction, drop=None):
         B, T, S, Lq, h, dk = dims
-        m8 = _mask_u8(tmask.reshape(B, T)) if tmask is not None else None
+        m8 = _mask_u8(tmask.reshape(B, T if direction == 0 else S)) if tmask is not None else None      # one entry per key
         out = ops.st_stage1_pv(scores, v, m8, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction, drop=drop)
         ctx.save_for_backward(scores, v, m8)
         ctx.cfg = (dims, direction)

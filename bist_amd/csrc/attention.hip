@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void st1_pv_kernel(const TS* __restrict__ scor
   const long TS_ = (long)T_ * S_;
   const int d = h * dk;
   const TS* sc = scores + (long)b * Lq * h * TS_;
-  const unsigned char* mk = (dir == 0 && tmask) ? tmask + (long)b * T_ : nullptr;
+  const unsigned char* mk = tmask ? tmask + (long)b * Kn : nullptr;       // key mask [B, K]: frames (t2s) -- or the keys of a permuted call
 
   // phase 1: gather the score slab (coalesced along the contiguous axis of each direction)
   const int total = Lq * gc * Kn;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void st1_pv_bwd_kernel(const float* __restrict
   const float* sc = scores + (long)b * Lq * h * TS_;
   float* dsc = reinterpret_cast<float*>(dscores) + (long)b * Lq * h * TS_;
   bf16_t* dsc16 = reinterpret_cast<bf16_t*>(dscores) + (long)b * Lq * h * TS_;
-  const unsigned char* mk = (dir == 0 && tmask) ? tmask + (long)b * T_ : nullptr;
+  const unsigned char* mk = tmask ? tmask + (long)b * Kn : nullptr;       // key mask [B, K]: frames (t2s) -- or the keys of a permuted call
   const int total = Lq * gc * Kn;
   for (int idx = tid; idx < total; idx += 256) {
     int i, gl, k;

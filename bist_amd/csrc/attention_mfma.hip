@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
     }
   }
   const TS* sc = reinterpret_cast<const TS*>(a.scores) + (long)b * Lq * h * TS_;
-  const unsigned char* mk = (dir == 0 && a.tmask) ? a.tmask + (long)b * T_ : nullptr;
+  const unsigned char* mk = a.tmask ? a.tmask + (long)b * Kn : nullptr;      // key mask [B, K]
   // ---- A: score slab ---------------------------------------------------------------------------------------
   if (a.dbg & 1) {
   } else if (dir == 1) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
           int gl = gl0, k = k0;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (e + j < run) dst[gl * KP + k] = v[j];
+            if (e + j < run) dst[gl * KP + k] = (mk && mk[k] == 0) ? MASK_FILL : v[j];
             if (++k == Kn) { k = 0; ++gl; }
           }
         }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
         int gl = 0, k = lane;
         while (k >= Kn) { k -= Kn; ++gl; }
         for (int e = lane; e < run; e += 64) {
-          dst[gl * KP + k] = to_f(src[e]);
+          dst[gl * KP + k] = (mk && mk[k] == 0) ? MASK_FILL : to_f(src[e]);
           k += 64;
           while (k >= Kn) { k -= Kn; ++gl; }
         }

@@ -238,6 +238,34 @@ __global__ __launch_bounds__(256) void add_n_kernel(const AddNPtrs src, int n, T
 }
 }  // namespace
 
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void permute_ts_kernel(const T* __restrict__ x, T* __restrict__ y, int T_, int S_, int d, long total16) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total16) return;
+  const int cpr = d / E;
+  const int c = (int)(idx % cpr); long r = idx / cpr;
+  const int s = (int)(r % S_); r /= S_;
+  const int t = (int)(r % T_); const long b = r / T_;
+  const uint4 v = *reinterpret_cast<const uint4*>(x + idx * E);
+  *reinterpret_cast<uint4*>(y + (((b * S_ + s) * T_ + t) * (long)d + (long)c * E)) = v;
+}
+}  // namespace
+
+extern "C" int bist_permute_ts(const void* x, void* y, int32_t B, int32_t T, int32_t S, int32_t d, int32_t dtype, void* stream) {
+  BIST_REQUIRE(x && y && B > 0 && T > 0 && S > 0 && d > 0, "bist_permute_ts: bad argument");
+  const long esz = dtype == BIST_BF16 ? 2 : 4;
+  BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && (d * esz) % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0,
+               "bist_permute_ts: rows must be whole 16-byte pieces, 16-byte aligned");
+  const long total16 = (long)B * T * S * (d * esz / 16);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == BIST_BF16) hipLaunchKernelGGL(permute_ts_kernel<bf16_t>, dim3(blocks_for(total16, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, T, S, d, total16);
+  else hipLaunchKernelGGL(permute_ts_kernel<float>, dim3(blocks_for(total16, 256)), dim3(256), 0, st, (const float*)x, (float*)y, T, S, d, total16);
+  BIST_LAUNCH_CHECK("bist_permute_ts");
+  return BIST_OK;
+}
+
 extern "C" int bist_add_n(const void* const* srcs, int32_t n, void* out, int64_t numel, int32_t dtype, void* stream) {
   BIST_REQUIRE(srcs && out && n >= 1 && n <= BIST_ADD_N_MAX && numel > 0, "bist_add_n: bad argument (n = %d)", (int)n);
   AddNPtrs p{};

@@ -129,6 +129,11 @@ def add(a, b):
     return ops.add(a, b)
 
 
+def permute_ts(x):
+    """The video tensor in region-major order [B,S,T,d] (one copy per step, shared by all layers; see bist_permute_ts)."""
+    return ag.PermuteTSFn.apply(x) if (_grad() and x.requires_grad) else ops.permute_ts(x)
+
+
 class Fan:
     """Hands out the aliases of FanOutFn one by one; once they are used up (or without autograd) the tensor itself."""
 
@@ -208,6 +213,9 @@ PIPELINE_DECODER = os.environ.get("BIST_PIPELINE_DECODER", "1") != "0"      # tu
 
 
 VALUES_AHEAD = os.environ.get("BIST_VALUES_AHEAD", "1") != "0"      # tuning aid: value projections of layer l+1 on the caption stream
+
+
+PERMUTED_T2S = os.environ.get("BIST_PERMUTED_T2S", "1") != "0"      # tuning aid: t2s stage 1 on the region-major copy (training)
 
 
 def join_side_streams() -> None:

@@ -121,10 +121,15 @@ class VidEncoderLayer4(nn.Module):
                                       "(decoder.py:123-124 overwrites the video tensor)" % args.enc_st_combine)
 
     # -- stage 1 ------------------------------------------------------------------------------
-    def _stage1(self, ai: int, si: int, x: Tensor, vft: Tensor, v: Tensor, tmask: Optional[Tensor], direction: int) -> Tensor:
-        """A1 (direction 0, encoder.py:110-123) / A4 (direction 1, encoder.py:142-150) -> [B,G,Lq,d]."""
+    def _stage1(self, ai: int, si: int, x: Tensor, vft: Tensor, v: Tensor, tmask: Optional[Tensor], direction: int,
+                permuted: bool = False) -> Tensor:
+        """A1 (direction 0, encoder.py:110-123) / A4 (direction 1, encoder.py:142-150) -> [B,G,Lq,d].
+        permuted (t2s only): vft and v are region-major [B,S,T,*] (Fn.permute_ts): the step is then the s2t form with the two
+        axes exchanged plus the frame mask -- contiguous score runs and value tiles instead of 16-byte pieces."""
         attn, sub = self.attn[ai], self.sublayer[si]
-        B, T, S, d = vft.shape
+        B, T, S, d = vft.shape              # permuted: (B, S, T, d) -- "T" counts the groups, "S" the keys
+        if permuted:
+            direction = 1
         Lq, h, dk = x.shape[1], attn.h, attn.d_k
         xn, xr = sub.norm.with_residual(x)
         q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)                           # [B*Lq, d]
@@ -199,7 +204,10 @@ class VidEncoderLayer4(nn.Module):
         vft = ft["spatiotemporal_ft"]
         fan = ft.get("_bist_vft_fan")                      # aliases whose gradients are summed in one pass (training)
         take = fan.take if fan is not None else (lambda: vft)
-        vft_t2s, vft_s2t = take(), take()
+        fan_p = ft.get("_bist_vftp_fan")                   # training: aliases of the region-major copy [B,S,T,d] for the t2s direction
+        permuted = fan_p is not None
+        take_t2s = fan_p.take if permuted else take
+        vft_t2s, vft_s2t = take_t2s(), take()
         t2s_on = (not hasattr(self.args, "t2s")) or self.args.t2s
         s2t_on = (not hasattr(self.args, "s2t")) or self.args.s2t
         concurrent = t2s_on and s2t_on and Fn.CONCURRENT and vft.is_cuda
@@ -207,9 +215,7 @@ class VidEncoderLayer4(nn.Module):
         main = torch.cuda.current_stream() if concurrent else None
 
         def branch_v(ai):
-            a = self.attn[ai]
-            B, T, S, d = vft.shape
-            return Fn.linear(take().view(B * T * S, d), a.linears[2].weight, a.linears[2].bias).view(B, T, S, d)
+            return self.train_value(take_t2s() if ai == 1 else take(), ai)
 
         per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V and "_bist_v_pre" not in ft
         v_t2s = v_s2t = None
@@ -225,7 +231,7 @@ class VidEncoderLayer4(nn.Module):
             # projection and its two backward products run on that branch's stream
             pass
         elif torch.is_grad_enabled() and t2s_on and s2t_on:
-            v_t2s, v_s2t = self.train_values(take(), take())
+            v_t2s, v_s2t = self.train_value(take_t2s(), 1), self.train_value(take(), 4)
         elif concurrent:
             # (inference only: under autograd a third forked stream makes hipGraph capture of the training step crash in
             # the HIP runtime -- also with every side stream joined explicitly after backward)
@@ -242,7 +248,8 @@ class VidEncoderLayer4(nn.Module):
 
         def t2s_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
-            y = self._stage1(ai + 1, si + 1, x, vft_t2s, branch_v(ai + 1) if per_branch_v else v_t2s, b.temporal_mask, 0)   # A1
+            y = self._stage1(ai + 1, si + 1, x, vft_t2s, branch_v(ai + 1) if per_branch_v else v_t2s, b.temporal_mask, 0,
+                             permuted=permuted)                                                  # A1
             z = self._stage2(ai + 2, si + 2, x, y, None)                                          # A2
             in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
 

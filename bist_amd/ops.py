@@ -261,7 +261,7 @@ def st_stage1_pv(scores: Tensor, v: Tensor, tmask: Optional[Tensor], *, B: int, 
         out = torch.empty((B, G, Lq, d), device=v.device, dtype=v.dtype)
     mptr = None
     if tmask is not None:
-        tmask = tmask.reshape(B, T)
+        tmask = tmask.reshape(B, T if direction == 0 else S)        # one entry per key
         tmask = (tmask.view(torch.uint8) if tmask.dtype == torch.bool else tmask.to(torch.uint8)).contiguous()
         mptr = tmask.data_ptr()
     check(lib.bist_st_stage1_pv_fwd(scores.data_ptr(), v.data_ptr(), mptr, out.data_ptr(), B, T, S, Lq, h, dk, ldv,
@@ -355,6 +355,16 @@ def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
     check(lib.bist_cast(x.data_ptr(), out.data_ptr(), x.numel(), dtype_code(x.dtype), dtype_code(dtype), _stream()), "bist_cast")
     return out
+
+
+def permute_ts(x: Tensor) -> Tensor:
+    """[B,T,S,d] -> [B,S,T,d] (contiguous copy, bist_permute_ts)."""
+    _dev(x)
+    x = x.contiguous()
+    B, T, S, d = x.shape
+    y = torch.empty((B, S, T, d), device=x.device, dtype=x.dtype)
+    check(lib.bist_permute_ts(x.data_ptr(), y.data_ptr(), B, T, S, d, dtype_code(x.dtype), _stream()), "bist_permute_ts")
+    return y
 
 
 ADD_N_MAX = 24

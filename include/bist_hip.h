@@ -165,7 +165,8 @@ int bist_mha_core_fwd(const void* Q, const void* K, const void* V, const uint8_t
  * softmax), row order r = i*h + hh.  V [B,T,S,*] is the value projection (row stride ldv).
  *   direction 0: softmax over t for every (b,s), masked by tmask[b,t] (uint8, nullable);
  *                O[b,s,i,hh*dk+c] = sum_t P[b,i,hh,t,s] V[b,t,s,hh*dk+c]        O: [B,S,Lq,d]
- *   direction 1: softmax over s for every (b,t), no mask;
+ *   direction 1: softmax over s for every (b,t), masked by tmask[b,s] if given (s2t itself has no mask here; the t2s step
+ *                on (s,t)-ordered tensors -- bist_permute_ts -- is this form with T and S exchanged and the frame mask);
  *                O[b,t,i,hh*dk+c] = sum_s P[b,i,hh,t,s] V[b,t,s,hh*dk+c]        O: [B,T,Lq,d]
  * which is attention() (modules.py:54-64) of every (b,s) / (b,t) group without materialising
  * K, the permuted video tensor or the expanded query.
@@ -219,6 +220,11 @@ int bist_fuse_modalities(const void* score, const void* const* xs, void* out, in
 /* out[i] = a[i] + b[i % nb]: the residual add of SublayerConnection (modules.py:44) when it is
  * not fused into a GEMM epilogue; nb < n broadcasts b.                                          */
 int bist_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t nb, int32_t dtype, void* stream);
+
+/* y[b,s,t,:] = x[b,t,s,:]  (x [B,T,S,d] contiguous): the video tensor in region-major order.  The t2s direction walks, for
+ * every region s, its T frames; on [B,T,S,d] those are rows S*d apart and the per-group score gather / gradient scatter are
+ * 16-byte pieces, on the permuted copy (made once per step, shared by all layers) they are contiguous runs.              */
+int bist_permute_ts(const void* x, void* y, int32_t B, int32_t T, int32_t S, int32_t d, int32_t dtype, void* stream);
 
 /* out[i] = sum_j srcs[j][i] for n <= BIST_ADD_N_MAX contiguous tensors of `numel` elements (fp32 accumulation): the
  * gradient of a tensor with n consumers (the video tensor feeds 3 products in each of the L reasoning layers) in ONE

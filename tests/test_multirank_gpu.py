@@ -41,7 +41,7 @@ def _worker(rank, world, port, q):
         t.step(batch)
     torch.cuda.synchronize()
     assert t._graph2 is not None
-    q.put((rank, t.master.cpu()))
+    q.put((rank, t.master.cpu().numpy()))         # by value (a torch tensor would travel as a shared-memory handle the exiting worker may close)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,6 +61,7 @@ def test_two_ranks_step_equals_adam_on_the_mean_gradient():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    got = {r: torch.from_numpy(a) for r, a in got.items()}
     assert torch.equal(got[0], got[1]), "ranks diverged"
 
     # reference in this process: per-rank gradients from the same weights, averaged, one Adam launch per step

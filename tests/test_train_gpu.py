@@ -613,7 +613,7 @@ def test_stage1_probability_dropout(env, dtype, direction):
     v = (eye.view(T, 1, d).expand(T, S, d) if direction == 0 else eye.view(1, S, d).expand(T, S, d))[None].repeat(B, 1, 1, 1).contiguous()
     scd = sc.float().cuda().requires_grad_(True)
     vd = v.to(dtype).cuda().requires_grad_(True)
-    out = Fn.st_stage1_pv(scd, vd, tm.cuda(), B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction, drop=DROP)
+    out = Fn.st_stage1_pv(scd, vd, tm.cuda() if direction == 0 else None, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction, drop=DROP)
     scr, vr = sc.clone().requires_grad_(True), v.clone().requires_grad_(True)
     s5 = scr.view(B, Lq, h, T, S)
     if direction == 0:
@@ -740,3 +740,32 @@ def test_exchange_path_matches_single_rank_step(env):
         os.environ.pop("BIST_FORCE_EXCHANGE", None)
         dist.destroy_process_group()
     assert all(abs(a - c) <= 2e-3 * (1 + i) * abs(a) for i, (a, c) in enumerate(zip(l1, l2))), (l1, l2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,S,Lq,h", [(2, 32, 49, 20, 8), (1, 128, 9, 7, 2)])
+def test_t2s_on_region_major_tensors_equals_t2s(env, dtype, B, T, S, Lq, h):
+    """The t2s stage-1 core on the region-major copies (Fn.permute_ts; the s2t form with the axes exchanged and the frame mask
+    as key mask) gives the t2s result: forward, d scores (back in (t, s) order) and dV."""
+    ag, Fn, ops = env
+    dk = 64
+    d = h * dk
+    sc = _rand(B, Lq * h, T * S, seed=80).float()
+    v = _rand(B, T, S, d, seed=81).to(dtype)
+    tm = torch.ones(B, 1, T, dtype=torch.bool); tm[0, 0, T // 2:] = False
+    go = _rand(B, S, Lq, d, seed=82).to(dtype)
+
+    def run(permuted):
+        s1 = sc.clone().cuda().requires_grad_(True)
+        v1 = v.clone().cuda().requires_grad_(True)
+        if permuted:
+            sp = s1.view(B, Lq * h, T, S).transpose(2, 3).reshape(B, Lq * h, S * T).contiguous()
+            out = Fn.st_stage1_pv(sp, Fn.permute_ts(v1), tm.cuda(), B=B, T=S, S=T, Lq=Lq, h=h, dk=dk, direction=1)
+        else:
+            out = Fn.st_stage1_pv(s1, v1, tm.cuda(), B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=0)
+        (out.float() * go.cuda().float()).sum().backward()
+        return out.detach().float().cpu(), s1.grad.float().cpu(), v1.grad.float().cpu()
+    a, b = run(False), run(True)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for name, x, y in zip(("out", "dscores", "dV"), a, b):
+        _close(y, x, f"permuted t2s {name}", tol)
