@@ -218,6 +218,9 @@ VALUES_AHEAD = os.environ.get("BIST_VALUES_AHEAD", "1") != "0"      # tuning aid
 PERMUTED_T2S = os.environ.get("BIST_PERMUTED_T2S", "1") != "0"      # tuning aid: t2s stage 1 on the region-major copy (training)
 
 
+FUSED_ST1 = os.environ.get("BIST_FUSED_ST1", "1") != "0"      # tuning aid: 0 = stage 1 of the inference path as separate launches
+
+
 def join_side_streams() -> None:
     """Order the current stream after everything queued on the side streams (end of a backward pass: the weight-gradient
     GEMMs of a side branch write the flat gradient directly, which autograd's own leaf-stream join does not see)."""

@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import ops
 from .modules import LayerNorm, MultiHeadedAttention, PositionwiseFeedForward, SublayerConnection, clones
 
 Tensor = torch.Tensor
@@ -134,6 +135,9 @@ class VidEncoderLayer4(nn.Module):
         xn, xr = sub.norm.with_residual(x)
         q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)                           # [B*Lq, d]
         qf = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq * h, d)   # rows (i, hh)
+        if v is None:           # inference: value projection, scores, softmax, P.V, output projection and residual in one launch
+            return ops.st_stage1_fused(qf, vft, tmask, attn.linears[2].weight, attn.linears[2].bias, attn.linears[3].weight,
+                                       attn.linears[3].bias, x, h=h, direction=direction)
         scores = Fn.st_scores(qf, vft.view(B, T * S, d))
         v_ready = self.__dict__.get("_v_ready")
         if v_ready is not None:
@@ -221,7 +225,15 @@ class VidEncoderLayer4(nn.Module):
         v_t2s = v_s2t = None
         pre = ft.pop("_bist_v_pre", None)                  # (v_t2s, v_s2t, event): projected ahead by the layer loop (decoder.py)
         self._v_event = None
-        if pre is not None:
+        # inference at the production width: each direction's stage 1 is one fused launch that projects the values itself
+        B_, T_, S_, d_ = vft.shape
+        x0 = in_ft["t2s"] if t2s_on else in_ft["s2t"]
+        fused = (Fn.FUSED_ST1 and not torch.is_grad_enabled() and vft.is_cuda and pre is None
+                 and all(ops.st_stage1_fused_ok(T_, S_, x0.shape[1], d_, self.attn[0].h, dr, vft.dtype)
+                         for dr, on in ((0, t2s_on), (1, s2t_on)) if on))
+        if fused:
+            pass
+        elif pre is not None:
             v_t2s, v_s2t, ev = pre
             main.wait_event(ev) if main is not None else torch.cuda.current_stream().wait_event(ev)
             if v_s2t is None:

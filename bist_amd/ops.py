@@ -270,6 +270,37 @@ def st_stage1_pv(scores: Tensor, v: Tensor, tmask: Optional[Tensor], *, B: int, 
     return out
 
 
+def st_stage1_fused_ok(T: int, S: int, Lq: int, d: int, h: int, direction: int, dtype: torch.dtype) -> bool:
+    """True when bist_st_stage1_fused_fwd covers the shape (bf16, d = 512, h = 8, Lq <= 32, at most 128 keys)."""
+    return dtype in _DT and bool(lib.bist_st_stage1_fused_ok(T, S, Lq, d, h, direction, _DT[dtype]))
+
+
+def st_stage1_fused(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: Tensor, bv: Tensor, wo: Tensor, bo: Tensor,
+                    xres: Tensor, *, h: int, direction: int, out: Optional[Tensor] = None) -> Tensor:
+    """Stage 1 of one direction in one launch (inference form): qf [B, Lq*h, d] folded query, vft [B,T,S,d], kmask [B,K] or
+    None, xres [B,Lq,d] -> Y [B,G,Lq,d]; see include/bist_hip.h (bist_st_stage1_fused_fwd)."""
+    _dev(qf, vft, kmask, wv, bv, wo, bo, xres)
+    B, T, S, d = vft.shape
+    Lq = xres.shape[1]
+    G, K = (S, T) if direction == 0 else (T, S)
+    for t_ in (qf, vft, wv, bv, wo, bo, xres):
+        if not t_.is_contiguous() or t_.dtype != vft.dtype:
+            raise ValueError("bist_amd.st_stage1_fused: operands must be contiguous and of one dtype")
+    if qf.numel() != B * Lq * h * d or wv.shape != (d, d) or wo.shape != (d, d) or xres.shape != (B, Lq, d):
+        raise ValueError("bist_amd.st_stage1_fused: operand shapes do not match [B,T,S,d] / Lq / h")
+    if out is None:
+        out = torch.empty((B, G, Lq, d), device=vft.device, dtype=vft.dtype)
+    mptr = None
+    if kmask is not None:
+        kmask = kmask.reshape(B, K)
+        kmask = (kmask.view(torch.uint8) if kmask.dtype == torch.bool else kmask.to(torch.uint8)).contiguous()
+        mptr = kmask.data_ptr()
+    check(lib.bist_st_stage1_fused_fwd(qf.data_ptr(), vft.data_ptr(), mptr, wv.data_ptr(), bv.data_ptr(), wo.data_ptr(),
+                                       bo.data_ptr(), xres.data_ptr(), out.data_ptr(), B, T, S, Lq, d, h, direction,
+                                       dtype_code(vft.dtype), _stream()), "bist_st_stage1_fused_fwd")
+    return out
+
+
 def st_stage2(q2f: Tensor, y: Tensor, gmask: Optional[Tensor], *, h: int, out: Optional[Tensor] = None, drop=None,
               want_rowsum: bool = False):
     """Stage-2 attention over the stage-1 outputs with K/V folded out; q2f [B,Lq,h,d], y [B,G,Lq,d].

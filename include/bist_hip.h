@@ -177,6 +177,24 @@ int bist_st_stage1_pv_fwd(const void* scores, const void* V, const uint8_t* tmas
                           int64_t ldv, int32_t direction, const BistDrop* drop, int32_t sc_dtype, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Stage 1 of one direction as ONE launch (forward, inference form: no dropout, nothing saved for a backward pass):
+ * replaces, for every group g of every clip, the whole SublayerConnection of encoder.py:121 / :148
+ *     Y[b,g,i,:] = x[b,i,:] + W_o . concat_h softmax_k( Qf[b,(i,hh),:] . X_g[k,:] (masked) ) (X_g W_v,hh^T + b_v,hh) + b_o
+ * i.e. MultiHeadedAttention.forward (modules.py:81-100) + attention() (modules.py:54-64) + the residual on the expanded query
+ * (modules.py:44), with X_g = vft[b,:,g,:] (direction 0: keys = frames, kmask[b,t] uint8 nullable, -1e9 REPLACES a masked score)
+ * or vft[b,g,:,:] (direction 1: keys = regions, kmask[b,s] normally NULL).  Qf [B, Lq*h, d] (row i*h + hh) is the query
+ * folded through W_k and pre-scaled by 1/sqrt(dk), exactly the operand of the score product feeding bist_st_stage1_pv_fwd;
+ * Wv / Wo are the [d,d] nn.Linear weights (row = output channel) of linears[2] / linears[3], bv / bo their biases; xres [B,Lq,d]
+ * is the un-expanded residual; Y [B,G,Lq,d] (G = S for direction 0, T for direction 1).  All operands bf16, 16-byte aligned.
+ * The value projection, the scores, the probabilities and the head-concatenated context never reach HBM.
+ * bist_st_stage1_fused_ok: 1 when the shape is inside the kernel's envelope (bf16, d = 512, h = 8, Lq <= 32, keys <= 128).
+ * ------------------------------------------------------------------------------------------ */
+int bist_st_stage1_fused_ok(int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype);
+int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv,
+                             const void* Wo, const void* bo, const void* xres, void* Y, int32_t B, int32_t T, int32_t S,
+                             int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Stage 2 of both directions (encoder.py:125-134 / 152-165): query position (b,i) attends,
  * alone, over the G stage-1 outputs Y[b,g,i,:] of its own position (G = S for t2s, T for s2t).
  * With the query folded through W_k (q2f [B,Lq,h,d], pre-scaled) and the value projection

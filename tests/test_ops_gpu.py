@@ -486,3 +486,38 @@ def test_embed_temporal_mask_fuse_cast(ops, dtype, tol):
     x = _rand(1000, seed=27)
     assert torch.equal(ops.cast(x.cuda(), torch.bfloat16).cpu(), x.to(torch.bfloat16))
     assert torch.equal(ops.cast(x.to(torch.bfloat16).cuda(), torch.float32).cpu(), x.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("B,T,S,Lq", [(2, 32, 49, 20), (1, 128, 49, 20), (2, 8, 9, 7), (2, 20, 49, 32), (3, 40, 5, 1), (1, 33, 64, 24)])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_st_stage1_fused_matches_textbook_attention(ops, B, T, S, Lq, direction):
+    """bist_st_stage1_fused_fwd against modules.py:54-64 / 81-100 + the residual of modules.py:44 written out per group in fp64 on the
+    bf16-rounded operands (K, V and the expanded query materialised, as the reference does): x + W_o MHA(.) + b_o for every (b, g)."""
+    d, h, dk = 512, 8, 64
+    dt = torch.bfloat16
+    assert ops.st_stage1_fused_ok(T, S, Lq, d, h, direction, dt)
+    G, K = (S, T) if direction == 0 else (T, S)
+    vft = _rand(B, T, S, d, seed=31)
+    qf = _rand(B, Lq * h, d, seed=32, scale=1.5 * d ** -0.5)          # folded, pre-scaled query rows (i, hh): scores of O(1.5)
+    wv, bv = _rand(d, d, seed=33, scale=d ** -0.5), _rand(d, seed=34, scale=0.1)
+    wo, bo = _rand(d, d, seed=35, scale=d ** -0.5), _rand(d, seed=36, scale=0.1)
+    x = _rand(B, Lq, d, seed=37)
+    km = None
+    if direction == 0 or B > 1:
+        km = torch.ones(B, K, dtype=torch.bool)
+        km[0, K // 2:] = False
+        if B > 1:
+            km[B - 1, :] = False                                       # fully masked clip -> uniform over the keys
+    X = _q(vft, dt)
+    Xg = X.permute(0, 2, 1, 3) if direction == 0 else X                # [B, G, K, d]
+    sc = torch.einsum("bihe,bgke->bgihk", _q(qf, dt).view(B, Lq, h, d), Xg)
+    if km is not None:
+        sc = sc.masked_fill(km.view(B, 1, 1, 1, K) == 0, -1e9)
+    p = torch.softmax(sc, -1)
+    v = (Xg @ _q(wv, dt).t() + _q(bv, dt)).view(B, G, K, h, dk)
+    ctx = torch.einsum("bgihk,bgkhc->bgihc", p, v).reshape(B, G, Lq, d)
+    ref = _q(x, dt).view(B, 1, Lq, d) + ctx @ _q(wo, dt).t() + _q(bo, dt)
+    c = lambda t: t.to(dt).cuda()
+    out = ops.st_stage1_fused(c(qf), c(vft), None if km is None else km.cuda(), c(wv), c(bv), c(wo), c(bo), c(x), h=h, direction=direction)
+    assert out.shape == (B, G, Lq, d)
+    _cmp(out, ref, 2e-2, f"st_stage1_fused dir{direction}")
