@@ -58,6 +58,7 @@ SIGNATURES = {
     "bist_mha_core_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32,
                                     _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.POINTER(BistDrop), _I32, _P]),
     "bist_st_stage1_pv_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, C.POINTER(BistDrop), _I32, _I32, _P]),
+    "bist_pack_frag_rows": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "bist_st_stage1_fused_ok": (C.c_int, [_I32] * 7),
     "bist_st_stage1_fused_fwd": (C.c_int, [_P] * 9 + [_I32] * 8 + [_P]),
     "bist_st_stage2_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, C.POINTER(BistDrop), _I32, _P]),

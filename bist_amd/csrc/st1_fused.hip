@@ -22,6 +22,9 @@
 // Neither K, V, the scores, the probabilities nor the head-concatenated context touch HBM: per group the kernel reads its video
 // rows once (K*1 KiB) and writes Lq output rows; the weights (1 MiB) and Qf (160 KiB per clip) stream from L2.
 #include "common.hpp"
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -33,6 +36,7 @@ struct St1F {
   const bf16_t* Wv; const bf16_t* bv; const bf16_t* Wo; const bf16_t* bo; const bf16_t* xres;
   bf16_t* Y;
   int B, T, S, Lq, dir, cpc;     // cpc = chunks per clip
+  int dbg;                       // BIST_ST1F_DBG timing ablation (0 in production): bit0/1/2 no weight loads in step 1/2/4, bit3 no X DMA, bit4 skip step 3
 };
 
 __device__ uint4 g_zero_line;      // 16 zero bytes: DMA source of every padding row
@@ -55,27 +59,66 @@ __device__ __forceinline__ void swap16(float& a, float& b) {      // see gemm.hi
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-// fragment of 16 rows x (K-slots of k-step pair kp, parity e) from a swizzled [rows][1024 B] image: lane (x, kg) -> row row0+x,
-// logical 16-byte chunk 8*kp + 2*kg + e
-__device__ __forceinline__ uint4 img_frag(const char* img, int row0, int kp, int e, int x, int kg) {
-  return *reinterpret_cast<const uint4*>(img + (row0 + x) * 1024 + (((8 * kp + 2 * kg + e) ^ x) << 4));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
+
+// Fragment stream over a swizzled LDS image for the 8 k-step pairs of a 512-deep product: NF fragments per pair, read by
+// inline-asm ds_read_b128 into a ring of R register slots, R-1 reads in flight ahead of the MFMAs that consume them (the
+// compiler's own schedule keeps two reads in flight and waits for each right before its use: the LDS latency was exposed on
+// every second fragment).  addr(kp, g) = LDS byte address of fragment g of pair kp; use(kp, f, frag) issues the MFMAs of f.
+template <int NF, int R, class AddrF, class UseF>
+__device__ __forceinline__ void frag_stream(AddrF addr, UseF use) {
+  static_assert(NF % R == 0 && R >= 3 && R <= 9, "ring slots must repeat every k-step pair");
+  u32x4 ring[R];
+  static_for<R - 1>([&ring, &addr](auto g) {
+    const unsigned a0 = addr(0, (int)g);
+    u32x4& slot = ring[g];
+    asm volatile("ds_read_b128 %0, %1" : "=v"(slot) : "v"(a0) : "memory");
+  });
+#pragma unroll 1
+  for (int kp = 0; kp < 8; ++kp) {
+    const int kn = min(kp + 1, 7);          // the reads past the last pair re-read it (never consumed)
+    static_for<NF>([&ring, &addr, &use, kp, kn](auto fc) {
+      constexpr int f = fc, gq = f + R - 1;
+      u32x4& cur = ring[f % R];
+      u32x4& fut = ring[gq % R];
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(R - 2) : "memory");
+      asm volatile("" : "+v"(cur));
+      const unsigned nxt = gq < NF ? addr(kp, gq) : addr(kn, gq - NF);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fut) : "v"(nxt) : "memory");
+      use(kp, fc, __builtin_bit_cast(uint4, cur));
+    });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  static_for<R>([&ring](auto g) {
+    u32x4& slot = ring[g];
+    asm volatile("" : "+v"(slot));
+  });
 }
 
-// weight fragments of k-step pair kp for four 16-row tiles: lane (x, kg) holds 32 consecutive bytes of row 16*nt + x (the two
-// parities), so that the four kg lanes of a row cover one whole 128-byte line
-__device__ __forceinline__ void load_rows4(uint4 (&f)[2][4], const bf16_t* base, int kp) {
+// Operand fragments that come straight from L2 into registers, as inline asm with counted waits: next to the inline-asm LDS
+// reads the compiler waits vmcnt(0) for its own loads, i.e. for the pair just issued instead of the one about to be used.
+// Weight fragments are in MFMA-fragment order (bist_pack_frag_rows): tile (16 rows) nt, k-step pair kp, parity e is one 1-KiB
+// block [lane][8 bf16], so a wave's dwordx4 load reads 1 KiB contiguously.  base = this wave's first tile + lane*8.
+__device__ __forceinline__ void gload(u32x4& dst, const bf16_t* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+template <int N>
+__device__ __forceinline__ void tie(u32x4 (&f)[N]) {
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    f[0][nt] = *reinterpret_cast<const uint4*>(base + nt * 16 * D + kp * 64);
-    f[1][nt] = *reinterpret_cast<const uint4*>(base + nt * 16 * D + kp * 64 + 8);
-  }
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i]));
 }
-__device__ __forceinline__ void load_q(uint4 (&f)[2][2], const bf16_t* q0, const bf16_t* q1, int kp) {
-  f[0][0] = *reinterpret_cast<const uint4*>(q0 + kp * 64);
-  f[1][0] = *reinterpret_cast<const uint4*>(q0 + kp * 64 + 8);
-  f[0][1] = *reinterpret_cast<const uint4*>(q1 + kp * 64);
-  f[1][1] = *reinterpret_cast<const uint4*>(q1 + kp * 64 + 8);
+__device__ __forceinline__ void load_packed4(u32x4 (&f)[4], const bf16_t* base, int kp, int e) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) gload(f[nt], base + (((nt * 8 + kp) * 2 + e) << 9));
 }
+__device__ __forceinline__ void load_q2(u32x4 (&f)[2], const bf16_t* q0, const bf16_t* q1, int kp, int e) {
+  gload(f[0], q0 + kp * 64 + e * 8);
+  gload(f[1], q1 + kp * 64 + e * 8);
+}
+__device__ __forceinline__ uint4 u4(const u32x4& v) { return __builtin_bit_cast(uint4, v); }
 
 template <int KT, int MT4>
 __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
@@ -102,8 +145,9 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
       const bool valid = gl < ng && kk < K;
       const int t = a.dir == 0 ? kk : g0 + gl, s = a.dir == 0 ? g0 + gl : kk;
       const bf16_t* src = valid ? vb + ((long)t * S_ + s) * D + ((lane ^ j) << 3) : reinterpret_cast<const bf16_t*>(&g_zero_line);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(smem + r * 1024), 16, 0, 0);
+      if (!(a.dbg & 8)) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(smem + r * 1024), 16, 0, 0);
     }
+    asm volatile("" ::: "memory");          // keep the loads below behind the DMAs in program order (counted wait in step 1)
   }
   // key mask bits of this lane's keys kk = 16*kt + 4*kg + r  ->  bit kt*4 + r  (1 = masked out); padding keys in `pad`
   unsigned mbits = 0, pad = 0;
@@ -118,8 +162,10 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
         else if (mk && mk[kk] == 0) mbits |= 1u << (kt * 4 + r);
       }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // fragment g (parity e = g / NM, tile mt = g % NM) of pair kp in a swizzled [rows][1024 B] image: lane (x, kg) reads row
+  // 16*mt + x, logical 16-byte chunk 8*kp + 2*kg + e, stored at chunk ^ x
+  const unsigned img0 = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)x * 1024u;
+  auto img_addr = [&](int kp, int e, int mt) -> unsigned { return img0 + (unsigned)mt * 16384u + (unsigned)(((8 * kp + 2 * kg + e) ^ x) << 4); };
 
   // ---- 1. V_hh = X . W_v,hh^T ------------------------------------------------------------------------------
   uint4 vpk[MT / 2][4];
@@ -129,26 +175,28 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* wv = a.Wv + (long)(w * 64 + x) * D + kg * 16;
-    uint4 bw[2][4];
-    load_rows4(bw, wv, 0);
-#pragma unroll 1
-    for (int kp = 0; kp < 8; ++kp) {
-      uint4 bn[2][4];
-      load_rows4(bn, wv, min(kp + 1, 7));          // next k-step pair in flight under this one's MFMAs
+    const bf16_t* wv = a.Wv + ((long)(w * 4) << 13) + lane * 8;       // tile = 8 pairs x 2 parities x 512 elements
+    u32x4 bw[2][4];
+    load_packed4(bw[0], wv, 0, 0);
+    load_packed4(bw[1], wv, 0, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the X image (16 DMAs per wave, issued first) has landed; the 8 weight loads may still fly
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    frag_stream<2 * MT, 4>([&](int kp, int g) { return img_addr(kp, g / MT, g % MT); },
+                           [&](int kp, auto fc, const uint4& ax) {
+                             constexpr int f = fc, e = f / MT, mt = f % MT;
+                             if constexpr (mt == 0) {            // this parity's weights have landed; the other parity's 4 loads stay in flight
+                               asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                               tie(bw[e]);
+                             }
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const uint4 ax = img_frag(smem, mt * 16, kp, e, x, kg);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(ax, bw[e][nt], acc[mt][nt]);
-        }
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bw[e][nt] = bn[e][nt];
-    }
+                             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(ax, u4(bw[e][nt]), acc[mt][nt]);
+                             if constexpr (mt == MT - 1) {       // last use of this parity's weights: fetch the next pair's in place
+                               if (!(a.dbg & 1)) load_packed4(bw[e], wv, min(kp + 1, 7), e);
+                             }
+                           });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the re-reads issued by the last pair (never consumed)
+    tie(bw[0]); tie(bw[1]);
     // acc[mt][nt][r] = V[key 16*mt + 4*kg + r][channel 16*nt + x]  ->  A fragments of step 3 (K-slots: tile 2p regs 0..3, tile 2p+1 regs 0..3)
 #pragma unroll
     for (int p = 0; p < MT / 2; ++p)
@@ -167,32 +215,31 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
       for (int it = 0; it < 2; ++it) sacc[mt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16_t* q0 = a.qf + (((long)b * Lq + min(x, Lq - 1)) * H + w) * D + kg * 16;
     const bf16_t* q1 = a.qf + (((long)b * Lq + min(16 + x, Lq - 1)) * H + w) * D + kg * 16;
-    uint4 bq[2][2];
-    load_q(bq, q0, q1, 0);
-#pragma unroll 1
-    for (int kp = 0; kp < 8; ++kp) {
-      uint4 bn[2][2];
-      load_q(bn, q0, q1, min(kp + 1, 7));
+    u32x4 bq[2][2];
+    load_q2(bq[0], q0, q1, 0, 0);
+    load_q2(bq[1], q0, q1, 0, 1);
+    frag_stream<2 * MT, 8>([&](int kp, int g) { return img_addr(kp, g / MT, g % MT); },
+                           [&](int kp, auto fc, const uint4& ax) {
+                             constexpr int f = fc, e = f / MT, mt = f % MT;
+                             if constexpr (mt == 0) {
+                               asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                               tie(bq[e]);
+                             }
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const uint4 ax = img_frag(smem, mt * 16, kp, e, x, kg);
-#pragma unroll
-          for (int it = 0; it < 2; ++it) sacc[mt][it] = mfma16(ax, bq[e][it], sacc[mt][it]);
-        }
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int it = 0; it < 2; ++it) bq[e][it] = bn[e][it];
-    }
+                             for (int it = 0; it < 2; ++it) sacc[mt][it] = mfma16(ax, u4(bq[e][it]), sacc[mt][it]);
+                             if constexpr (mt == MT - 1) {
+                               if (!(a.dbg & 2)) load_q2(bq[e], q0, q1, min(kp + 1, 7), e);
+                             }
+                           });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie(bq[0]); tie(bq[1]);
   }
   __syncthreads();          // every wave is done with the X image: it becomes the context image
 
   // ---- 3. softmax, O^T = V^T . P^T, context rows ---------------------------------------------------------------
 #pragma unroll
   for (int gl = 0; gl < NG; ++gl) {
-    if (gl >= ng) break;
+    if (gl >= ng || (a.dbg & 16)) break;
     uint4 pf[2][KT / 2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -251,26 +298,26 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
     for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* wo = a.Wo + (long)(w * 64 + x) * D + kg * 16;
-    uint4 aw[2][4];
-    load_rows4(aw, wo, 0);
-#pragma unroll 1
-    for (int kp = 0; kp < 8; ++kp) {
-      uint4 an[2][4];
-      load_rows4(an, wo, min(kp + 1, 7));
+    const bf16_t* wo = a.Wo + ((long)(w * 4) << 13) + lane * 8;
+    u32x4 aw[2][4];
+    load_packed4(aw[0], wo, 0, 0);
+    load_packed4(aw[1], wo, 0, 1);
+    constexpr int R4 = MT4 == 5 ? 5 : MT4 == 3 ? 6 : 4;
+    frag_stream<2 * MT4, R4>([&](int kp, int g) { return img_addr(kp, g / MT4, g % MT4); },
+                             [&](int kp, auto fc, const uint4& cx) {
+                               constexpr int f = fc, e = f / MT4, mt = f % MT4;
+                               if constexpr (mt == 0) {
+                                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                                 tie(aw[e]);
+                               }
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int mt = 0; mt < MT4; ++mt) {
-          const uint4 cx = img_frag(smem, mt * 16, kp, e, x, kg);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(aw[e][nt], cx, acc[mt][nt]);
-        }
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) aw[e][nt] = an[e][nt];
-    }
+                               for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(u4(aw[e][nt]), cx, acc[mt][nt]);
+                               if constexpr (mt == MT4 - 1) {
+                                 if (!(a.dbg & 4)) load_packed4(aw[e], wo, min(kp + 1, 7), e);
+                               }
+                             });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie(aw[0]); tie(aw[1]);
     // acc[mt][nt][r] = Y[row 16*mt + x][column 64*w + 16*nt + 4*kg + r]; after the swap a lane holds 8 consecutive columns
     const int cofs = (kg & 1) * 16 + (kg >> 1) * 8;
     const int rows = ng * Lq;
@@ -302,6 +349,19 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
   }
 }
 
+// W [rows][cols] row-major -> fragment order [rows/16][cols/64][2][64 lanes][8]: lane (x = lane & 15, kg = lane >> 4) of block
+// (tile nt, pair kp, parity e) holds W[16*nt + x][64*kp + 16*kg + 8*e .. +7] -- the operand of one v_mfma_f32_16x16x32_bf16
+__global__ void pack_frag_rows_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ out, int rows, int cols) {
+  const long piece = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece per thread
+  const int kps = cols >> 6;
+  if (piece >= (long)rows * cols / 8) return;
+  const int lane = piece & 63, e = (piece >> 6) & 1;
+  const long blk = piece >> 7;
+  const int kp = blk % kps, nt = blk / kps;
+  const bf16_t* src = W + (long)(16 * nt + (lane & 15)) * cols + 64 * kp + 16 * (lane >> 4) + 8 * e;
+  reinterpret_cast<uint4*>(out)[piece] = *reinterpret_cast<const uint4*>(src);
+}
+
 template <int KT, int MT4>
 int launch(const St1F& a, hipStream_t st) {
   static bool attr_set = false;
@@ -320,6 +380,17 @@ int launch(const St1F& a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int bist_pack_frag_rows(const void* W, void* out, int32_t rows, int32_t cols, int32_t dtype, void* stream) {
+  BIST_REQUIRE(W && out && W != out && rows > 0 && cols > 0, "bist_pack_frag_rows: bad argument");
+  BIST_REQUIRE(dtype == BIST_BF16 && rows % 16 == 0 && cols % 64 == 0, "bist_pack_frag_rows: bf16 [rows %% 16 == 0][cols %% 64 == 0] only");
+  BIST_REQUIRE(((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "bist_pack_frag_rows: 16-byte alignment");
+  const long pieces = (long)rows * cols / 8;
+  hipLaunchKernelGGL(pack_frag_rows_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)W, (bf16_t*)out, rows, cols);
+  BIST_LAUNCH_CHECK("bist_pack_frag_rows");
+  return BIST_OK;
+}
+
 extern "C" int bist_st_stage1_fused_ok(int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype) {
   const int K = direction == 0 ? T : S;
   return dtype == BIST_BF16 && d == D && h == H && Lq >= 1 && Lq <= 32 && K >= 1 && K <= 128 && T >= 1 && S >= 1 &&
@@ -337,7 +408,8 @@ extern "C" int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const u
   const int K = direction == 0 ? T : S, G = direction == 0 ? S : T;
   const int KT = K <= 32 ? 2 : K <= 64 ? 4 : 8, NG = MT / KT;
   St1F a{(const bf16_t*)qf, (const bf16_t*)vft, kmask, (const bf16_t*)Wv, (const bf16_t*)bv, (const bf16_t*)Wo, (const bf16_t*)bo,
-         (const bf16_t*)xres, (bf16_t*)Y, B, T, S, Lq, direction, (G + NG - 1) / NG};
+         (const bf16_t*)xres, (bf16_t*)Y, B, T, S, Lq, direction, (G + NG - 1) / NG, 0};
+  if (const char* e = getenv("BIST_ST1F_DBG")) a.dbg = atoi(e);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int need = (NG * Lq + 15) / 16;          // 16-row tiles of the output projection
   if (KT == 2) return need <= 5 ? launch<2, 5>(a, st) : launch<2, 8>(a, st);

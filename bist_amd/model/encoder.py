@@ -136,8 +136,8 @@ class VidEncoderLayer4(nn.Module):
         q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)                           # [B*Lq, d]
         qf = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq * h, d)   # rows (i, hh)
         if v is None:           # inference: value projection, scores, softmax, P.V, output projection and residual in one launch
-            return ops.st_stage1_fused(qf, vft, tmask, attn.linears[2].weight, attn.linears[2].bias, attn.linears[3].weight,
-                                       attn.linears[3].bias, x, h=h, direction=direction)
+            wv, wo = self._frag_weights(ai)
+            return ops.st_stage1_fused(qf, vft, tmask, wv, attn.linears[2].bias, wo, attn.linears[3].bias, x, h=h, direction=direction)
         scores = Fn.st_scores(qf, vft.view(B, T * S, d))
         v_ready = self.__dict__.get("_v_ready")
         if v_ready is not None:
@@ -149,6 +149,21 @@ class VidEncoderLayer4(nn.Module):
         G = o.shape[1]
         y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=xr, res_map=(G * Lq, Lq), **Fn.drop_args(sub))
         return y.view(B, G, Lq, d)
+
+    def _frag_weights(self, ai: int):
+        """W_v and W_o of attention `ai` in MFMA-fragment order (ops.pack_frag_rows), re-packed INTO THE SAME BUFFERS whenever the
+        parameters change (ops.weights_key covers in-place updates and the trainer's raw Adam kernel), so that captured hipGraphs
+        that read them stay valid."""
+        attn = self.attn[ai]
+        wv, wo = attn.linears[2].weight, attn.linears[3].weight
+        key = ops.weights_key(wv, wo)
+        cache = self.__dict__.setdefault("_frag_cache", {})
+        hit = cache.get(ai)
+        if hit is None or hit[0] != key or hit[1].device != wv.device:
+            bufs = (None, None) if hit is None or hit[1].device != wv.device or hit[1].dtype != wv.dtype else (hit[1], hit[2])
+            hit = (key, ops.pack_frag_rows(wv.detach(), bufs[0]), ops.pack_frag_rows(wo.detach(), bufs[1]))
+            cache[ai] = hit
+        return hit[1], hit[2]
 
     # -- stage 2 ------------------------------------------------------------------------------
     def _stage2(self, ai: int, si: int, x: Tensor, y: Tensor, gmask: Optional[Tensor]) -> Tensor:

@@ -275,10 +275,31 @@ def st_stage1_fused_ok(T: int, S: int, Lq: int, d: int, h: int, direction: int, 
     return dtype in _DT and bool(lib.bist_st_stage1_fused_ok(T, S, Lq, d, h, direction, _DT[dtype]))
 
 
+WEIGHTS_EPOCH = 0      # bumped by whoever rewrites parameters behind autograd's back (Trainer.step: raw Adam kernel on flat views)
+
+
+def weights_key(*params: Tensor):
+    """Identity of a set of parameter VALUES for derived-operand caches (packed / re-ordered weights): storage, in-place
+    version counter and the epoch of out-of-band updates."""
+    return (WEIGHTS_EPOCH,) + tuple((p.data_ptr(), p._version) for p in params)
+
+
+def pack_frag_rows(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """[rows, cols] bf16 weight in MFMA-fragment order (bist_pack_frag_rows); `out` keeps a cached copy's address stable."""
+    _dev(w)
+    if not w.is_contiguous() or w.dim() != 2:
+        raise ValueError("bist_amd.pack_frag_rows: contiguous [rows, cols] expected")
+    if out is None:
+        out = torch.empty_like(w)
+    check(lib.bist_pack_frag_rows(w.data_ptr(), out.data_ptr(), w.shape[0], w.shape[1], dtype_code(w.dtype), _stream()),
+          "bist_pack_frag_rows")
+    return out
+
+
 def st_stage1_fused(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: Tensor, bv: Tensor, wo: Tensor, bo: Tensor,
                     xres: Tensor, *, h: int, direction: int, out: Optional[Tensor] = None) -> Tensor:
     """Stage 1 of one direction in one launch (inference form): qf [B, Lq*h, d] folded query, vft [B,T,S,d], kmask [B,K] or
-    None, xres [B,Lq,d] -> Y [B,G,Lq,d]; see include/bist_hip.h (bist_st_stage1_fused_fwd)."""
+    None, wv / wo in fragment order (pack_frag_rows), xres [B,Lq,d] -> Y [B,G,Lq,d]; see include/bist_hip.h."""
     _dev(qf, vft, kmask, wv, bv, wo, bo, xres)
     B, T, S, d = vft.shape
     Lq = xres.shape[1]

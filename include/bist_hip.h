@@ -184,11 +184,16 @@ int bist_st_stage1_pv_fwd(const void* scores, const void* V, const uint8_t* tmas
  * (modules.py:44), with X_g = vft[b,:,g,:] (direction 0: keys = frames, kmask[b,t] uint8 nullable, -1e9 REPLACES a masked score)
  * or vft[b,g,:,:] (direction 1: keys = regions, kmask[b,s] normally NULL).  Qf [B, Lq*h, d] (row i*h + hh) is the query
  * folded through W_k and pre-scaled by 1/sqrt(dk), exactly the operand of the score product feeding bist_st_stage1_pv_fwd;
- * Wv / Wo are the [d,d] nn.Linear weights (row = output channel) of linears[2] / linears[3], bv / bo their biases; xres [B,Lq,d]
- * is the un-expanded residual; Y [B,G,Lq,d] (G = S for direction 0, T for direction 1).  All operands bf16, 16-byte aligned.
+ * Wv / Wo are the [d,d] nn.Linear weights (row = output channel) of linears[2] / linears[3] IN FRAGMENT ORDER (bist_pack_frag_rows,
+ * done once per set of weights), bv / bo their biases; xres [B,Lq,d] is the un-expanded residual; Y [B,G,Lq,d] (G = S for
+ * direction 0, T for direction 1).  All operands bf16, 16-byte aligned.
  * The value projection, the scores, the probabilities and the head-concatenated context never reach HBM.
  * bist_st_stage1_fused_ok: 1 when the shape is inside the kernel's envelope (bf16, d = 512, h = 8, Lq <= 32, keys <= 128).
  * ------------------------------------------------------------------------------------------ */
+/* W [rows][cols] (row-major bf16, rows % 16 == 0, cols % 64 == 0) -> out, same size, in MFMA-fragment order
+ * [rows/16][cols/64][2][64][8]: the 16 bytes lane (x, kg) feeds a v_mfma_f32_16x16x32_bf16 for row tile nt, k-step pair kp, parity
+ * e are W[16*nt + x][64*kp + 16*kg + 8*e .. +7], and one wave load of a block reads 1 KiB contiguously.                       */
+int bist_pack_frag_rows(const void* W, void* out, int32_t rows, int32_t cols, int32_t dtype, void* stream);
 int bist_st_stage1_fused_ok(int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype);
 int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv,
                              const void* Wo, const void* bo, const void* xres, void* Y, int32_t B, int32_t T, int32_t S,

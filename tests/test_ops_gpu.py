@@ -518,6 +518,19 @@ def test_st_stage1_fused_matches_textbook_attention(ops, B, T, S, Lq, direction)
     ctx = torch.einsum("bgihk,bgkhc->bgihc", p, v).reshape(B, G, Lq, d)
     ref = _q(x, dt).view(B, 1, Lq, d) + ctx @ _q(wo, dt).t() + _q(bo, dt)
     c = lambda t: t.to(dt).cuda()
-    out = ops.st_stage1_fused(c(qf), c(vft), None if km is None else km.cuda(), c(wv), c(bv), c(wo), c(bo), c(x), h=h, direction=direction)
+    out = ops.st_stage1_fused(c(qf), c(vft), None if km is None else km.cuda(), ops.pack_frag_rows(c(wv)), c(bv), ops.pack_frag_rows(c(wo)), c(bo), c(x),
+                              h=h, direction=direction)
     assert out.shape == (B, G, Lq, d)
     _cmp(out, ref, 2e-2, f"st_stage1_fused dir{direction}")
+
+
+def test_pack_frag_rows_layout(ops):
+    """bist_pack_frag_rows: block (tile nt, pair kp, parity e), lane (x, kg) holds W[16 nt + x][64 kp + 16 kg + 8 e .. +7]."""
+    R, Ccols = 48, 192
+    w = torch.arange(R * Ccols, dtype=torch.float32).reshape(R, Ccols) % 251
+    got = ops.pack_frag_rows(w.to(torch.bfloat16).cuda()).float().cpu().reshape(R // 16, Ccols // 64, 2, 64, 8)
+    for nt, kp, e, lane in [(0, 0, 0, 0), (1, 2, 1, 17), (2, 1, 0, 63), (2, 2, 1, 38)]:
+        x, kg = lane & 15, lane >> 4
+        c0 = 64 * kp + 16 * kg + 8 * e
+        assert torch.equal(got[nt, kp, e, lane], w[16 * nt + x, c0:c0 + 8]), (nt, kp, e, lane)
+    assert torch.equal(got.reshape(-1).sort().values, w.reshape(-1).sort().values)          # a permutation
