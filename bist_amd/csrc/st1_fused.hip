@@ -36,6 +36,7 @@ struct St1F {
   const bf16_t* Wv; const bf16_t* bv; const bf16_t* Wo; const bf16_t* bo; const bf16_t* xres;
   bf16_t* Y;
   int B, T, S, Lq, dir, cpc;     // cpc = chunks per clip
+  unsigned long long* stamps;    // BIST_ST1F_STAMPS (development): per workgroup 8 s_memtime stamps at the phase boundaries, or null
   int dbg;                       // BIST_ST1F_DBG timing ablation (0 in production): bit0/1/2 no weight loads in step 1/2/4, bit3 no X DMA, bit4 skip step 3
 };
 
@@ -120,37 +121,53 @@ __device__ __forceinline__ void load_q2(u32x4 (&f)[2], const bf16_t* q0, const b
 }
 __device__ __forceinline__ uint4 u4(const u32x4& v) { return __builtin_bit_cast(uint4, v); }
 
-template <int KT, int MT4>
-__global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
-  constexpr int NG = MT / KT;
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+// wave-wide max / sum over the four 16-lane rows of a wave (lanes x, x+16, x+32, x+48) without LDS traffic: v_permlane16_swap and
+// v_permlane32_swap of a value with its own copy leave the partner rows' values in the second register
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_max(float v) {
+  float p = v, q = v;
+  swap16(p, q); v = fmaxf(p, q);
+  p = v; q = v;
+  swap32(p, q); return fmaxf(p, q);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  float p = v, q = v;
+  swap16(p, q); v = p + q;
+  p = v; q = v;
+  swap32(p, q); return p + q;
+}
+
+struct Chunk { int b, g0, ng, w, lane; };
+#define STAMP(i_) do { if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+// The work of one chunk with MTA active key tiles (NGA = MTA / KT groups) and MT4A row tiles in the output projection.  The full
+// chunk is <KT, 8, MT4>; the last chunk of a clip (G % NG groups) runs the smallest instantiation that holds it.
+template <int KT, int MTA, int MT4A>
+__device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* smem) {
+  constexpr int NGA = MTA / KT;
+  const int w = c.w, lane = c.lane, b = c.b, g0 = c.g0, ng = c.ng;
   const int x = lane & 15, kg = lane >> 4;
   const int T_ = a.T, S_ = a.S, Lq = a.Lq;
   const int G = a.dir == 0 ? S_ : T_, K = a.dir == 0 ? T_ : S_;
-  // XCD-contiguous chunk order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous range of chunks, so
-  // that the Qf rows of the few clips it works on stay in that L2
-  const unsigned nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qq = nwg >> 3, rr = nwg & 7u;
-  const unsigned lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int b = lid / a.cpc, g0 = (lid % a.cpc) * NG;
-  const int ng = min(NG, G - g0);
 
+  STAMP(0);
   // ---- 0. X image -----------------------------------------------------------------------------------------
+  constexpr int NDMA = 2 * MTA;                 // rows per wave
   {
     const bf16_t* vb = a.vft + (long)b * T_ * S_ * D;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int r = w * 16 + j, gl = r / (16 * KT), kk = r % (16 * KT);
+    for (int j = 0; j < NDMA; ++j) {
+      const int r = w * NDMA + j, gl = r / (16 * KT), kk = r % (16 * KT);
       const bool valid = gl < ng && kk < K;
       const int t = a.dir == 0 ? kk : g0 + gl, s = a.dir == 0 ? g0 + gl : kk;
-      const bf16_t* src = valid ? vb + ((long)t * S_ + s) * D + ((lane ^ j) << 3) : reinterpret_cast<const bf16_t*>(&g_zero_line);
+      const bf16_t* src = valid ? vb + ((long)t * S_ + s) * D + ((lane ^ (r & 15)) << 3) : reinterpret_cast<const bf16_t*>(&g_zero_line);
       if (!(a.dbg & 8)) __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(smem + r * 1024), 16, 0, 0);
     }
     asm volatile("" ::: "memory");          // keep the loads below behind the DMAs in program order (counted wait in step 1)
   }
-  // key mask bits of this lane's keys kk = 16*kt + 4*kg + r  ->  bit kt*4 + r  (1 = masked out); padding keys in `pad`
-  unsigned mbits = 0, pad = 0;
+  // mask of this lane's keys kk = 16*kt + 4*kg + r (the same for every group and query row): bit kt*4 + r of `repl` set = the score
+  // is replaced (by -1e9 where the key mask is 0, modules.py:60; by -inf on padding keys, which then get probability 0)
+  unsigned repl = 0, padb = 0;
   {
     const unsigned char* mk = a.kmask ? a.kmask + (long)b * K : nullptr;
 #pragma unroll
@@ -158,59 +175,62 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = 16 * kt + 4 * kg + r;
-        if (kk >= K) pad |= 1u << (kt * 4 + r);
-        else if (mk && mk[kk] == 0) mbits |= 1u << (kt * 4 + r);
+        if (kk >= K) { repl |= 1u << (kt * 4 + r); padb |= 1u << (kt * 4 + r); }
+        else if (mk && mk[kk] == 0) repl |= 1u << (kt * 4 + r);
       }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::: "memory");
   // fragment g (parity e = g / NM, tile mt = g % NM) of pair kp in a swizzled [rows][1024 B] image: lane (x, kg) reads row
   // 16*mt + x, logical 16-byte chunk 8*kp + 2*kg + e, stored at chunk ^ x
   const unsigned img0 = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)x * 1024u;
   auto img_addr = [&](int kp, int e, int mt) -> unsigned { return img0 + (unsigned)mt * 16384u + (unsigned)(((8 * kp + 2 * kg + e) ^ x) << 4); };
 
   // ---- 1. V_hh = X . W_v,hh^T ------------------------------------------------------------------------------
-  uint4 vpk[MT / 2][4];
+  uint4 vpk[MTA / 2][4];
   {
-    f32x4 acc[MT][4];
+    f32x4 acc[MTA][4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MTA; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16_t* wv = a.Wv + ((long)(w * 4) << 13) + lane * 8;       // tile = 8 pairs x 2 parities x 512 elements
     u32x4 bw[2][4];
     load_packed4(bw[0], wv, 0, 0);
     load_packed4(bw[1], wv, 0, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the X image (16 DMAs per wave, issued first) has landed; the 8 weight loads may still fly
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();            // every wave's share of the X image has landed (vmcnt(0) above); the 8 weight loads fly on
     asm volatile("" ::: "memory");
-    frag_stream<2 * MT, 4>([&](int kp, int g) { return img_addr(kp, g / MT, g % MT); },
-                           [&](int kp, auto fc, const uint4& ax) {
-                             constexpr int f = fc, e = f / MT, mt = f % MT;
-                             if constexpr (mt == 0) {            // this parity's weights have landed; the other parity's 4 loads stay in flight
-                               asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                               tie(bw[e]);
-                             }
+    STAMP(1);
+    frag_stream<2 * MTA, 4>([&](int kp, int g) { return img_addr(kp, g / MTA, g % MTA); },
+                            [&](int kp, auto fc, const uint4& ax) {
+                              constexpr int f = fc, e = f / MTA, mt = f % MTA;
+                              if constexpr (mt == 0) {            // this parity's weights have landed; the other parity's 4 loads stay in flight
+                                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                                tie(bw[e]);
+                              }
 #pragma unroll
-                             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(ax, u4(bw[e][nt]), acc[mt][nt]);
-                             if constexpr (mt == MT - 1) {       // last use of this parity's weights: fetch the next pair's in place
-                               if (!(a.dbg & 1)) load_packed4(bw[e], wv, min(kp + 1, 7), e);
-                             }
-                           });
+                              for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(ax, u4(bw[e][nt]), acc[mt][nt]);
+                              if constexpr (mt == MTA - 1) {      // last use of this parity's weights: fetch the next pair's in place
+                                if (!(a.dbg & 1)) load_packed4(bw[e], wv, min(kp + 1, 7), e);
+                              }
+                            });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the re-reads issued by the last pair (never consumed)
     tie(bw[0]); tie(bw[1]);
     // acc[mt][nt][r] = V[key 16*mt + 4*kg + r][channel 16*nt + x]  ->  A fragments of step 3 (K-slots: tile 2p regs 0..3, tile 2p+1 regs 0..3)
 #pragma unroll
-    for (int p = 0; p < MT / 2; ++p)
+    for (int p = 0; p < MTA / 2; ++p)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         vpk[p][nt] = make_uint4(pack2(acc[2 * p][nt][0], acc[2 * p][nt][1]), pack2(acc[2 * p][nt][2], acc[2 * p][nt][3]),
                                 pack2(acc[2 * p + 1][nt][0], acc[2 * p + 1][nt][1]), pack2(acc[2 * p + 1][nt][2], acc[2 * p + 1][nt][3]));
   }
 
+  STAMP(2);
   // ---- 2. S_hh^T = X . Qf_hh^T -----------------------------------------------------------------------------
-  f32x4 sacc[MT][2];
+  f32x4 sacc[MTA][2];
   {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MTA; ++mt)
 #pragma unroll
       for (int it = 0; it < 2; ++it) sacc[mt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16_t* q0 = a.qf + (((long)b * Lq + min(x, Lq - 1)) * H + w) * D + kg * 16;
@@ -218,115 +238,139 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
     u32x4 bq[2][2];
     load_q2(bq[0], q0, q1, 0, 0);
     load_q2(bq[1], q0, q1, 0, 1);
-    frag_stream<2 * MT, 8>([&](int kp, int g) { return img_addr(kp, g / MT, g % MT); },
-                           [&](int kp, auto fc, const uint4& ax) {
-                             constexpr int f = fc, e = f / MT, mt = f % MT;
-                             if constexpr (mt == 0) {
-                               asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                               tie(bq[e]);
-                             }
+    frag_stream<2 * MTA, (MTA >= 4 ? 8 : 4)>([&](int kp, int g) { return img_addr(kp, g / MTA, g % MTA); },
+                            [&](int kp, auto fc, const uint4& ax) {
+                              constexpr int f = fc, e = f / MTA, mt = f % MTA;
+                              if constexpr (mt == 0) {
+                                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                                tie(bq[e]);
+                              }
 #pragma unroll
-                             for (int it = 0; it < 2; ++it) sacc[mt][it] = mfma16(ax, u4(bq[e][it]), sacc[mt][it]);
-                             if constexpr (mt == MT - 1) {
-                               if (!(a.dbg & 2)) load_q2(bq[e], q0, q1, min(kp + 1, 7), e);
-                             }
-                           });
+                              for (int it = 0; it < 2; ++it) sacc[mt][it] = mfma16(ax, u4(bq[e][it]), sacc[mt][it]);
+                              if constexpr (mt == MTA - 1) {
+                                if (!(a.dbg & 2)) load_q2(bq[e], q0, q1, min(kp + 1, 7), e);
+                              }
+                            });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tie(bq[0]); tie(bq[1]);
   }
+  float bvf[4][4];                               // value bias of this lane's output channels hh*64 + 16*nt + 4*kg + r
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const uint2 q = *reinterpret_cast<const uint2*>(a.bv + w * 64 + nt * 16 + kg * 4);
+    bvf[nt][0] = bf_lo(q.x); bvf[nt][1] = bf_hi(q.x); bvf[nt][2] = bf_lo(q.y); bvf[nt][3] = bf_hi(q.y);
+  }
+  // softmax of every (group, query row) over the group's keys, in registers, BEFORE the barrier: the two waves of a SIMD do not
+  // finish steps 1-2 together, and this vector work of the first runs under the matrix work of the second
+  uint4 pf[NGA][2][KT / 2];
+  if (!(a.dbg & 16)) {
+    const bool plain = repl == 0;            // per lane; uniform in the common case (no padding keys, nothing masked)
+#pragma unroll
+    for (int gl = 0; gl < NGA; ++gl)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        float sv[KT][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = sacc[gl * KT + kt][it][r];
+            if (!plain) v = (repl >> (kt * 4 + r) & 1u) ? ((padb >> (kt * 4 + r) & 1u) ? -INFINITY : MASK_FILL) : v;
+            sv[kt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx = rows_max(mx);
+        float den = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { sv[kt][r] = __expf(sv[kt][r] - mx); den += sv[kt][r]; }
+        const float inv = 1.f / rows_sum(den);
+#pragma unroll
+        for (int k2 = 0; k2 < KT / 2; ++k2)
+          pf[gl][it][k2] = make_uint4(pack2(sv[2 * k2][0] * inv, sv[2 * k2][1] * inv), pack2(sv[2 * k2][2] * inv, sv[2 * k2][3] * inv),
+                                      pack2(sv[2 * k2 + 1][0] * inv, sv[2 * k2 + 1][1] * inv), pack2(sv[2 * k2 + 1][2] * inv, sv[2 * k2 + 1][3] * inv));
+      }
+  }
+  STAMP(3);
   __syncthreads();          // every wave is done with the X image: it becomes the context image
+  STAMP(4);
 
-  // ---- 3. softmax, O^T = V^T . P^T, context rows ---------------------------------------------------------------
+  // ---- 3. context rows: O^T = V^T . P^T per group, + b_v, as bf16 rows (g, i) of the context image ------------------------------
 #pragma unroll
-  for (int gl = 0; gl < NG; ++gl) {
+  for (int gl = 0; gl < NGA; ++gl) {
     if (gl >= ng || (a.dbg & 16)) break;
-    uint4 pf[2][KT / 2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      float sv[KT][4];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = sacc[gl * KT + kt][it][r];
-          if (pad >> (kt * 4 + r) & 1u) v = -INFINITY;
-          else if (mbits >> (kt * 4 + r) & 1u) v = MASK_FILL;
-          sv[kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float den = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { sv[kt][r] = __expf(sv[kt][r] - mx); den += sv[kt][r]; }
-      den += __shfl_xor(den, 16, 64);
-      den += __shfl_xor(den, 32, 64);
-      const float inv = 1.f / den;
-#pragma unroll
-      for (int k2 = 0; k2 < KT / 2; ++k2)
-        pf[it][k2] = make_uint4(pack2(sv[2 * k2][0] * inv, sv[2 * k2][1] * inv), pack2(sv[2 * k2][2] * inv, sv[2 * k2][3] * inv),
-                                pack2(sv[2 * k2 + 1][0] * inv, sv[2 * k2 + 1][1] * inv), pack2(sv[2 * k2 + 1][2] * inv, sv[2 * k2 + 1][3] * inv));
-    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int c0 = w * 64 + nt * 16 + kg * 4;                    // this lane's 4 consecutive output channels
-      const uint2 bq = *reinterpret_cast<const uint2*>(a.bv + c0);
-      const float bias[4] = {bf_lo(bq.x), bf_hi(bq.x), bf_lo(bq.y), bf_hi(bq.y)};
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k2 = 0; k2 < KT / 2; ++k2) o = mfma16(vpk[gl * (KT / 2) + k2][nt], pf[it][k2], o);
+        for (int k2 = 0; k2 < KT / 2; ++k2) o = mfma16(vpk[gl * (KT / 2) + k2][nt], pf[gl][it][k2], o);
         const int i = it * 16 + x;
         if (i < Lq) {
           const int row = gl * Lq + i;
           char* dst = smem + row * 1024 + ((((c0 >> 3)) ^ (row & 15)) << 4) + (kg & 1) * 8;
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o[0] + bias[0], o[1] + bias[1]), pack2(o[2] + bias[2], o[3] + bias[3]));
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o[0] + bvf[nt][0], o[1] + bvf[nt][1]), pack2(o[2] + bvf[nt][2], o[3] + bvf[nt][3]));
         }
       }
     }
   }
   __syncthreads();
+  STAMP(5);
 
   // ---- 4. Y = ctx . W_o^T + b_o + x ----------------------------------------------------------------------------
   {
-    f32x4 acc[MT4][4];
+    f32x4 acc[MT4A][4];
 #pragma unroll
-    for (int mt = 0; mt < MT4; ++mt)
+    for (int mt = 0; mt < MT4A; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16_t* wo = a.Wo + ((long)(w * 4) << 13) + lane * 8;
     u32x4 aw[2][4];
     load_packed4(aw[0], wo, 0, 0);
     load_packed4(aw[1], wo, 0, 1);
-    constexpr int R4 = MT4 == 5 ? 5 : MT4 == 3 ? 6 : 4;
-    frag_stream<2 * MT4, R4>([&](int kp, int g) { return img_addr(kp, g / MT4, g % MT4); },
-                             [&](int kp, auto fc, const uint4& cx) {
-                               constexpr int f = fc, e = f / MT4, mt = f % MT4;
-                               if constexpr (mt == 0) {
-                                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                                 tie(aw[e]);
-                               }
-#pragma unroll
-                               for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(u4(aw[e][nt]), cx, acc[mt][nt]);
-                               if constexpr (mt == MT4 - 1) {
-                                 if (!(a.dbg & 4)) load_packed4(aw[e], wo, min(kp + 1, 7), e);
-                               }
-                             });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    tie(aw[0]); tie(aw[1]);
-    // acc[mt][nt][r] = Y[row 16*mt + x][column 64*w + 16*nt + 4*kg + r]; after the swap a lane holds 8 consecutive columns
+    // residual rows x[b, i] and output offsets of this lane's rows (row = 16*mt + x), fetched under the product below
     const int cofs = (kg & 1) * 16 + (kg >> 1) * 8;
     const int rows = ng * Lq;
+    constexpr bool PRE = MT4A <= 5;                       // (with 8 row tiles the registers are the accumulators')
+    uint4 xr[PRE ? MT4A : 1][2];
+    long yoff[MT4A], xoff[MT4A];
+#pragma unroll
+    for (int mt = 0; mt < MT4A; ++mt) {
+      const int row = min(mt * 16 + x, rows - 1), gl = row / Lq, i = row - gl * Lq;
+      yoff[mt] = (((long)b * G + g0 + gl) * Lq + i) * D + w * 64 + cofs;
+      xoff[mt] = ((long)b * Lq + i) * D + w * 64 + cofs;
+      if constexpr (PRE) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) xr[mt][jp] = *reinterpret_cast<const uint4*>(a.xres + xoff[mt] + jp * 32);
+      }
+    }
+    constexpr int R4 = MT4A == 5 ? 5 : MT4A == 3 ? 6 : 4;
+    frag_stream<2 * MT4A, R4>([&](int kp, int g) { return img_addr(kp, g / MT4A, g % MT4A); },
+                              [&](int kp, auto fc, const uint4& cx) {
+                                constexpr int f = fc, e = f / MT4A, mt = f % MT4A;
+                                if constexpr (mt == 0) {
+                                  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                                  tie(aw[e]);
+                                }
+#pragma unroll
+                                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(u4(aw[e][nt]), cx, acc[mt][nt]);
+                                if constexpr (mt == MT4A - 1) {
+                                  if (!(a.dbg & 4)) load_packed4(aw[e], wo, min(kp + 1, 7), e);
+                                }
+                              });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie(aw[0]); tie(aw[1]);
+    STAMP(6);
+    // acc[mt][nt][r] = Y[row 16*mt + x][column 64*w + 16*nt + 4*kg + r]; after the swap a lane holds 8 consecutive columns
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      const int n0 = w * 64 + jp * 32 + cofs;
-      const uint4 bq = *reinterpret_cast<const uint4*>(a.bo + n0);
+      const uint4 bq = *reinterpret_cast<const uint4*>(a.bo + w * 64 + jp * 32 + cofs);
 #pragma unroll
-      for (int mt = 0; mt < MT4; ++mt) {
+      for (int mt = 0; mt < MT4A; ++mt) {
         float v[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -334,19 +378,46 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
           swap16(p, q);
           v[r] = p; v[4 + r] = q;
         }
-        const int row = mt * 16 + x;
-        if (row < rows) {
-          const int gl = row / Lq, i = row - gl * Lq;
-          const uint4 xr = *reinterpret_cast<const uint4*>(a.xres + ((long)b * Lq + i) * D + n0);
-          const uint4 o = make_uint4(pack2(v[0] + bf_lo(bq.x) + bf_lo(xr.x), v[1] + bf_hi(bq.x) + bf_hi(xr.x)),
-                                     pack2(v[2] + bf_lo(bq.y) + bf_lo(xr.y), v[3] + bf_hi(bq.y) + bf_hi(xr.y)),
-                                     pack2(v[4] + bf_lo(bq.z) + bf_lo(xr.z), v[5] + bf_hi(bq.z) + bf_hi(xr.z)),
-                                     pack2(v[6] + bf_lo(bq.w) + bf_lo(xr.w), v[7] + bf_hi(bq.w) + bf_hi(xr.w)));
-          *reinterpret_cast<uint4*>(a.Y + (((long)b * G + g0 + gl) * Lq + i) * D + n0) = o;
-        }
+        uint4 xq;
+        if constexpr (PRE) xq = xr[mt][jp]; else xq = *reinterpret_cast<const uint4*>(a.xres + xoff[mt] + jp * 32);
+        const uint4 o = make_uint4(pack2(v[0] + bf_lo(bq.x) + bf_lo(xq.x), v[1] + bf_hi(bq.x) + bf_hi(xq.x)),
+                                   pack2(v[2] + bf_lo(bq.y) + bf_lo(xq.y), v[3] + bf_hi(bq.y) + bf_hi(xq.y)),
+                                   pack2(v[4] + bf_lo(bq.z) + bf_lo(xq.z), v[5] + bf_hi(bq.z) + bf_hi(xq.z)),
+                                   pack2(v[6] + bf_lo(bq.w) + bf_lo(xq.w), v[7] + bf_hi(bq.w) + bf_hi(xq.w)));
+        if (mt * 16 + x < rows) *reinterpret_cast<uint4*>(a.Y + yoff[mt] + jp * 32) = o;
       }
     }
   }
+  STAMP(7);
+}
+
+template <int KT, int MT4>
+__global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
+  constexpr int NG = MT / KT;
+  constexpr int LQC = MT4 * 16 / NG;                    // the query-length class of this instantiation (20 or 32 rows per group)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int G = a.dir == 0 ? a.S : a.T;
+  // Block order: the B * (G / NG) full chunks first, in XCD-contiguous order (blocks b, b+8, ... share an XCD and its L2: each XCD
+  // walks a contiguous range of chunks, so the Qf rows of the few clips it works on stay in that L2), then the B short chunks
+  // (G % NG groups) -- they cost less and fill the last, partly empty round of workgroups.
+  const int fpc = G / NG;                                // full chunks per clip
+  const unsigned nfull = (unsigned)(a.B * fpc), bid = blockIdx.x;
+  Chunk c;
+  if (bid < nfull) {
+    const unsigned xcd = bid & 7u, qq = nfull >> 3, rr = nfull & 7u;
+    const unsigned lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    c.b = lid / fpc; c.g0 = (lid % fpc) * NG; c.ng = NG;
+  } else {
+    c.b = bid - nfull; c.g0 = fpc * NG; c.ng = G - c.g0;
+  }
+  c.lane = threadIdx.x & 63; c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (KT == 2) {
+    if (c.ng == 1) { chunk_body<2, 2, (LQC + 15) / 16>(a, c, smem); return; }
+    if (c.ng == 2) { chunk_body<2, 4, (2 * LQC + 15) / 16>(a, c, smem); return; }
+  } else if constexpr (KT == 4) {
+    if (c.ng == 1) { chunk_body<4, 4, (LQC + 15) / 16>(a, c, smem); return; }
+  }
+  chunk_body<KT, MT, MT4>(a, c, smem);
 }
 
 // W [rows][cols] row-major -> fragment order [rows/16][cols/64][2][64 lanes][8]: lane (x = lane & 15, kg = lane >> 4) of block
@@ -408,7 +479,8 @@ extern "C" int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const u
   const int K = direction == 0 ? T : S, G = direction == 0 ? S : T;
   const int KT = K <= 32 ? 2 : K <= 64 ? 4 : 8, NG = MT / KT;
   St1F a{(const bf16_t*)qf, (const bf16_t*)vft, kmask, (const bf16_t*)Wv, (const bf16_t*)bv, (const bf16_t*)Wo, (const bf16_t*)bo,
-         (const bf16_t*)xres, (bf16_t*)Y, B, T, S, Lq, direction, (G + NG - 1) / NG, 0};
+         (const bf16_t*)xres, (bf16_t*)Y, B, T, S, Lq, direction, (G + NG - 1) / NG, nullptr, 0};
+  if (const char* e = getenv("BIST_ST1F_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10));
   if (const char* e = getenv("BIST_ST1F_DBG")) a.dbg = atoi(e);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int need = (NG * Lq + 15) / 16;          // 16-row tiles of the output projection

@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bist_amd import ops
 
-B = int(os.environ.get("B", "64")); T = int(os.environ.get("T", "32")); S, Lq, d, h = 49, 20, 512, 8
+B = int(os.environ.get("B", "64")); T = int(os.environ.get("T", "32")); S = int(os.environ.get("S", "49")); Lq, d, h = 20, 512, 8
 g = torch.Generator().manual_seed(0)
 r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(torch.bfloat16).cuda()
 vft, qf, x = r(B, T, S, d), r(B, Lq * h, d, sc=d ** -0.5), r(B, Lq, d)
