@@ -11,6 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libbist_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GATE = 0, 1, 2
+# kernel families of bist_launch_count (include/bist_hip.h: BIST_K_*)
+K_ST1_MFMA_FWD, K_ST1_MFMA_BWD, K_ST1_VALU, K_ST2_MFMA_FWD, K_ST2_MFMA_BWD, K_ST2_VALU, K_MHA_FWD, K_MHA_BWD_MFMA, K_MHA_BWD_VALU, K_ST1_FUSED = range(10)
 
 
 class BistGemm(C.Structure):
@@ -51,6 +53,8 @@ SIGNATURES = {
     "bist_version": (C.c_int, []),
     "bist_last_error": (C.c_char_p, []),
     "bist_device_ok": (C.c_int, []),
+    "bist_launch_count": (C.c_int64, [_I32]),
+    "bist_launch_count_reset": (None, []),
     "bist_gemm": (C.c_int, [C.POINTER(BistGemm), _P]),
     "bist_gemm_pair": (C.c_int, [C.POINTER(BistGemm), C.POINTER(BistGemm), _P]),
     "bist_gemm_is_fast": (C.c_int, [C.POINTER(BistGemm)]),
@@ -93,6 +97,7 @@ SIGNATURES = {
     "bist_cast_from_f32": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "bist_add_f32_into": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "bist_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _I32, _F, _I32, _I32, _P]),
+    "bist_noam_hyper": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "bist_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _P]),
     "bist_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _P]),
 }

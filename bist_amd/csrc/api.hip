@@ -1,6 +1,7 @@
 // Library-wide plumbing: version, error string, device probe.
 #include "common.hpp"
 #include <string.h>
+#include <atomic>
 
 namespace {
 thread_local char g_err[512] = "";
@@ -12,6 +13,13 @@ void bist_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// Host-side launch counters per kernel family (BIST_K_*): lets tests and the bench state WHICH implementation ran for a shape
+// (e.g. the matrix-core stage-1 kernel rather than the fp32 fallback) without a profiler.
+namespace { std::atomic<long long> g_launches[BIST_K_COUNT]; }
+void bist_count_launch(int family) { if (family >= 0 && family < BIST_K_COUNT) g_launches[family].fetch_add(1, std::memory_order_relaxed); }
+extern "C" int64_t bist_launch_count(int32_t family) { return family >= 0 && family < BIST_K_COUNT ? (int64_t)g_launches[family].load() : -1; }
+extern "C" void bist_launch_count_reset(void) { for (auto& c : g_launches) c.store(0); }
 
 extern "C" int bist_version(void) { return 100; }   // 0.1.0
 

@@ -271,6 +271,7 @@ extern "C" int bist_mha_core_fwd(const void* Q, const void* K, const void* V, co
                        (float*)O, p_attn, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, dr, kvec);
   else { bist_set_error("bist_mha_core_fwd: bad dtype %d", dtype); return BIST_EINVAL; }
   BIST_LAUNCH_CHECK("bist_mha_core_fwd");
+  bist_count_launch(BIST_K_MHA_FWD);
   return BIST_OK;
 }
 
@@ -290,6 +291,7 @@ extern "C" int bist_st_stage1_pv_fwd(const void* scores, const void* V, const ui
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage1_pv_fwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
   }
+  bist_count_launch(BIST_K_ST1_VALU);
   const int G = direction == 0 ? S : T, Kn = direction == 0 ? T : S;
   // groups per workgroup: as many as fit a 60 KiB slab, but keep >= ~2 workgroups per CU in flight
   int Gc = (int)((60 * 1024) / ((long)Lq * (Kn + 1) * sizeof(float)));
@@ -324,6 +326,7 @@ extern "C" int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t*
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage2_fwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
   }
+  bist_count_launch(BIST_K_ST2_VALU);
   const size_t lds = ((size_t)h * d + (size_t)h * G) * sizeof(float);
   BIST_REQUIRE(lds <= 64 * 1024, "bist_st_stage2_fwd: h*(d+G) too large for LDS");
   hipStream_t st = (hipStream_t)stream;

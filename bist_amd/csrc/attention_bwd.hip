@@ -335,6 +335,7 @@ extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, co
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_mha_core_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
   }
+  bist_count_launch(BIST_K_MHA_BWD_VALU);
   const size_t lds = (size_t)2 * Lq * Lk * sizeof(float);
   BIST_REQUIRE(lds <= 64 * 1024, "bist_mha_core_bwd: Lq*Lk=%d too large for LDS", Lq * Lk);
   hipStream_t st = (hipStream_t)stream;
@@ -366,6 +367,7 @@ extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const u
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage1_pv_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
   }
+  bist_count_launch(BIST_K_ST1_VALU);
   const int G = direction == 0 ? S : T, Kn = direction == 0 ? T : S;
   const long per_g = ((long)2 * Lq * (Kn + 1) + (long)Lq * dk) * sizeof(float);
   int Gc = (int)((60 * 1024) / per_g);
@@ -395,6 +397,7 @@ extern "C" int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t*
     if (r == 1) return BIST_OK;
     if (r < 0) { bist_set_error("bist_st_stage2_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
   }
+  bist_count_launch(BIST_K_ST2_VALU);
   const size_t lds = ((size_t)2 * h * d + (size_t)2 * h * G) * sizeof(float);
   BIST_REQUIRE(lds <= 64 * 1024, "bist_st_stage2_bwd: h*(d+G) too large for LDS");
   hipStream_t st = (hipStream_t)stream;

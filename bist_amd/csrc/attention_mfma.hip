@@ -320,6 +320,7 @@ int launch_one(const St1Args& a, int B, size_t lds, hipStream_t st) {
   const int G = a.dir == 0 ? a.S : a.T;
   dim3 grid((unsigned)((G + a.Gc - 1) / a.Gc), (unsigned)a.h, (unsigned)B);
   hipLaunchKernelGGL((st1_mfma_kernel<TS, KSTEPS, BWD>), grid, dim3(256), lds, st, a);
+  bist_count_launch(BWD ? BIST_K_ST1_MFMA_BWD : BIST_K_ST1_MFMA_FWD);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 
@@ -745,6 +746,7 @@ int bist_mha_bwd_mfma(const void* Q, const void* K, const void* V, const unsigne
   MhaBwdArgs a{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, mask, dPext, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV,
                Lq, Lk, h, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, drop, dk / 64};
   hipLaunchKernelGGL(mha_bwd_mfma_kernel, dim3((unsigned)h, (unsigned)N), dim3(256), 0, st, a);
+  bist_count_launch(BIST_K_MHA_BWD_MFMA);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 
@@ -767,6 +769,7 @@ int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, vo
   if (bwd) { if (gb == 2) ST2_GO(true, 2); else ST2_GO(true, 1); }
   else { if (gb == 2) ST2_GO(false, 2); else ST2_GO(false, 1); }
 #undef ST2_GO
+  bist_count_launch(bwd ? BIST_K_ST2_MFMA_BWD : BIST_K_ST2_MFMA_FWD);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 

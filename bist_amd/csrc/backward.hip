@@ -745,6 +745,26 @@ extern "C" int bist_adam_step(float* p, const void* g, float* m, float* v, void*
   return BIST_OK;
 }
 
+// {lr, 1 - beta1^t, 1 - beta2^t, grad_scale} of optimiser step t = ctr[0], computed on the device (one thread, double precision)
+__global__ void noam_hyper_kernel(const long long* __restrict__ ctr, float* __restrict__ hyper, double d_model, double factor, double warmup,
+                                  double b1, double b2, float gscale) {
+  const double t = (double)ctr[0];
+  const double lr = factor * (pow(d_model, -0.5) * fmin(pow(t, -0.5), t * pow(warmup, -1.5)));
+  hyper[0] = (float)lr;
+  hyper[1] = (float)(1.0 - pow(b1, t));
+  hyper[2] = (float)(1.0 - pow(b2, t));
+  hyper[3] = gscale;
+}
+
+extern "C" int bist_noam_hyper(const int64_t* step_ctr, float* hyper, float d_model, float factor, float warmup, float beta1, float beta2,
+                               float grad_scale, void* stream) {
+  BIST_REQUIRE(step_ctr && hyper && d_model > 0.f && warmup > 0.f, "bist_noam_hyper: bad argument");
+  hipLaunchKernelGGL(noam_hyper_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const long long*)step_ctr, hyper, (double)d_model,
+                     (double)factor, (double)warmup, (double)beta1, (double)beta2, grad_scale);
+  BIST_LAUNCH_CHECK("bist_noam_hyper");
+  return BIST_OK;
+}
+
 extern "C" int bist_adam_step_dev(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
                                   float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream) {
   BIST_REQUIRE(p && g && m && v && hyper && n > 0, "bist_adam_step_dev: bad argument");

@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // ---- host-side error plumbing (defined in api.hip) -------------------------------------------
 void bist_set_error(const char* fmt, ...);
+void bist_count_launch(int family);       // BIST_K_* launch counters (api.hip)
 #define BIST_REQUIRE(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

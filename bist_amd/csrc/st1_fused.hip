@@ -446,6 +446,7 @@ int launch(const St1F& a, hipStream_t st) {
   }
   hipLaunchKernelGGL((st1_fused_kernel<KT, MT4>), dim3((unsigned)(a.B * a.cpc)), dim3(512), MT * 16 * 1024, st, a);
   BIST_LAUNCH_CHECK("bist_st_stage1_fused_fwd");
+  bist_count_launch(BIST_K_ST1_FUSED);
   return BIST_OK;
 }
 

@@ -56,6 +56,7 @@ class DeviceFeeder:
         self._pinned = [{}, {}]
         self._dev = [{}, {}]
         self._free = [None, None]          # event: the slot's previous consumer is done (recorded when its Batch is replaced)
+        self._copied = [None, None]        # event: the slot's last H2D copies have finished READING their host buffers
 
     # -- staging ---------------------------------------------------------------------------------
     def _slot(self, table, name, like: torch.Tensor, dtype, pinned: bool):
@@ -76,6 +77,10 @@ class DeviceFeeder:
         returns (device tensors, ready event)."""
         pin, dev = self._pinned[slot], self._dev[slot]
         out = {}
+        if self._copied[slot] is not None:
+            # The H2D copies of batch i-2 read this slot's pinned staging buffers asynchronously (they may still be queued behind
+            # the consumer's work when the host runs ahead): the HOST must not rewrite those buffers before they are done.
+            self._copied[slot].synchronize()
         if self._free[slot] is not None:
             self.copy_stream.wait_event(self._free[slot])          # the device slot is still being read by step i-2
         with torch.cuda.stream(self.copy_stream):
@@ -98,7 +103,16 @@ class DeviceFeeder:
                 out[name] = d
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
+        self._copied[slot] = ready
         return out, ready
+
+    def host_buffers_reusable(self, batches_ago: int = 2) -> None:
+        """Block the host until the copies of the batch staged `batches_ago` (1 or 2) calls ago have read their host buffers.
+        Producers that hand over their OWN pinned tensors and reuse them must call this before overwriting them; pageable
+        producers need nothing (their staging copy is guarded inside the feeder)."""
+        for ev in self._copied if batches_ago <= 1 else self._copied[:]:
+            if ev is not None:
+                ev.synchronize()
 
     def _batch(self, tensors, ready) -> Batch:
         torch.cuda.current_stream(self.device).wait_event(ready)

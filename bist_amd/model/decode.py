@@ -88,6 +88,17 @@ def _descending(lp_vec, k):
     return top[np.argsort(vals)[::-1]][:k]
 
 
+def _graph_store(model):
+    """The model's captured step graphs, dropped when the parameter VALUES changed since they were captured: the graphs bake the
+    addresses of derived operands (packed / fragment-ordered weights), whose contents are refreshed only by eager code."""
+    from .. import ops
+    key = (ops.WEIGHTS_EPOCH, sum(p._version for p in model.parameters()))
+    if model.__dict__.get("_bist_step_graphs_key") != key:
+        model.__dict__["_bist_step_graphs"] = {}
+        model.__dict__["_bist_step_graphs_key"] = key
+    return model.__dict__["_bist_step_graphs"]
+
+
 def _graph_step(model, bn, fn, trg, train_args):
     """decode + generator for the n hypothesis rows of one step, replayed from a hipGraph (captured once per geometry:
     row count, prefix length, dialogue lengths, dtype); returns the log-probs [n, 1, V] as a numpy array."""
@@ -95,7 +106,7 @@ def _graph_step(model, bn, fn, trg, train_args):
     n, Lt = trg.shape
     geom = (n, tuple(bn.query.shape), tuple(bn.his.shape), None if bn.cap is None else tuple(bn.cap.shape), fn["encoded_query"].dtype,
             len(fn["_bist_reasoning"]))
-    store = model.__dict__.setdefault("_bist_step_graphs", {})
+    store = model.__dict__.setdefault("_bist_step_graphs", {})          # (checked against the weights once per turn: _graph_first_step)
     tb = store.get(("turn",) + geom)
     if tb is None:
         tb = store[("turn",) + geom] = _TurnBuffers(bn, fn)
@@ -137,7 +148,7 @@ def _graph_first_step(model, batch, start_symbol, train_args):
     ft (encoded text, per-layer reasoning) lives in the graph's static outputs until the next turn of this geometry."""
     dev = batch.query.device
     geom = tuple((f, None if getattr(batch, f, None) is None else (tuple(getattr(batch, f).shape), getattr(batch, f).dtype)) for f in _TURN_FIELDS)
-    store = model.__dict__.setdefault("_bist_step_graphs", {})
+    store = _graph_store(model)
     g = store.get(("first",) + geom)
     if g is None:
         sb = types.SimpleNamespace(**vars(batch))

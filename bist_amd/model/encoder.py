@@ -193,12 +193,19 @@ class VidEncoderLayer4(nn.Module):
                 return (Fn.linear(x2, a1.linears[2].weight, a1.linears[2].bias).view(B, T, S, d),
                         Fn.linear(x2, a4.linears[2].weight, a4.linears[2].bias).view(B, T, S, d))
             else:
-                key = tuple((p.data_ptr(), p._version) for p in (a1.linears[2].weight, a4.linears[2].weight,
-                                                                 a1.linears[2].bias, a4.linears[2].bias))
+                key = ops.weights_key(a1.linears[2].weight, a4.linears[2].weight, a1.linears[2].bias, a4.linears[2].bias)
                 hit = self.__dict__.get("_vpack")
                 if hit is None or hit[0] != key:
-                    hit = (key, Fn.pack_rows(a1.linears[2].weight, a4.linears[2].weight),
-                           Fn.pack_rows(a1.linears[2].bias, a4.linears[2].bias))
+                    # re-packed INTO the same buffers (captured hipGraphs keep reading them) whenever the parameters changed --
+                    # in place (optimizer.step, load_state_dict: _version) or behind autograd's back (Trainer: ops.WEIGHTS_EPOCH)
+                    same = hit is not None and hit[1].device == a1.linears[2].weight.device and hit[1].dtype == a1.linears[2].weight.dtype
+                    w_new = Fn.pack_rows(a1.linears[2].weight, a4.linears[2].weight)
+                    b_new = Fn.pack_rows(a1.linears[2].bias, a4.linears[2].bias)
+                    if same:
+                        hit[1].copy_(w_new); hit[2].copy_(b_new)
+                        hit = (key, hit[1], hit[2])
+                    else:
+                        hit = (key, w_new, b_new)
                     self.__dict__["_vpack"] = hit
                 w, bb = hit[1], hit[2]
             v = Fn.linear(vft.view(B * T * S, d), w, bb).view(B, T, S, 2 * d)

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import ops
 
 Tensor = torch.Tensor
 
@@ -89,13 +90,16 @@ class MultiHeadedAttention(nn.Module):
             return pk[tuple(idx)]        # the packed operands (and their gradients) are plain views
         ws = [self.linears[i].weight for i in idx]
         bs = [self.linears[i].bias for i in idx]
-        key = (tuple(idx),) + tuple((w.data_ptr(), w._version) for w in ws + bs)
+        key = (tuple(idx),) + ops.weights_key(*ws, *bs)
         cache = self.__dict__.setdefault("_pack_cache", {})
         hit = cache.get(tuple(idx))
         if hit is not None and hit[0] == key and not torch.is_grad_enabled():
             return hit[1], hit[2]
         w, b = Fn.pack_rows(*ws), Fn.pack_rows(*bs)
         if not torch.is_grad_enabled():
+            if hit is not None and hit[1].shape == w.shape and hit[1].device == w.device and hit[1].dtype == w.dtype:
+                hit[1].copy_(w); hit[2].copy_(b)            # same buffers: captured hipGraphs keep reading them
+                w, b = hit[1], hit[2]
             cache[tuple(idx)] = (key, w, b)
         return w, b
 

@@ -22,6 +22,7 @@ low-precision weights.  No per-parameter optimiser launches, no per-tensor colle
 """
 from __future__ import annotations
 
+import copy
 import os
 from typing import Dict, List, Optional
 
@@ -121,8 +122,9 @@ class Trainer:
         self.acc32 = torch.zeros(self.n32, device=dev, dtype=torch.float32)
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)          # {lr, 1 - beta1^t, 1 - beta2^t, grad_scale} of the current step
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
+        # {lr, 1 - beta1^t, 1 - beta2^t, grad_scale} of the current step, derived ON THE DEVICE from the step counter (drop_ctr) by
+        # bist_noam_hyper at the head of the step: no host buffer that a later step could rewrite while this one is still queued
+        self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)
 
         for p in order:
             o, k = offs[id(p)], p.numel()
@@ -220,6 +222,9 @@ class Trainer:
         """forward + backward; leaves the complete gradient in ``flat_grad``.  optimizer=True (single rank) also applies
         Adam with the scalars in ``self.hyper``: the big matrices on a side stream BESIDE the closing reductions, the
         prefix of biases / LayerNorm parameters after them."""
+        if optimizer:
+            check(lib.bist_noam_hyper(self.drop_ctr.data_ptr(), self.hyper.data_ptr(), float(self.args.d_model), float(self.factor),
+                                      float(self.warmup), self.betas[0], self.betas[1], 1.0, _stream()), "bist_noam_hyper")
         terms = self._backward_open(batch)
         side = None
         if optimizer and self.flat_grad.is_cuda:
@@ -248,6 +253,7 @@ class Trainer:
         """Record the launches of forward+backward (+ Adam on one rank) into hipGraphs (the batch tensors become the graphs'
         static inputs).  Warm-up runs on a side stream first, as graph capture requires.  Several ranks: TWO graphs, the
         cut where the big matrices' gradients are final, so that their all-reduce starts under the closing reductions."""
+        batch = self._own_copy(batch)             # the graphs read trainer-owned buffers, never the caller's (a feeder slot is rewritten in flight)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -266,11 +272,20 @@ class Trainer:
                 terms = self.backward(batch, optimizer=self.adam_in_step)
         self._graph, self._graph2, self._graph_key, self._static_batch, self._static_terms = graph, graph2, key, batch, terms
 
+    def _own_copy(self, batch):
+        """A shallow copy of the batch whose tensor fields are clones owned by the trainer."""
+        own = copy.copy(batch)
+        for f in self._BATCH_FIELDS:
+            v = getattr(batch, f, None)
+            if v is not None:
+                setattr(own, f, v.clone())
+        return own
+
     def _graph_open(self, batch):
         key = self._shape_key(batch)
         if self._graph is None or key != self._graph_key:
             self._capture(batch, key)
-        elif batch is not self._static_batch:
+        else:
             for f in self._BATCH_FIELDS:
                 src = getattr(batch, f, None)
                 if src is not None:
@@ -282,12 +297,8 @@ class Trainer:
         """One optimiser step; returns the (detached, device-side) loss terms."""
         self._step += 1
         self.drop_ctr.fill_(self._step)
-        if self.adam_in_step:                # this step's optimiser scalars, read by the Adam launches inside backward()
-            self._hyper_host[0] = self.rate()
-            self._hyper_host[1] = 1.0 - self.betas[0] ** self._step
-            self._hyper_host[2] = 1.0 - self.betas[1] ** self._step
-            self._hyper_host[3] = 1.0
-            self.hyper.copy_(self._hyper_host, non_blocking=True)
+        ops.WEIGHTS_EPOCH += 1               # the parameters change behind autograd's back: derived operands (packed weights) are stale
+        if self.adam_in_step:                # the optimiser scalars are derived from drop_ctr inside backward() (bist_noam_hyper)
             terms = self._graph_open(batch) if self.use_graph else self.backward(batch, optimizer=True)
             return {k: v.detach() for k, v in terms.items()}
         work = None if self.compute_dtype == torch.float32 else self.flat_param

@@ -44,6 +44,20 @@ int bist_version(void);
 const char* bist_last_error(void);
 /* 1 when a HIP device is visible and is gfx950, else 0 (host-side probe, no kernel launch). */
 int bist_device_ok(void);
+/* Host-side counters of launches per attention-kernel family since the last reset (tests / bench report: WHICH implementation ran). */
+#define BIST_K_ST1_MFMA_FWD 0   /* st1_mfma_kernel forward (bf16 stage-1 core on the matrix cores)          */
+#define BIST_K_ST1_MFMA_BWD 1
+#define BIST_K_ST1_VALU 2       /* st1_pv / st1_pv_bwd VALU kernels (fp32 path, shapes outside the envelope) */
+#define BIST_K_ST2_MFMA_FWD 3
+#define BIST_K_ST2_MFMA_BWD 4
+#define BIST_K_ST2_VALU 5
+#define BIST_K_MHA_FWD 6        /* mha_core forward (VALU)                                                   */
+#define BIST_K_MHA_BWD_MFMA 7
+#define BIST_K_MHA_BWD_VALU 8
+#define BIST_K_ST1_FUSED 9      /* bist_st_stage1_fused_fwd                                                  */
+#define BIST_K_COUNT 10
+int64_t bist_launch_count(int32_t family);
+void bist_launch_count_reset(void);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM  C[z] = epilogue( alpha * A[z] . B[z]^T )            (fp32 accumulate on the MFMA units)
@@ -362,6 +376,11 @@ int bist_adam_step(float* p, const void* g, float* m, float* v, void* work, int6
 /* The same step with the per-step scalars read from device memory: hyper = {lr, 1 - beta1^t, 1 - beta2^t, grad_scale} (f32).
  * A launch inside a captured hipGraph freezes its kernel arguments; with this form the optimiser is part of the replayed
  * step (the host refreshes `hyper` before each replay) and can run beside the tail of the backward pass.                */
+/* hyper[0..3] = {Noam rate of step t (NoamOpt.rate, model/optimize.py:28-34), 1 - beta1^t, 1 - beta2^t, grad_scale} with t read from
+ * the DEVICE counter step_ctr[0]: the scalars of bist_adam_step_dev without a host buffer that a later step could overwrite
+ * while an earlier one is still queued.                                                                                     */
+int bist_noam_hyper(const int64_t* step_ctr, float* hyper, float d_model, float factor, float warmup, float beta1, float beta2,
+                    float grad_scale, void* stream);
 int bist_adam_step_dev(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
                        float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream);
 

@@ -44,3 +44,20 @@ def test_feeder_matches_direct_batches(feature_dtype, pinned):
         torch.cuda.synchronize()                                    # batch i+1 is already crossing PCIe into the other slot:
         assert torch.equal(b.fts, ref.fts)                          # the current batch is untouched by it
     assert len(kept) == 5
+
+
+def test_feeder_host_running_ahead_of_a_slow_consumer():
+    """No per-iteration synchronise and a consumer that is slow on the device: the host runs several batches ahead, so the
+    pinned staging buffers of batch i-2 are rewritten while its H2D copy may still be queued -- the feeder must hold the host
+    until that copy has read them (pageable producers, big features so the copies take a while)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    from bist_amd.data.feeder import DeviceFeeder
+    hbs = _host_batches(8, B=4, T=16, S=49, C=512, seed=3)
+    sums = []
+    for b in DeviceFeeder(hbs, feature_dtype=torch.float32):
+        torch.cuda._sleep(40_000_000)                               # ~20 ms of device time in front of the consumer's read
+        sums.append(b.fts.double().sum())                           # stays on the device: nothing here waits for the GPU
+    torch.cuda.synchronize()
+    for i, s in enumerate(sums):
+        assert abs(float(s) - float(hbs[i].fts.double().sum())) < 1e-6, i

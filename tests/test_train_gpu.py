@@ -769,3 +769,44 @@ def test_t2s_on_region_major_tensors_equals_t2s(env, dtype, B, T, S, Lq, h):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     for name, x, y in zip(("out", "dscores", "dV"), a, b):
         _close(y, x, f"permuted t2s {name}", tol)
+
+
+@pytest.mark.parametrize("d_model,h,C,dtype", [(64, 4, 64, torch.float32), (512, 8, 128, torch.bfloat16)])
+def test_eval_after_training_steps_sees_the_updated_weights(env, d_model, h, C, dtype):
+    """train -> eval -> train -> eval (the reference validates every epoch, train.py:137-160): the trainer updates the parameters
+    with a raw kernel on flat views, so every operand DERIVED from them on the inference path (packed value weights, fragment-ordered
+    W_v / W_o of the fused stage-1 kernel, captured beam-search graphs) must follow.  Checked against a fresh model that loads the
+    trained weights."""
+    import copy
+    import bist_amd.model as M
+    from bist_amd.data.synthetic import synthetic_batch
+    from bist_amd.model.decode import beam_search_decode
+    from bist_amd.train import Trainer
+    cfg = O.Cfg(d_model=d_model, att_h=h, nb_blocks=1, nb_venc_blocks=1, nb_cenc_blocks=1)
+    args = _args(cfg)
+    torch.manual_seed(0)
+    model = M.make_model(80, 80, args, ft_sizes=[C]).cuda()
+    fresh = copy.deepcopy(model)
+    tr = Trainer(model, args, 80, compute_dtype=dtype, warmup=5, factor=4.0)
+    kw = dict(T=6, S=9, C=C, Lq=7, Lh=9, Lc=6, Lt=6, vocab=80, dtype=dtype)
+    b, b1 = synthetic_batch(4, seed=1, **kw), synthetic_batch(1, seed=2, **kw)
+
+    def evaluate(m):
+        m.eval()
+        with torch.no_grad():
+            ft = m.forward(b)
+            lp = m.generator(ft, b, args).float()
+            nbest, _ = beam_search_decode(m, b1, 5, 2, 0, 3, 1, beam=3, penalty=1.0, nbest=3, train_args=args)
+        return lp, nbest
+
+    lp0, _ = evaluate(model)                                  # fills the derived-operand caches and the decode graphs
+    for _ in range(3):
+        model.train()
+        tr.step(b)
+    lp1, nb1 = evaluate(model)
+    assert (lp1 - lp0).abs().max().item() > 1e-3              # the steps did move the weights
+    fresh.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()})
+    fresh = fresh.cuda().to(dtype)
+    lp2, nb2 = evaluate(fresh)
+    assert (lp1 - lp2).abs().max().item() <= (1e-5 if dtype == torch.float32 else 1e-6 + 0.0), (lp1 - lp2).abs().max().item()
+    assert [h_[0] for h_ in nb1] == [h_[0] for h_ in nb2]
