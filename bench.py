@@ -8,20 +8,26 @@ A *step* is one training step of the reference's loop (train.py:29-37: forward, 
 log-probs, 4 label-smoothed losses, backward, Adam with the Noam rate) on one synthetic batch of
 BASELINE.json configs[1]: L=6, d_model=512, h=8, ResNeXt features [B=16, T=32, 7x7, 2048] bf16 already
 resident in HBM, 20-token queries.  With N GPUs every rank runs its own B=16 batch (weak scaling,
-batch-data-parallel), gradients are summed by one RCCL all-reduce of the flat gradient buffer.
+batch-data-parallel), gradients are summed by RCCL all-reduces of the flat gradient buffer; the loss terms are
+normalised by the token counts of the WHOLE batch (one all-reduce of two integers), as the reference does.
+`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run as a child process,
+before this process touches the GPU).
 
 value       = target tokens (non-pad trg_y, the quantity train.py:36 accumulates) of all ranks / second.
-roofline    = the dominant kernel by FLOPs, the video input projection GEMM (P0: [B*T*S,2048]x[2048,512],
-              bist_gemm LDS-DMA MFMA kernel): algorithmic 2*M*N*K FLOPs / its mean launch duration,
-              measured with HIP events on the launch stream inside the timed steps, against the dense
-              bf16 MFMA peak.  `attn_fwd` adds the north_star's second figure: the fused BiST attention
-              forward (F_P0 + F_VL of SURVEY.md 8d) timed on the same batch.
-cpu_baseline= the CPU oracle's (oracle/bist_oracle.py, a port) training step (fwd + loss + backward; no
-              optimiser) on a bounded sample of the same workload on the host cores, rank 0, N=1 only.
+roofline    = the north_star's region: the fused BiST attention forward (F_P0 + F_VL of SURVEY.md 8d: the video input
+              projection + LayerNorm and ONE VidEncoderLayer4, both directions) at B=64, T=32, 7x7, C=2048 in inference
+              mode: algorithmic FLOPs of the reference formulation / time of one replay of the region's hipGraph (HIP
+              events on the launch stream), against the dense bf16 MFMA peak.  `kernels` lists the region's three
+              dominant kernels (P0 GEMM, the two fused stage-1 launches) timed one by one with HIP events on their
+              launch streams; `traffic` is the region's HBM bytes from the committed rocprofv3 --pmc passes.
+cpu_baseline= the CPU oracle (oracle/bist_oracle.py, a port of the reference verified against it) on the host cores,
+              rank 0, N=1 only, BASELINE.md section 2 protocol: full training step (forward + losses + backward + Adam)
+              at B=16 in target tokens/s, 2 warm-up + 5 timed, median; `rows` adds the eval forwards and a decode turn.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,20 +40,19 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICRO
 CFG = dict(L=6, d=512, h=8, B=16, T=32, S=49, C=2048, Lq=20, Lh=60, Lc=25, Lt=20, V=3000)
 
 
-def p0_traffic(M, K, N):
-    """HBM bytes per P0 launch from the committed PMC passes (profiles/r01_p0_traffic_pmc.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this benchmark, FETCH_SIZE doubled per the gfx950 note of
-    MI355X_MICROARCH.md); None when the geometry differs from the profiled one.  Counters cannot be read from
-    inside a timed run, so this is the offline figure of the same kernel and shape."""
+def region_traffic(B, T):
+    """HBM bytes of one pass over the roofline region from the committed PMC passes (profiles/r02_attn_fwd_B64_pmc.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of scripts/prof_attn.py, FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md); None when the geometry differs from the profiled one.  Counters cannot be read from inside a timed
+    run, so this is the offline figure of the same kernels and shapes."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_p0_traffic_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_attn_fwd_B64_pmc.json")) as f:
             t = json.load(f)
     except OSError:
         return None
-    if t.get("algorithmic_bytes_per_launch") != (M * K + N * K + M * N) * 2:
+    if t.get("B") != B or t.get("T") != T:
         return None
-    return {"bytes_per_launch": t["traffic_bytes_per_launch"], "algorithmic_bytes": t["algorithmic_bytes_per_launch"],
-            "ratio": t["ratio"], "source": "profiles/r01_p0_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"}
+    return t
 
 
 def model_args(L, d, h, dropout):
@@ -69,44 +74,86 @@ def flops_alg(B, T, S, C, d, Lq, h):
     return f_p0, float(a1 + a2 + a4 + a5 + a03 + ff)
 
 
-def cpu_baseline(sample_B, steps, dropout):
-    """The oracle (port of the reference) on the host cores: forward + losses + backward at the bench geometry."""
+def flops_stage1(B, T, S, d, Lq, direction):
+    """Reference-formulation FLOPs of stage 1 of one direction (the A1 / A4 terms above)."""
+    G, K = (S, T) if direction == 0 else (T, S)
+    return float(4 * B * G * K * d * d + 2 * B * Lq * d * d + 4 * B * G * Lq * K * d + 2 * B * G * Lq * d * d)
+
+
+def cpu_baseline(rows_wanted, threads):
+    """The oracle (port of the reference) on the host cores, BASELINE.md section 2: fp32, fixed seeds, 2 warm-up + 5 timed
+    iterations, median (fewer iterations for the big rows, stated per row).  Threads: the CPU share of a one-GPU box (16 by
+    default; on the 2 x 64-core host of the MI355X boxes the step takes 2.8 s with 16 threads, 3.2 s with 32, 15 s with 128)."""
     from oracle import bist_oracle as O
     c = CFG
+    torch.set_num_threads(threads)
     cfg = O.Cfg(d_model=c["d"], att_h=c["h"], nb_blocks=c["L"], nb_venc_blocks=c["L"], nb_cenc_blocks=c["L"])
-    torch.manual_seed(1)
-    shapes = O.state_shapes(cfg, c["V"], c["C"])
+    torch.manual_seed(1234)
     sd = {}
-    for k, s in shapes.items():
+    for k, s in O.state_shapes(cfg, c["V"], c["C"]).items():
         t = torch.randn(s) * (0.02 if len(s) > 1 else 0.01)
         if k.endswith(".a_2"):
             t = 1 + t
         sd[k] = t.requires_grad_(True)
     for alias in ("tgt_embed.0.lut.weight", "generator.vocab_gen", "ae_generator.proj"):
         sd[alias] = sd["query_embed.0.lut.weight"]
-    ob = O.det_batch(sample_B, c["T"], c["S"], c["C"], c["Lq"], c["Lh"], c["Lc"], c["Lt"], c["V"], seed=99)
-    times = []
-    for it in range(steps + 1):
-        t0 = time.perf_counter()
+    params = list({id(v): v for v in sd.values()}.values())
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9)          # train.py:129-130
+
+    def batch(B, T, seed=1234):
+        return O.det_batch(B, T, c["S"], c["C"], c["Lq"], c["Lh"], c["Lc"], c["Lt"], c["V"], seed=seed)
+
+    def med(fn, warm, n):
+        ts = []
+        for it in range(warm + n):
+            t0 = time.perf_counter()
+            fn()
+            if it >= warm:
+                ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    ob = batch(c["B"], c["T"])
+
+    def train_step():
         ft = O.mtn_forward(sd, cfg, ob)
         O.loss_compute(sd, cfg, ft, ob, c["V"])["total"].backward()
-        for v in sd.values():
-            v.grad = None
-        if it > 0:
-            times.append(time.perf_counter() - t0)
-    dt = sorted(times)[len(times) // 2]
-    return {"value": float(ob.ntokens) / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fwd+loss+bwd (no optimiser), B={sample_B} clips of the same geometry, median of {steps} steps, fp32",
-            "s_per_step": dt}
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    s_step = med(train_step, 2, 5)
+    out = {"value": float(ob.ntokens) / s_step, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"oracle (fp32, dropout off) full training step: forward + 4 losses + backward + torch Adam, B={c['B']} clips, "
+                     f"T={c['T']}, L={c['L']}, 2 warm-up + 5 timed steps, median",
+           "s_per_step": s_step, "nproc": os.cpu_count()}
+    if rows_wanted == "all":
+        rows = {}
+        with torch.no_grad():
+            rows["eval_forward_B16_T32_s"] = med(lambda: O.mtn_forward(sd, cfg, ob), 2, 5)
+            ob64 = batch(64, c["T"])
+            rows["eval_forward_B64_T32_s"] = med(lambda: O.mtn_forward(sd, cfg, ob64), 1, 3)
+            del ob64
+            ob128 = batch(c["B"], 128)
+            rows["eval_forward_B16_T128_s"] = med(lambda: O.mtn_forward(sd, cfg, ob128), 1, 3)
+            del ob128
+            ob1 = batch(1, c["T"], seed=99)
+            rows["decode_turn_beam5_maxlen12_s"] = med(lambda: O.beam_search(sd, cfg, ob1, 12, beam=5), 0, 1)
+        rows["protocol"] = "median; B16: 2 warm-up + 5 timed, B64 / T128: 1 + 3, decode turn (60 re-evaluations of the reasoning layers, decode.py:59-66): 1 run"
+        out["rows"] = rows
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a torch.distributed.run child (this process has not
+    touched the GPU) and leave with its exit code; rank 0 of the child writes the JSON line to our stdout."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
-    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout of rank 0 when its
-    # communicator is created, so file descriptor 1 is pointed at stderr for the whole run and the result line is written
-    # to the saved descriptor.
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -116,17 +163,28 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (the CPU share of a one-GPU box)")
+    ap.add_argument("--cpu-rows", default="all", choices=["all", "step"], help="cpu_baseline: every BASELINE.md row, or the training step only")
     ap.add_argument("--no-decode", action="store_true", help="skip the beam-search turn timing (BASELINE configs[4])")
-    ap.add_argument("--cpu-sample", type=int, default=2)
-    ap.add_argument("--no-graph", action="store_true", help="launch the ~2.7k kernels of a step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-t128", action="store_true", help="skip the T=128 (BASELINE configs[3]) step / forward timing")
+    ap.add_argument("--no-graph", action="store_true", help="launch the kernels of a step eagerly instead of replaying a hipGraph")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
+
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout of rank 0 when its
+    # communicator is created, so file descriptor 1 is pointed at stderr for the whole run and the result line is written
+    # to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {a.gpus} inside a launcher of {world} ranks")
     # rehearsal aid (one-GPU box): BIST_BENCH_REHEARSAL=1 puts every rank on cuda:0 and exchanges through gloo, so the
     # multi-rank control flow (barriers, gradient all-reduce, max-over-ranks timing) can be run without a second GPU
     rehearsal = os.environ.get("BIST_BENCH_REHEARSAL") == "1"
@@ -150,43 +208,40 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
 
     import bist_amd.model as M
-    from bist_amd import functional as Fn, ops
+    from bist_amd import _lib, functional as Fn, ops
     from bist_amd.data.synthetic import synthetic_batch
     from bist_amd.train import Trainer
 
     c = dict(CFG, B=a.batch, T=a.T)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     args = model_args(c["L"], c["d"], c["h"], a.dropout)
+
+    def make_batch(B, T, seed):
+        return synthetic_batch(B, T=T, S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"], seed=seed, dtype=dtype)
+
     torch.manual_seed(1)                         # identical initial weights on every rank
     model = M.make_model(c["V"], c["V"], args, ft_sizes=[c["C"]]).cuda()
     model.train()
     Fn.manual_seed(1234 + rank)
     trainer = Trainer(model, args, c["V"], compute_dtype=dtype, use_graph=not a.no_graph)
-    batch = synthetic_batch(c["B"], T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"],
-                            seed=1234 + rank, dtype=dtype)
+    batch = make_batch(c["B"], c["T"], 1234 + rank)
     ntok = int(batch.ntokens.item())
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        trainer.step(batch)
-    torch.cuda.synchronize(); barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        trainer.step(batch)
-    torch.cuda.synchronize(); barrier()
-    dt = time.perf_counter() - t0
-    # Dominant-kernel timing: HIP events around every P0 GEMM launch of three further training passes run
-    # eagerly (the timed steps replay a hipGraph, whose kernel nodes cannot carry timing events on ROCm:
-    # "External events are disallowed in rocm"), same process, same batch, same stream.
-    ops.GEMM_TIMING, ops.GEMM_TIMING_SHAPE = [], (c["B"] * c["T"] * c["S"], c["d"], c["C"])
-    for _ in range(3):
-        trainer.backward(batch)
-    torch.cuda.synchronize()
-    timing, ops.GEMM_TIMING, ops.GEMM_TIMING_SHAPE = ops.GEMM_TIMING, None, None
+    def timed_steps(tr, bt, warm, steps):
+        for _ in range(warm):
+            tr.step(bt)
+        torch.cuda.synchronize(); barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(bt)
+        torch.cuda.synchronize(); barrier()
+        return time.perf_counter() - t0
 
+    dt = timed_steps(trainer, batch, a.warmup, a.steps)
     tot = torch.tensor([dt, float(ntok)], device="cuda", dtype=torch.float64)
     if world > 1:
         tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -195,19 +250,7 @@ def main():
     else:
         ntok_all = float(ntok)
 
-    # dominant kernel: the P0 GEMM (M = B*T*S, N = d, K = C), forward launches only
-    M_p0 = c["B"] * c["T"] * c["S"]
-    p0 = [e0.elapsed_time(e1) for (m, n, k, z), e0, e1, _ in timing if (m, n, k, z) == (M_p0, c["d"], c["C"], 1)]
-    p0_plan = {plan for (m, n, k, z), _, _, plan in timing if (m, n, k, z) == (M_p0, c["d"], c["C"], 1)}
-    p0_kernel = {4: "gemm_big_kernel<bf16> (256x256 tiles)", 1: "gemm_fast_kernel<bf16> (128x128 tiles)"}.get(
-        next(iter(p0_plan)) if len(p0_plan) == 1 else -1, "bist_gemm")
-    p0_ms = sum(p0) / max(1, len(p0))
-    p0_flops = 2.0 * M_p0 * c["d"] * c["C"]
-    achieved = p0_flops / (p0_ms * 1e-3) / 1e12 if p0_ms > 0 else 0.0
-
-    # fused BiST attention forward (F_P0 + F_VL): P0 + one VidEncoderLayer4, eval mode, replayed from a hipGraph
-    # (the two directions run as parallel graph branches).  Measured on the bench batch (B=16) and at the
-    # north_star's roofline point B=64 on a second synthetic batch.
+    # ---- the roofline region: P0 + one VidEncoderLayer4, inference, replayed from a hipGraph ------------------------------------
     model.eval()
 
     def attn_forward_ms(bt):
@@ -235,14 +278,40 @@ def main():
             for _ in range(20):
                 g.replay()
             e1.record(); torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / 20
+            ms = e0.elapsed_time(e1) / 20
+            # the dominant kernels one by one: HIP events around each launch on its launch stream, three eager passes
+            ops.GEMM_TIMING, ops.GEMM_TIMING_SHAPE, ops.ST1F_TIMING = [], (bt.fts.shape[0] * bt.fts.shape[1] * c["S"], c["d"], c["C"]), []
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            gt, st = ops.GEMM_TIMING, ops.ST1F_TIMING
+            ops.GEMM_TIMING = ops.GEMM_TIMING_SHAPE = ops.ST1F_TIMING = None
+            p0 = [e_0.elapsed_time(e_1) for _, e_0, e_1, _ in gt]
+            plan = {pl for *_, pl in gt}
+            st1 = {d_: [e_0.elapsed_time(e_1) for (_, _, _, _, dd), e_0, e_1 in st if dd == d_] for d_ in (0, 1)}
+            return ms, (sum(p0) / max(1, len(p0)), plan), {d_: sum(v) / max(1, len(v)) for d_, v in st1.items()}
+
+    def region_report(B, T, bt):
+        ms, (p0_ms, p0_plan), st1_ms = attn_forward_ms(bt)
+        f_p0, f_vl = flops_alg(B, T, c["S"], c["C"], c["d"], c["Lq"], c["h"])
+        tfl = (f_p0 + f_vl) / (ms * 1e-3) / 1e12
+        p0_kernel = {4: "gemm_big_kernel<bf16> (256x256 tiles)", 1: "gemm_fast_kernel<bf16> (128x128 tiles)"}.get(
+            next(iter(p0_plan)) if len(p0_plan) == 1 else -1, "bist_gemm")
+        kernels = [{"kernel": f"{p0_kernel} P0 [{B * T * c['S']}x{c['C']}]x[{c['C']}x{c['d']}]", "avg_launch_ms": p0_ms, "gflop_alg": f_p0 / 1e9,
+                    "tflops": f_p0 / (p0_ms * 1e-3) / 1e12 if p0_ms > 0 else 0.0}]
+        for d_, name in ((0, "t2s"), (1, "s2t")):
+            fl = flops_stage1(B, T, c["S"], c["d"], c["Lq"], d_)
+            kernels.append({"kernel": f"st1_fused_kernel {name} stage 1 (value projection + QK^T + softmax + PV + output projection + residual)",
+                            "avg_launch_ms": st1_ms[d_], "gflop_alg": fl / 1e9, "tflops": fl / (st1_ms[d_] * 1e-3) / 1e12 if st1_ms[d_] > 0 else 0.0})
+        return {"B": B, "T": T, "gflop_alg": (f_p0 + f_vl) / 1e9, "ms": ms, "tflops": tfl, "frac_of_mfma_peak": tfl / MFMA_BF16_PEAK_TFLOPS,
+                "kernels": kernels}
 
     def decode_turn_ms():
         """BASELINE configs[4]: one dialogue turn of beam_search_decode (B=1, beam 5, maxlen 12) with and without the
         per-turn reuse of the target-independent reasoning."""
         from bist_amd.model.decode import beam_search_decode
         from bist_amd.model.decoder import MultimodalDecoder8
-        b1 = synthetic_batch(1, T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"], seed=99, dtype=dtype)
+        b1 = make_batch(1, c["T"], 99)
         res = {}
         with torch.no_grad():
             for name, flag in (("cached", True), ("recompute", False)):
@@ -260,18 +329,29 @@ def main():
                 "ms_per_turn_reasoning_recomputed": res["recompute"]}
 
     decode = decode_turn_ms() if (rank == 0 and not a.no_decode) else None
-    attn_ms = attn_forward_ms(batch)
-    f_p0, f_vl = flops_alg(c["B"], c["T"], c["S"], c["C"], c["d"], c["Lq"], c["h"])
-    attn_tflops = (f_p0 + f_vl) / (attn_ms * 1e-3) / 1e12
+    attn = region_report(c["B"], c["T"], batch)
     attn64 = None
     if rank == 0 and c["B"] != 64:
-        b64 = synthetic_batch(64, T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"],
-                              seed=4321, dtype=dtype)
-        ms64 = attn_forward_ms(b64)
-        p64, v64 = flops_alg(64, c["T"], c["S"], c["C"], c["d"], c["Lq"], c["h"])
-        attn64 = {"B": 64, "gflop_alg": (p64 + v64) / 1e9, "ms": ms64, "tflops": (p64 + v64) / (ms64 * 1e-3) / 1e12,
-                  "frac_of_mfma_peak": (p64 + v64) / (ms64 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        b64 = make_batch(64, c["T"], 4321)
+        attn64 = region_report(64, c["T"], b64)
         del b64
+    roof = attn64 if attn64 is not None else attn
+    traffic = region_traffic(roof["B"], roof["T"]) if rank == 0 else None
+    dom = max(roof["kernels"], key=lambda k: k["avg_launch_ms"])
+
+    # BASELINE configs[3]: T=128 on the same model (its own trainer; rank 0 of a one-GPU run only)
+    t128 = None
+    if rank == 0 and world == 1 and not a.no_t128 and c["T"] != 128:
+        del trainer
+        torch.cuda.empty_cache()
+        model.train()
+        b128 = make_batch(c["B"], 128, 777)
+        tr128 = Trainer(model, args, c["V"], compute_dtype=dtype, use_graph=not a.no_graph)
+        dt128 = timed_steps(tr128, b128, 3, 5)
+        model.eval()
+        t128 = {"what": "BASELINE configs[3]: T=128 temporal segments, same model and batch size, training step and the roofline region",
+                "ms_per_step": dt128 / 5 * 1e3, "tokens_per_s": float(b128.ntokens.item()) * 5 / dt128, "attn_fwd": region_report(c["B"], 128, b128)}
+        del tr128, b128
 
     out = {
         "metric": "training-step tokens/sec (BiST hot path: fwd + pointer-generator losses + bwd + Adam)",
@@ -282,18 +362,18 @@ def main():
                                f"[B={c['B']}/GPU,T={c['T']},7x7,2048] {a.dtype} + 20-token queries, dropout={a.dropout}",
                    "global_batch": c["B"] * world, "tokens_per_step": ntok_all, "parallelism": f"dp{world}",
                    "clips_per_s": c["B"] * world * a.steps / dt},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": (p0_traffic(M_p0, c["C"], c["d"]) or {}).get("bytes_per_launch"),
-                     "traffic_detail": p0_traffic(M_p0, c["C"], c["d"]),
-                     "kernel": f"{p0_kernel} P0 [{M_p0}x{c['C']}]x[{c['C']}x{c['d']}]", "avg_launch_ms": p0_ms,
-                     "launches_timed": len(p0)},
-        "attn_fwd": {"what": "fused BiST attention forward F_P0+F_VL (SURVEY 8d), one layer, eval, hipGraph replay", "B": c["B"], "gflop_alg": (f_p0 + f_vl) / 1e9,
-                     "ms": attn_ms, "tflops": attn_tflops, "frac_of_mfma_peak": attn_tflops / MFMA_BF16_PEAK_TFLOPS,
-                     "at_B64": attn64},
+        "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": roof["frac_of_mfma_peak"], "traffic": (traffic or {}).get("traffic_bytes"),
+                     "traffic_detail": traffic,
+                     "region": f"fused BiST attention forward F_P0+F_VL (SURVEY 8d): P0 + LayerNorm + one VidEncoderLayer4, inference, "
+                               f"B={roof['B']}, T={roof['T']}, 7x7, C=2048, one hipGraph replay",
+                     "gflop_alg": roof["gflop_alg"], "avg_launch_ms": roof["ms"], "kernel": dom["kernel"], "kernels": roof["kernels"]},
+        "attn_fwd": {"what": "the same region on the bench batch", **attn, "at_B64": attn64},
         "decode": decode,
+        "t128": t128,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, 3, a.dropout)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_rows, a.cpu_threads)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -238,7 +238,7 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
     u32x4 bq[2][2];
     load_q2(bq[0], q0, q1, 0, 0);
     load_q2(bq[1], q0, q1, 0, 1);
-    frag_stream<2 * MTA, (MTA >= 4 ? 8 : 4)>([&](int kp, int g) { return img_addr(kp, g / MTA, g % MTA); },
+    frag_stream<2 * MTA, 4>([&](int kp, int g) { return img_addr(kp, g / MTA, g % MTA); },
                             [&](int kp, auto fc, const uint4& ax) {
                               constexpr int f = fc, e = f / MTA, mt = f % MTA;
                               if constexpr (mt == 0) {

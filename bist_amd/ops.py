@@ -270,6 +270,9 @@ def st_stage1_pv(scores: Tensor, v: Tensor, tmask: Optional[Tensor], *, B: int, 
     return out
 
 
+ST1F_TIMING = None        # set to a list to collect ((B,T,S,Lq,direction), start_event, end_event) per fused stage-1 launch
+
+
 def st_stage1_fused_ok(T: int, S: int, Lq: int, d: int, h: int, direction: int, dtype: torch.dtype) -> bool:
     """True when bist_st_stage1_fused_fwd covers the shape (bf16, d = 512, h = 8, Lq <= 32, at most 128 keys)."""
     return dtype in _DT and bool(lib.bist_st_stage1_fused_ok(T, S, Lq, d, h, direction, _DT[dtype]))
@@ -316,9 +319,17 @@ def st_stage1_fused(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: Tensor
         kmask = kmask.reshape(B, K)
         kmask = (kmask.view(torch.uint8) if kmask.dtype == torch.bool else kmask.to(torch.uint8)).contiguous()
         mptr = kmask.data_ptr()
+    timed = ST1F_TIMING is not None
+    if timed:       # bench.py: HIP events around the launch on the launch stream (see gemm())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(200_000)
+        e0.record()
     check(lib.bist_st_stage1_fused_fwd(qf.data_ptr(), vft.data_ptr(), mptr, wv.data_ptr(), bv.data_ptr(), wo.data_ptr(),
                                        bo.data_ptr(), xres.data_ptr(), out.data_ptr(), B, T, S, Lq, d, h, direction,
                                        dtype_code(vft.dtype), _stream()), "bist_st_stage1_fused_fwd")
+    if timed:
+        e1.record()
+        ST1F_TIMING.append(((B, T, S, Lq, direction), e0, e1))
     return out
 
 

@@ -272,6 +272,18 @@ class Trainer:
                 terms = self.backward(batch, optimizer=self.adam_in_step)
         self._graph, self._graph2, self._graph_key, self._static_batch, self._static_terms = graph, graph2, key, batch, terms
 
+    def _globally_normalised(self, batch):
+        """The reference normalises each loss term by the token count of the WHOLE batch (optimize.py:48-50: ``/ batch.ntokens``,
+        ``/ batch.qntokens``).  With the batch sharded over ranks, every rank divides its own sum by the GLOBAL counts (one
+        all-reduce of two integers, asynchronous on the device) and the gradients are SUMMED: exactly the reference's update,
+        also when the ranks hold different numbers of tokens.  (A mean of per-rank-normalised gradients would weight tokens of
+        short shards more.)"""
+        tok = torch.stack([batch.ntokens.reshape(()), batch.qntokens.reshape(())]).to(torch.int64)
+        dist.all_reduce(tok, op=dist.ReduceOp.SUM, group=self.pg)
+        gb = copy.copy(batch)
+        gb.ntokens, gb.qntokens = tok[0], tok[1]
+        return gb
+
     def _own_copy(self, batch):
         """A shallow copy of the batch whose tensor fields are clones owned by the trainer."""
         own = copy.copy(batch)
@@ -319,6 +331,7 @@ class Trainer:
         # point-to-point: a few large messages keep all 7 links busy) -- starts under those reductions, the prefix follows,
         # and Adam runs on a piece as soon as its own all-reduce has finished, i.e. under the next piece's (the compute
         # stream waits on the collective's event, never the host).
+        batch = self._globally_normalised(batch)
         terms = self._graph_open(batch) if self.use_graph else self._backward_open(batch)
         big = [(self.n32 + lo, self.n32 + hi) for lo, hi in parallel.chunk_bounds(self.numel - self.n32, EXCHANGE_CHUNKS, ALIGN)]
         works = parallel.exchange_gradients_async(self.flat_grad, big, self.pg)
@@ -330,5 +343,5 @@ class Trainer:
         works += parallel.exchange_gradients_async(self.flat_grad, [(0, self.n32)], self.pg)
         for (lo, hi), wk in zip(bounds, works):
             wk.wait()
-            adam(lo, hi, 1.0 / self.world)
+            adam(lo, hi, 1.0)            # every rank divided by the GLOBAL token counts: the summed gradient is the reference's
         return {k: v.detach() for k, v in terms.items()}

@@ -1,7 +1,8 @@
 """The several-rank training step on ONE GPU: two processes share cuda:0 and exchange through gloo (RCCL refuses two ranks on
-one device), so that the step's two-graph cut, the exchange of both gradient regions and the 1/world scaling run with real
-rank-dependent data.  Checked: both ranks hold bit-identical weights after every step, and those weights are what ONE process
-gets from Adam on the MEAN of the two ranks' gradients."""
+one device), so that the step's two-graph cut, the exchange of both gradient regions and the global token normalisation run with
+real rank-dependent data (the two ranks hold DIFFERENT numbers of target and query tokens).  Checked: both ranks hold
+bit-identical weights after every step, and those weights are what ONE process gets from Adam on the gradient of the reference's
+loss over the union of the two shards (each term divided by the token count of the whole batch, optimize.py:48-50)."""
 import argparse
 import os
 import socket
@@ -46,7 +47,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_step_equals_adam_on_the_mean_gradient():
+def test_two_ranks_step_equals_adam_on_the_globally_normalised_gradient():
     import torch.multiprocessing as mp
     from bist_amd._lib import check, lib
     from bist_amd.ops import dtype_code
@@ -64,9 +65,16 @@ def test_two_ranks_step_equals_adam_on_the_mean_gradient():
     got = {r: torch.from_numpy(a) for r, a in got.items()}
     assert torch.equal(got[0], got[1]), "ranks diverged"
 
-    # reference in this process: per-rank gradients from the same weights, averaged, one Adam launch per step
+    # reference in this process: the two shards' gradients of the GLOBALLY normalised loss from the same weights, summed, one
+    # Adam launch per step
+    import copy
     model, args, b0 = _make(100)
     _, _, b1 = _make(101)
+    assert int(b0.ntokens) != int(b1.ntokens) and int(b0.qntokens) != int(b1.qntokens), "the shards must differ in token counts"
+    nt, qn = b0.ntokens + b1.ntokens, b0.qntokens + b1.qntokens
+    b0, b1 = copy.copy(b0), copy.copy(b1)
+    b0.ntokens = b1.ntokens = nt
+    b0.qntokens = b1.qntokens = qn
     ref = Trainer(model, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=False)
     st = torch.cuda.current_stream().cuda_stream
     for step in (1, 2):
@@ -77,7 +85,7 @@ def test_two_ranks_step_equals_adam_on_the_mean_gradient():
         ref.backward(b1)
         ref.flat_grad.add_(g)
         check(lib.bist_adam_step(ref.master.data_ptr(), ref.flat_grad.data_ptr(), ref.m.data_ptr(), ref.v.data_ptr(), None, ref.numel,
-                                 ref.rate(), ref.betas[0], ref.betas[1], ref.eps, step, 0.5, dtype_code(torch.float32),
+                                 ref.rate(), ref.betas[0], ref.betas[1], ref.eps, step, 1.0, dtype_code(torch.float32),
                                  dtype_code(torch.float32), st), "bist_adam_step")
     torch.cuda.synchronize()
     want = ref.master.cpu()
