@@ -71,6 +71,7 @@ SIGNATURES = {
     "bist_embed_pe_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_temporal_mask": (C.c_int, [_P, _P, _I64, _I64, _I32, _P]),
     "bist_fuse_modalities": (C.c_int, [_P, C.POINTER(C.c_void_p), _P, _I64, _I32, _I32, _I32, _P]),
+    "bist_add_dropout_fwd": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_add_bcast": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _P]),
     "bist_add_n": (C.c_int, [_P, _I32, _P, _I64, _I32, _P]),
     "bist_permute_ts": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),

@@ -514,6 +514,23 @@ class AddFn(Function):
         return dy, dy
 
 
+class AddDropoutFn(Function):
+    """mode 0: a + dropout(b) (SublayerConnection.forward, modules.py:44); mode 1: dropout(a + b) with b a constant table
+    (PositionalEncoding.forward, modules.py:144).  The backward regenerates the mask (bist_epilogue_bwd)."""
+
+    @staticmethod
+    def forward(ctx, a, b, drop, mode):
+        ctx.drop, ctx.mode, ctx.same = drop, mode, a.shape == b.shape
+        return ops.add_dropout(a.contiguous(), b.contiguous(), drop, mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dm = ops.dropout_mask_grad(dy, ctx.drop)
+        if ctx.mode == 0:
+            return dy, (dm if ctx.same else None), None, None
+        return dm, (dm if ctx.same else None), None, None
+
+
 class PermuteTSFn(Function):
     """[B,T,S,d] -> [B,S,T,d]; the gradient takes the same kernel back."""
 

@@ -130,9 +130,38 @@ __global__ void add_bcast_kernel(const T* __restrict__ a, const T* __restrict__ 
   if (i < n) out[i] = from_f<T>(to_f(a[i]) + to_f(b[i % nb]));
 }
 
+// mode 0: out[i] = a[i] + drop(b[i % nb])      x + dropout(sublayer(norm(x)))   (SublayerConnection.forward, modules.py:44)
+// mode 1: out[i] = drop(a[i] + b[i % nb])      dropout(x + pe)                  (PositionalEncoding.forward, modules.py:142-144)
+// the mask of element i is drop_keep(key, i): bist_epilogue_bwd on the same contiguous tensor regenerates it for the backward
+template <typename T>
+__global__ void add_dropout_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long n, long nb, int mode,
+                                   const DropArg dr) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float m = drop_mul(dr.key(), (unsigned long long)i, dr.p, dr.keep_scale());
+  const float av = to_f(a[i]), bv = to_f(b[i % nb]);
+  out[i] = from_f<T>(mode == 0 ? av + m * bv : m * (av + bv));
+}
+
 inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
+
+extern "C" int bist_add_dropout_fwd(const void* a, const void* b, void* out, int64_t n, int64_t nb, int32_t mode, const BistDrop* drop,
+                                    int32_t dtype, void* stream) {
+  BIST_REQUIRE(a && b && out && n > 0 && nb > 0 && (mode == 0 || mode == 1), "bist_add_dropout_fwd: bad argument");
+  BIST_REQUIRE(drop && drop->p > 0.f && drop->p < 1.f, "bist_add_dropout_fwd: drop p must be in (0, 1)");
+  const DropArg dr = make_drop(drop);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = blocks_for(n, 256);
+  if (dtype == BIST_BF16)
+    hipLaunchKernelGGL(add_dropout_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (long)n, (long)nb, mode, dr);
+  else if (dtype == BIST_F32)
+    hipLaunchKernelGGL(add_dropout_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, (long)n, (long)nb, mode, dr);
+  else { bist_set_error("bist_add_dropout_fwd: bad dtype %d", dtype); return BIST_EINVAL; }
+  BIST_LAUNCH_CHECK("bist_add_dropout_fwd");
+  return BIST_OK;
+}
 
 extern "C" int bist_layernorm_fwd(const void* x, const void* a, const void* b, void* y, int64_t rows, int32_t d,
                                   int64_t ldx, int64_t ldy, float eps, int32_t dtype, void* stream) {

@@ -129,6 +129,11 @@ def add(a, b):
     return ops.add(a, b)
 
 
+def add_dropout(a, b, drop, mode: int):
+    """mode 0: a + dropout(b); mode 1: dropout(a + b) -- the stand-alone dropout sites of modules.py:44 / :144."""
+    return ag.AddDropoutFn.apply(a, b, drop, mode) if _grad() else ops.add_dropout(a.contiguous(), b.contiguous(), drop, mode)
+
+
 def permute_ts(x):
     """The video tensor in region-major order [B,S,T,d] (one copy per step, shared by all layers; see bist_permute_ts)."""
     return ag.PermuteTSFn.apply(x) if (_grad() and x.requires_grad) else ops.permute_ts(x)

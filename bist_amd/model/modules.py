@@ -54,12 +54,17 @@ class SublayerConnection(nn.Module):
         super().__init__()
         self.norm = LayerNorm(size)
         self.dropout = nn.Dropout(dropout)   # holds p; the mask itself is generated inside the kernels
-        self.p = dropout
+
+    @property
+    def p(self) -> float:
+        """drop probability (a property, not an attribute: a whole-module pickle written by the reference has only ``dropout``)"""
+        return float(self.dropout.p)
 
     def forward(self, x: Tensor, sublayer) -> Tensor:
+        y = sublayer(self.norm(x))
         if self.training and self.p > 0:
-            raise NotImplementedError("generic SublayerConnection.forward has no fused dropout; use the layer classes")
-        return Fn.add(x, sublayer(self.norm(x)))
+            return Fn.add_dropout(x, y, (self.p, Fn.next_seed()), 0)
+        return Fn.add(x, y)
 
 
 class MultiHeadedAttention(nn.Module):
@@ -69,6 +74,8 @@ class MultiHeadedAttention(nn.Module):
     ``self.keep_attn`` is set: the pointer generators are its only readers (generator.py:62-63,
     109-110) and writing it for every attention on the path would be pure HBM traffic.
     """
+
+    keep_attn = False      # class default (instances unpickled from a reference checkpoint have no such attribute)
 
     def __init__(self, h: int, d_model: int, d_in: int = -1, dropout: float = 0.1):
         super().__init__()
@@ -80,7 +87,6 @@ class MultiHeadedAttention(nn.Module):
         self.linears = clones(nn.Linear(d_in, d_model), 3)
         self.linears.append(nn.Linear(d_model, d_in))
         self.attn: Optional[Tensor] = None
-        self.keep_attn = False
         self.dropout = nn.Dropout(p=dropout)
 
     # -- packed projection weights (device-side concatenation, cached while parameters are unchanged)
@@ -103,7 +109,7 @@ class MultiHeadedAttention(nn.Module):
             cache[tuple(idx)] = (key, w, b)
         return w, b
 
-    def context(self, query: Tensor, key: Tensor, value: Tensor, mask: Optional[Tensor]) -> Tensor:
+    def context(self, query: Tensor, key: Tensor, value: Tensor, mask: Optional[Tensor], want_p: Optional[bool] = None) -> Tensor:
         """Head-concatenated attention output BEFORE the output projection, [N,Lq,d].
 
         The Q/K/V projections are as few GEMMs as the aliasing of the arguments allows (one packed
@@ -113,27 +119,30 @@ class MultiHeadedAttention(nn.Module):
         readers being the pointer attentions, which are built with dropout=0 (mtn.py:89-92)."""
         d = self.h * self.d_k
         n, lq = query.shape[0], query.shape[1]
+        keep = self.keep_attn if want_p is None else want_p
         if query is key and key is value:
             w, b = self._packed((0, 1, 2))
             qkv = Fn.linear(query, w, b).view(n, lq, 3 * d)
-            ctx, p = Fn.mha_packed(qkv, None, None, "qkv", mask, self.h, self.keep_attn, Fn.attn_drop(self))
+            ctx, p = Fn.mha_packed(qkv, None, None, "qkv", mask, self.h, keep, Fn.attn_drop(self))
         else:
             lk = key.shape[1]
             if key is value:
                 w, b = self._packed((1, 2))
                 q, kv = Fn.linear_pair(query, self.linears[0].weight, self.linears[0].bias, key, w, b)      # one launch
                 q, kv = q.view(n, lq, d), kv.view(n, lk, 2 * d)
-                ctx, p = Fn.mha_packed(q, kv, None, "q_kv", mask, self.h, self.keep_attn, Fn.attn_drop(self))
+                ctx, p = Fn.mha_packed(q, kv, None, "q_kv", mask, self.h, keep, Fn.attn_drop(self))
             else:
                 q = Fn.linear(query, self.linears[0].weight, self.linears[0].bias).view(n, lq, d)
                 k = Fn.linear(key, self.linears[1].weight, self.linears[1].bias).view(n, lk, d)
                 v = Fn.linear(value, self.linears[2].weight, self.linears[2].bias).view(n, lk, d)
-                ctx, p = Fn.mha_packed(q, k, v, "q_k_v", mask, self.h, self.keep_attn, Fn.attn_drop(self))
+                ctx, p = Fn.mha_packed(q, k, v, "q_k_v", mask, self.h, keep, Fn.attn_drop(self))
         self.attn = p
         return ctx
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, mask: Optional[Tensor] = None) -> Tensor:
-        ctx = self.context(query, key, value, mask)
+        """The reference's call form: like modules.py:94 it always leaves the probabilities in ``self.attn`` (the fused layer
+        classes call ``context`` instead and skip that HBM write unless ``keep_attn`` is set)."""
+        ctx = self.context(query, key, value, mask, want_p=True)
         out = Fn.linear(ctx, self.linears[3].weight, self.linears[3].bias)
         return out.view(query.shape[0], query.shape[1], -1)
 
@@ -208,9 +217,10 @@ class PositionalEncoding(nn.Module):
         if x is None:
             return x
         L = x.shape[1]
+        pe = self.table()[:L].to(x.dtype).contiguous()
         if self.training and self.dropout.p > 0:
-            raise NotImplementedError("stand-alone PositionalEncoding has no fused dropout; use embed_with_position")
-        return Fn.add(x, self.table()[:L].to(x.dtype))
+            return Fn.add_dropout(x, pe, (float(self.dropout.p), Fn.next_seed()), 1)
+        return Fn.add(x, pe)
 
 
 def embed_with_position(seq: nn.Sequential, ids: Tensor) -> Tensor:

@@ -463,6 +463,29 @@ def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def add_dropout(a: Tensor, b: Tensor, drop, mode: int) -> Tensor:
+    """mode 0: a + dropout(b); mode 1: dropout(a + b); b may be a broadcast operand whose numel divides a's (see bist_add_dropout_fwd)."""
+    _dev(a, b)
+    if not (a.is_contiguous() and b.is_contiguous()) or a.dtype != b.dtype or a.numel() % b.numel():
+        raise ValueError("bist_amd.add_dropout: contiguous operands of one dtype, b broadcastable by period")
+    out = torch.empty_like(a)
+    check(lib.bist_add_dropout_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), b.numel(), mode, drop_ref(drop), dtype_code(a.dtype),
+                                   _stream()), "bist_add_dropout_fwd")
+    return out
+
+
+def dropout_mask_grad(dy: Tensor, drop) -> Tensor:
+    """dy * mask / (1 - p) with the mask of add_dropout (element index order of the contiguous tensor)."""
+    _dev(dy)
+    dy = dy.contiguous()
+    dz = torch.empty_like(dy)
+    N = dy.shape[-1]
+    M = dy.numel() // N
+    check(lib.bist_epilogue_bwd(dy.data_ptr(), None, dz.data_ptr(), M, N, N, N, N, ACT_NONE, float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF,
+                                _ptr(DROP_CTR), dtype_code(dy.dtype), _stream()), "bist_epilogue_bwd")
+    return dz
+
+
 def pointer_mix(logits: Tensor, switch_logits: Tensor, ptr_p: Sequence[Tensor], ptr_text: Sequence[Tensor], Lt: int,
                 sigmoid_switch: bool = False) -> Tensor:
     """log of the pointer/vocabulary mixture (generator.py:84-127); logits f32 [rows,V] -> f32 [rows,V]."""

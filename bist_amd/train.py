@@ -345,3 +345,28 @@ class Trainer:
             wk.wait()
             adam(lo, hi, 1.0)            # every rank divided by the GLOBAL token counts: the summed gradient is the reference's
         return {k: v.detach() for k, v in terms.items()}
+
+
+def run_epoch(data, loader, vocab, epoch, model, loss_compute, eval=False, gen_valid_indices=None, report=None):
+    """The reference's epoch loop (train.py:21-52) with its signature: for every batch ``model.forward`` then ``loss_compute``
+    (a ``SimpleLossCompute``; with ``opt`` set it also runs backward and the optimiser step), accumulating the un-normalised
+    losses and the token counts.  Batches must already live on the device (the reference calls ``batch.move_to_cuda()`` here,
+    train.py:30; bist_amd.data.Batch objects built from device tensors need nothing).  ``report(j, losses, batch)`` replaces
+    the reference's print / CSV logging (train.py:38-47).  Returns the same three per-token averages, without the
+    reference's floor division on the spatial term (train.py:51, a logging slip)."""
+    total_tokens = total_qtokens = 0
+    total_loss = total_t = total_s = 0.0
+    for j, batch in enumerate(loader):
+        if hasattr(batch, "move_to_cuda") and not batch.query.is_cuda:
+            batch.move_to_cuda()
+        out = model.forward(batch)
+        losses = loss_compute(out, batch)
+        total_loss = total_loss + losses["out"]
+        total_t = total_t + losses["temporal_ae"]
+        total_s = total_s + losses["spatial_ae"]
+        total_tokens = total_tokens + batch.ntokens
+        total_qtokens = total_qtokens + batch.qntokens
+        if report is not None and not eval:
+            report(j, losses, batch)
+    return {"out": total_loss / total_tokens.float(), "temporal_ae": total_t / total_qtokens.float(),
+            "spatial_ae": total_s / total_qtokens.float()}

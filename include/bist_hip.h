@@ -256,6 +256,12 @@ int bist_fuse_modalities(const void* score, const void* const* xs, void* out, in
 
 /* out[i] = a[i] + b[i % nb]: the residual add of SublayerConnection (modules.py:44) when it is
  * not fused into a GEMM epilogue; nb < n broadcasts b.                                          */
+/* The generic forms of the reference's two dropout-carrying adds (training mode), for callers that use the modules one by one
+ * instead of the fused layer classes:  mode 0: out = a + dropout(b)  (SublayerConnection.forward, modules.py:42-44),
+ * mode 1: out = dropout(a + b)  (PositionalEncoding.forward, modules.py:142-144); b is broadcast with period nb.  The mask of
+ * element i is the counter-based drop_keep((seed, ctr), i), so bist_epilogue_bwd on the same contiguous [M,N] view is its backward. */
+int bist_add_dropout_fwd(const void* a, const void* b, void* out, int64_t n, int64_t nb, int32_t mode, const BistDrop* drop,
+                         int32_t dtype, void* stream);
 int bist_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t nb, int32_t dtype, void* stream);
 
 /* y[b,s,t,:] = x[b,t,s,:]  (x [B,T,S,d] contiguous): the video tensor in region-major order.  The t2s direction walks, for

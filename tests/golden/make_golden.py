@@ -15,7 +15,7 @@ Capture-process-only shims (never shipped, the reference is not modified):
   * generator.py:66,113 / decode.py:63-65 hard-code ``.cuda()`` -> identity on
     this CPU-only box.
 
-usage:  python tests/golden/make_golden.py        (from the repo root)
+usage:  python tests/golden/make_golden.py [g6]   (from the repo root; "g6" regenerates the full-size digests only)
 """
 import argparse
 import json
@@ -195,12 +195,83 @@ def case_beam(tag, cfg, dims, out, beam):
     out[f"{tag}_cfg"] = np.asarray(json.dumps({"cfg": cfg.__dict__, "dims": dims, "beam": beam}))
 
 
+def digest(t, k=64):
+    """What is kept of a full-size tensor: its element sum and absolute sum (float64), its first k values and k values at a fixed
+    stride through the flattened tensor."""
+    x = t.detach().double().reshape(-1)
+    idx = torch.linspace(0, x.numel() - 1, k).long()
+    return np.concatenate([[float(x.sum()), float(x.abs().sum())], x[:k].numpy(), x[idx].numpy()])
+
+
+def case_fullsize(tag, cfg, dims, out, beam=None):
+    """SURVEY 8c "G6": the reference at d_model=512, L=6 (BASELINE configs[1] / configs[3] model) regenerated from seed; only digests
+    of the outputs are stored (plus the greedy argmax and, with `beam`, the n-best of a beam search on clip 0's dialogue)."""
+    vocab = dims["V"]
+    model, sd = build(cfg, vocab, dims["C"])
+    ob = O.det_batch(dims["B"], dims["T"], dims["S"], dims["C"], dims["Lq"], dims["Lh"], dims["Lc"], dims["Lt"], vocab, seed=dims["seed"])
+    rb = ref_batch(ob)
+    with torch.no_grad():
+        ft = model.forward(rb)
+        logp = model.generator(ft, rb, ref_args(cfg))
+    for k, v in ft.items():
+        out[f"{tag}_dg_{k}"] = digest(v)
+    out[f"{tag}_dg_logp"] = digest(logp)
+    out[f"{tag}_argmax"] = npy(logp.argmax(-1))
+    out[f"{tag}_logp_row0"] = npy(logp[0, 0])
+    if beam:
+        ob1 = O.det_batch(1, dims["T"], dims["S"], dims["C"], dims["Lq"], dims["Lh"], dims["Lc"], dims["Lt"], vocab, seed=dims["seed"] + 1)
+        with torch.no_grad():
+            hyps, best = RD.beam_search_decode(model, ref_batch(ob1), 12, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID, beam=beam, penalty=1.0,
+                                               nbest=5, train_args=ref_args(cfg))
+        out[f"{tag}_beam_n"] = np.asarray(len(hyps))
+        for i, (toks, score) in enumerate(hyps):
+            out[f"{tag}_beam_hyp{i}"] = np.asarray([int(t) for t in toks], dtype=np.int64)
+            out[f"{tag}_beam_score{i}"] = np.asarray(float(score))
+    out[f"{tag}_cfg"] = np.asarray(json.dumps({"cfg": cfg.__dict__, "dims": dims, "beam": beam}))
+
+
 SMALL = dict(B=2, T=6, S=9, C=48, Lq=7, Lh=11, Lc=8, Lt=6, V=60)
+FULL = dict(B=4, S=49, C=2048, Lq=20, Lh=60, Lc=25, Lt=20, V=3000, seed=4242)
 MID = dict(B=3, T=8, S=49, C=64, Lq=20, Lh=24, Lc=12, Lt=10, V=120)
+
+
+def main_g7():
+    """A whole-module pickle written by the REFERENCE (train.py:161 ``torch.save(model, path)``) for a tiny model, with its outputs:
+    generate.py:93 unpickles such a file by ``model.*`` class paths, which INTEGRATION.md section 2 maps onto this build."""
+    cfg = O.Cfg(d_model=16, att_h=2, nb_blocks=1, nb_venc_blocks=1, nb_cenc_blocks=1)
+    dims = dict(B=2, T=4, S=9, C=8, Lq=5, Lh=6, Lc=4, Lt=5, V=30, seed=5)
+    model, sd = build(cfg, dims["V"], dims["C"])
+    torch.save(model, os.path.join(HERE, "g7_reference_module.pth.tar"))
+    ob = O.det_batch(dims["B"], dims["T"], dims["S"], dims["C"], dims["Lq"], dims["Lh"], dims["Lc"], dims["Lt"], dims["V"], seed=dims["seed"])
+    rb = ref_batch(ob)
+    out = {}
+    with torch.no_grad():
+        ft = model.forward(rb)
+        out["logp"] = npy(model.generator(ft, rb, ref_args(cfg)))
+    for k, v in ft.items():
+        out[f"ft_{k}"] = npy(v)
+    out["cfg"] = np.asarray(json.dumps({"cfg": cfg.__dict__, "dims": dims}))
+    np.savez_compressed(os.path.join(HERE, "g7_reference_module.npz"), **out)
+
+
+def main_g6():
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=6, nb_venc_blocks=6, nb_cenc_blocks=6)
+    out = {}
+    case_fullsize("T32", cfg, dict(FULL, T=32), out, beam=5)
+    case_fullsize("T128", cfg, dict(FULL, T=128), out)
+    np.savez_compressed(os.path.join(HERE, "g6_fullsize.npz"), **out)
 
 
 def main():
     os.makedirs(HERE, exist_ok=True)
+    if sys.argv[1:] == ["g6"]:                 # the full-size digests alone (the other fixtures are untouched)
+        main_g6()
+        print("g6_fullsize.npz", os.path.getsize(os.path.join(HERE, "g6_fullsize.npz")) // 1024, "KiB")
+        return
+    if sys.argv[1:] == ["g7"]:
+        main_g7()
+        print("g7_reference_module.pth.tar", os.path.getsize(os.path.join(HERE, "g7_reference_module.pth.tar")) // 1024, "KiB")
+        return
     out = {}
     case_primitives(out)
     np.savez_compressed(os.path.join(HERE, "g1_primitives.npz"), **out)
@@ -219,6 +290,8 @@ def main():
     case_beam("beam5", cfg, bd, out, beam=5)
     case_beam("beam1", cfg, bd, out, beam=1)
     np.savez_compressed(os.path.join(HERE, "g5_beam.npz"), **out)
+    main_g6()
+    main_g7()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -43,3 +43,28 @@ def test_ops_refuse_cpu_tensors():
     from bist_amd import ops
     with pytest.raises(RuntimeError):
         ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_reference_pickle_resolves_to_this_build_on_cpu(golden_dir):
+    """generate.py:93 ``torch.load`` of a whole-module pickle written by the reference (class paths ``model.*``): with
+    INTEGRATION.md's module mapping it becomes an instance of this build's MTN with every submodule present (no compute)."""
+    import os
+    import sys
+    import torch
+    import bist_amd.model as m
+    names = ("", ".mtn", ".modules", ".encoder", ".decoder", ".generator", ".label_smoothing", ".optimize", ".decode")
+    saved = {("model" + n): sys.modules.get("model" + n) for n in names}
+    try:
+        for n in names:
+            sys.modules["model" + n] = sys.modules["bist_amd.model" + n] if n else m
+        obj = torch.load(os.path.join(golden_dir, "g7_reference_module.pth.tar"), weights_only=False)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    assert type(obj) is m.mtn.MTN
+    assert obj.generator.vocab_gen is obj.query_embed[0].lut.weight          # the shared embedding survives the pickle
+    sub = obj.mutlimodal_decoder.v_layers[0].sublayer[0]
+    assert sub.p == sub.dropout.p and obj.mutlimodal_decoder.v_layers[0].attn[0].keep_attn is False

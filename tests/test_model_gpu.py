@@ -220,3 +220,36 @@ def test_generic_module_signatures(hip):
     with torch.no_grad():
         out = att(q.cuda(), kv.cuda(), kv.cuda(), mask.cuda())
     assert _err(out, ref) < 1e-4 and _err(att.attn, pref) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["T32", "T128"])
+def test_full_size_fp32_matches_reference_digests(hip, golden_dir, tag):
+    """the fp32 HIP path at d_model=512, L=6, T=32 / T=128 against digests of the REFERENCE's own outputs
+    (tests/golden/g6_fullsize.npz, regenerated from seed): every ft tensor and the log-probs within 1e-3, argmax identical; at
+    T=32 also the beam-5 n-best of a dialogue decoded with the full-size model."""
+    from test_oracle_golden import _digest, check_digest
+    from bist_amd.model.decode import beam_search_decode
+    M, Batch = hip
+    g = np.load(os.path.join(golden_dir, "g6_fullsize.npz"))
+    meta = json.loads(str(g[f"{tag}_cfg"]))
+    cfg, dm = O.Cfg(**meta["cfg"]), meta["dims"]
+    ob = O.det_batch(dm["B"], dm["T"], dm["S"], dm["C"], dm["Lq"], dm["Lh"], dm["Lc"], dm["Lt"], dm["V"], seed=dm["seed"])
+    model, sd = build_model(M, cfg, dm["V"], dm["C"])
+    b = to_batch(Batch, ob)
+    with torch.no_grad():
+        ft = model.forward(b)
+        logp = model.generator(ft, b, _args(cfg))
+    for k in [k for k in g.files if k.startswith(f"{tag}_dg_") and k != f"{tag}_dg_logp"]:
+        name = k[len(tag) + 4:]
+        check_digest(_digest(ft[name].float().cpu()), g[k], f"{tag} {name}", TOL)
+    check_digest(_digest(logp.float().cpu()), g[f"{tag}_dg_logp"], f"{tag} logp", TOL)
+    assert np.array_equal(logp.argmax(-1).cpu().numpy(), g[f"{tag}_argmax"])
+    if meta.get("beam"):
+        ob1 = O.det_batch(1, dm["T"], dm["S"], dm["C"], dm["Lq"], dm["Lh"], dm["Lc"], dm["Lt"], dm["V"], seed=dm["seed"] + 1)
+        with torch.no_grad():
+            hyps, _ = beam_search_decode(model, to_batch(Batch, ob1), 12, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID, beam=meta["beam"],
+                                         penalty=1.0, nbest=5, train_args=_args(cfg))
+        assert len(hyps) == int(g[f"{tag}_beam_n"])
+        for i, (toks, score) in enumerate(hyps):
+            assert [int(t) for t in toks] == g[f"{tag}_beam_hyp{i}"].tolist(), i
+            assert abs(float(score) - float(g[f"{tag}_beam_score{i}"])) <= 1e-3 * max(1.0, abs(float(g[f"{tag}_beam_score{i}"])))

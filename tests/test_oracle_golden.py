@@ -136,3 +136,37 @@ def test_beam_search(golden_dir, tag):
         assert [int(t) for t in toks] == g[f"{tag}_hyp{i}"].tolist(), f"hyp {i}"
         assert abs(float(score) - float(g[f"{tag}_score{i}"])) < 1e-3
     assert abs(float(best) - float(g[f"{tag}_best"])) < 1e-3
+
+
+def _digest(t, k=64):
+    """tests/golden/make_golden.py::digest -- what the full-size fixtures keep of a tensor."""
+    x = t.detach().double().reshape(-1)
+    idx = torch.linspace(0, x.numel() - 1, k).long()
+    return np.concatenate([[float(x.sum()), float(x.abs().sum())], x[:k].numpy(), x[idx].numpy()])
+
+
+def check_digest(got, ref, what, tol):
+    """sum / absolute sum relative to the absolute sum, the 128 sampled values absolutely."""
+    assert abs(got[0] - ref[0]) <= tol * max(1.0, ref[1]) * 1e-2 + tol, (what, "sum", got[0], ref[0])
+    assert abs(got[1] - ref[1]) <= tol * max(1.0, ref[1]) * 1e-2 + tol, (what, "abs sum", got[1], ref[1])
+    err = np.abs(got[2:] - ref[2:]).max()
+    assert err <= tol, (what, "samples", err)
+
+
+@pytest.mark.parametrize("tag", ["T32", "T128"])
+def test_oracle_matches_reference_at_full_size(golden_dir, tag):
+    """d_model=512, L=6, T=32 / T=128 (BASELINE configs[1] / configs[3] model), regenerated from seed; the
+    reference's outputs are pinned by digests (tests/golden/g6_fullsize.npz)."""
+    g = np.load(os.path.join(golden_dir, "g6_fullsize.npz"))
+    meta = json.loads(str(g[f"{tag}_cfg"]))
+    cfg, dm = O.Cfg(**meta["cfg"]), meta["dims"]
+    sd = O.det_state(cfg, dm["V"], dm["C"])
+    ob = O.det_batch(dm["B"], dm["T"], dm["S"], dm["C"], dm["Lq"], dm["Lh"], dm["Lc"], dm["Lt"], dm["V"], seed=dm["seed"])
+    with torch.no_grad():
+        ft = O.mtn_forward(sd, cfg, ob)
+        logp = O.multi_pointer_generator(sd, cfg, ft, ob)
+    for k in ft:
+        check_digest(_digest(ft[k]), g[f"{tag}_dg_{k}"], f"{tag} {k}", 2e-4)
+    check_digest(_digest(logp), g[f"{tag}_dg_logp"], f"{tag} logp", 2e-4)
+    assert np.array_equal(logp.argmax(-1).numpy(), g[f"{tag}_argmax"])
+    assert np.abs(logp[0, 0].numpy() - g[f"{tag}_logp_row0"]).max() <= 2e-4
