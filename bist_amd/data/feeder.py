@@ -100,6 +100,7 @@ class DeviceFeeder:
                     check(lib.bist_cast(d.data_ptr(), c.data_ptr(), d.numel(), dtype_code(d.dtype), dtype_code(self.feature_dtype),
                                         self.copy_stream.cuda_stream), "bist_cast")
                     d = c
+                d._bist_generation = getattr(d, "_bist_generation", 0) + 1      # the slot tensor is reused: tell consumers that cache by identity
                 out[name] = d
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)

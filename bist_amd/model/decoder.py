@@ -217,6 +217,7 @@ class MultimodalDecoder8(nn.Module):
         ft.pop("_bist_vftp_fan", None)
         ft.pop("_bist_mem_fan", None)
         ft.pop("_bist_v_pre", None)
+        ft.pop("_bist_pre_vid", None)
         if cache is not None:
             ft["_bist_reasoning"] = cache
         ft["decoded_text"] = self.norm(x)                                                    # :185

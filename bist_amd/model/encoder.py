@@ -78,6 +78,12 @@ class VidEncoder8(nn.Module):
             if fts.dtype != self.W.weight.dtype:
                 fts = Fn.cast(fts, self.W.weight.dtype)
             B, T, S, C = fts.shape
+            if fts.is_cuda and not torch.is_grad_enabled():
+                # inference: everything queued so far (the text encoders) is done at this point of the stream; the first reasoning
+                # layer forks its query-side chains from HERE, so that they run under the input projection instead of after it
+                ev = torch.cuda.Event()
+                ev.record()
+                ft["_bist_pre_vid"] = ev
             act = Fn.linear(fts.reshape(B * T * S, C), self.W.weight, self.W.bias, act=Fn.ACT_RELU)
             ft["spatiotemporal_ft"] = self.in_norm(act).view(B, T, S, -1)
         return ft
@@ -149,6 +155,21 @@ class VidEncoderLayer4(nn.Module):
         G = o.shape[1]
         y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=xr, res_map=(G * Lq, Lq), **Fn.drop_args(sub))
         return y.view(B, G, Lq, d)
+
+    def _stage1_query(self, ai: int, si: int, x_in: Tensor, query_mask):
+        """Query side of one direction up to the fused stage-1 launch: self-attention sublayer (A0 / A3), then LayerNorm, query
+        projection and the fold through W_k of the stage-1 attention -> (x, Qf [B, Lq*h, d])."""
+        x = _self_attention(self.sublayer[si], self.attn[ai], x_in, query_mask)
+        attn, sub = self.attn[ai + 1], self.sublayer[si + 1]
+        B, Lq, d = x.shape
+        xn, _ = sub.norm.with_residual(x)
+        q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)
+        return x, Fn.head_fold(q, attn.linears[1].weight, attn.h, 1.0 / math.sqrt(attn.d_k)).view(B, Lq * attn.h, d)
+
+    def _stage1_fused(self, ai: int, x: Tensor, qf: Tensor, vft: Tensor, kmask, direction: int) -> Tensor:
+        attn = self.attn[ai]
+        wv, wo = self._frag_weights(ai)
+        return ops.st_stage1_fused(qf, vft, kmask, wv, attn.linears[2].bias, wo, attn.linears[3].bias, x, h=attn.h, direction=direction)
 
     def _frag_weights(self, ai: int):
         """W_v and W_o of attention `ai` in MFMA-fragment order (ops.pack_frag_rows), re-packed INTO THE SAME BUFFERS whenever the
@@ -293,7 +314,57 @@ class VidEncoderLayer4(nn.Module):
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
 
-        if concurrent:
+        pre_vid = ft.pop("_bist_pre_vid", None)
+        if concurrent and fused and Fn.EVAL_SCHED == 1:
+            # both directions as whole chains on two side streams, forked ahead of the input projection when this is the first layer
+            side, side2 = Fn.side_stream(0), Fn.side_stream(2)
+            for st_ in (side, side2):
+                if pre_vid is not None:
+                    st_.wait_event(pre_vid)
+                else:
+                    st_.wait_stream(main)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side2):
+                xt, qft = self._stage1_query(0, 0, in_ft["t2s"], b.query_mask)
+                side2.wait_event(ev)
+                yt = self._stage1_fused(1, xt, qft, vft_t2s, b.temporal_mask, 0)
+                in_ft["t2s"] = _feed_forward(self.sublayer[3], self.ff[0], self._stage2(2, 2, xt, yt, None))
+            with torch.cuda.stream(side):
+                xs, qfs = self._stage1_query(3, 4, in_ft["s2t"], b.query_mask)
+                side.wait_event(ev)
+                ys = self._stage1_fused(4, xs, qfs, vft_s2t, None, 1)
+                in_ft["s2t"] = _feed_forward(self.sublayer[7], self.ff[1], self._stage2(5, 6, xs, ys, b.temporal_mask))
+            main.wait_stream(side2); main.wait_stream(side)
+        elif concurrent and fused and Fn.EVAL_SCHED == 2:
+            # Inference at the production width.  Main stream: the two fused stage-1 launches (each fills the chip), back to back;
+            # side stream: the query-side chains of BOTH directions ahead of them (self-attention, LayerNorm, query projection,
+            # fold: small launches that depend on the encoded query only -- in the first layer they are forked from BEFORE the
+            # input projection and run under it), then the t2s tail (stage 2, feed-forward) under the s2t stage-1 launch.
+            side = Fn.side_stream(0)
+            if pre_vid is not None:
+                side.wait_event(pre_vid)
+            else:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                xt, qft = self._stage1_query(0, 0, in_ft["t2s"], b.query_mask)
+                xs, qfs = self._stage1_query(3, 4, in_ft["s2t"], b.query_mask)
+                for t_ in (xt, qft, xs, qfs):
+                    t_.record_stream(main)
+            main.wait_stream(side)
+            yt = self._stage1_fused(1, xt, qft, vft_t2s, b.temporal_mask, 0)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            ys = self._stage1_fused(4, xs, qfs, vft_s2t, None, 1)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                yt.record_stream(side)
+                zt = self._stage2(2, 2, xt, yt, None)
+                in_ft["t2s"] = _feed_forward(self.sublayer[3], self.ff[0], zt)
+            zs = self._stage2(5, 6, xs, ys, b.temporal_mask)
+            in_ft["s2t"] = _feed_forward(self.sublayer[7], self.ff[1], zs)
+            main.wait_stream(side)
+        elif concurrent:
             side = Fn.side_stream(0)
             side.wait_stream(main)                    # fork: the two directions share only read-only inputs
             with torch.cuda.stream(side):

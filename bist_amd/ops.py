@@ -89,7 +89,10 @@ def _workspace(device) -> Tensor:
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
-        ws = torch.zeros(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)      # zeroed: its head holds split-K ticket counters
+        # only the head (split-K ticket counters, 4 KiB) must start as zeros; a captured hipGraph replays this fill, so it is
+        # kept to the head instead of the whole 64 MiB (10 us per replay per stream)
+        ws = torch.empty(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)
+        ws[:4096].zero_()
         _WS[key] = ws
     return ws
 
