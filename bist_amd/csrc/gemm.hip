@@ -1636,7 +1636,9 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
       // 51.3 us in-kernel at K = 2048: the K loop is bound by the L2 -> LDS stream, which more active CUs only load further.)
       const long pad8 = (long)((g->M + 255) / 256) * 256, pad5 = (long)((g->M + 159) / 160) * 160;
       const bool stamps = (g->hint & 15) == BIST_GEMM_TILE256 && (g->hint >> 4) == 1;       // development aid (FR = 8 only)
-      const int fr = (!stamps && pad5 < pad8) ? 5 : 8;
+      int fr = (!stamps && pad5 < pad8) ? 5 : 8;
+      static const int force_fr = [] { const char* e = getenv("BIST_GEMM_BIG_FR"); return e ? atoi(e) : 0; }();      // tuning aid
+      if (!stamps && force_fr >= 5 && force_fr <= 8) fr = force_fr;
       k.tiles_m = (g->M + 32 * fr - 1) / (32 * fr); k.tiles_n = (g->N + BIG - 1) / BIG;
       k.split_k = 1; k.ws = nullptr;
       const dim3 gb((unsigned)((long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2));
@@ -1645,6 +1647,10 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
         hipLaunchKernelGGL((gemm_big_kernel<TO, 8, 1>), gb, dim3(512), 0, st, k);
       } else if (fr == 5) {
         hipLaunchKernelGGL((gemm_big_kernel<TO, 5, 0>), gb, dim3(512), 0, st, k);
+      } else if (fr == 6) {
+        hipLaunchKernelGGL((gemm_big_kernel<TO, 6, 0>), gb, dim3(512), 0, st, k);
+      } else if (fr == 7) {
+        hipLaunchKernelGGL((gemm_big_kernel<TO, 7, 0>), gb, dim3(512), 0, st, k);
       } else {
         hipLaunchKernelGGL((gemm_big_kernel<TO, 8, 0>), gb, dim3(512), 0, st, k);
       }
