@@ -71,9 +71,9 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // inline-asm ds_read_b128 into a ring of R register slots, R-1 reads in flight ahead of the MFMAs that consume them (the
 // compiler's own schedule keeps two reads in flight and waits for each right before its use: the LDS latency was exposed on
 // every second fragment).  addr(kp, g) = LDS byte address of fragment g of pair kp; use(kp, f, frag) issues the MFMAs of f.
-template <int NF, int R, class AddrF, class UseF>
+template <int NF, int R, int ITERS, class AddrF, class UseF>
 __device__ __forceinline__ void frag_stream(AddrF addr, UseF use) {
-  static_assert(NF % R == 0 && R >= 3 && R <= 9, "ring slots must repeat every k-step pair");
+  static_assert(NF % R == 0 && R >= 3 && R <= 9, "ring slots must repeat every step");
   u32x4 ring[R];
   static_for<R - 1>([&ring, &addr](auto g) {
     const unsigned a0 = addr(0, (int)g);
@@ -81,8 +81,8 @@ __device__ __forceinline__ void frag_stream(AddrF addr, UseF use) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(slot) : "v"(a0) : "memory");
   });
 #pragma unroll 1
-  for (int kp = 0; kp < 8; ++kp) {
-    const int kn = min(kp + 1, 7);          // the reads past the last pair re-read it (never consumed)
+  for (int kp = 0; kp < ITERS; ++kp) {
+    const int kn = min(kp + 1, ITERS - 1);  // the reads past the last step re-read it (never consumed)
     static_for<NF>([&ring, &addr, &use, kp, kn](auto fc) {
       constexpr int f = fc, gq = f + R - 1;
       u32x4& cur = ring[f % R];
@@ -201,7 +201,7 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
     __builtin_amdgcn_s_barrier();            // every wave's share of the X image has landed (vmcnt(0) above); the 8 weight loads fly on
     asm volatile("" ::: "memory");
     STAMP(1);
-    frag_stream<2 * MTA, 4>([&](int kp, int g) { return img_addr(kp, g / MTA, g % MTA); },
+    frag_stream<2 * MTA, 4, 8>([&](int kp, int g) { return img_addr(kp, g / MTA, g % MTA); },
                             [&](int kp, auto fc, const uint4& ax) {
                               constexpr int f = fc, e = f / MTA, mt = f % MTA;
                               if constexpr (mt == 0) {            // this parity's weights have landed; the other parity's 4 loads stay in flight
@@ -238,7 +238,7 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
     u32x4 bq[2][2];
     load_q2(bq[0], q0, q1, 0, 0);
     load_q2(bq[1], q0, q1, 0, 1);
-    frag_stream<2 * MTA, 4>([&](int kp, int g) { return img_addr(kp, g / MTA, g % MTA); },
+    frag_stream<2 * MTA, 4, 8>([&](int kp, int g) { return img_addr(kp, g / MTA, g % MTA); },
                             [&](int kp, auto fc, const uint4& ax) {
                               constexpr int f = fc, e = f / MTA, mt = f % MTA;
                               if constexpr (mt == 0) {
@@ -329,13 +329,35 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16_t* wo = a.Wo + ((long)(w * 4) << 13) + lane * 8;
-    u32x4 aw[2][4];
-    load_packed4(aw[0], wo, 0, 0);
-    load_packed4(aw[1], wo, 0, 1);
-    // residual rows x[b, i] and output offsets of this lane's rows (row = 16*mt + x), fetched under the product below
+    // W_o fragments of NP k-step pairs in registers (aw[pair parity][k parity][tile]); each set of four fragments is re-fetched in
+    // place, NP pairs ahead, right after its last MFMA.  NP = 2 where the accumulators leave room (a pair of this step is only
+    // 8 * MT4A MFMAs per wave: one pair ahead does not cover the L2 latency), NP = 1 with 8 row tiles.
+    constexpr int NP = MT4A <= 5 ? 2 : 1;
+    u32x4 aw[NP][2][4];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) load_packed4(aw[p][e], wo, p, e);
+    frag_stream<2 * NP * MT4A, 4, 8 / NP>([&](int it, int g) { return img_addr(NP * it + g / (2 * MT4A), (g / MT4A) & 1, g % MT4A); },
+                                          [&](int it, auto fc, const uint4& cx) {
+                                            constexpr int f = fc, p = f / (2 * MT4A), e = (f / MT4A) & 1, mt = f % MT4A;
+                                            if constexpr (mt == 0) {        // this set has landed; the sets issued after it stay in flight
+                                              asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (2 * NP - 1)) : "memory");
+                                              tie(aw[p][e]);
+                                            }
+#pragma unroll
+                                            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(u4(aw[p][e][nt]), cx, acc[mt][nt]);
+                                            if constexpr (mt == MT4A - 1) {
+                                              if (!(a.dbg & 4)) load_packed4(aw[p][e], wo, min(NP * it + p + NP, 7), e);
+                                            }
+                                          });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { tie(aw[p][0]); tie(aw[p][1]); }
+    // residual rows x[b, i] and output offsets of this lane's rows (row = 16*mt + x)
     const int cofs = (kg & 1) * 16 + (kg >> 1) * 8;
     const int rows = ng * Lq;
-    constexpr bool PRE = MT4A <= 5;                       // (with 8 row tiles the registers are the accumulators')
+    constexpr bool PRE = MT4A <= 5;                       // all residual rows in flight together, ahead of the swaps and stores below
     uint4 xr[PRE ? MT4A : 1][2];
     long yoff[MT4A], xoff[MT4A];
 #pragma unroll
@@ -348,22 +370,6 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
         for (int jp = 0; jp < 2; ++jp) xr[mt][jp] = *reinterpret_cast<const uint4*>(a.xres + xoff[mt] + jp * 32);
       }
     }
-    constexpr int R4 = MT4A == 5 ? 5 : MT4A == 3 ? 6 : 4;
-    frag_stream<2 * MT4A, R4>([&](int kp, int g) { return img_addr(kp, g / MT4A, g % MT4A); },
-                              [&](int kp, auto fc, const uint4& cx) {
-                                constexpr int f = fc, e = f / MT4A, mt = f % MT4A;
-                                if constexpr (mt == 0) {
-                                  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                                  tie(aw[e]);
-                                }
-#pragma unroll
-                                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(u4(aw[e][nt]), cx, acc[mt][nt]);
-                                if constexpr (mt == MT4A - 1) {
-                                  if (!(a.dbg & 4)) load_packed4(aw[e], wo, min(kp + 1, 7), e);
-                                }
-                              });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    tie(aw[0]); tie(aw[1]);
     STAMP(6);
     // acc[mt][nt][r] = Y[row 16*mt + x][column 64*w + 16*nt + 4*kg + r]; after the swap a lane holds 8 consecutive columns
 #pragma unroll
