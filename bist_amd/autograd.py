@@ -69,6 +69,20 @@ def _mask_u8(mask: Optional[Tensor]):
 # ----------------------------------------------------------------------------------------------
 # linear
 # ----------------------------------------------------------------------------------------------
+class GateTag:
+    """Travels with y = drop(relu(z)) of a producing linear layer (attribute ``_bist_gate`` of y, ``gate_tag`` of its autograd node).
+    A consuming linear layer that sees it computes its dX already gated by y > 0 and scaled by 1/(1-p) -- the gradient of z -- and
+    records that here, so that the producer's backward can tell "the hand-off arrived" from "it was lost on the way" (a second
+    consumer, a hook or a view re-wrapping the gradient): the latter would silently mask and scale twice, and raises instead."""
+    __slots__ = ("p", "seed", "gated")
+
+    def __init__(self, p, seed):
+        self.p, self.seed, self.gated = float(p), int(seed), 0
+
+    def __getitem__(self, i):                      # (p, seed) view for the consumers
+        return (self.p, self.seed)[i]
+
+
 class LinearFn(Function):
     """y = drop(act(alpha * x.W^T + bias)) + residual[row map]   (GEMM epilogue, include/bist_hip.h)."""
 
@@ -113,8 +127,14 @@ class LinearFn(Function):
             else:
                 dres = dy.view(res_shape)
         dz = dy if dy.dtype == x2.dtype else ops.cast(dy, x2.dtype)
-        if pre is not None and len(pre) == 4 and act == ACT_RELU and pre[1:3] == (float(drop_p), int(drop_seed)) \
-                and pre[0].numel() == M * N and pre[0].dtype == x2.dtype:
+        tag = getattr(ctx, "gate_tag", None)
+        handed = (pre is not None and len(pre) == 4 and act == ACT_RELU and pre[1:3] == (float(drop_p), int(drop_seed))
+                  and pre[0].numel() == M * N and pre[0].dtype == x2.dtype)
+        if tag is not None and tag.gated and not handed:
+            raise RuntimeError("bist_amd: a consuming linear layer gated its input gradient with this layer's drop(relu(.)) output, but "
+                               "the gated tensor did not reach this backward (second consumer, hook or view on the hidden activation): "
+                               "masking it again would be wrong -- set BIST_GATE_HANDOFF=0 for such graphs")
+        if handed:
             dz = pre[0].view(M, N)                     # already gated (y > 0, 1/(1-p)) by the consumer's dX product
         elif pre is not None and len(pre) == 3 and act == ACT_NONE and pre[1:] == (float(drop_p), int(drop_seed)) and pre[0].numel() == M * N \
                 and pre[0].dtype == x2.dtype:
@@ -134,6 +154,8 @@ class LinearFn(Function):
             dx = dx.view(x_shape)
             if ctx.gate is not None:
                 dx._bist_dz = (dx, ctx.gate[0], ctx.gate[1], "gate")      # survives only if autograd hands THIS tensor to the producer
+                if isinstance(ctx.gate, GateTag):
+                    ctx.gate.gated += 1
         return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
@@ -233,7 +255,9 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, res_map=(0, 0), alph
     if act == ACT_RELU and residual is None and out_shape is None and GATE_HANDOFF:
         # y = drop(relu(z)): a linear layer that consumes y gates its dX product with y > 0 and hands the result back as the
         # gradient of z (LinearFn.backward), so no separate masking pass runs between the two backward products
-        y._bist_gate = (float(drop_p), int(drop_seed))
+        y._bist_gate = GateTag(drop_p, drop_seed)
+        if y.grad_fn is not None:
+            y.grad_fn.gate_tag = y._bist_gate          # the node object is the ctx of LinearFn.backward
     return y
 
 

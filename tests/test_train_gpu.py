@@ -810,3 +810,25 @@ def test_eval_after_training_steps_sees_the_updated_weights(env, d_model, h, C, 
     lp2, nb2 = evaluate(fresh)
     assert (lp1 - lp2).abs().max().item() <= (1e-5 if dtype == torch.float32 else 1e-6 + 0.0), (lp1 - lp2).abs().max().item()
     assert [h_[0] for h_ in nb1] == [h_[0] for h_ in nb2]
+
+
+def test_gate_handoff_that_cannot_arrive_fails_loudly(env):
+    """y = drop(relu(z)) consumed by TWO linear layers: each hands back an already gated input gradient, autograd sums them into a
+    new tensor and the hand-off tag is gone -- the producer must not mask a second time silently: it raises."""
+    ag, Fn, ops = env
+    x = torch.randn(16, 64, device="cuda", requires_grad=True)
+    w1 = torch.randn(128, 64, device="cuda", requires_grad=True)
+    w2 = torch.randn(64, 128, device="cuda", requires_grad=True)
+    w3 = torch.randn(64, 128, device="cuda", requires_grad=True)
+    hid = Fn.linear(x, w1, None, act=Fn.ACT_RELU)
+    assert isinstance(getattr(hid, "_bist_gate", None), ag.GateTag)
+    y = Fn.linear(hid, w2, None) + Fn.linear(hid, w3, None)
+    with pytest.raises(RuntimeError, match="gated"):
+        y.sum().backward()
+    # one consumer: the hand-off arrives and the result equals torch's
+    x2 = x.detach().clone().requires_grad_(True)
+    hid2 = Fn.linear(x2, w1.detach(), None, act=Fn.ACT_RELU)
+    Fn.linear(hid2, w2.detach(), None).sum().backward()
+    ref = x.detach().clone().requires_grad_(True)
+    (torch.relu(ref @ w1.detach().t()) @ w2.detach().t()).sum().backward()
+    assert (x2.grad - ref.grad).abs().max().item() <= 2e-4 * ref.grad.abs().max().item()
