@@ -37,6 +37,14 @@ class BistDrop(C.Structure):
     _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("ctr", C.c_void_p)]
 
 
+class BistDecLayer(C.Structure):
+    _fields_ = [("ln_a", C.c_void_p * 5), ("ln_b", C.c_void_p * 5), ("Wqkv", C.c_void_p), ("bqkv", C.c_void_p),
+                ("Wq", C.c_void_p * 3), ("bq", C.c_void_p * 3), ("Wo", C.c_void_p * 4), ("bo", C.c_void_p * 4),
+                ("Kc", C.c_void_p * 3), ("VTc", C.c_void_p * 3), ("cmask", C.c_void_p * 3),
+                ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
+                ("Lk", C.c_int32 * 3), ("LkP", C.c_int32 * 3)]
+
+
 class BistLnGrad(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("a", C.c_void_p), ("da", C.c_void_p), ("db", C.c_void_p),
                 ("rows", C.c_int64), ("lddy", C.c_int64), ("ldx", C.c_int64), ("eps", C.c_float)]
@@ -65,6 +73,9 @@ SIGNATURES = {
     "bist_pack_frag_rows": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "bist_st_stage1_fused_ok": (C.c_int, [_I32] * 7),
     "bist_st_stage1_fused_fwd": (C.c_int, [_P] * 9 + [_I32] * 8 + [_P]),
+    "bist_decoder_stack_ok": (C.c_int, [_I32] * 5),
+    "bist_decoder_layer_desc_bytes": (C.c_int64, []),
+    "bist_decoder_stack_fwd": (C.c_int, [_P, _I32] + [_P] * 8 + [_I32, _I32, _P, _I32, _P]),
     "bist_st_stage2_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_scaled_bias_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "bist_scaled_bias_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),

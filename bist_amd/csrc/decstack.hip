@@ -1,0 +1,495 @@
+// The response-decoder stack of one beam-search step as ONE persistent launch (bf16, d = 512, h = 8, <= 64 rows).
+//
+// Reference semantics: MultimodalDecoderLayer12.forward (model/decoder.py:20-60) with enc_vc_combine != 'none' -- causal self-attention,
+// attention to the dialogue history, to the query, to the fused modalities (each x + W_o MHA(LN(x), mem, mem, mask) + b_o,
+// modules.py:42-44, 54-64, 81-100), feed-forward (modules.py:112-113) -- for every layer of MultimodalDecoder8's loop
+// (decoder.py:114-182) on the R = hypotheses x prefix-length rows of a decode step (decode.py:62-66).  In eval mode the key/value
+// projections of the three memories do not depend on the prefix: they arrive precomputed per turn (K [LkP][512], V^T [512][LkP]).
+//
+// One step of the unfused path is ~120 launches of 5-17 us on these <= 60 rows (pure latency).  Here 32 workgroups of 256 threads
+// (one per CU, all resident) walk the 10 phases of each layer and meet at a grid barrier after each:
+//     A(s): LN_s(x) for all rows into an LDS image (every workgroup, redundantly), then its 16-column tiles of the projection
+//           (QKV: 3 tiles of 1536, cross query: 1 of 512, FFN hidden: 4 of 2048), K split over the 4 waves, partial tiles summed in LDS
+//     B(s): the attention core of ALL heads and rows on MFMA (every workgroup, redundantly: 2 heads per wave, scores, masked softmax
+//           and P.V in registers as in st1_fused.hip) into the LDS image, then its 16 columns of the output projection + residual;
+//           FFN: its 16 columns of W_2 over the 2048-wide hidden rows
+// The weight fragments of the NEXT phase are fetched into registers before the barrier, so the HBM / L2 latency of the 12.6 MB of
+// weights per layer hides behind the barrier and the previous phase's tail.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int D = 512, H = 8, NWG = 32, NT = 256;
+constexpr float MASK_FILL = -1e9f;
+
+struct DecLayerDev {            // one per layer, in device memory (all pointers device pointers)
+  const bf16_t* ln_a[5]; const bf16_t* ln_b[5];
+  const bf16_t* Wqkv; const bf16_t* bqkv;            // packed [1536][512] / [1536] of the self-attention
+  const bf16_t* Wq[3]; const bf16_t* bq[3];          // query projections of the three cross-attentions
+  const bf16_t* Wo[4]; const bf16_t* bo[4];          // output projections: self, history, query, fused modalities
+  const bf16_t* Kc[3]; const bf16_t* VTc[3];         // per turn: K [LkP][512], V^T [512][LkP] of the three memories
+  const unsigned char* cmask[3];                     // key masks [LkP] (1 = attend)
+  const bf16_t* W1; const bf16_t* b1; const bf16_t* W2; const bf16_t* b2;
+  int Lk[3]; int LkP[3];
+};
+
+struct DecArgs {
+  const DecLayerDev* layers; int nl;
+  const bf16_t* x_in;            // [R][512]
+  bf16_t* xbuf[2];               // residual stream, ping-pong [RP][512]
+  bf16_t* qbuf; bf16_t* kbuf;    // [RP][512]
+  bf16_t* vT;                    // [512][LkS]   (LkS = self keys padded to a multiple of 32)
+  bf16_t* hbuf;                  // [RP][2048]
+  const unsigned char* smask;    // [R][LkS] self-attention mask (1 = attend)
+  int R, LkS;
+  unsigned* sync;                // 8 words, zero before the first call: [0] barrier arrivals, [1] exits (both zero again when a call ends),
+                                 // [4] STICKY error flag (a barrier timed out)
+  int dbg;                       // BIST_DECSTACK_DBG (development): 1 = agent-scope acquire after every barrier
+  unsigned long long* stamps;    // BIST_DECSTACK_STAMPS (development): s_memtime stamps of workgroup 0 in layer 0, or null
+};
+
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_max(float v) {      // over lanes x, x+16, x+32, x+48
+  float p = v, q = v; swap16(p, q); v = fmaxf(p, q);
+  p = v; q = v; swap32(p, q); return fmaxf(p, q);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  float p = v, q = v; swap16(p, q); v = p + q;
+  p = v; q = v; swap32(p, q); return p + q;
+}
+
+// Hand-off protocol (MI355X guide, G16 recipe R1): every byte another workgroup reads later in the launch is stored WRITE-THROUGH
+// (st8: an 8-byte sc1 store), so the barrier needs no L2 write-back: every storing wave drains its stores, the workgroup meets, lane 0
+// arrives on the monotonic counter (agent-scope atomic) and polls it relaxed with a BOUNDED spin, and the workgroup meets again before
+// anyone loads.  Every load of handed-off bytes is an sc1 load to registers (ld16 / ld8: served by L2, never by this CU's L1), which
+// is the guide's measured form that needs no acquire fence (valid-forms table, row "one lane of each storing workgroup adds"):
+// hipMalloc memory, one workgroup per CU, 8-byte sc1 stores, 8- / 16-byte sc1 loads.  Weights, biases, masks and the per-turn
+// key / value caches are never written inside the launch and use plain loads.
+typedef __attribute__((address_space(1))) unsigned long long gu64;       // shared words and payload: GLOBAL accesses, never flat
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ void st8(void* p, uint2 v) {
+  __hip_atomic_store((gu64*)p, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// sc1 loads (L2-served, never from this CU's L1): EVERY load of handed-off bytes is one of these, so no acquire fence either
+__device__ __forceinline__ uint4 ld16(const void* base, long byte_off) {          // base wave-uniform
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 ld8(const void* p) {
+  const unsigned long long v = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ void grid_barrier(unsigned* sync_, unsigned target, int dbg = 0) {
+  gu32* sync = (gu32*)sync_;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 20)) {                      // ~1 s: a workgroup is missing -- give up (every workgroup will), flag it
+        __hip_atomic_store(sync + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // no instruction: keeps the loads below the poll
+    if (dbg & 1) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  }
+  __syncthreads();
+}
+
+// swizzled [rows][1024 B] image: 16-byte chunk c of row r at chunk c ^ (r & 15)
+__device__ __forceinline__ char* img_at(char* img, int row, int chunk) { return img + row * 1024 + ((chunk ^ (row & 15)) << 4); }
+__device__ __forceinline__ uint4 img_frag(const char* img, int mt, int ks, int x, int kg) {       // rows 16*mt + x, channels 32*ks + 8*kg ..
+  return *reinterpret_cast<const uint4*>(img + (mt * 16 + x) * 1024 + (((4 * ks + kg) ^ x) << 4));
+}
+
+// LN_s(x) of all rows into the image (rows >= R zero): wave w takes rows 16w .. 16w+15, sixteen lanes per row (32 channels each), four
+// rows per pass; all 16 row loads of a lane are in flight together
+__device__ __forceinline__ void layernorm_to_image(const bf16_t* x, const bf16_t* ga, const bf16_t* gb, char* img, int R, int RP, int w, int lane) {
+  if (w * 16 >= RP) return;
+  const int sub = lane & 15, rq = lane >> 4;
+  uint4 q[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = w * 16 + 4 * p + rq;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q[p][c] = ld16(x, (long)min(row, R - 1) * (D * 2) + (sub * 4 + c) * 16);
+  }
+  uint4 qa[4], qb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { qa[c] = reinterpret_cast<const uint4*>(ga)[sub * 4 + c]; qb[c] = reinterpret_cast<const uint4*>(gb)[sub * 4 + c]; }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = w * 16 + 4 * p + rq;
+    const bool live = row < R;
+    float v[32];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t u[4] = {q[p][c].x, q[p][c].y, q[p][c].z, q[p][c].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[c * 8 + 2 * e] = bf_lo(u[e]); v[c * 8 + 2 * e + 1] = bf_hi(u[e]); sum += v[c * 8 + 2 * e] + v[c * 8 + 2 * e + 1]; }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum * (1.f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) { const float dlt = v[e] - mean; ss += dlt * dlt; }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = 1.f / (sqrtf(ss * (1.f / (D - 1))) + 1e-6f);          // unbiased std, eps outside the root (modules.py:28-31)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t ua[4] = {qa[c].x, qa[c].y, qa[c].z, qa[c].w}, ub[4] = {qb[c].x, qb[c].y, qb[c].z, qb[c].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y0 = live ? bf_lo(ua[e]) * (v[c * 8 + 2 * e] - mean) * inv + bf_lo(ub[e]) : 0.f;
+        const float y1 = live ? bf_hi(ua[e]) * (v[c * 8 + 2 * e + 1] - mean) * inv + bf_hi(ub[e]) : 0.f;
+        o[e] = pack2(y0, y1);
+      }
+      *reinterpret_cast<uint4*>(img_at(img, row, sub * 4 + c)) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// weight fragments of NTILES 16-column tiles starting at col0, this wave's KS k-steps (ks = w + 4*i): lane (x, kg) holds
+// W[col0 + 16*t + x][32*ks + 8*kg .. +7]  (nn.Linear layout [out][in], row length ldw)
+template <int NTILES, int KS>
+__device__ __forceinline__ void load_w(uint4 (&wr)[16], const bf16_t* W, int ldw, int col0, int w, int x, int kg) {
+#pragma unroll
+  for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+    for (int i = 0; i < KS; ++i)
+      wr[t * KS + i] = *reinterpret_cast<const uint4*>(W + (long)(col0 + 16 * t + x) * ldw + 32 * (w + 4 * i) + 8 * kg);
+}
+
+// partial products of this wave: acc[t][mt][r] = sum over its k-steps of W[col 4lg+r of tile t][k] * A[row x of tile mt][k]
+template <int NTILES, int KS, class AF>
+__device__ __forceinline__ void partial_product(f32x4 (&acc)[4][4], const uint4 (&wr)[16], AF afrag, int MTR, int w) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (mt >= MTR) break;
+      const uint4 a = afrag(mt, w + 4 * i);
+#pragma unroll
+      for (int t = 0; t < NTILES; ++t) acc[t][mt] = mfma16(wr[t * KS + i], a, acc[t][mt]);
+    }
+  }
+}
+
+// the same for ONE tile with the A fragments read from global rows: requested in batches of four k-steps, the next batch in flight
+// while the current one is multiplied (<= 32 loads per lane outstanding)
+template <int KS, bool DB, class AF>
+__device__ __forceinline__ void partial_product_glob(f32x4 (&acc)[4][4], const uint4 (&wr)[16], AF afrag, int MTR, int w) {
+  constexpr int NB = KS / 4;
+  uint4 af[2][4][4];
+  auto request = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        if (mt < MTR) af[b & 1][i][mt] = afrag(mt, w + 4 * (4 * b + i));
+  };
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (DB) request(0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (!DB) request(b);
+    else if (b + 1 < NB) request(b + 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        if (mt < MTR) acc[0][mt] = mfma16(wr[4 * b + i], af[b & 1][i][mt], acc[0][mt]);
+  }
+}
+
+// sum the four waves' partial tiles through LDS and hand every (tile, row tile) to `epi(t, mt, v)`: lane (x, lg) gets the 4 consecutive
+// columns 4*lg .. 4*lg+3 of row x -- or, for tiles with transposed(t), to `epi_t(t, mt, v)`: lane (x, lg) gets column x of the four
+// consecutive rows 4*lg .. 4*lg+3 (element (column c, row r) of a tile sits in lane (r, c/4), component c%4)
+template <int NTILES, class TP, class EPI, class EPIT>
+__device__ __forceinline__ void reduce_tiles(f32x4 (&acc)[4][4], char* part, int MTR, int w, int lane, TP transposed, EPI epi, EPIT epi_t) {
+  f32x4* pw = reinterpret_cast<f32x4*>(part);
+  const float* pf = reinterpret_cast<const float*>(part);
+  const int x = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      if (mt < MTR) pw[((w * 16) + t * 4 + mt) * 64 + lane] = acc[t][mt];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (mt >= MTR || ((t * 4 + mt) & 3) != w) continue;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (transposed(t)) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += pf[(((o * 16 + t * 4 + mt) * 64) + (x >> 2) * 16 + 4 * lg + j) * 4 + (x & 3)];
+        epi_t(t, mt, v);
+      } else {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const f32x4 u = pw[(o * 16 + t * 4 + mt) * 64 + lane];
+          v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+        }
+        epi(t, mt, v);
+      }
+    }
+  __syncthreads();
+}
+template <int NTILES, class EPI>
+__device__ __forceinline__ void reduce_tiles(f32x4 (&acc)[4][4], char* part, int MTR, int w, int lane, EPI epi) {
+  reduce_tiles<NTILES>(acc, part, MTR, w, lane, [](int) { return false; }, epi, [](int, int, const f32x4&) {});
+}
+
+// attention core of ONE (head, 16-row tile) unit, written to the context rows in global memory (bf16 [rows][512], write-through):
+// Q [RP][512], K [LkP][512] rows, V^T [512][LkP], mask[row * mrs + key] (mrs = 0: per key only; rows padded to LkP bytes, 4-byte
+// aligned), Lk valid keys.  The four waves each compute the scores and the masked softmax of the unit (16 rows x <= 64 keys, in
+// registers) and ONE 16-channel tile of P.V (wave w: channels 64*head + 16*w ..).  All loads of the unit are requested together.
+__device__ __forceinline__ void core_unit(const bf16_t* Q, const bf16_t* K, const bf16_t* VT, const unsigned char* mask, int mrs, int Lk, int LkP,
+                                          bf16_t* ctx, int R, int head, int mt, int w, int x, int kg) {
+  const int KT = LkP >> 4;                                  // key tiles (2 or 4)
+  const int row = 16 * mt + x, rowc = min(row, R - 1);
+  uint4 qf[2], kf[2][4];
+  uint32_t mk[4];
+  uint2 vv[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    qf[ks] = ld16(Q, ((long)rowc * D + head * 64 + 32 * ks + 8 * kg) * 2);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < KT) kf[ks][kt] = ld16(K, ((long)(16 * kt + x) * D + head * 64 + 32 * ks + 8 * kg) * 2);
+  }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+    if (kt < KT) mk[kt] = *reinterpret_cast<const uint32_t*>(mask + (long)rowc * mrs + 16 * kt + 4 * kg);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (2 * j >= KT) break;
+    const bf16_t* vp = VT + (long)(head * 64 + 16 * w + x) * LkP + 32 * j + 4 * kg;
+    vv[j][0] = ld8(vp);
+    vv[j][1] = ld8(vp + 16);
+  }
+  f32x4 s[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kt < KT) {
+      s[kt] = mfma16(kf[0][kt], qf[0], s[kt]);              // S^T[key 4lg+r][row x]
+      s[kt] = mfma16(kf[1][kt], qf[1], s[kt]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = s[kt][r] * 0.125f;                          // 1 / sqrt(64)
+      if (kt < KT && ((mk[kt] >> (8 * r)) & 0xffu) == 0) v = MASK_FILL;
+      if (kt >= KT || 16 * kt + 4 * kg + r >= Lk) v = -INFINITY;
+      s[kt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  }
+  mx = rows_max(mx);
+  float den = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - mx); den += s[kt][r]; }
+  const float inv = 1.f / rows_sum(den);
+  // O^T[c][row] = sum_key V^T[c][key] P[row][key]: the 8 K-slots of an MFMA = 4 keys of tile 2j and 4 of tile 2j+1 per lane
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (2 * j >= KT) break;
+    const uint4 vf = make_uint4(vv[j][0].x, vv[j][0].y, vv[j][1].x, vv[j][1].y);
+    const uint4 pf = make_uint4(pack2(s[2 * j][0] * inv, s[2 * j][1] * inv), pack2(s[2 * j][2] * inv, s[2 * j][3] * inv),
+                                pack2(s[2 * j + 1][0] * inv, s[2 * j + 1][1] * inv), pack2(s[2 * j + 1][2] * inv, s[2 * j + 1][3] * inv));
+    o = mfma16(vf, pf, o);                                  // O^T[channel 4lg+r][row x]
+  }
+  if (row < R) st8(ctx + (long)row * D + head * 64 + 16 * w + 4 * kg, make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3])));
+}
+
+__global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* img = smem;                       // [64][1024 B]
+  char* part = smem + 64 * 1024;          // 4 waves x 16 (tile, row tile) x 64 lanes x 16 B
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kg = lane >> 4;
+  const int wg = blockIdx.x, R = a.R, RP = (R + 15) & ~15, MTR = RP >> 4;
+  unsigned phase = 0;
+  int nst = 0;
+#define STAMP() do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && nst < 128) a.stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+  STAMP();
+  const bf16_t* xcur = a.x_in;
+  int nxt = 0;
+  bf16_t* const ctx = a.hbuf;             // context rows [RP][512] of the attention sublayers (the hidden rows are live in the FFN only)
+  uint4 wr[16];
+  f32x4 acc[4][4];
+  auto a_img = [&](int mt, int ks) { return img_frag(img, mt, ks, x, kg); };
+  // row-major bf16 store of a reduced tile: lane (x = row, lg = kg) holds columns col0 + 4*kg .. +3
+  auto store_rows = [&](bf16_t* out, int ld, int col0, int mt, const float (&v)[4]) {
+    const int row = 16 * mt + x;
+    if (row < R) st8(out + (long)row * ld + col0 + 4 * kg, make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3])));
+  };
+  auto bias4 = [&](const bf16_t* b, int col0, float (&bv)[4]) {
+    const uint2 q = *reinterpret_cast<const uint2*>(b + col0 + 4 * kg);
+    bv[0] = bf_lo(q.x); bv[1] = bf_hi(q.x); bv[2] = bf_lo(q.y); bv[3] = bf_hi(q.y);
+  };
+
+  // weights of the first phase
+  load_w<3, 4>(wr, a.layers[0].Wqkv, D, wg * 48, w, x, kg);
+#pragma unroll 1
+  for (int l = 0; l < a.nl; ++l) {
+    const DecLayerDev* Lp = a.layers + l;
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) {          // sublayers: 0 causal self-attention, 1..3 history / query / fused modalities, 4 feed-forward
+      // ---------------- A(j): LN_j(x) -> this workgroup's columns of the sublayer's first projection ----------------
+      layernorm_to_image(xcur, Lp->ln_a[j], Lp->ln_b[j], img, R, RP, w, lane);
+      __syncthreads();
+      if (j == 0) {
+        partial_product<3, 4>(acc, wr, a_img, MTR, w);
+        load_w<1, 4>(wr, Lp->Wo[0], D, wg * 16, w, x, kg);                 // the next product's weights fly over the barriers
+        const bf16_t* bqkv = Lp->bqkv;
+        reduce_tiles<3>(acc, part, MTR, w, lane, [&](int t) { return wg * 48 + 16 * t >= 1024; },
+          [&](int t, int mt, const f32x4& v) {
+            const int col0 = wg * 48 + 16 * t;                             // column of the packed [q; k; v] output
+            float bv[4]; bias4(bqkv, col0, bv);
+            const float o[4] = {v[0] + bv[0], v[1] + bv[1], v[2] + bv[2], v[3] + bv[3]};
+            if (col0 < 512) store_rows(a.qbuf, D, col0, mt, o);
+            else store_rows(a.kbuf, D, col0 - 512, mt, o);
+          },
+          [&](int t, int mt, const f32x4& v) {                             // V^T[channel][key rows 16*mt + 4*kg ..] (padding keys carry P = 0)
+            const int ch = wg * 48 + 16 * t - 1024 + x;
+            const float bv = (float)bqkv[1024 + ch];
+            st8(a.vT + (long)ch * a.LkS + 16 * mt + 4 * kg, make_uint2(pack2(v[0] + bv, v[1] + bv), pack2(v[2] + bv, v[3] + bv)));
+          });
+      } else if (j < 4) {
+        partial_product<1, 4>(acc, wr, a_img, MTR, w);
+        load_w<1, 4>(wr, Lp->Wo[j], D, wg * 16, w, x, kg);
+        const bf16_t* bq = Lp->bq[j - 1];
+        reduce_tiles<1>(acc, part, MTR, w, lane, [&](int t, int mt, const f32x4& v) {
+          float bv[4]; bias4(bq, wg * 16, bv);
+          const float o[4] = {v[0] + bv[0], v[1] + bv[1], v[2] + bv[2], v[3] + bv[3]};
+          store_rows(a.qbuf, D, wg * 16, mt, o);
+        });
+      } else {
+        partial_product<4, 4>(acc, wr, a_img, MTR, w);
+        load_w<1, 16>(wr, Lp->W2, 4 * D, wg * 16, w, x, kg);
+        const bf16_t* b1 = Lp->b1;
+        reduce_tiles<4>(acc, part, MTR, w, lane, [&](int t, int mt, const f32x4& v) {
+          const int col0 = wg * 64 + 16 * t;
+          float bv[4]; bias4(b1, col0, bv);
+          const float o[4] = {fmaxf(v[0] + bv[0], 0.f), fmaxf(v[1] + bv[1], 0.f), fmaxf(v[2] + bv[2], 0.f), fmaxf(v[3] + bv[3], 0.f)};
+          store_rows(a.hbuf, 4 * D, col0, mt, o);
+        });
+      }
+      grid_barrier(a.sync, ++phase * NWG, a.dbg);
+      STAMP();
+      // ---------------- C(j): the attention core, one (head, 16-row tile) unit per workgroup ----------------
+      if (j < 4) {
+        const int head = wg & 7, mt = wg >> 3;
+        if (mt < MTR) {
+          if (j == 0) core_unit(a.qbuf, a.kbuf, a.vT, a.smask, a.LkS, R, a.LkS, ctx, R, head, mt, w, x, kg);
+          else core_unit(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], 0, Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, head, mt, w, x, kg);
+        }
+        grid_barrier(a.sync, ++phase * NWG, a.dbg);
+        STAMP();
+      }
+      // ---------------- B(j): this workgroup's 16 columns of the output projection (W_o over the context rows, W_2 over the hidden
+      //                  rows, both read as MFMA fragments straight from L2) + bias + residual ----------------
+      {
+        const bf16_t* src = j < 4 ? ctx : a.hbuf;
+        const int ld = j < 4 ? D : 4 * D;
+        auto a_glob = [&](int mt, int ks) {  // lane (x, kg) -> row 16*mt + x, channels 32*ks + 8*kg ..
+          return ld16(src, ((long)min(16 * mt + x, R - 1) * ld + 32 * ks + 8 * kg) * 2);
+        };
+        if (j < 4) partial_product_glob<4, true>(acc, wr, a_glob, MTR, w);
+        else if (a.dbg & 2) partial_product_glob<16, false>(acc, wr, a_glob, MTR, w);
+        else partial_product_glob<16, true>(acc, wr, a_glob, MTR, w);
+        if (j == 3) load_w<4, 4>(wr, Lp->W1, D, wg * 64, w, x, kg);
+        else if (j < 3) load_w<1, 4>(wr, Lp->Wq[j], D, wg * 16, w, x, kg);
+        else if (l + 1 < a.nl) load_w<3, 4>(wr, Lp[1].Wqkv, D, wg * 48, w, x, kg);
+        const bf16_t* bo = j < 4 ? Lp->bo[j] : Lp->b2;
+        bf16_t* xn = a.xbuf[nxt];
+        const bf16_t* xo = xcur;
+        reduce_tiles<1>(acc, part, MTR, w, lane, [&](int t, int mt, const f32x4& v) {
+          const int col0 = wg * 16, row = min(16 * mt + x, R - 1);
+          float bv[4]; bias4(bo, col0, bv);
+          const uint2 xr = ld8(xo + (long)row * D + col0 + 4 * kg);
+          const float o[4] = {v[0] + bv[0] + bf_lo(xr.x), v[1] + bv[1] + bf_hi(xr.x), v[2] + bv[2] + bf_lo(xr.y), v[3] + bv[3] + bf_hi(xr.y)};
+          store_rows(xn, D, col0, mt, o);
+        });
+        xcur = xn; nxt ^= 1;
+      }
+      grid_barrier(a.sync, ++phase * NWG, a.dbg);
+      STAMP();
+    }
+  }
+  // the counter is zero again for the next call: the workgroup that leaves last (everybody is past the final barrier) resets it
+  if (tid == 0) {
+    gu32* sync = (gu32*)a.sync;
+    if (__hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NWG - 1) {
+      __hip_atomic_store(sync + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk_max, int32_t dtype) {
+  return dtype == BIST_BF16 && d == D && h == H && R >= 1 && R <= 64 && Lk_max >= 1 && Lk_max <= 64;
+}
+
+extern "C" int64_t bist_decoder_layer_desc_bytes(void) { return (int64_t)sizeof(DecLayerDev); }
+
+extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, const void* x_in, void* xbuf0, void* xbuf1, void* qbuf,
+                                      void* kbuf, void* vT, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, void* sync,
+                                      int32_t dtype, void* stream) {
+  BIST_REQUIRE(layers_dev && x_in && xbuf0 && xbuf1 && qbuf && kbuf && vT && hbuf && self_mask && sync, "bist_decoder_stack_fwd: null pointer");
+  BIST_REQUIRE(dtype == BIST_BF16 && n_layers >= 1 && R >= 1 && R <= 64 && LkS >= R && LkS <= 64 && LkS % 32 == 0,
+               "bist_decoder_stack_fwd: bf16, 1..64 rows, self keys padded to 32 or 64");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decstack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
+      bist_set_error("bist_decoder_stack_fwd: cannot reserve 128 KiB of LDS");
+      return BIST_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  DecArgs a{(const DecLayerDev*)layers_dev, n_layers, (const bf16_t*)x_in, {(bf16_t*)xbuf0, (bf16_t*)xbuf1}, (bf16_t*)qbuf, (bf16_t*)kbuf,
+            (bf16_t*)vT, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, nullptr};
+  if (const char* e = getenv("BIST_DECSTACK_DBG")) a.dbg = atoi(e);
+  if (const char* e = getenv("BIST_DECSTACK_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10));
+  hipLaunchKernelGGL(decstack_kernel, dim3(NWG), dim3(NT), 128 * 1024, st, a);
+  BIST_LAUNCH_CHECK("bist_decoder_stack_fwd");
+  return BIST_OK;
+}

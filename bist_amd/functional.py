@@ -226,6 +226,9 @@ PERMUTED_T2S = os.environ.get("BIST_PERMUTED_T2S", "1") != "0"      # tuning aid
 FUSED_ST1 = os.environ.get("BIST_FUSED_ST1", "1") != "0"      # tuning aid: 0 = stage 1 of the inference path as separate launches
 
 
+FUSED_DECODE = os.environ.get("BIST_FUSED_DECODE", "1") != "0"      # tuning aid: 0 = the decoder layers of a decode step as separate launches
+
+
 EVAL_SCHED = int(os.environ.get("BIST_EVAL_SCHED", "1"))      # tuning aid: stream schedule of the fused inference layer (0: one fork after the input projection, 1: two chains forked ahead of it, 2: stage-1 launches on the main stream)
 
 

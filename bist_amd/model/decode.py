@@ -48,7 +48,8 @@ class _TurnBuffers:
     """Static device copies of a turn's inputs for `n` hypothesis rows (ids, masks, encoded text, per-layer reasoning).
     Every step graph of this geometry reads THESE tensors, so a new turn costs one round of small copies, not a capture."""
 
-    def __init__(self, bn, fn):
+    def __init__(self, bn, fn, decoder=None):
+        self.decoder = decoder
         self.b = types.SimpleNamespace(**vars(bn))
         for name in ("query", "his", "cap", "query_mask", "his_mask", "cap_mask"):
             v = getattr(bn, name, None)
@@ -71,6 +72,10 @@ class _TurnBuffers:
             for k, v in src.items():
                 dst[k].copy_(v)
         self.loaded = fn
+        if self.decoder is not None:          # the static buffers now hold a new turn: re-project the memories' keys / values
+            dec = self.decoder
+            if dec._fused_decode_ok(self.b, self.f, self.f["encoded_query"][:, :1]):
+                dec.prepare_decode_cache(self.b, self.f, src=fn["_bist_reasoning"])
 
 
 def _descending(lp_vec, k):
@@ -109,7 +114,7 @@ def _graph_step(model, bn, fn, trg, train_args):
     store = model.__dict__.setdefault("_bist_step_graphs", {})          # (checked against the weights once per turn: _graph_first_step)
     tb = store.get(("turn",) + geom)
     if tb is None:
-        tb = store[("turn",) + geom] = _TurnBuffers(bn, fn)
+        tb = store[("turn",) + geom] = _TurnBuffers(bn, fn, getattr(model, "mutlimodal_decoder", None))
     tb.load(bn, fn)
     g = store.get((Lt,) + geom)
     if g is None:
@@ -253,6 +258,9 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
                     if len(new_hyplist) == beam:
                         argmin = min(enumerate(new_hyplist), key=lambda e: e[1][1])[0]
         hyplist = new_hyplist
+    dec = getattr(model, "mutlimodal_decoder", None)
+    if hasattr(dec, "check_decode_errors"):
+        dec.check_decode_errors()            # a timed-out grid barrier of the persistent decoder kernel voids the turn: raise
     if comp_hyplist:
         return sorted(comp_hyplist, key=lambda e: -e[1])[:nbest], best_state
     return [([], 0)], None

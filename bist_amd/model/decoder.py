@@ -7,7 +7,11 @@ from typing import Dict
 import torch
 import torch.nn as nn
 
+import ctypes as C
+
 from .. import functional as Fn
+from .. import ops
+from .._lib import BistDecLayer, lib
 from .encoder import _cross_attention, _feed_forward, _self_attention
 from .modules import LayerNorm, SublayerConnection, clones
 
@@ -123,6 +127,127 @@ class MultimodalDecoder8(nn.Module):
             return                                          # the reference defines no encoded_ft here (decoder.py:168-181)
         ft["encoded_ft"] = Fn.fuse_modalities(score.view(*parts[0].shape[:-1], -1), xs)
 
+    # ---- one persistent launch for all decoder layers of a decode step (bist_decoder_stack_fwd) ------------------------------
+    FUSED_DECODE = True
+
+    def _fused_decode_ok(self, b, ft, x) -> bool:
+        a = self.args
+        if not (self.FUSED_DECODE and Fn.FUSED_DECODE and x.is_cuda and x.dim() == 3):
+            return False
+        if not (self.v_N > 0 and self.c_N > 0 and getattr(a, "enc_vc_combine", "none") != "none"):
+            return False                     # the layer must be the four-attention form of decoder.py:27-29
+        n, Lt, d = x.shape
+        Lk = max(ft["encoded_his"].shape[1], ft["encoded_query"].shape[1])
+        return ops.decoder_stack_ok(n * Lt, d, self.layers[0].attn[0].h, Lk, x.dtype) and len(self.layers[0].attn) == 4
+
+    def _decode_state(self, dev, dtype):
+        """Scratch of the persistent kernel and the per-turn key / value caches: allocated once per decoder (fixed addresses, so
+        captured step graphs stay valid), zero-initialised (padding rows must be finite)."""
+        st = self.__dict__.get("_bist_dec_state")
+        if st is None or st["x0"].device != dev or st["x0"].dtype != dtype:
+            z = lambda *shape, dt=dtype: torch.zeros(*shape, device=dev, dtype=dt)
+            st = {"x0": z(64, 512), "x1": z(64, 512), "q": z(64, 512), "k": z(64, 512), "vT": z(512, 64), "h": z(64, 2048),
+                  "sync": z(8, dt=torch.int32), "masks": {}, "kv": None, "desc": None, "desc_key": None}
+            self.__dict__["_bist_dec_state"] = st
+        return st
+
+    def prepare_decode_cache(self, b, ft, src=None) -> None:
+        """Keys and (transposed) values of the three memories of every decoder layer for this turn: they depend on the encoded
+        history / query and on the layer's fused modalities only, not on the prefix (the unfused path recomputes them in every
+        decode step).  All hypothesis rows of a turn hold the same memories: row 0 is used."""
+        dev, dtype = ft["encoded_his"].device, ft["encoded_his"].dtype
+        st = self._decode_state(dev, dtype)
+        cache = ft["_bist_reasoning"]
+        if src is not None and st["kv"] is not None and st["kv"].get("src") is src:
+            st["kv"]["owner"] = cache        # another row-count view of the turn already projected: same values
+            return
+        nl = len(self.layers)
+        mems = lambda l: (ft["encoded_his"][0], ft["encoded_query"][0], cache[l]["encoded_ft"][0])
+        masks = (b.his_mask[0].reshape(-1), b.query_mask[0].reshape(-1), b.query_mask[0].reshape(-1))
+        Lks = [m.shape[0] for m in mems(0)]
+        LkPs = [32 if k <= 32 else 64 for k in Lks]
+        kv = st["kv"]
+        if kv is None or kv["Lks"] != Lks or kv["nl"] != nl:
+            kv = {"Lks": Lks, "nl": nl,
+                  "K": [[torch.zeros(LkPs[c], 512, device=dev, dtype=dtype) for c in range(3)] for _ in range(nl)],
+                  "VT": [[torch.zeros(512, LkPs[c], device=dev, dtype=dtype) for c in range(3)] for _ in range(nl)],
+                  "mask": [torch.zeros(LkPs[c], device=dev, dtype=torch.uint8) for c in range(3)]}
+            st["kv"], st["desc"] = kv, None
+        for c in range(3):
+            kv["mask"][c][:Lks[c]].copy_(masks[c].to(torch.uint8))
+        for l, layer in enumerate(self.layers):
+            for c, mem in enumerate(mems(l)):
+                w, bias = layer.attn[1 + c]._packed((1, 2))                                   # [W_k; W_v], one product per memory
+                kvp = Fn.linear(mem, w, bias)                                                 # [Lk, 1024]
+                kv["K"][l][c][:Lks[c]].copy_(kvp[:, :512])
+                kv["VT"][l][c][:, :Lks[c]].copy_(kvp[:, 512:].t())
+        kv["owner"], kv["src"] = cache, src  # the reasoning results these keys / values were projected from (one list per turn)
+
+    def _decode_desc(self, st):
+        """Device array of BistDecLayer descriptors (rebuilt when the parameters or the cache buffers change)."""
+        kv = st["kv"]
+        ps = [p for layer in self.layers for p in layer.parameters()]
+        key = ops.weights_key(*ps) + (id(kv),)
+        if st["desc"] is not None and st["desc_key"] == key:
+            return st["desc"]
+        descs = (BistDecLayer * len(self.layers))()
+        keep = []
+        for l, layer in enumerate(self.layers):
+            dsc = descs[l]
+            for s_ in range(5):
+                dsc.ln_a[s_], dsc.ln_b[s_] = layer.sublayer[s_].norm.a_2.data_ptr(), layer.sublayer[s_].norm.b_2.data_ptr()
+            w, bias = layer.attn[0]._packed((0, 1, 2))
+            keep += [w, bias]
+            dsc.Wqkv, dsc.bqkv = w.data_ptr(), bias.data_ptr()
+            for c in range(3):
+                at = layer.attn[1 + c]
+                dsc.Wq[c], dsc.bq[c] = at.linears[0].weight.data_ptr(), at.linears[0].bias.data_ptr()
+                dsc.Kc[c], dsc.VTc[c], dsc.cmask[c] = kv["K"][l][c].data_ptr(), kv["VT"][l][c].data_ptr(), kv["mask"][c].data_ptr()
+                dsc.Lk[c], dsc.LkP[c] = kv["Lks"][c], kv["K"][l][c].shape[0]
+            for j in range(4):
+                dsc.Wo[j], dsc.bo[j] = layer.attn[j].linears[3].weight.data_ptr(), layer.attn[j].linears[3].bias.data_ptr()
+            dsc.W1, dsc.b1 = layer.ff.w_1.weight.data_ptr(), layer.ff.w_1.bias.data_ptr()
+            dsc.W2, dsc.b2 = layer.ff.w_2.weight.data_ptr(), layer.ff.w_2.bias.data_ptr()
+        assert C.sizeof(BistDecLayer) == lib.bist_decoder_layer_desc_bytes()
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(st["x0"].device)
+        st["desc"], st["desc_key"], st["desc_keep"] = raw, key, keep
+        return raw
+
+    def _self_mask(self, st, b, n: int, Lt: int, LkS: int):
+        """[n*Lt, LkS] uint8: row (j,t) attends key (j',t') iff j' == j and trg_mask[j or 0][t][t'] (dataset.py:101-105)."""
+        tm = b.trg_mask
+        key = (n, Lt, LkS, tm.data_ptr(), tm._version, tuple(tm.shape))
+        hit = st["masks"].get(key[:3])
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        m = torch.zeros(n * Lt, LkS, device=tm.device, dtype=torch.uint8)
+        blk = tm.to(torch.uint8).expand(n, Lt, Lt)
+        for j in range(n):
+            m[j * Lt:(j + 1) * Lt, j * Lt:(j + 1) * Lt] = blk[j]
+        st["masks"][key[:3]] = (key, m)
+        return m
+
+    def check_decode_errors(self) -> None:
+        """After a turn: the persistent kernel's sticky error word (one 4-byte read).  Non-zero = one of its grid barriers timed
+        out (its 32 workgroups were not resident together), so the rows it returned are not the decoder's output."""
+        st = self.__dict__.get("_bist_dec_state")
+        if st is not None and st.get("used") and int(st["sync"][4].item()) != 0:
+            st["sync"].zero_()
+            raise RuntimeError("bist_amd: bist_decoder_stack_fwd timed out at a grid barrier (workgroups not co-resident); "
+                               "set BIST_FUSED_DECODE=0 to run the decoder layers as separate launches")
+
+    def _decode_fused(self, b, ft, x):
+        n, Lt, d = x.shape
+        st = self._decode_state(x.device, x.dtype)
+        if st["kv"] is None or st["kv"].get("owner") is not ft["_bist_reasoning"]:
+            self.prepare_decode_cache(b, ft)
+        st["used"] = True
+        R = n * Lt
+        LkS = 32 if R <= 32 else 64
+        out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(R, d).contiguous(), st, self._self_mask(st, b, n, Lt, LkS), R, LkS)
+        ft.update(ft["_bist_reasoning"][-1])
+        return out.view(n, Lt, d)
+
     # Keys the reasoning layers write per decoder layer (decoder.py:126-181); everything else in ``ft`` is static.
     _REASONING_KEYS = ("temporal_ft", "spatial_ft", "cap_ft", "encoded_ft")
     REASONING_CACHE = True      # inference only; set False to recompute the reasoning on every decode() like the reference
@@ -136,9 +261,12 @@ class MultimodalDecoder8(nn.Module):
         use_cache = self.REASONING_CACHE and not self.training and not torch.is_grad_enabled()
         cache = ft.get("_bist_reasoning") if use_cache else None
         if cache is not None and len(cache) == len(self.layers):
-            for l, layer in enumerate(self.layers):
-                ft.update(cache[l])
-                x = layer(b, ft, x)
+            if self._fused_decode_ok(b, ft, x):
+                x = self._decode_fused(b, ft, x)
+            else:
+                for l, layer in enumerate(self.layers):
+                    ft.update(cache[l])
+                    x = layer(b, ft, x)
             ft["decoded_text"] = self.norm(x)
             return ft
         cache = [] if use_cache else None

@@ -336,6 +336,21 @@ def st_stage1_fused(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: Tensor
     return out
 
 
+def decoder_stack_ok(R: int, d: int, h: int, Lk_max: int, dtype: torch.dtype) -> bool:
+    return dtype in _DT and bool(lib.bist_decoder_stack_ok(R, d, h, Lk_max, _DT[dtype]))
+
+
+def decoder_stack(desc: Tensor, n_layers: int, x_in: Tensor, bufs: dict, self_mask: Tensor, R: int, LkS: int) -> Tensor:
+    """All decoder layers of one decode step in one persistent launch (bist_decoder_stack_fwd); desc: device bytes of n_layers
+    BistDecLayer; bufs: the caller-owned scratch (zero-initialised once); returns the [R, 512] rows of the output buffer."""
+    _dev(desc, x_in, self_mask)
+    check(lib.bist_decoder_stack_fwd(desc.data_ptr(), n_layers, x_in.data_ptr(), bufs["x0"].data_ptr(), bufs["x1"].data_ptr(),
+                                     bufs["q"].data_ptr(), bufs["k"].data_ptr(), bufs["vT"].data_ptr(), bufs["h"].data_ptr(),
+                                     self_mask.data_ptr(), R, LkS, bufs["sync"].data_ptr(), dtype_code(x_in.dtype), _stream()),
+          "bist_decoder_stack_fwd")
+    return bufs["x0" if (5 * n_layers - 1) % 2 == 0 else "x1"][:R]       # the residual stream ping-pongs: write k lands in buffer (k - 1) % 2
+
+
 def st_stage2(q2f: Tensor, y: Tensor, gmask: Optional[Tensor], *, h: int, out: Optional[Tensor] = None, drop=None,
               want_rowsum: bool = False):
     """Stage-2 attention over the stage-1 outputs with K/V folded out; q2f [B,Lq,h,d], y [B,G,Lq,d].

@@ -214,6 +214,43 @@ int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const uint8_t* kma
                              int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The response-decoder stack of one beam-search step as ONE persistent launch (inference; bf16, d = 512, h = 8, R <= 64 rows).
+ * Replaces, for all layers of MultimodalDecoder8's loop (model/decoder.py:114-182, reasoning results cached per turn), the
+ * MultimodalDecoderLayer12.forward of decoder.py:20-60 with enc_vc_combine != 'none': causal self-attention, attention to the
+ * history, to the query and to the fused modalities (each x + W_o MHA(LN(x), mem, mem, mask) + b_o; modules.py:42-44, 54-64,
+ * 81-100) and the feed-forward block (modules.py:112-113), on the R = hypotheses x prefix-length rows of a decode step
+ * (model/decode.py:62-66).  One unfused step is ~120 launches of 5-17 us on these rows; here 32 resident workgroups walk the
+ * 14 phases of a layer (per attention sublayer: LN + projection, one (head, 16-row tile) core unit per workgroup, output
+ * projection + residual; two for the feed-forward block) with a grid barrier after each and prefetch the next product's weights
+ * across it; hand-offs are write-through stores + sc1 loads, no cache fences.
+ *   layers_dev  device array of n_layers BistDecLayer (below): LayerNorm gains/offsets, nn.Linear weights [out][in] and biases,
+ *               and per memory c = 0 (history), 1 (query), 2 (fused modalities) the keys K = mem W_k^T + b_k as [LkP][512] and
+ *               the values TRANSPOSED, V^T [512][LkP] (LkP = Lk rounded up to 32 or 64, padding zero), computed once per turn
+ *               (they do not depend on the prefix), with the key mask [LkP] (uint8, 1 = attend; -1e9 REPLACES a masked score)
+ *   x_in [R][512] the embedded prefix rows (hypothesis-major); xbuf0 / xbuf1 [64][512], qbuf / kbuf [64][512], vT [512][LkS],
+ *   hbuf [64][2048]: caller-owned scratch, ZERO when first handed over; self_mask [R][LkS] uint8: row (j,t) may attend key (j',t')
+ *   iff j' == j and trg_mask allows (data/dataset.py:101-105); LkS = R rounded up to 32 or 64; sync: 32 bytes = 8 words the caller zeroes ONCE: words 0, 1
+ *   the barrier's arrival / exit counters (the kernel leaves them zero for the next call -- no memset node per call), word 4 a STICKY
+ *   error flag to read after a turn: non-zero = a barrier timed out (the 32 workgroups were not co-resident), the results of that call are invalid.
+ * Result: the rows of xbuf[(5 * n_layers - 1) % 2] (the residual stream ping-pongs between the two buffers, five writes per layer).  Returns BIST_EINVAL outside the envelope (bist_decoder_stack_ok).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct BistDecLayer {
+  const void* ln_a[5]; const void* ln_b[5];
+  const void* Wqkv; const void* bqkv;
+  const void* Wq[3]; const void* bq[3];
+  const void* Wo[4]; const void* bo[4];
+  const void* Kc[3]; const void* VTc[3];
+  const uint8_t* cmask[3];
+  const void* W1; const void* b1; const void* W2; const void* b2;
+  int32_t Lk[3]; int32_t LkP[3];
+} BistDecLayer;
+int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk_max, int32_t dtype);
+int64_t bist_decoder_layer_desc_bytes(void);
+int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, const void* x_in, void* xbuf0, void* xbuf1, void* qbuf,
+                           void* kbuf, void* vT, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, void* sync,
+                           int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Stage 2 of both directions (encoder.py:125-134 / 152-165): query position (b,i) attends,
  * alone, over the G stage-1 outputs Y[b,g,i,:] of its own position (G = S for t2s, T for s2t).
  * With the query folded through W_k (q2f [B,Lq,h,d], pre-scaled) and the value projection

@@ -253,3 +253,37 @@ def test_full_size_fp32_matches_reference_digests(hip, golden_dir, tag):
         for i, (toks, score) in enumerate(hyps):
             assert [int(t) for t in toks] == g[f"{tag}_beam_hyp{i}"].tolist(), i
             assert abs(float(score) - float(g[f"{tag}_beam_score{i}"])) <= 1e-3 * max(1.0, abs(float(g[f"{tag}_beam_score{i}"])))
+
+
+@pytest.mark.parametrize("n,Lt", [(1, 1), (3, 5), (5, 12), (2, 7)])
+def test_fused_decoder_stack_matches_the_layer_by_layer_path(hip, n, Lt):
+    """bist_decoder_stack_fwd (one persistent launch for all decoder layers of a decode step) against the same layers run one
+    launch per operation, bf16, d_model=512, h=8, on the replicated turn of a beam-search step (n hypotheses x Lt prefix tokens)."""
+    from bist_amd import _lib, functional as Fn
+    from bist_amd.data.batch import subsequent_mask
+    from bist_amd.model.decode import _turn_for_rows
+    M, Batch = hip
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=3, nb_venc_blocks=3, nb_cenc_blocks=3)
+    V, C = 300, 256
+    ob = O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=21)
+    model, _ = build_model(M, cfg, V, C, torch.bfloat16)
+    b = to_batch(Batch, ob, torch.bfloat16)
+    g = torch.Generator().manual_seed(n * 100 + Lt)
+    trg = torch.randint(4, V, (n, Lt), generator=g).cuda()
+    outs = {}
+    with torch.no_grad():
+        ft = model.encode(b)
+        b.trg, b.trg_mask = trg[:1, :1].contiguous(), subsequent_mask(1, "cuda")
+        ft = model.decode(b, ft)                                   # fills ft['_bist_reasoning'] (the first call of a turn)
+        for fused in (False, True):
+            Fn.FUSED_DECODE = fused
+            try:
+                bn, fn = _turn_for_rows(b, ft, n, {})
+                bn.trg, bn.trg_mask = trg, subsequent_mask(Lt, "cuda")
+                outs[fused] = model.decode(bn, dict(fn))["decoded_text"].float().cpu()
+            finally:
+                Fn.FUSED_DECODE = True
+    assert outs[True].shape == (n, Lt, 512)
+    err = (outs[True] - outs[False]).abs().max().item()
+    assert err <= 6e-2, err                                         # layer-normed outputs, bf16 storage between every operation in both
+    assert torch.isfinite(outs[True]).all()
