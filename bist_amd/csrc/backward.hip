@@ -474,6 +474,12 @@ __global__ void add_f32_into_kernel(const float* __restrict__ s, T* __restrict__
 // (torch.optim.Adam semantics, the optimiser the reference wraps in NoamOpt, train.py:129-130)
 // hyper (nullable, device): {lr, 1 - beta1^t, 1 - beta2^t, grad_scale} of THIS step -- lets the launch live inside a captured
 // hipGraph, whose kernel arguments are frozen at capture time
+// one element of torch.optim.Adam (both kernels below call this, so they round alike)
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  p = p - lr * ((m / bc1) / (sqrtf(v / bc2) + eps));
+}
 template <typename TG, typename TW>
 __global__ void adam_kernel(float* __restrict__ p, const TG* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             TW* __restrict__ work, long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float gscale,
@@ -481,14 +487,74 @@ __global__ void adam_kernel(float* __restrict__ p, const TG* __restrict__ g, flo
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; gscale = hyper[3]; }
-  const float gi = to_f(g[i]) * gscale;
-  const float mi = b1 * m[i] + (1.f - b1) * gi;
-  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  float mi = m[i], vi = v[i], pi = p[i];
+  adam_elem(pi, mi, vi, to_f(g[i]) * gscale, lr, b1, b2, eps, bc1, bc2);
   m[i] = mi; v[i] = vi;
-  const float upd = (mi / bc1) / (sqrtf(vi / bc2) + eps);
-  const float pi = p[i] - lr * upd;
   p[i] = pi;
   if (work) work[i] = from_f<TW>(pi);
+}
+
+// Adam on 4 elements per thread with the step's scalars in hyper = {lr, 1 - beta1^t, 1 - beta2^t, grad_scale, apply}; the gradient is
+// CLEARED after it is read, so the next backward pass accumulates into zeros without a memset of its own.  apply == 0 (nothing
+// pending): only the clear.
+template <typename TG, typename TW>
+__global__ __launch_bounds__(256) void adam_apply4_kernel(float* __restrict__ p, TG* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          TW* __restrict__ work, long n4, float b1, float b2, float eps,
+                                                          const float* __restrict__ hyper) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gscale = hyper[3];
+  const bool apply = hyper[4] != 0.f;
+  float gi[4];
+  if constexpr (sizeof(TG) == 2) {
+    uint2* gp = reinterpret_cast<uint2*>(g) + i;
+    if (apply) {
+      const uint2 q = *gp;
+      gi[0] = __builtin_bit_cast(float, q.x << 16); gi[1] = __builtin_bit_cast(float, q.x & 0xffff0000u);
+      gi[2] = __builtin_bit_cast(float, q.y << 16); gi[3] = __builtin_bit_cast(float, q.y & 0xffff0000u);
+    }
+    *gp = make_uint2(0u, 0u);
+  } else {
+    float4* gp = reinterpret_cast<float4*>(g) + i;
+    if (apply) { const float4 q = *gp; gi[0] = q.x; gi[1] = q.y; gi[2] = q.z; gi[3] = q.w; }
+    *gp = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (!apply) return;
+  float4 pm = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vm = reinterpret_cast<float4*>(v)[i];
+  float pv[4] = {pm.x, pm.y, pm.z, pm.w}, mv[4] = {mm.x, mm.y, mm.z, mm.w}, vv[4] = {vm.x, vm.y, vm.z, vm.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    adam_elem(pv[e], mv[e], vv[e], gi[e] * gscale, lr, b1, b2, eps, bc1, bc2);
+  }
+  reinterpret_cast<float4*>(m)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+  reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  reinterpret_cast<float4*>(p)[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+  if (work) {
+    if constexpr (sizeof(TW) == 2) {
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      const f32x2 lo = {pv[0], pv[1]}, hi = {pv[2], pv[3]};
+      reinterpret_cast<uint2*>(work)[i] = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)),
+                                                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2)));
+    } else {
+      reinterpret_cast<float4*>(work)[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    }
+  }
+}
+
+// The scalars of the PENDING optimiser step t = pending[0] (0 = none) and pending[0] <- 0: the head of a step applies the previous
+// step's update (bist_adam_apply_dev) beside its own forward pass
+__global__ void noam_hyper_pending_kernel(long long* __restrict__ pending, float* __restrict__ hyper, double d_model, double factor,
+                                          double warmup, double b1, double b2, float gscale) {
+  const long long ti = pending[0];
+  if (ti <= 0) { hyper[0] = 0.f; hyper[1] = 1.f; hyper[2] = 1.f; hyper[3] = gscale; hyper[4] = 0.f; return; }
+  const double t = (double)ti;
+  hyper[0] = (float)(factor * (pow(d_model, -0.5) * fmin(pow(t, -0.5), t * pow(warmup, -1.5))));
+  hyper[1] = (float)(1.0 - pow(b1, t));
+  hyper[2] = (float)(1.0 - pow(b2, t));
+  hyper[3] = gscale;
+  hyper[4] = 1.f;
+  pending[0] = 0;
 }
 
 }  // namespace
@@ -778,5 +844,33 @@ extern "C" int bist_adam_step_dev(float* p, const void* g, float* m, float* v, v
   else { bist_set_error("bist_adam_step_dev: bad dtype combination"); return BIST_EINVAL; }
 #undef ADAM
   BIST_LAUNCH_CHECK("bist_adam_step_dev");
+  return BIST_OK;
+}
+
+extern "C" int bist_noam_hyper_pending(int64_t* pending, float* hyper, float d_model, float factor, float warmup, float beta1, float beta2,
+                                       float grad_scale, void* stream) {
+  BIST_REQUIRE(pending && hyper && d_model > 0.f && warmup > 0.f, "bist_noam_hyper_pending: bad argument");
+  hipLaunchKernelGGL(noam_hyper_pending_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)pending, hyper, (double)d_model,
+                     (double)factor, (double)warmup, (double)beta1, (double)beta2, grad_scale);
+  BIST_LAUNCH_CHECK("bist_noam_hyper_pending");
+  return BIST_OK;
+}
+
+extern "C" int bist_adam_apply_dev(float* p, void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
+                                   float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream) {
+  BIST_REQUIRE(p && g && m && v && hyper && n > 0, "bist_adam_apply_dev: bad argument");
+  BIST_REQUIRE(n % 4 == 0 && ((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) % 16 == 0 && (uintptr_t)g % (grad_dtype == BIST_BF16 ? 8 : 16) == 0 &&
+               (!work || (uintptr_t)work % (work_dtype == BIST_BF16 ? 8 : 16) == 0),
+               "bist_adam_apply_dev: ranges must be multiples of 4 elements and 16-byte aligned (fp32) / 8-byte aligned (bf16)");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = blocks_for(n / 4, 256);
+#define ADAM(TG, TW) hipLaunchKernelGGL((adam_apply4_kernel<TG, TW>), dim3(grid), dim3(256), 0, st, p, (TG*)g, m, v, (TW*)work, (long)(n / 4), beta1, beta2, eps, hyper)
+  if (grad_dtype == BIST_F32 && (work == nullptr || work_dtype == BIST_F32)) ADAM(float, float);
+  else if (grad_dtype == BIST_F32 && work_dtype == BIST_BF16) ADAM(float, bf16_t);
+  else if (grad_dtype == BIST_BF16 && (work == nullptr || work_dtype == BIST_BF16)) ADAM(bf16_t, bf16_t);
+  else if (grad_dtype == BIST_BF16 && work_dtype == BIST_F32) ADAM(bf16_t, float);
+  else { bist_set_error("bist_adam_apply_dev: bad dtype combination"); return BIST_EINVAL; }
+#undef ADAM
+  BIST_LAUNCH_CHECK("bist_adam_apply_dev");
   return BIST_OK;
 }

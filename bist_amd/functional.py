@@ -217,6 +217,17 @@ BRANCH_V = os.environ.get("BIST_BRANCH_V", "0") != "0"      # tuning aid: value 
 PIPELINE_DECODER = os.environ.get("BIST_PIPELINE_DECODER", "1") != "0"      # tuning aid: decoder layer l under reasoning layer l+1
 
 
+# Deferred optimiser (bist_amd/train.py): while a step applies the previous step's update piece by piece on its own stream, the model
+# announces -- on the MAIN stream -- that it is about to read the parameters of piece k for the first time (piece 0: everything
+# outside the layer stacks, piece 1 + l: reasoning / caption / decoder layer l); the trainer's gate waits for that piece's event.
+PARAM_GATE = None
+
+
+def param_gate(k: int) -> None:
+    if PARAM_GATE is not None:
+        PARAM_GATE(k)
+
+
 VALUES_AHEAD = os.environ.get("BIST_VALUES_AHEAD", "1") != "0"      # tuning aid: value projections of layer l+1 on the caption stream
 
 

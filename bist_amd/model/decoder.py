@@ -303,9 +303,11 @@ class MultimodalDecoder8(nn.Module):
                 ev = torch.cuda.Event()                           # an edge between two side streams crashes hipGraph capture
                 ev.record(side_)
             ft["_bist_v_pre"] = (v1, None, ev)
+        Fn.param_gate(1)                     # deferred optimiser: layer 0's parameters (and everything outside the layer stacks) are final
         if values_ahead:
             issue_values(0)
         for l, layer in enumerate(self.layers):
+            Fn.param_gate(1 + min(l + 1, len(self.layers) - 1))      # layer l + 1: its value projection is issued during layer l
             fork_cap = self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda
             if fork_cap:                     # the caption reasoning layer is independent of the visual one
                 main, side = torch.cuda.current_stream(), Fn.side_stream(1)

@@ -19,6 +19,8 @@ from .generator import Generator, MultiPointerGenerator, PointerGenerator
 from .modules import (Embeddings, MultiHeadedAttention, PositionalEncoding, PositionwiseFeedForward,
                       embed_with_position)
 
+from .. import functional as Fn
+
 Tensor = torch.Tensor
 
 
@@ -39,6 +41,30 @@ class MTN(nn.Module):
         self.ptr_gen = ptr_gen
         self.args = args
 
+    _bist_param_gates = True      # this model calls Fn.param_gate before the first read of every parameter piece (bist_amd/train.py)
+
+    def _flush_trainer(self) -> None:
+        """A trainer with the deferred optimiser leaves the last step's update pending: apply it before the weights are read."""
+        ref = self.__dict__.get("_bist_trainer")
+        tr = ref() if ref is not None else None
+        if tr is not None:
+            tr.flush()
+
+    def __getstate__(self):           # torch.save(model): flush, and leave the (unpicklable, per-process) trainer reference behind
+        self._flush_trainer()
+        state = self.__dict__.copy()
+        state.pop("_bist_trainer", None)
+        return state
+
+    def train(self, mode: bool = True):
+        if not mode:
+            self._flush_trainer()
+        return super().train(mode)
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_trainer()
+        return super().state_dict(*args, **kwargs)
+
     def forward(self, b) -> Dict[str, Tensor]:
         return self.decode(b, self.encode(b))
 
@@ -46,6 +72,7 @@ class MTN(nn.Module):
         return self.encode_vid(b, self.encode_text(b, {}))
 
     def encode_text(self, b, ft):
+        Fn.param_gate(0)
         e = self.query_embed
         q, c, h = self.text_encoder(embed_with_position(e, b.query),
                                     embed_with_position(e, b.cap) if b.cap is not None else None,

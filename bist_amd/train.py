@@ -24,6 +24,8 @@ from __future__ import annotations
 
 import copy
 import os
+import re
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -40,6 +42,8 @@ from .ops import _stream, dtype_code
 ALIGN = 64      # elements; keeps every parameter view 16-byte aligned for the LDS-DMA GEMM path
 
 
+ADAM_CLEARS = os.environ.get("BIST_ADAM_CLEARS", "0") != "0"      # tuning aid: 1 = Adam on 4 elements per thread that also clears the gradients it consumed, no memset of the gradient
+                                                                  # buffer at the head of a replayed step (measured 11.83-11.91 vs 11.72-11.79 ms per step: not adopted)
 EXCHANGE_CHUNKS = int(os.environ.get("BIST_EXCHANGE_CHUNKS", "4"))        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
 
 
@@ -50,7 +54,8 @@ def _round(n: int) -> int:
 class Trainer:
     def __init__(self, model: torch.nn.Module, args, vocab_size: int, *, compute_dtype: torch.dtype = torch.bfloat16,
                  warmup: int = 4000, factor: float = 1.0, smoothing: float = 0.1, pad: int = 1,
-                 betas=(0.9, 0.98), eps: float = 1e-9, process_group=None, use_graph: bool = False):
+                 betas=(0.9, 0.98), eps: float = 1e-9, process_group=None, use_graph: bool = False,
+                 deferred_adam: Optional[bool] = None):
         self.model, self.args = model, args
         self.use_graph = use_graph
         self._graph = self._graph2 = self._graph_key = self._static_batch = self._static_terms = None
@@ -65,6 +70,16 @@ class Trainer:
         self.exchanging = self.world > 1 or (os.environ.get("BIST_FORCE_EXCHANGE") == "1" and dist.is_available()
                                              and dist.is_initialized())          # (one-rank rehearsal aid, bench.py)
         self.adam_in_step = not self.exchanging and os.environ.get("BIST_ADAM_IN_STEP", "1") != "0"
+        # Deferred optimiser (one rank, replayed step): the update of step t is applied at the HEAD of step t+1 -- piece by piece in
+        # the order the forward pass first reads the parameters, on a stream of its own, beside that forward pass -- and by flush()
+        # after the last step.  The tail of a step is then the backward pass and its closing reductions only.
+        # Measured SLOWER at BASELINE configs[1] (12.05 vs 11.71 ms per step: the HBM-bound update competes with the input projection
+        # and slows the forward pass's small launches more than it saves at the tail, where Adam already runs beside the closing
+        # reductions), so opt-in.
+        if deferred_adam is None:
+            deferred_adam = os.environ.get("BIST_DEFERRED_ADAM", "0") != "0"
+        self.deferred = bool(deferred_adam) and self.adam_in_step and use_graph
+        self._pending_host = False
 
         params: List[torch.nn.Parameter] = []
         seen = set()
@@ -90,11 +105,29 @@ class Trainer:
                 place(p)
         place(lut)                                        # ... and the shared embedding matrix
         n_prefix_params = len(order)
-        for m in attns:                                   # packed attention weights
-            for j in range(3):
-                place(m.linears[j].weight)
-        for p in params:
-            place(p)
+        # The matrices behind the prefix, grouped into PIECES in the order the forward pass first reads them: piece 0 = everything
+        # outside the layer stacks (input projection, text encoders, generator), piece 1 + l = reasoning / caption / decoder layer l.
+        # Within a piece the packed attention weights come first.  (The deferred optimiser updates piece by piece.)
+        names = {}
+        for nme, p in model.named_parameters():
+            names.setdefault(id(p), nme)
+
+        def piece_of(p) -> int:
+            mt = re.match(r"mutlimodal_decoder\.(?:v_layers|c_layers|layers)\.(\d+)\.", names.get(id(p), ""))
+            return 1 + int(mt.group(1)) if mt else 0
+        units = []                                        # (piece, kind, sequence, [parameters placed back to back])
+        for i, m in enumerate(attns):
+            units.append((piece_of(m.linears[0].weight), 0, i, [m.linears[j].weight for j in range(3)]))
+        packed_ids = {id(q) for u in units for q in u[3]}
+        for i, p in enumerate(params):
+            if id(p) not in placed and id(p) not in packed_ids:
+                units.append((piece_of(p), 1, i, [p]))
+        units.sort(key=lambda u: u[:3])
+        first_of_piece = {}
+        for piece, _, _, ps in units:
+            first_of_piece.setdefault(piece, ps[0])
+            for q in ps:
+                place(q)
 
         offs, n = {}, 0
         packed_w, packed_b = {}, {}
@@ -106,6 +139,10 @@ class Trainer:
             if idx == n_prefix_params - 1:
                 self.n32 = n                               # end of the fp32-accumulated prefix
         self.numel = n
+        starts = sorted(offs[id(q)] for q in first_of_piece.values())
+        assert not starts or starts[0] == self.n32
+        # (lo, hi) of the fp32-accumulated prefix, then of every piece, in flat elements
+        self.pieces = [(0, self.n32)] + [(lo, hi) for lo, hi in zip(starts, starts[1:] + [n]) if hi > lo]
         for m in attns:                                   # a packed member must start 16-byte aligned
             for t in ("bias", "weight"):
                 o0 = offs[id(getattr(m.linears[0], t))]
@@ -125,7 +162,15 @@ class Trainer:
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
         # {lr, 1 - beta1^t, 1 - beta2^t, grad_scale} of the current step, derived ON THE DEVICE from the step counter (drop_ctr) by
         # bist_noam_hyper at the head of the step: no host buffer that a later step could rewrite while this one is still queued
-        self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.hyper = torch.zeros(8, device=dev, dtype=torch.float32)
+        self.hyper[4] = 1.0                   # bist_adam_apply_dev: apply (the deferred form rewrites it at every head)
+        self._dirty = False                   # the gradient buffer holds a gradient no optimiser step consumed (and cleared)
+        self._skip_head_clear = False
+        self.pending = torch.zeros(1, device=dev, dtype=torch.int64)     # deferred optimiser: the step whose update is still to be applied (0: none)
+        self.deferred = self.deferred and dev.type == "cuda"
+        self._adam_stream = torch.cuda.Stream(device=dev) if self.deferred else None
+        if self.deferred:
+            object.__setattr__(model, "_bist_trainer", weakref.ref(self))     # model.eval() / state_dict() flush the pending update
 
         for p in order:
             o, k = offs[id(p)], p.numel()
@@ -180,12 +225,74 @@ class Trainer:
                                      hi - lo, self.hyper.data_ptr(), self.betas[0], self.betas[1], self.eps,
                                      dtype_code(self.compute_dtype), dtype_code(self.compute_dtype), _stream()), "bist_adam_step_dev")
 
-    def _backward_open(self, batch):
+    def _adam_apply(self, lo: int, hi: int) -> None:
+        """bist_adam_apply_dev on flat elements [lo, hi): Adam with ``self.hyper`` (skipped when nothing is pending) + clear of the gradient."""
+        if hi <= lo:
+            return
+        work = None if self.compute_dtype == torch.float32 else self.flat_param
+        gsz = self.flat_grad.element_size()
+        check(lib.bist_adam_apply_dev(self.master.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + gsz * lo, self.m.data_ptr() + 4 * lo,
+                                      self.v.data_ptr() + 4 * lo, (work.data_ptr() + work.element_size() * lo) if work is not None else None,
+                                      hi - lo, self.hyper.data_ptr(), self.betas[0], self.betas[1], self.eps,
+                                      dtype_code(self.compute_dtype), dtype_code(self.compute_dtype), _stream()), "bist_adam_apply_dev")
+
+    def _pending_hyper(self) -> None:
+        check(lib.bist_noam_hyper_pending(self.pending.data_ptr(), self.hyper.data_ptr(), float(self.args.d_model), float(self.factor),
+                                          float(self.warmup), self.betas[0], self.betas[1], 1.0, _stream()), "bist_noam_hyper_pending")
+
+    def flush(self) -> None:
+        """Deferred optimiser: apply the update the last step() left pending (a no-op otherwise).  Called by model.eval() and
+        model.state_dict(); call it before reading parameter tensors directly after a step."""
+        if not self.deferred or not self._pending_host:
+            return
+        self._pending_hyper()
+        for lo, hi in self.pieces:
+            self._adam_apply(lo, hi)
+        self._pending_host = False
+        ops.WEIGHTS_EPOCH += 1
+
+    def _backward_deferred(self, batch):
+        """One replayed step with the deferred optimiser.  Head: the scalars of the pending step, then -- on the optimiser's own
+        stream -- Adam piece by piece (each also clears its gradients), an event after each piece; the forward pass waits for a
+        piece just before it first reads it (Fn.param_gate, called by the model on the main stream).  Tail: backward, closing
+        reductions, pending <- this step."""
+        self._pending_hyper()
+        main, ad = torch.cuda.current_stream(), self._adam_stream
+        ad.wait_stream(main)
+        events = []
+        with torch.cuda.stream(ad):
+            for lo, hi in self.pieces:
+                self._adam_apply(lo, hi)
+                ev = torch.cuda.Event()
+                ev.record(ad)
+                events.append(ev)
+        waited = [0]
+
+        def gate(k: int) -> None:            # the prefix and pieces 0 .. k are final (main stream only)
+            upto = min(len(events), k + 2)
+            while waited[0] < upto:
+                main.wait_event(events[waited[0]])
+                waited[0] += 1
+        if not getattr(self.model, "_bist_param_gates", False):
+            gate(len(events))                 # a model that does not announce its first reads waits for the whole update
+        Fn.PARAM_GATE = gate
+        try:
+            terms = self._backward_open(batch, clear=False, after_forward=lambda: gate(len(events)))
+        finally:
+            Fn.PARAM_GATE = None
+        self._backward_close()
+        self.pending.copy_(self.drop_ctr)
+        return terms
+
+    def _backward_open(self, batch, clear: bool = True, after_forward=None):
         """forward + backward up to the point where every gradient BEHIND the fp32-accumulated prefix (the big matrices, 98 %
         of the elements) is final; the bias / LayerNorm-parameter reductions stay queued for _backward_close()."""
-        self.flat_grad.zero_()
+        if clear:
+            self.flat_grad.zero_()
         self.acc32.zero_()
         loss, terms = self.forward_loss(batch)
+        if after_forward is not None:
+            after_forward()
         ops.COLSUM_QUEUE = []                 # bias gradients: queued by LinearFn.backward, summed in a few launches by _backward_close
         ops.LNGRAD_QUEUE = []                 # LayerNorm gain/offset gradients: likewise
         wg = self._wgrad_stream if (self.wgrad_side_stream and loss.is_cuda) else None
@@ -223,23 +330,29 @@ class Trainer:
         """forward + backward; leaves the complete gradient in ``flat_grad``.  optimizer=True (single rank) also applies
         Adam with the scalars in ``self.hyper``: the big matrices on a side stream BESIDE the closing reductions, the
         prefix of biases / LayerNorm parameters after them."""
+        if optimizer and self.deferred and self.flat_grad.is_cuda:
+            return self._backward_deferred(batch)
         if optimizer:
             check(lib.bist_noam_hyper(self.drop_ctr.data_ptr(), self.hyper.data_ptr(), float(self.args.d_model), float(self.factor),
                                       float(self.warmup), self.betas[0], self.betas[1], 1.0, _stream()), "bist_noam_hyper")
-        terms = self._backward_open(batch)
+        # one rank, optimiser in the step: Adam clears every gradient it consumes (bist_adam_apply_dev), so a REPLAYED step starts from a
+        # clean buffer without a memset of its own (_graph_open clears it when something else left a gradient behind)
+        terms = self._backward_open(batch, clear=not (optimizer and self._skip_head_clear))
         side = None
         if optimizer and self.flat_grad.is_cuda:
             main, side = torch.cuda.current_stream(), Fn.side_stream(0)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._adam_dev(self.n32, self.numel)
+                (self._adam_apply if ADAM_CLEARS else self._adam_dev)(self.n32, self.numel)
         self._backward_close()
         if optimizer:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
-                self._adam_dev(0, self.n32)
+                (self._adam_apply if ADAM_CLEARS else self._adam_dev)(0, self.n32)
             else:
                 self._adam_dev(0, self.numel)
+        else:
+            self._dirty = True
         return terms
 
     # ---- hipGraph path: forward + backward + gradient fold captured once per batch geometry ----------------
@@ -269,8 +382,12 @@ class Trainer:
             with torch.cuda.graph(graph2, capture_error_mode="thread_local"):
                 self._backward_close()
         else:
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                terms = self.backward(batch, optimizer=self.adam_in_step)
+            self._skip_head_clear = self.adam_in_step and self.flat_grad.is_cuda and ADAM_CLEARS
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    terms = self.backward(batch, optimizer=self.adam_in_step)
+            finally:
+                self._skip_head_clear = False
         self._graph, self._graph2, self._graph_key, self._static_batch, self._static_terms = graph, graph2, key, batch, terms
         self._static_src = {}
 
@@ -312,6 +429,9 @@ class Trainer:
             if last is None or last[0] is not src or last[1] != sig:
                 getattr(self._static_batch, f).copy_(src, non_blocking=True)
                 self._static_src[f] = (src, sig)
+        if self._dirty and self.adam_in_step:        # warm-up passes / a backward() without optimiser left a gradient behind
+            self.flat_grad.zero_()
+        self._dirty = False
         self._graph.replay()
         return self._static_terms
 
@@ -322,6 +442,7 @@ class Trainer:
         ops.WEIGHTS_EPOCH += 1               # the parameters change behind autograd's back: derived operands (packed weights) are stale
         if self.adam_in_step:                # the optimiser scalars are derived from drop_ctr inside backward() (bist_noam_hyper)
             terms = self._graph_open(batch) if self.use_graph else self.backward(batch, optimizer=True)
+            self._pending_host = self.deferred
             return {k: v.detach() for k, v in terms.items()}
         work = None if self.compute_dtype == torch.float32 else self.flat_param
         gsz = self.flat_grad.element_size()

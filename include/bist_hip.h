@@ -426,6 +426,16 @@ int bist_noam_hyper(const int64_t* step_ctr, float* hyper, float d_model, float 
                     float grad_scale, void* stream);
 int bist_adam_step_dev(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
                        float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream);
+/* Deferred form: the update of optimiser step t is applied at the HEAD of step t+1, beside its forward pass (the tail of a step is
+ * then the backward pass alone).  bist_noam_hyper_pending reads t = pending[0] (device int64; 0 = nothing pending), writes
+ * hyper[0..4] = {rate(t), 1 - beta1^t, 1 - beta2^t, grad_scale, apply = (t > 0)} and sets pending[0] = 0; the caller sets
+ * pending[0] = t when step t's gradients are complete.  bist_adam_apply_dev is bist_adam_step_dev on 4 elements per thread that
+ * also CLEARS g (the next backward accumulates into zeros; with apply = 0 it only clears): n a multiple of 4, pointers 16-byte
+ * (fp32) / 8-byte (bf16) aligned.  Element for element the same arithmetic as bist_adam_step.                                */
+int bist_noam_hyper_pending(int64_t* pending, float* hyper, float d_model, float factor, float warmup, float beta1, float beta2,
+                            float grad_scale, void* stream);
+int bist_adam_apply_dev(float* p, void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
+                        float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream);
 
 /* dst = cast(src) between f32 and bf16 (n elements). */
 int bist_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, void* stream);

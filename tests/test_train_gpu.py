@@ -531,6 +531,54 @@ def test_trainer_graph_replay_matches_eager(env):
     assert l1[-1] < l1[0]
 
 
+def test_deferred_optimiser_is_the_same_training_run(env):
+    """Trainer(use_graph=True) applies the update of step t at the head of step t+1, beside the forward pass, and on flush():
+    the same losses step for step as with Adam at the end of the step, the same weights after flush(), and the last update is
+    pending (the weights are those of the previous step) until flush() / model.eval() / state_dict()."""
+    import copy
+    import bist_amd.model as M
+    from bist_amd.data.synthetic import synthetic_batch
+    from bist_amd.train import Trainer
+    cfg = O.Cfg(d_model=64, att_h=4, nb_blocks=3, nb_venc_blocks=3, nb_cenc_blocks=3)
+    args = _args(cfg)
+    torch.manual_seed(0)
+    m1 = M.make_model(80, 80, args, ft_sizes=[64]).cuda().eval()
+    m2 = copy.deepcopy(m1)
+    bs = [synthetic_batch(4, T=6, S=9, C=64, Lq=7, Lh=9, Lc=6, Lt=6, vocab=80, seed=s_, dtype=torch.float32) for s_ in (1, 2)]
+    t1 = Trainer(m1, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=True, deferred_adam=False)
+    t2 = Trainer(m2, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=True, deferred_adam=True)
+    assert not t1.deferred and t2.deferred and len(t2.pieces) == 1 + 1 + 3 and t2.pieces[-1][1] == t2.numel
+    assert all(a[1] == b_[0] for a, b_ in zip(t2.pieces, t2.pieces[1:])) and t2.pieces[0][0] == 0
+    l1, l2 = [], []
+    for i in range(6):
+        l1.append(t1.step(bs[i % 2])["out"].item())
+        l2.append(t2.step(bs[i % 2])["out"].item())
+    assert all(abs(a - c) <= 2e-3 * (1 + i) * abs(a) for i, (a, c) in enumerate(zip(l1, l2))), (l1, l2)
+    torch.cuda.synchronize()
+    w1, w2 = t1.master.clone(), t2.master.clone()
+    lag = (w1 - w2).abs().max().item()
+    assert lag > 1e-5 and int(t2.pending.item()) == 6, (lag, t2.pending)          # step 6's update is still pending
+    m2.eval()                                                                    # flushes
+    torch.cuda.synchronize()
+    assert int(t2.pending.item()) == 0 and float(t2.flat_grad.abs().max()) == 0.0
+    # same order of the two parameter layouts is not guaranteed element for element: compare through the parameters
+    p1, p2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    # (key-projection biases have an exactly-zero gradient -- softmax is shift invariant -- so theirs is rounding noise that Adam
+    # normalises into full-size steps of random sign in BOTH runs: left out)
+    keys = [k for k in p1 if not k.endswith("linears.1.bias")]
+    worst = max((p1[k].detach() - p2[k].detach()).abs().max().item() for k in keys)
+    scale = max(p1[k].detach().abs().max().item() for k in keys)
+    assert worst <= 2e-2 * scale, (worst, scale)      # six Adam steps apart by the fp32-atomics order only (see the test above)
+    step = (w2 - t2.master).abs().max().item()
+    assert step > 1e-5                                # and flush() did move the weights
+    t2.flush()                                        # idempotent
+    torch.cuda.synchronize()
+    assert torch.equal(t2.master, t2.master.clone()) and int(t2.pending.item()) == 0
+    l2b = t2.step(bs[0])["out"].item()                # training goes on after a flush
+    l1b = t1.step(bs[0])["out"].item()
+    assert abs(l1b - l2b) <= 2e-2 * abs(l1b), (l1b, l2b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_trainer_reduces_loss(env, dtype):
     import bist_amd.model as M
