@@ -30,6 +30,8 @@ class BistGemm(C.Structure):
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_ctr", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("hint", C.c_int32), ("reserved", C.c_int32),
+        ("ln_gain", C.c_void_p), ("ln_offset", C.c_void_p), ("ln_out", C.c_void_p), ("ln_ld", C.c_int64), ("ln_eps", C.c_float),
+        ("reserved2", C.c_int32),
     ]
 
 
@@ -66,6 +68,7 @@ SIGNATURES = {
     "bist_gemm": (C.c_int, [C.POINTER(BistGemm), _P]),
     "bist_gemm_pair": (C.c_int, [C.POINTER(BistGemm), C.POINTER(BistGemm), _P]),
     "bist_gemm_is_fast": (C.c_int, [C.POINTER(BistGemm)]),
+    "bist_gemm_ln_ok": (C.c_int, [C.POINTER(BistGemm)]),
     "bist_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I64, _I64, _F, _I32, _P]),
     "bist_mha_core_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32,
                                     _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.POINTER(BistDrop), _I32, _P]),

@@ -89,9 +89,12 @@ class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, residual, act, res_map, alpha, drop_p, drop_seed, out_dtype, out_shape=None):
         K = x.shape[-1]
+        ln = getattr(x, "_bist_ln", None)              # x is a pending LayerNorm output: this product normalises the rows itself and fills x
+        if ln is not None:
+            x._bist_ln = None
         x2 = x.reshape(-1, K)
         y = ops.linear(x2, w, bias, act=act, residual=residual, res_map=res_map, alpha=alpha, out_dtype=out_dtype,
-                       drop_p=drop_p, drop_seed=drop_seed)
+                       drop_p=drop_p, drop_seed=drop_seed, ln=ln)
         ctx.save_for_backward(x2, w, y if act == ACT_RELU else None)
         ctx.cfg = (act, res_map, alpha, drop_p, drop_seed, bias is not None, bias.dtype if bias is not None else None,
                    residual is not None, tuple(residual.shape) if residual is not None else None, tuple(x.shape))
@@ -204,6 +207,7 @@ class LinearPairFn(Function):
 
     @staticmethod
     def forward(ctx, x1, w1, b1, x2, w2, b2):
+        ops.ensure_ln(x1); ops.ensure_ln(x2)          # (the paired launch has no LayerNorm prologue)
         xs = (x1.reshape(-1, x1.shape[-1]), x2.reshape(-1, x2.shape[-1]))
         ys, descs = [], []
         for x, w, b in ((xs[0], w1, b1), (xs[1], w2, b2)):
@@ -452,16 +456,16 @@ def _ln_backward(ctx, dy, dres):
 
 class LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, a, b, eps, up_drop=None):
+    def forward(ctx, x, a, b, eps, up_drop=None, lazy=False):
         ctx.save_for_backward(x, a)
         ctx.cfg = (eps, b.dtype)
         ctx.up_drop = up_drop
         ctx.a_dst, ctx.b_dst = getattr(a, "_acc32", None), getattr(b, "_acc32", None)
-        return ops.layernorm(x, a, b, eps)
+        return ops.layernorm(x, a, b, eps, lazy=lazy)
 
     @staticmethod
     def backward(ctx, dy):
-        return _ln_backward(ctx, dy, None) + (None,)
+        return _ln_backward(ctx, dy, None) + (None, None)
 
 
 class LayerNormResFn(Function):
@@ -470,17 +474,17 @@ class LayerNormResFn(Function):
     autograd never launches a separate add for the two uses of x."""
 
     @staticmethod
-    def forward(ctx, x, a, b, eps, up_drop=None):
+    def forward(ctx, x, a, b, eps, up_drop=None, lazy=False):
         ctx.save_for_backward(x, a)
         ctx.cfg = (eps, b.dtype)
         ctx.up_drop = up_drop
         ctx.a_dst, ctx.b_dst = getattr(a, "_acc32", None), getattr(b, "_acc32", None)
         ctx.set_materialize_grads(False)
-        return ops.layernorm(x, a, b, eps), x
+        return ops.layernorm(x, a, b, eps, lazy=lazy), x
 
     @staticmethod
     def backward(ctx, dy, dres):
-        return _ln_backward(ctx, dy, dres) + (None,)
+        return _ln_backward(ctx, dy, dres) + (None, None)
 
 
 class EmbedFn(Function):

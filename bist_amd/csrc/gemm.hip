@@ -48,6 +48,8 @@ struct GemmK {   // device-side argument block (by value)
   int split_k; float* ws;            // split_k > 1: raw fp32 partial tiles go to ws[z][split][M][N]
   int vec_c, vec_r;                  // 16-byte aligned output / residual rows: vector epilogue allowed
   int dbg;                           // BIST_GEMM_DBG ablation aid (0 in production): 1 exit at entry, 2 skip the K loop, 3 skip the epilogue
+  // LayerNorm prologue (gemm_t64_pre_kernel, K = 512 bf16): A rows are normalised in LDS before the products and written to ln_out
+  const char* ln_a; const char* ln_b; char* ln_out; long ln_ld; float ln_eps;
 };
 
 template <typename T> struct Mma;
@@ -869,7 +871,11 @@ template <> struct FragRd<float, true> {                   // [32 K-rows][256 B]
 // own LDS stage (NK x 16 KiB), all DMAs are issued up front, and tile t is consumed as soon as each wave's own
 // share of it has landed (counted vmcnt, 4 DMA instructions per tile per wave) and the barrier has published
 // the other waves' shares: the DRAM latency is paid once.
-template <typename T, typename TO, bool ATR, bool BTR, int NK>
+// LNP (NK = 8, bf16, A rows K-contiguous): the A operand is LayerNorm(A) -- modules.py:28-31: gain * (x - mean) / (std + eps) + offset with
+// the unbiased std over the K = 512 channels -- computed IN the LDS stages once all of them have landed (four threads per row, the
+// arithmetic of layernorm_vec_kernel), instead of by a launch of its own in front of this one; the workgroups of column tiles 0..7
+// each store one 64-channel slice of the normalised rows to ln_out (the weight-gradient product of the backward pass reads them).
+template <typename T, typename TO, bool ATR, bool BTR, int NK, bool LNP = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_t64_pre_kernel(const GemmK g) {
   __shared__ __attribute__((aligned(16))) char l0[2 * T64_BYTES];
   __shared__ __attribute__((aligned(16))) char l1[2 * T64_BYTES];
@@ -893,6 +899,73 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_pre_kernel(const GemmK g) {
 #define PRE_IN(L_, t_) if constexpr ((t_) < NK) { sa.issue(L_, w); sb.issue(L_ + T64_BYTES, w); }
   PRE_IN(l0, 0) PRE_IN(l1, 1) PRE_IN(l2, 2) PRE_IN(l3, 3) PRE_IN(l4, 4) PRE_IN(l5, 5) PRE_IN(l6, 6) PRE_IN(l7, 7)
 #undef PRE_IN
+  if constexpr (LNP) {
+    static_assert(NK == 8 && !ATR && sizeof(T) == 2, "LayerNorm prologue: K = 512 bf16, A rows K-contiguous");
+    __shared__ __attribute__((aligned(16))) uint4 ln_ab[128];             // gain chunks 0..63, offset chunks 64..127
+    uint4 gq = make_uint4(0, 0, 0, 0);
+    if (tid < 128) gq = *reinterpret_cast<const uint4*>((tid < 64 ? g.ln_a : g.ln_b) + (tid & 63) * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every K tile (this wave's share) and the gains
+    if (tid < 128) ln_ab[tid] = gq;
+    __syncthreads();
+    auto stg = [&](int t) -> char* { return t == 0 ? l0 : t == 1 ? l1 : t == 2 ? l2 : t == 3 ? l3 : t == 4 ? l4 : t == 5 ? l5 : t == 6 ? l6 : l7; };
+    const int row = tid >> 2, part = tid & 3, sw = (row >> 1) & 7;          // logical chunk pc of a row sits at physical chunk pc ^ sw; the
+                                                                            // sums run over LOGICAL chunks: the same order for every row position
+    uint4 q[2][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) {
+        q[u][pc] = *reinterpret_cast<const uint4*>(stg(part + 4 * u) + row * ROW_BYTES + ((pc ^ sw) << 4));
+        const unsigned e4[4] = {q[u][pc].x, q[u][pc].y, q[u][pc].z, q[u][pc].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += __builtin_bit_cast(float, e4[e] << 16) + __builtin_bit_cast(float, e4[e] & 0xffff0000u);
+      }
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+    const float mean = sum / 512.f;
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) {
+        const unsigned e4[4] = {q[u][pc].x, q[u][pc].y, q[u][pc].z, q[u][pc].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __builtin_bit_cast(float, e4[e] << 16) - mean, hi = __builtin_bit_cast(float, e4[e] & 0xffff0000u) - mean;
+          ss += lo * lo; ss += hi * hi;
+        }
+      }
+    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
+    const float inv = 1.f / (sqrtf(ss / 511.f) + g.ln_eps);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) {
+        const int lc = (part + 4 * u) * 8 + pc;                             // logical 8-channel chunk of the row
+        const uint4 qa = ln_ab[lc], qb = ln_ab[64 + lc];
+        const unsigned e4[4] = {q[u][pc].x, q[u][pc].y, q[u][pc].z, q[u][pc].w}, a4[4] = {qa.x, qa.y, qa.z, qa.w}, b4[4] = {qb.x, qb.y, qb.z, qb.w};
+        unsigned o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __builtin_bit_cast(float, a4[e] << 16) * (__builtin_bit_cast(float, e4[e] << 16) - mean) * inv + __builtin_bit_cast(float, b4[e] << 16);
+          const float hi = __builtin_bit_cast(float, a4[e] & 0xffff0000u) * (__builtin_bit_cast(float, e4[e] & 0xffff0000u) - mean) * inv +
+                           __builtin_bit_cast(float, b4[e] & 0xffff0000u);
+          const T lo16 = from_f<T>(lo), hi16 = from_f<T>(hi);
+          o4[e] = (unsigned)__builtin_bit_cast(unsigned short, lo16) | ((unsigned)__builtin_bit_cast(unsigned short, hi16) << 16);
+        }
+        *reinterpret_cast<uint4*>(stg(part + 4 * u) + row * ROW_BYTES + ((pc ^ sw) << 4)) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+      }
+    __syncthreads();
+    if (tn < 8 && g.ln_out) {                                              // this workgroup's 64-channel slice of the normalised rows
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int lcl = part * 2 + u;                                       // logical chunk within the slice
+        if (m0 + row < g.M)
+          *reinterpret_cast<uint4*>(g.ln_out + ((long)(m0 + row) * g.ln_ld + tn * 64 + lcl * 8) * 2) =
+              *reinterpret_cast<const uint4*>(stg(tn) + row * ROW_BYTES + ((lcl ^ sw) << 4));
+      }
+    }
+  }
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -1604,7 +1677,19 @@ Plan make_plan(const BistGemm* g) {
 // scripts/bench_gemm_big.py (SWEEP=1 COLD=1): from ~140 tiles of 256x256 the 256-tile kernel is ahead of the 128-tile
 // kernel on every K-contiguous bf16 product of the path (M = 25088: 23.5 vs 29.3 us at K = 512, 53 vs 78 us at K = 2048),
 // below that the finer tiles fill the chip better.
+// The LayerNorm prologue exists in gemm_t64_pre_kernel<NK = 8> only: bf16, K = 512, A rows K-contiguous and 16-byte aligned, unbatched,
+// a launch of at most 256 64x64 tiles (one per CU), N >= 512 so that column tiles 0..7 exist to write ln_out.
+bool ln_fusable(const BistGemm* g, const Plan& p) {
+  if (!(g->ln_gain && g->ln_offset)) return false;
+  static const int off = [] { const char* e = getenv("BIST_GEMM_NO_LN"); return e ? atoi(e) : 0; }();      // tuning aid
+  const long t64s = (long)((g->M + 63) / 64) * ((g->N + 63) / 64);
+  return !off && g->in_dtype == BIST_BF16 && g->K == 512 && g->batch1 == 1 && g->batch2 == 1 && p.fast && p.t64 && !p.atr && p.split == 1 &&
+         t64s <= 256 && g->N >= 512 && g->N % 64 == 0 && !skinny_kind(g) && ((uintptr_t)g->ln_gain % 16 == 0) && ((uintptr_t)g->ln_offset % 16 == 0) &&
+         (!g->ln_out || (((uintptr_t)g->ln_out % 16 == 0) && g->ln_ld % 8 == 0 && g->ln_ld >= 512));
+}
+
 bool use_tile256(const BistGemm* g, const Plan& p) {
+  if (g->ln_gain) return false;
   if (g->in_dtype != BIST_BF16) return false;
   const long big_tiles = (long)((g->M + BIG - 1) / BIG) * ((g->N + BIG - 1) / BIG) * g->batch1 * g->batch2;
   const bool legal = p.fast && !p.atr && !p.btr && g->K % 64 == 0 && g->K >= 128;
@@ -1615,6 +1700,7 @@ bool use_tile256(const BistGemm* g, const Plan& p) {
 
 template <typename T, typename TO>
 int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
+  if (k.ln_a && !ln_fusable(g, make_plan(g))) { bist_set_error("bist_gemm: LayerNorm prologue outside its envelope (bist_gemm_ln_ok)"); return BIST_EINVAL; }
   if (const int sk = skinny_kind(g)) return launch_skinny<T, TO>(g, k, sk, st);
   const Plan p = make_plan(g);
   k.split_k = p.split;
@@ -1668,6 +1754,15 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
     const bool whole_cu = g64.x <= 256 && !no_pre;                        // one workgroup per CU: 128+ KiB of LDS is free
     const bool whole = g->K % bk64 == 0 && whole_cu;
     const dim3 g64s((unsigned)(g64.x * p.split));                 // in-launch split-K: `split` neighbouring workgroups per tile
+    if (k.ln_a) {                                                  // LayerNorm prologue: only the all-in-flight K = 512 kernel has it
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        if (!(ln_fusable(g, p) && whole && nk64 == 8)) { bist_set_error("bist_gemm: LayerNorm prologue outside its envelope (bist_gemm_ln_ok)"); return BIST_EINVAL; }
+        if (p.btr) hipLaunchKernelGGL((gemm_t64_pre_kernel<T, TO, false, true, 8, true>), g64, block, 0, st, k);
+        else hipLaunchKernelGGL((gemm_t64_pre_kernel<T, TO, false, false, 8, true>), g64, block, 0, st, k);
+        BIST_LAUNCH_CHECK("bist_gemm(64-tile, LayerNorm prologue)");
+        return BIST_OK;
+      } else { bist_set_error("bist_gemm: LayerNorm prologue needs bf16 operands"); return BIST_EINVAL; }
+    }
 #define GO64(ATR_, BTR_)                                                                                  \
   do {                                                                                                    \
     if (p.split > 1) hipLaunchKernelGGL((gemm_t64_ring_kernel<T, TO, ATR_, BTR_>), g64s, block, 0, st, k);             \
@@ -1708,6 +1803,13 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int bist_gemm_ln_ok(const BistGemm* g) {
+  if (!g || !g->ln_gain) return 0;
+  const Plan p = make_plan(g);
+  static const int no_pre = [] { const char* e = getenv("BIST_GEMM_NO_PRE"); return e ? atoi(e) : 0; }();
+  return ln_fusable(g, p) && !no_pre ? 1 : 0;
+}
+
 extern "C" int bist_gemm_is_fast(const BistGemm* g) {
   if (!g) return 0;
   if (skinny_kind(g)) return 3;
@@ -1741,6 +1843,8 @@ int fill_gemmk(const BistGemm* g, GemmK& k) {
   k.drop_p = g->drop_p; k.drop_seed = g->drop_seed; k.drop_ctr = (const unsigned long long*)g->drop_ctr;
   k.tiles_m = (g->M + BM - 1) / BM; k.tiles_n = (g->N + BN - 1) / BN;
   k.split_k = 1; k.ws = nullptr;
+  BIST_REQUIRE((g->ln_gain == nullptr) == (g->ln_offset == nullptr), "bist_gemm: LayerNorm prologue needs gain and offset");
+  k.ln_a = (const char*)g->ln_gain; k.ln_b = (const char*)g->ln_offset; k.ln_out = (char*)g->ln_out; k.ln_ld = g->ln_ld; k.ln_eps = g->ln_eps;
   { static const int dbg = [] { const char* e = getenv("BIST_GEMM_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
   {
     const long so = g->out_dtype == BIST_BF16 ? 2 : 4;
@@ -1780,6 +1884,7 @@ int launch_pair(const BistGemm* a, const BistGemm* b, GemmK& ka, GemmK& kb, int 
 
 extern "C" int bist_gemm_pair(const BistGemm* a, const BistGemm* b, void* stream) {
   BIST_REQUIRE(a && b, "bist_gemm_pair: null descriptor");
+  BIST_REQUIRE(!a->ln_gain && !b->ln_gain, "bist_gemm_pair: no LayerNorm prologue in the paired launch");
   GemmK ka, kb;
   if (const int rc = fill_gemmk(a, ka)) return rc;
   if (const int rc = fill_gemmk(b, kb)) return rc;

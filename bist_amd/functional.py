@@ -38,16 +38,29 @@ def linear_pair(x1: Tensor, w1: Tensor, b1: Optional[Tensor], x2: Tensor, w2: Te
     return y1.view(*x1.shape[:-1], -1), y2.view(*x2.shape[:-1], -1)
 
 
-def layernorm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
-    return ag.LayerNormFn.apply(x, a, b, eps, getattr(x, "_bist_drop", None)) if _grad() else ops.layernorm(x, a, b, eps)
+def _tag_ln(y: Tensor, x: Tensor, a: Tensor, b: Tensor, eps: float) -> Tensor:
+    y._bist_ln = (x.detach().reshape(-1, x.shape[-1]), a.detach(), b.detach(), eps)       # (set on the tensor the CALLER holds)
+    return y
 
 
-def layernorm_res(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6):
+def layernorm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6, lazy: bool = False) -> Tensor:
+    """lazy: the caller hands the result to exactly ONE ``linear`` and nothing else reads it -- the LayerNorm then runs as that
+    projection's prologue (ops.layernorm / bist_gemm's LayerNorm prologue) instead of a launch of its own."""
+    lazy = lazy and ops.ln_lazy_ok(x, a, b)
+    if _grad():
+        y = ag.LayerNormFn.apply(x, a, b, eps, getattr(x, "_bist_drop", None), lazy)
+        return _tag_ln(y, x, a, b, eps) if lazy else y
+    return ops.layernorm(x, a, b, eps, lazy=lazy)
+
+
+def layernorm_res(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6, lazy: bool = False):
     """(LN(x), x) for x + sublayer(LN(x)): hand the second value to the residual add, so that its gradient
-    is folded into the LayerNorm backward kernel instead of a separate accumulation pass."""
+    is folded into the LayerNorm backward kernel instead of a separate accumulation pass.  lazy: see layernorm."""
     if _grad() and x.requires_grad:
-        return ag.LayerNormResFn.apply(x, a, b, eps, getattr(x, "_bist_drop", None))
-    return layernorm(x, a, b, eps), x
+        lazy = lazy and ops.ln_lazy_ok(x, a, b)
+        y, r = ag.LayerNormResFn.apply(x, a, b, eps, getattr(x, "_bist_drop", None), lazy)
+        return (_tag_ln(y, x, a, b, eps) if lazy else y), r
+    return layernorm(x, a, b, eps, lazy=lazy), x
 
 
 def head_fold(q: Tensor, wk: Tensor, h: int, alpha: float) -> Tensor:

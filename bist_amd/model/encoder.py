@@ -91,7 +91,7 @@ class VidEncoder8(nn.Module):
 
 def _self_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Tensor, mask: Optional[Tensor]) -> Tensor:
     """x + MHA(LN(x), LN(x), LN(x), mask): A0/A3 and every other self-attention sublayer."""
-    xn, xr = sub.norm.with_residual(x)
+    xn, xr = sub.norm.with_residual(x, lazy=True)        # one consumer: the packed Q/K/V projection
     ctx = attn.context(xn, xn, xn, mask)
     return Fn.linear(ctx, attn.linears[3].weight, attn.linears[3].bias, residual=xr, out_shape=x.shape, **Fn.drop_args(sub))
 
@@ -105,7 +105,7 @@ def _cross_attention(sub: SublayerConnection, attn: MultiHeadedAttention, x: Ten
 
 def _feed_forward(sub: SublayerConnection, ff: PositionwiseFeedForward, x: Tensor) -> Tensor:
     """x + FFN(LN(x)); the residual is the second GEMM's epilogue."""
-    xn, xr = sub.norm.with_residual(x)
+    xn, xr = sub.norm.with_residual(x, lazy=True)        # one consumer: w_1
     return ff(xn, residual=xr, out_drop=Fn.drop_args(sub))
 
 
@@ -138,7 +138,7 @@ class VidEncoderLayer4(nn.Module):
         if permuted:
             direction = 1
         Lq, h, dk = x.shape[1], attn.h, attn.d_k
-        xn, xr = sub.norm.with_residual(x)
+        xn, xr = sub.norm.with_residual(x, lazy=True)
         q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)                           # [B*Lq, d]
         qf = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq * h, d)   # rows (i, hh)
         if v is None:           # inference: value projection, scores, softmax, P.V, output projection and residual in one launch
@@ -162,7 +162,7 @@ class VidEncoderLayer4(nn.Module):
         x = _self_attention(self.sublayer[si], self.attn[ai], x_in, query_mask)
         attn, sub = self.attn[ai + 1], self.sublayer[si + 1]
         B, Lq, d = x.shape
-        xn, _ = sub.norm.with_residual(x)
+        xn, _ = sub.norm.with_residual(x, lazy=True)
         q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)
         return x, Fn.head_fold(q, attn.linears[1].weight, attn.h, 1.0 / math.sqrt(attn.d_k)).view(B, Lq * attn.h, d)
 
@@ -192,7 +192,7 @@ class VidEncoderLayer4(nn.Module):
         attn, sub = self.attn[ai], self.sublayer[si]
         B, G, Lq, d = y.shape
         h, dk = attn.h, attn.d_k
-        xn, xr = sub.norm.with_residual(x)
+        xn, xr = sub.norm.with_residual(x, lazy=True)
         q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)
         q2f = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq, h, d)
         py, rowsum = Fn.st_stage2(q2f, y, gmask, h=h, drop=Fn.attn_drop(attn))

@@ -37,9 +37,10 @@ class LayerNorm(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         return Fn.layernorm(x, self.a_2, self.b_2, self.eps)
 
-    def with_residual(self, x: Tensor):
-        """(LN(x), x'): use x' as the residual operand of the sublayer's last GEMM (see Fn.layernorm_res)."""
-        return Fn.layernorm_res(x, self.a_2, self.b_2, self.eps)
+    def with_residual(self, x: Tensor, lazy: bool = False):
+        """(LN(x), x'): use x' as the residual operand of the sublayer's last GEMM (see Fn.layernorm_res).
+        lazy: LN(x) goes to exactly one ``Fn.linear`` and nowhere else -- it then runs as that projection's prologue."""
+        return Fn.layernorm_res(x, self.a_2, self.b_2, self.eps, lazy=lazy)
 
 
 class SublayerConnection(nn.Module):

@@ -111,7 +111,20 @@ typedef struct BistGemm {
    * P0 56 vs 78 us against the 128-tile kernel), with 160-row tiles when M pads better to 160 than to 256.            */
   int32_t hint;
   int32_t reserved;
+  /* Optional LayerNorm PROLOGUE (all NULL / 0 = none): the product is taken of LayerNorm(A) = ln_gain * (a - mean) / (std + ln_eps)
+   * + ln_offset per row (unbiased std over the K channels, eps outside the root: LayerNorm.forward, model/modules.py:28-31), i.e. the
+   * `sublayer(self.norm(x))` of SublayerConnection (modules.py:44) with the norm folded into the sublayer's first projection instead
+   * of a launch of its own.  ln_out (nullable) receives the normalised rows [M][ln_ld] in in_dtype (the weight-gradient product of
+   * the backward pass reads them).  Envelope (bist_gemm_ln_ok): bf16, K = 512, A rows K-contiguous, unbatched, N a multiple of 64
+   * and >= 512, at most 256 tiles of 64x64; outside it bist_gemm returns BIST_EINVAL (the caller runs bist_layernorm_fwd first). */
+  const void* ln_gain;
+  const void* ln_offset;
+  void* ln_out;
+  int64_t ln_ld;
+  float ln_eps;
+  int32_t reserved2;
 } BistGemm;
+int bist_gemm_ln_ok(const BistGemm* g);       /* 1 if bist_gemm(g) will run g's LayerNorm prologue */
 #define BIST_GEMM_TILE256 2
 #define BIST_GEMM_SPLIT64 4   /* hint bit: cut a long K of a small 64-tile product over neighbouring workgroups and combine
                                * them inside the launch (agent-scope release / ticket / acquire); measured slower than the

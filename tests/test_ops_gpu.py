@@ -534,3 +534,37 @@ def test_pack_frag_rows_layout(ops):
         c0 = 64 * kp + 16 * kg + 8 * e
         assert torch.equal(got[nt, kp, e, lane], w[16 * nt + x, c0:c0 + 8]), (nt, kp, e, lane)
     assert torch.equal(got.reshape(-1).sort().values, w.reshape(-1).sort().values)          # a permutation
+
+
+@pytest.mark.parametrize("M,N,act,res", [(320, 512, 0, True), (320, 1536, 0, False), (320, 2048, 1, False), (400, 512, 0, True), (37, 512, 0, False)])
+def test_layernorm_prologue_of_the_projection(M, N, act, res, monkeypatch):
+    """bist_gemm's LayerNorm prologue (K = 512, bf16): x.W^T of LayerNorm(x) with the norm inside the GEMM, against
+    bist_layernorm_fwd followed by the plain GEMM; also the normalised rows it stores (ln_out) and the pending-tensor plumbing
+    of ops.layernorm(lazy=True) -> ops.linear."""
+    from bist_amd import ops
+    from bist_amd._lib import lib
+    monkeypatch.setattr(ops, "LAZY_LN", True)          # (opt-in: BIST_LAZY_LN=1)
+    torch.manual_seed(M + N)
+    x = (torch.randn(M, 512) * 1.7 + 0.3).cuda().bfloat16()
+    a = (1 + 0.2 * torch.randn(512)).cuda().bfloat16()
+    b = (0.1 * torch.randn(512)).cuda().bfloat16()
+    w = (torch.randn(N, 512) * 0.05).cuda().bfloat16()
+    bias = (torch.randn(N) * 0.1).cuda().bfloat16()
+    r = torch.randn(M, N).cuda().bfloat16() if res else None
+    assert ops.ln_lazy_ok(x, a, b)
+    want_n = ops.layernorm(x, a, b, 1e-6)
+    want = ops.linear(want_n, w, bias, act=act, residual=r)
+    pend = ops.layernorm(x, a, b, 1e-6, lazy=True)
+    assert getattr(pend, "_bist_ln", None) is not None
+    lib.bist_launch_count_reset()
+    got = ops.linear(pend, w, bias, act=act, residual=r)
+    assert getattr(pend, "_bist_ln", None) is None
+    torch.cuda.synchronize()
+    # the normalised rows: same arithmetic, another summation order -> at most one bf16 step on a few elements
+    dn = (pend.float() - want_n.float()).abs()
+    assert dn.max().item() <= 2 ** -6 * max(1.0, want_n.float().abs().max().item()) and (dn > 0).float().mean().item() < 0.02, (dn.max(), (dn > 0).float().mean())
+    d = (got.float() - want.float()).abs().max().item()
+    assert d <= 3e-2 * max(1.0, want.float().abs().max().item()), d
+    # pending output consumed by something that is not a fusable projection: materialised on demand
+    pend2 = ops.layernorm(x, a, b, 1e-6, lazy=True)
+    assert torch.equal(ops.ensure_ln(pend2), want_n)
