@@ -1727,6 +1727,28 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
       if (!stamps && force_fr >= 5 && force_fr <= 8) fr = force_fr;
       k.tiles_m = (g->M + 32 * fr - 1) / (32 * fr); k.tiles_n = (g->N + BIG - 1) / BIG;
       k.split_k = 1; k.ws = nullptr;
+      // Wave quantisation: one tile per CU per round, so 784 tiles (P0 at B = 64: 392 row blocks x 2) are 3 full rounds plus a
+      // fourth with 16 of 256 CUs busy.  When at least two rounds are full and the last one would be less than 1/8 full, its row
+      // blocks leave this launch and go through bist_gemm as a product of their own (few rows: finer tiles / split K fill the
+      // chip).  Only for products whose epilogue does not depend on the global row index (no dropout, no row-mapped residual).
+      static const int no_tail = [] { const char* e = getenv("BIST_GEMM_NO_TAIL"); return e ? atoi(e) : 0; }();      // tuning aid
+      const long tiles_all = (long)k.tiles_m * k.tiles_n;
+      const long tail_tiles = tiles_all % 256;
+      if (!no_tail && !stamps && g->batch1 == 1 && g->batch2 == 1 && tiles_all >= 512 && tail_tiles > 0 && tail_tiles <= 32 &&
+          tail_tiles % k.tiles_n == 0 && g->drop_p == 0.f && g->res_outer == 0 && g->M % (32 * fr) == 0) {
+        const int tail_blocks = (int)(tail_tiles / k.tiles_n);
+        const long rows_main = (long)(k.tiles_m - tail_blocks) * 32 * fr;
+        BistGemm tail = *g;
+        const long si = 2, so = g->out_dtype == BIST_BF16 ? 2 : 4;
+        tail.A = (const char*)g->A + rows_main * g->a_rs * si;
+        tail.C = (char*)g->C + rows_main * g->ldc * so;
+        if (g->residual) tail.residual = (const char*)g->residual + rows_main * g->ldr * so;
+        tail.M = g->M - (int)rows_main;
+        tail.hint = 0;
+        if (const int rc = bist_gemm(&tail, (void*)st)) return rc;
+        k.M = (int)rows_main;
+        k.tiles_m -= tail_blocks;
+      }
       const dim3 gb((unsigned)((long)k.tiles_m * k.tiles_n * g->batch1 * g->batch2));
       if (stamps) {                                  // in-kernel stamps into the workspace
         k.ws = (float*)g->workspace;

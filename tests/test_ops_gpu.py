@@ -568,3 +568,22 @@ def test_layernorm_prologue_of_the_projection(M, N, act, res, monkeypatch):
     # pending output consumed by something that is not a fusable projection: materialised on demand
     pend2 = ops.layernorm(x, a, b, 1e-6, lazy=True)
     assert torch.equal(ops.ensure_ln(pend2), want_n)
+
+
+def test_gemm_256_tile_launch_sheds_its_underfilled_last_round():
+    """[100352 x 2048] x [2048 -> 512] (P0 at B = 64) is 784 tiles of 256 x 256 = 3 rounds of 256 CUs + 16 tiles: the last 8 row blocks
+    go through bist_gemm as a product of their own.  Every row against a float64 reference of sampled rows (also across the seam)."""
+    from bist_amd import ops
+    torch.manual_seed(5)
+    M, K, N = 100352, 2048, 512
+    x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.03).bfloat16()
+    bias = (torch.randn(N, device="cuda") * 0.1).bfloat16()
+    res = torch.randn(M, N, device="cuda").bfloat16()
+    y = ops.linear(x, w, bias, residual=res)
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, 64), torch.arange(98304 - 64, 98304 + 64), torch.arange(M - 64, M), torch.randint(0, M, (256,))]).cuda()
+    want = x[rows].double() @ w.double().t() + bias.double() + res[rows].double()
+    err = (y[rows].double() - want).abs().max().item()
+    assert err <= 2e-2 * max(1.0, want.abs().max().item()), err
+    assert torch.isfinite(y.float()).all()
