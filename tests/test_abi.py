@@ -31,11 +31,29 @@ def test_version_and_error_string_without_gpu():
     assert isinstance(_lib.lib.bist_last_error(), bytes)
 
 
-def test_gemm_struct_layout_matches_header():
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of the by-reference structs as a C compiler sees include/bist_hip.h against the ctypes mirrors."""
+    import os
+    import subprocess
     from bist_amd import _lib
-    # values printed by a C program including include/bist_hip.h (sizeof, offsetof)
-    assert ctypes.sizeof(_lib.BistGemm) == 256
-    assert _lib.BistGemm.a_rs.offset == 56 and _lib.BistGemm.alpha.offset == 184 and _lib.BistGemm.drop_seed.offset == 216
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"BistGemm": ["a_rs", "alpha", "drop_seed", "workspace", "hint", "ln_gain", "ln_ld", "ln_eps"],
+               "BistDecLayer": ["Wqkv", "Wo", "cmask", "W1", "Lk", "LkP"], "BistDrop": ["seed", "ctr"]}
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "bist_hip.h"', "int main(void) {"]
+    for st, fields in structs.items():
+        src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        src += [f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));' for f in fields]
+    src += ["  return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(c), "-o", str(exe)], check=True)
+    seen = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for st, fields in structs.items():
+        cls = getattr(_lib, st)
+        assert ctypes.sizeof(cls) == int(seen[st]), st
+        for f in fields:
+            assert getattr(cls, f).offset == int(seen[f"{st}.{f}"]), (st, f)
 
 
 def test_ops_refuse_cpu_tensors():
