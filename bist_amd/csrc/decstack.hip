@@ -38,8 +38,10 @@ struct DecArgs {
   const DecLayerDev* layers; int nl;
   const bf16_t* x_in;            // [R][512]
   bf16_t* xbuf[2];               // residual stream, ping-pong [RP][512]
-  bf16_t* qbuf; bf16_t* kbuf;    // [RP][512]
-  bf16_t* vT;                    // [512][LkS]   (LkS = self keys padded to a multiple of 32)
+  bf16_t* qbuf;                  // [RP][512]
+  bf16_t* kcache; bf16_t* vcache; // self-attention keys / values of the rows seen so far, per layer [64 slots][512] (layer l at + l * 64 * 512):
+                                 // this call's row r is slot slot0 + r; self_mask [R][LkS] names the slots a row attends
+  int slot0;
   bf16_t* hbuf;                  // [RP][2048]
   const unsigned char* smask;    // [R][LkS] self-attention mask (1 = attend)
   int R, LkS;
@@ -230,13 +232,10 @@ __device__ __forceinline__ void partial_product_glob(f32x4 (&acc)[4][4], const u
 }
 
 // sum the four waves' partial tiles through LDS and hand every (tile, row tile) to `epi(t, mt, v)`: lane (x, lg) gets the 4 consecutive
-// columns 4*lg .. 4*lg+3 of row x -- or, for tiles with transposed(t), to `epi_t(t, mt, v)`: lane (x, lg) gets column x of the four
-// consecutive rows 4*lg .. 4*lg+3 (element (column c, row r) of a tile sits in lane (r, c/4), component c%4)
-template <int NTILES, class TP, class EPI, class EPIT>
-__device__ __forceinline__ void reduce_tiles(f32x4 (&acc)[4][4], char* part, int MTR, int w, int lane, TP transposed, EPI epi, EPIT epi_t) {
+// columns 4*lg .. 4*lg+3 of row x
+template <int NTILES, class EPI>
+__device__ __forceinline__ void reduce_tiles(f32x4 (&acc)[4][4], char* part, int MTR, int w, int lane, EPI epi) {
   f32x4* pw = reinterpret_cast<f32x4*>(part);
-  const float* pf = reinterpret_cast<const float*>(part);
-  const int x = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int t = 0; t < NTILES; ++t)
 #pragma unroll
@@ -249,32 +248,23 @@ __device__ __forceinline__ void reduce_tiles(f32x4 (&acc)[4][4], char* part, int
     for (int mt = 0; mt < 4; ++mt) {
       if (mt >= MTR || ((t * 4 + mt) & 3) != w) continue;
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (transposed(t)) {
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += pf[(((o * 16 + t * 4 + mt) * 64) + (x >> 2) * 16 + 4 * lg + j) * 4 + (x & 3)];
-        epi_t(t, mt, v);
-      } else {
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-          const f32x4 u = pw[(o * 16 + t * 4 + mt) * 64 + lane];
-          v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
-        }
-        epi(t, mt, v);
+      for (int o = 0; o < 4; ++o) {
+        const f32x4 u = pw[(o * 16 + t * 4 + mt) * 64 + lane];
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
       }
+      epi(t, mt, v);
     }
   __syncthreads();
-}
-template <int NTILES, class EPI>
-__device__ __forceinline__ void reduce_tiles(f32x4 (&acc)[4][4], char* part, int MTR, int w, int lane, EPI epi) {
-  reduce_tiles<NTILES>(acc, part, MTR, w, lane, [](int) { return false; }, epi, [](int, int, const f32x4&) {});
 }
 
 // attention core of ONE (head, 16-row tile) unit, written to the context rows in global memory (bf16 [rows][512], write-through):
 // Q [RP][512], K [LkP][512] rows, V^T [512][LkP], mask[row * mrs + key] (mrs = 0: per key only; rows padded to LkP bytes, 4-byte
 // aligned), Lk valid keys.  The four waves each compute the scores and the masked softmax of the unit (16 rows x <= 64 keys, in
 // registers) and ONE 16-channel tile of P.V (wave w: channels 64*head + 16*w ..).  All loads of the unit are requested together.
+// VROW: the values lie row-major [key][512] like the keys (the self-attention cache: rows arrive one decode step at a time) and are
+// fetched as 4-byte words (two channels of one key); otherwise transposed V^T [512][LkP] (the per-turn memories), 8-byte loads.
+template <bool VROW>
 __device__ __forceinline__ void core_unit(const bf16_t* Q, const bf16_t* K, const bf16_t* VT, const unsigned char* mask, int mrs, int Lk, int LkP,
                                           bf16_t* ctx, int R, int head, int mt, int w, int x, int kg) {
   const int KT = LkP >> 4;                                  // key tiles (2 or 4)
@@ -295,9 +285,22 @@ __device__ __forceinline__ void core_unit(const bf16_t* Q, const bf16_t* K, cons
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if (2 * j >= KT) break;
-    const bf16_t* vp = VT + (long)(head * 64 + 16 * w + x) * LkP + 32 * j + 4 * kg;
-    vv[j][0] = ld8(vp);
-    vv[j][1] = ld8(vp + 16);
+    if constexpr (VROW) {
+      const int ch = head * 64 + 16 * w + x;
+      unsigned e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {                          // K slot u: key 32j + 16 (u / 4) + 4 kg + u % 4
+        const int key = 32 * j + 16 * (u >> 2) + 4 * kg + (u & 3);
+        const unsigned wd = __hip_atomic_load((gu32*)(VT + (long)key * D + (ch & ~1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e[u] = (ch & 1) ? (wd >> 16) : (wd & 0xffffu);
+      }
+      vv[j][0] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+      vv[j][1] = make_uint2(e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    } else {
+      const bf16_t* vp = VT + (long)(head * 64 + 16 * w + x) * LkP + 32 * j + 4 * kg;
+      vv[j][0] = ld8(vp);
+      vv[j][1] = ld8(vp + 16);
+    }
   }
   f32x4 s[4];
   float mx = -INFINITY;
@@ -377,19 +380,16 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
         partial_product<3, 4>(acc, wr, a_img, MTR, w);
         load_w<1, 4>(wr, Lp->Wo[0], D, wg * 16, w, x, kg);                 // the next product's weights fly over the barriers
         const bf16_t* bqkv = Lp->bqkv;
-        reduce_tiles<3>(acc, part, MTR, w, lane, [&](int t) { return wg * 48 + 16 * t >= 1024; },
-          [&](int t, int mt, const f32x4& v) {
-            const int col0 = wg * 48 + 16 * t;                             // column of the packed [q; k; v] output
-            float bv[4]; bias4(bqkv, col0, bv);
-            const float o[4] = {v[0] + bv[0], v[1] + bv[1], v[2] + bv[2], v[3] + bv[3]};
-            if (col0 < 512) store_rows(a.qbuf, D, col0, mt, o);
-            else store_rows(a.kbuf, D, col0 - 512, mt, o);
-          },
-          [&](int t, int mt, const f32x4& v) {                             // V^T[channel][key rows 16*mt + 4*kg ..] (padding keys carry P = 0)
-            const int ch = wg * 48 + 16 * t - 1024 + x;
-            const float bv = (float)bqkv[1024 + ch];
-            st8(a.vT + (long)ch * a.LkS + 16 * mt + 4 * kg, make_uint2(pack2(v[0] + bv, v[1] + bv), pack2(v[2] + bv, v[3] + bv)));
-          });
+        bf16_t* const kc = a.kcache + (long)l * (64 * D) + (long)a.slot0 * D;     // this call's rows: slots slot0 ..
+        bf16_t* const vc = a.vcache + (long)l * (64 * D) + (long)a.slot0 * D;
+        reduce_tiles<3>(acc, part, MTR, w, lane, [&](int t, int mt, const f32x4& v) {
+          const int col0 = wg * 48 + 16 * t;                               // column of the packed [q; k; v] output
+          float bv[4]; bias4(bqkv, col0, bv);
+          const float o[4] = {v[0] + bv[0], v[1] + bv[1], v[2] + bv[2], v[3] + bv[3]};
+          if (col0 < 512) store_rows(a.qbuf, D, col0, mt, o);
+          else if (col0 < 1024) store_rows(kc, D, col0 - 512, mt, o);
+          else store_rows(vc, D, col0 - 1024, mt, o);
+        });
       } else if (j < 4) {
         partial_product<1, 4>(acc, wr, a_img, MTR, w);
         load_w<1, 4>(wr, Lp->Wo[j], D, wg * 16, w, x, kg);
@@ -416,8 +416,8 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
       if (j < 4) {
         const int head = wg & 7, mt = wg >> 3;
         if (mt < MTR) {
-          if (j == 0) core_unit(a.qbuf, a.kbuf, a.vT, a.smask, a.LkS, R, a.LkS, ctx, R, head, mt, w, x, kg);
-          else core_unit(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], 0, Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, head, mt, w, x, kg);
+          if (j == 0) core_unit<true>(a.qbuf, a.kcache + (long)l * (64 * D), a.vcache + (long)l * (64 * D), a.smask, a.LkS, a.slot0 + R, a.LkS, ctx, R, head, mt, w, x, kg);
+          else core_unit<false>(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], 0, Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, head, mt, w, x, kg);
         }
         grid_barrier(a.sync, ++phase * NWG, a.dbg);
         STAMP();
@@ -471,11 +471,11 @@ extern "C" int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk
 extern "C" int64_t bist_decoder_layer_desc_bytes(void) { return (int64_t)sizeof(DecLayerDev); }
 
 extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, const void* x_in, void* xbuf0, void* xbuf1, void* qbuf,
-                                      void* kbuf, void* vT, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, void* sync,
-                                      int32_t dtype, void* stream) {
-  BIST_REQUIRE(layers_dev && x_in && xbuf0 && xbuf1 && qbuf && kbuf && vT && hbuf && self_mask && sync, "bist_decoder_stack_fwd: null pointer");
-  BIST_REQUIRE(dtype == BIST_BF16 && n_layers >= 1 && R >= 1 && R <= 64 && LkS >= R && LkS <= 64 && LkS % 32 == 0,
-               "bist_decoder_stack_fwd: bf16, 1..64 rows, self keys padded to 32 or 64");
+                                      void* kcache, void* vcache, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, int32_t slot0,
+                                      void* sync, int32_t dtype, void* stream) {
+  BIST_REQUIRE(layers_dev && x_in && xbuf0 && xbuf1 && qbuf && kcache && vcache && hbuf && self_mask && sync, "bist_decoder_stack_fwd: null pointer");
+  BIST_REQUIRE(dtype == BIST_BF16 && n_layers >= 1 && R >= 1 && R <= 64 && slot0 >= 0 && slot0 + R <= 64 && LkS >= slot0 + R && LkS <= 64 && LkS % 32 == 0,
+               "bist_decoder_stack_fwd: bf16, 1..64 rows, slots slot0 .. slot0 + R - 1 inside the LkS (32 or 64) key slots");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static bool attr_set = false;
   if (!attr_set) {
@@ -485,8 +485,8 @@ extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, 
     }
     attr_set = true;
   }
-  DecArgs a{(const DecLayerDev*)layers_dev, n_layers, (const bf16_t*)x_in, {(bf16_t*)xbuf0, (bf16_t*)xbuf1}, (bf16_t*)qbuf, (bf16_t*)kbuf,
-            (bf16_t*)vT, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, nullptr};
+  DecArgs a{(const DecLayerDev*)layers_dev, n_layers, (const bf16_t*)x_in, {(bf16_t*)xbuf0, (bf16_t*)xbuf1}, (bf16_t*)qbuf, (bf16_t*)kcache,
+            (bf16_t*)vcache, slot0, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, nullptr};
   if (const char* e = getenv("BIST_DECSTACK_DBG")) a.dbg = atoi(e);
   if (const char* e = getenv("BIST_DECSTACK_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10));
   hipLaunchKernelGGL(decstack_kernel, dim3(NWG), dim3(NT), 128 * 1024, st, a);

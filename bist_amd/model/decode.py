@@ -13,8 +13,10 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+import os
 import types
 
+from .. import functional as Fn
 from ..data.batch import subsequent_mask
 
 BATCH_HYPOTHESES = True      # False: one model.decode call per hypothesis, like the reference
@@ -37,6 +39,8 @@ def _turn_for_rows(batch, ft, n, cache):
         b.fts = None
         f = {k: _rows(ft[k], n) for k in ("encoded_query", "encoded_his", "encoded_cap") if ft.get(k) is not None}
         f["_bist_reasoning"] = [{k: _rows(v, n) for k, v in layer.items()} for layer in ft["_bist_reasoning"]]
+        if "_bist_turn" in ft:
+            f["_bist_turn"] = ft["_bist_turn"]
         hit = cache[n] = (b, f)
     return hit
 
@@ -54,28 +58,41 @@ class _TurnBuffers:
         for name in ("query", "his", "cap", "query_mask", "his_mask", "cap_mask"):
             v = getattr(bn, name, None)
             setattr(self.b, name, v.clone() if v is not None else None)
-        self.f = {k: v.clone() for k, v in fn.items() if k != "_bist_reasoning"}
+        self.f = {k: v.clone() for k, v in fn.items() if k not in ("_bist_reasoning", "_bist_turn")}
         self.f["_bist_reasoning"] = [{k: v.clone() for k, v in layer.items()} for layer in fn["_bist_reasoning"]]
         self.loaded = None               # the (bn, fn) pair currently held
 
     def load(self, bn, fn):
         if self.loaded is fn:
             return
+        dsts, srcs = [], []
         for name in ("query", "his", "cap", "query_mask", "his_mask", "cap_mask"):
             v = getattr(bn, name, None)
             if v is not None:
-                getattr(self.b, name).copy_(v)
+                dsts.append(getattr(self.b, name)); srcs.append(v)
         for k, v in fn.items():
-            if k != "_bist_reasoning":
-                self.f[k].copy_(v)
+            if k not in ("_bist_reasoning", "_bist_turn"):
+                dsts.append(self.f[k]); srcs.append(v)
         for dst, src in zip(self.f["_bist_reasoning"], fn["_bist_reasoning"]):
             for k, v in src.items():
-                dst[k].copy_(v)
+                dsts.append(dst[k]); srcs.append(v)
+        # ~40 small tensors per turn: grouped by dtype into multi-tensor copies (one launch per group instead of one per tensor)
+        groups = {}
+        for d_, s_ in zip(dsts, srcs):
+            groups.setdefault((d_.dtype, s_.dtype), ([], []))
+            groups[(d_.dtype, s_.dtype)][0].append(d_); groups[(d_.dtype, s_.dtype)][1].append(s_.expand_as(d_) if s_.shape != d_.shape else s_)
+        for (dd, sd), (ds, ss) in groups.items():
+            if dd == sd and len(ds) > 1:
+                torch._foreach_copy_(ds, ss)
+            else:
+                for d_, s_ in zip(ds, ss):
+                    d_.copy_(s_)
         self.loaded = fn
         if self.decoder is not None:          # the static buffers now hold a new turn: re-project the memories' keys / values
             dec = self.decoder
             if dec._fused_decode_ok(self.b, self.f, self.f["encoded_query"][:, :1]):
-                dec.prepare_decode_cache(self.b, self.f, src=fn["_bist_reasoning"])
+                # (the turn's first step -- the replayed encode + first-step graph -- has usually projected them already: same turn token)
+                dec.prepare_decode_cache(self.b, self.f, src=fn["_bist_reasoning"], turn=fn.get("_bist_turn"))
 
 
 def _descending(lp_vec, k):
@@ -144,6 +161,55 @@ def _graph_step(model, bn, fn, trg, train_args):
     return out.cpu().numpy()
 
 
+INCREMENTAL = os.environ.get("BIST_INCREMENTAL_DECODE", "1") != "0"      # tuning aid: 0 = every step recomputes all prefix rows, like the reference
+
+
+def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args):
+    """One decode step for the NEW position only (``pos``) of n hypotheses: the decoder stack's persistent kernel appends the rows'
+    self-attention keys / values to its per-layer pools at slots slot0 .. and attends, per hypothesis, the slots named by mask_np
+    [n, LkS] (its ancestors' rows from the earlier steps and its own).  The decoder is causal, so the earlier positions' rows are
+    what a recompute of the whole prefix (decode.py:62-66) would produce again.  One hipGraph per (n, pos)."""
+    dev = bn.query.device
+    n = new_tokens.shape[0]
+    LkS = mask_np.shape[1]
+    geom = (n, tuple(bn.query.shape), tuple(bn.his.shape), None if bn.cap is None else tuple(bn.cap.shape), fn["encoded_query"].dtype,
+            len(fn["_bist_reasoning"]))
+    store = model.__dict__.setdefault("_bist_step_graphs", {})
+    tb = store.get(("turn",) + geom)
+    if tb is None:
+        tb = store[("turn",) + geom] = _TurnBuffers(bn, fn, getattr(model, "mutlimodal_decoder", None))
+    tb.load(bn, fn)
+    key = ("incr", pos, slot0, LkS) + geom
+    g = store.get(key)
+    if g is None:
+        strg = torch.zeros((n, 1), dtype=torch.long, device=dev)
+        smask = torch.zeros((n, LkS), dtype=torch.uint8, device=dev)
+        sb = types.SimpleNamespace(**vars(tb.b))
+        sb.trg, sb.trg_mask = strg, None
+
+        def run():
+            f = dict(tb.f)
+            f["_bist_incr"] = (slot0, smask)
+            f2 = model.decode(sb, f, pos)
+            return model.generator(f2, sb, train_args).float()
+        strg.copy_(new_tokens)
+        smask.copy_(torch.from_numpy(mask_np))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            out = run()
+        g = store[key] = (graph, strg, smask, out)
+    graph, strg, smask, out = g
+    strg.copy_(new_tokens)
+    smask.copy_(torch.from_numpy(mask_np))
+    graph.replay()
+    return out.cpu().numpy()
+
+
 _TURN_FIELDS = ("query", "his", "cap", "fts", "query_mask", "his_mask", "cap_mask", "temporal_mask")
 
 
@@ -177,15 +243,23 @@ def _graph_first_step(model, batch, start_symbol, train_args):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
             f2, out = run()
-        g = store[("first",) + geom] = (graph, sb, f2, out)
-    graph, sb, f2, out = g
+        fused = "_bist_fused_first" in f2
+        g = store[("first",) + geom] = (graph, sb, f2, out, fused)
+    graph, sb, f2, out, _ = g
     for f in _TURN_FIELDS:
         v = getattr(batch, f, None)
         if v is not None:
             getattr(sb, f).copy_(v)
     graph.replay()
-    ft = {k: v for k, v in f2.items() if k != "_bist_reasoning"}
+    ft = {k: v for k, v in f2.items() if k not in ("_bist_reasoning", "_bist_incr", "_bist_fused_first")}
     ft["_bist_reasoning"] = [dict(layer) for layer in f2["_bist_reasoning"]]
+    # the replay projected this turn's memories into the decoder's key / value caches (and left position 0's self-attention
+    # keys / values in slot 0 of the pools): the step graphs of this turn need not project them again
+    ft["_bist_turn"] = object()
+    dec = getattr(model, "mutlimodal_decoder", None)
+    if hasattr(dec, "select_decode_cache"):
+        # True: the replayed first step ran the decoder layers through the persistent kernel (position 0 sits in slot 0 of its pools)
+        ft["_bist_pool_ready"] = bool(g[4]) and dec.select_decode_cache(ft, ft["_bist_turn"])
     return ft, out.cpu().numpy()
 
 
@@ -204,6 +278,12 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
     hyplist = [([], 0.0, torch.full((1, 1), start_symbol, dtype=torch.long))]
     best_state, comp_hyplist = None, []
     rows_cache = {}
+    dec = getattr(model, "mutlimodal_decoder", None)
+    # one decode step at a time: position l of hypothesis j is computed ONCE, at step l, into slot l * beam + j of the decoder
+    # kernel's self-attention pools; a hypothesis carries the slots of its prefix (``_bist_slots`` on its token tensor)
+    incremental = bool(use_graphs and INCREMENTAL and lp_first is not None and max_len * beam <= 64 and dec is not None
+                       and getattr(dec, "FUSED_DECODE", False) and Fn.FUSED_DECODE and ft.get("_bist_pool_ready", False))
+    hyplist[0][2]._bist_slots = ()
     for l in range(max_len):
         new_hyplist, argmin = [], 0
         lp_rows = lp_first if l == 0 else None
@@ -213,7 +293,14 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
             n = len(hyplist)
             bn, fn = _turn_for_rows(batch, ft, n, rows_cache)
             trg = torch.cat([st for _, _, st in hyplist], dim=0)
-            if use_graphs:
+            if incremental and all(len(getattr(st, "_bist_slots", ())) == l for _, _, st in hyplist):
+                slot0 = l * beam
+                mask_np = np.zeros((n, 32 if slot0 + n <= 32 else 64), dtype=np.uint8)
+                for j, (_, _, st) in enumerate(hyplist):
+                    mask_np[j, list(st._bist_slots) + [slot0 + j]] = 1
+                lp_rows = _graph_step_incr(model, bn, fn, trg[:, -1:], l, slot0, mask_np, train_args)     # [n, 1, V]
+            elif use_graphs:
+                incremental = False              # (the pools no longer hold every hypothesis's prefix)
                 lp_rows = _graph_step(model, bn, fn, trg, train_args)                        # [n, 1, V]
             else:
                 trg = trg.to(dev)
@@ -225,6 +312,7 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
                 step["encoded_tgt"] = f2["encoded_tgt"][:, -1:].contiguous()
                 lp_rows = model.generator(step, bn, train_args).float().cpu().numpy()    # [n, 1, V]
         for idx, (out, lp, st) in enumerate(hyplist):
+            own_slots = tuple(getattr(st, "_bist_slots", ())) + (l * beam + idx,)       # the rows of this hypothesis's prefix, this step's included
             if lp_rows is not None:
                 lp_vec = np.squeeze(lp_rows[idx:idx + 1] + lp)
             else:
@@ -248,12 +336,14 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
                 if len(new_hyplist) == beam:
                     if new_hyplist[argmin][1] < new_lp:
                         new_st = torch.cat([st, torch.full((1, 1), int(o), dtype=torch.long)], dim=1)
+                        new_st._bist_slots = own_slots
                         new_hyplist[argmin] = (out + [o], new_lp, new_st)
                         argmin = min(enumerate(new_hyplist), key=lambda e: e[1][1])[0]
                     else:
                         break
                 else:
                     new_st = torch.cat([st, torch.full((1, 1), int(o), dtype=torch.long)], dim=1)
+                    new_st._bist_slots = own_slots
                     new_hyplist.append((out + [o], new_lp, new_st))
                     if len(new_hyplist) == beam:
                         argmin = min(enumerate(new_hyplist), key=lambda e: e[1][1])[0]

@@ -146,33 +146,38 @@ class MultimodalDecoder8(nn.Module):
         st = self.__dict__.get("_bist_dec_state")
         if st is None or st["x0"].device != dev or st["x0"].dtype != dtype:
             z = lambda *shape, dt=dtype: torch.zeros(*shape, device=dev, dtype=dt)
-            st = {"x0": z(64, 512), "x1": z(64, 512), "q": z(64, 512), "k": z(64, 512), "vT": z(512, 64), "h": z(64, 2048),
-                  "sync": z(8, dt=torch.int32), "masks": {}, "kv": None, "desc": None, "desc_key": None}
+            nl = len(self.layers)
+            st = {"x0": z(64, 512), "x1": z(64, 512), "q": z(64, 512), "kc": z(nl, 64, 512), "vc": z(nl, 64, 512), "h": z(64, 2048),
+                  "sync": z(8, dt=torch.int32), "masks": {}, "kv": None}
             self.__dict__["_bist_dec_state"] = st
         return st
 
-    def prepare_decode_cache(self, b, ft, src=None) -> None:
+    def prepare_decode_cache(self, b, ft, src=None, turn=None) -> None:
         """Keys and (transposed) values of the three memories of every decoder layer for this turn: they depend on the encoded
         history / query and on the layer's fused modalities only, not on the prefix (the unfused path recomputes them in every
         decode step).  All hypothesis rows of a turn hold the same memories: row 0 is used."""
         dev, dtype = ft["encoded_his"].device, ft["encoded_his"].dtype
         st = self._decode_state(dev, dtype)
         cache = ft["_bist_reasoning"]
-        if src is not None and st["kv"] is not None and st["kv"].get("src") is src:
-            st["kv"]["owner"] = cache        # another row-count view of the turn already projected: same values
+        if st["kv"] is not None and ((src is not None and st["kv"].get("src") is src) or (turn is not None and st["kv"].get("turn") is turn)):
+            st["kv"]["owner"] = cache        # another view of a turn whose memories are already projected: same values
             return
         nl = len(self.layers)
         mems = lambda l: (ft["encoded_his"][0], ft["encoded_query"][0], cache[l]["encoded_ft"][0])
         masks = (b.his_mask[0].reshape(-1), b.query_mask[0].reshape(-1), b.query_mask[0].reshape(-1))
         Lks = [m.shape[0] for m in mems(0)]
         LkPs = [32 if k <= 32 else 64 for k in Lks]
-        kv = st["kv"]
-        if kv is None or kv["Lks"] != Lks or kv["nl"] != nl:
-            kv = {"Lks": Lks, "nl": nl,
-                  "K": [[torch.zeros(LkPs[c], 512, device=dev, dtype=dtype) for c in range(3)] for _ in range(nl)],
-                  "VT": [[torch.zeros(512, LkPs[c], device=dev, dtype=dtype) for c in range(3)] for _ in range(nl)],
-                  "mask": [torch.zeros(LkPs[c], device=dev, dtype=torch.uint8) for c in range(3)]}
-            st["kv"], st["desc"] = kv, None
+        # one set of cache buffers per dialogue geometry, kept for the decoder's lifetime: captured step graphs of that geometry hold
+        # their addresses (and the descriptor's), so they are never freed or re-used for another geometry
+        kvs = st.setdefault("kv_by_len", {})
+        kv = kvs.get((tuple(Lks), nl))
+        if kv is None:
+            kv = kvs[(tuple(Lks), nl)] = {
+                "Lks": Lks, "nl": nl,
+                "K": [[torch.zeros(LkPs[c], 512, device=dev, dtype=dtype) for c in range(3)] for _ in range(nl)],
+                "VT": [[torch.zeros(512, LkPs[c], device=dev, dtype=dtype) for c in range(3)] for _ in range(nl)],
+                "mask": [torch.zeros(LkPs[c], device=dev, dtype=torch.uint8) for c in range(3)]}
+        st["kv"] = kv
         for c in range(3):
             kv["mask"][c][:Lks[c]].copy_(masks[c].to(torch.uint8))
         for l, layer in enumerate(self.layers):
@@ -181,15 +186,31 @@ class MultimodalDecoder8(nn.Module):
                 kvp = Fn.linear(mem, w, bias)                                                 # [Lk, 1024]
                 kv["K"][l][c][:Lks[c]].copy_(kvp[:, :512])
                 kv["VT"][l][c][:, :Lks[c]].copy_(kvp[:, 512:].t())
-        kv["owner"], kv["src"] = cache, src  # the reasoning results these keys / values were projected from (one list per turn)
+        kv["owner"], kv["src"], kv["turn"] = cache, src, turn  # the reasoning results these keys / values were projected from (one list per turn)
+
+    def select_decode_cache(self, ft, turn) -> bool:
+        """A captured graph has just projected this turn's memories (it wrote the cache buffers of ``ft``'s dialogue geometry): make
+        those buffers the current ones and mark them as holding turn ``turn``.  False if that geometry has no buffers yet."""
+        st = self.__dict__.get("_bist_dec_state")
+        if st is None or not st.get("used"):
+            return False
+        Lks = (ft["encoded_his"].shape[1], ft["encoded_query"].shape[1], ft["_bist_reasoning"][0]["encoded_ft"].shape[1])
+        kv = st.get("kv_by_len", {}).get((Lks, len(self.layers)))
+        if kv is None:
+            return False
+        st["kv"] = kv
+        kv["turn"], kv["src"], kv["owner"] = turn, None, None
+        return True
 
     def _decode_desc(self, st):
-        """Device array of BistDecLayer descriptors (rebuilt when the parameters or the cache buffers change)."""
+        """Device array of BistDecLayer descriptors for the current cache buffers (one per dialogue geometry; its CONTENT is rebuilt in
+        place when the parameters change, so its address stays valid for captured graphs)."""
         kv = st["kv"]
         ps = [p for layer in self.layers for p in layer.parameters()]
-        key = ops.weights_key(*ps) + (id(kv),)
-        if st["desc"] is not None and st["desc_key"] == key:
-            return st["desc"]
+        key = ops.weights_key(*ps)
+        hit = kv.get("desc")
+        if hit is not None and hit[0] == key:
+            return hit[1]
         descs = (BistDecLayer * len(self.layers))()
         keep = []
         for l, layer in enumerate(self.layers):
@@ -209,8 +230,10 @@ class MultimodalDecoder8(nn.Module):
             dsc.W1, dsc.b1 = layer.ff.w_1.weight.data_ptr(), layer.ff.w_1.bias.data_ptr()
             dsc.W2, dsc.b2 = layer.ff.w_2.weight.data_ptr(), layer.ff.w_2.bias.data_ptr()
         assert C.sizeof(BistDecLayer) == lib.bist_decoder_layer_desc_bytes()
-        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(st["x0"].device)
-        st["desc"], st["desc_key"], st["desc_keep"] = raw, key, keep
+        host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+        raw = hit[1] if hit is not None else torch.empty(host.numel(), dtype=torch.uint8, device=st["x0"].device)
+        raw.copy_(host)
+        kv["desc"], kv["desc_keep"] = (key, raw), keep
         return raw
 
     def _self_mask(self, st, b, n: int, Lt: int, LkS: int):
@@ -242,9 +265,18 @@ class MultimodalDecoder8(nn.Module):
         if st["kv"] is None or st["kv"].get("owner") is not ft["_bist_reasoning"]:
             self.prepare_decode_cache(b, ft)
         st["used"] = True
-        R = n * Lt
-        LkS = 32 if R <= 32 else 64
-        out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(R, d).contiguous(), st, self._self_mask(st, b, n, Lt, LkS), R, LkS)
+        incr = ft.get("_bist_incr")
+        if incr is not None:
+            # one decode step at a time (decode.py's step graphs): x holds only the NEW position's rows [n, 1, d]; the keys / values of
+            # the earlier positions are in the per-layer pools from the earlier steps of this turn; incr = (first free slot, mask
+            # [n, LkS] over the pool slots: a hypothesis attends its ancestors' slots and its own)
+            slot0, mask = incr
+            assert Lt == 1 and mask.shape[0] == n
+            out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(n, d).contiguous(), st, mask, n, mask.shape[1], slot0)
+        else:
+            R = n * Lt
+            LkS = 32 if R <= 32 else 64
+            out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(R, d).contiguous(), st, self._self_mask(st, b, n, Lt, LkS), R, LkS)
         ft.update(ft["_bist_reasoning"][-1])
         return out.view(n, Lt, d)
 
@@ -287,6 +319,9 @@ class MultimodalDecoder8(nn.Module):
         if torch.is_grad_enabled():
             ft["_bist_mem_fan"] = {k: Fn.Fan(ft[k], len(self.layers)) for k in ("encoded_his", "encoded_query") if k in ft}
         dec_pending = None
+        # inference with the reasoning cache: the decoder layers run AFTER the reasoning layers, as the persistent launch of later decode
+        # steps (bist_decoder_stack_fwd) -- which also leaves this call's self-attention keys / values in the per-layer pools
+        fused_after = cache is not None and self._fused_decode_ok(b, ft, x)
         # Training: the value projections of layer l+1 (two big GEMMs that depend on the video tensor only) are issued on the
         # caption stream ahead of decoder layer l, and awaited through an event just before the stage-1 cores; their
         # backward products then run on that stream under the small-kernel chains of the two directions.
@@ -331,7 +366,9 @@ class MultimodalDecoder8(nn.Module):
                 cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})
             if values_ahead and l + 1 < len(self.layers):
                 issue_values(l + 1)
-            if fork_cap and Fn.PIPELINE_DECODER:
+            if fused_after:
+                pass                             # inference: all decoder layers as one launch after the loop (they need only the cached results)
+            elif fork_cap and Fn.PIPELINE_DECODER:
                 # The decoder layer needs this layer's fused memory, the NEXT reasoning layer does not need the decoder
                 # layer: it goes to the caption stream (ahead of the next caption layer) and runs under the next
                 # layer's visual reasoning; the join at the end of that layer (or below) waits for it.
@@ -343,6 +380,10 @@ class MultimodalDecoder8(nn.Module):
                 x = layer(b, ft, x)                                                          # :182
         if dec_pending is not None:
             torch.cuda.current_stream().wait_stream(dec_pending)
+        if fused_after:
+            ft["_bist_reasoning"] = cache
+            x = self._decode_fused(b, ft, x)
+            ft["_bist_fused_first"] = True       # (decode.py: position 0 of the turn is in the kernel's pools)
         ft.pop("_bist_vft_fan", None)
         ft.pop("_bist_vftp_fan", None)
         ft.pop("_bist_mem_fan", None)

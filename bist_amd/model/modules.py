@@ -224,10 +224,10 @@ class PositionalEncoding(nn.Module):
         return Fn.add(x, pe)
 
 
-def embed_with_position(seq: nn.Sequential, ids: Tensor) -> Tensor:
-    """Fused ``nn.Sequential(Embeddings, PositionalEncoding)`` (mtn.py:79-82) in one kernel."""
+def embed_with_position(seq: nn.Sequential, ids: Tensor, pos0: int = 0) -> Tensor:
+    """Fused ``nn.Sequential(Embeddings, PositionalEncoding)`` (mtn.py:79-82) in one kernel; the ids are positions pos0 .. of their sequences."""
     emb, pos = seq[0], seq[1]
     drop = None
     if pos.training and pos.dropout.p > 0:                 # dropout after the position is added (modules.py:144)
         drop = (float(pos.dropout.p), Fn.next_seed())
-    return Fn.embed_pe(ids, emb.lut.weight, pos.table(), drop)
+    return Fn.embed_pe(ids, emb.lut.weight, pos.table()[pos0:] if pos0 else pos.table(), drop)

@@ -83,11 +83,12 @@ class MTN(nn.Module):
     def encode_vid(self, b, ft):
         return self.vid_encoder(b, ft)
 
-    def decode(self, b, ft):
-        return self.multimodal_decode_text(b, ft)
+    def decode(self, b, ft, pos0: int = 0):
+        """pos0 (beam search, one decode step at a time): ``b.trg`` holds only the tokens at positions pos0 .. of the prefixes."""
+        return self.multimodal_decode_text(b, ft, pos0)
 
-    def multimodal_decode_text(self, b, ft):
-        ft["encoded_tgt"] = embed_with_position(self.tgt_embed, b.trg)     # not layer-normed (mtn.py:58-59)
+    def multimodal_decode_text(self, b, ft, pos0: int = 0):
+        ft["encoded_tgt"] = embed_with_position(self.tgt_embed, b.trg, pos0)     # not layer-normed (mtn.py:58-59)
         return self.mutlimodal_decoder(b, ft, ft["encoded_tgt"])
 
 

@@ -240,9 +240,16 @@ int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const uint8_t* kma
  *               and per memory c = 0 (history), 1 (query), 2 (fused modalities) the keys K = mem W_k^T + b_k as [LkP][512] and
  *               the values TRANSPOSED, V^T [512][LkP] (LkP = Lk rounded up to 32 or 64, padding zero), computed once per turn
  *               (they do not depend on the prefix), with the key mask [LkP] (uint8, 1 = attend; -1e9 REPLACES a masked score)
- *   x_in [R][512] the embedded prefix rows (hypothesis-major); xbuf0 / xbuf1 [64][512], qbuf / kbuf [64][512], vT [512][LkS],
- *   hbuf [64][2048]: caller-owned scratch, ZERO when first handed over; self_mask [R][LkS] uint8: row (j,t) may attend key (j',t')
- *   iff j' == j and trg_mask allows (data/dataset.py:101-105); LkS = R rounded up to 32 or 64; sync: 32 bytes = 8 words the caller zeroes ONCE: words 0, 1
+ *   x_in [R][512] the embedded rows of this call; xbuf0 / xbuf1 [64][512], qbuf [64][512], hbuf [64][2048]: caller-owned scratch, ZERO
+ *   when first handed over.  kcache / vcache [n_layers][64][512]: the self-attention keys / values (row-major) of every row the
+ *   stack has seen in this turn, one 64-slot pool per layer; this call's row r is written to slot slot0 + r, and self_mask [R][LkS]
+ *   (uint8, 1 = attend) says which slots < slot0 + R a row attends (LkS = 32 or 64 >= slot0 + R; -1e9 REPLACES a masked score).
+ *     - all prefix rows in one call (decode.py:62-66 as written): slot0 = 0, R = hypotheses x prefix length, self_mask = the
+ *       block-diagonal causal mask of data/dataset.py:101-105;
+ *     - one decode step at a time: R = hypotheses (only the NEW position's rows), slot0 = the first free slot, self_mask row j = the
+ *       slots of hypothesis j's ancestors and its own -- the keys / values of earlier positions are the ones earlier calls left in
+ *       the pool (row-wise the same arithmetic: the decoder is causal).
+ *   sync: 32 bytes = 8 words the caller zeroes ONCE: words 0, 1
  *   the barrier's arrival / exit counters (the kernel leaves them zero for the next call -- no memset node per call), word 4 a STICKY
  *   error flag to read after a turn: non-zero = a barrier timed out (the 32 workgroups were not co-resident), the results of that call are invalid.
  * Result: the rows of xbuf[(5 * n_layers - 1) % 2] (the residual stream ping-pongs between the two buffers, five writes per layer).  Returns BIST_EINVAL outside the envelope (bist_decoder_stack_ok).
@@ -260,8 +267,8 @@ typedef struct BistDecLayer {
 int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk_max, int32_t dtype);
 int64_t bist_decoder_layer_desc_bytes(void);
 int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, const void* x_in, void* xbuf0, void* xbuf1, void* qbuf,
-                           void* kbuf, void* vT, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, void* sync,
-                           int32_t dtype, void* stream);
+                           void* kcache, void* vcache, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, int32_t slot0,
+                           void* sync, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 2 of both directions (encoder.py:125-134 / 152-165): query position (b,i) attends,

@@ -287,3 +287,35 @@ def test_fused_decoder_stack_matches_the_layer_by_layer_path(hip, n, Lt):
     err = (outs[True] - outs[False]).abs().max().item()
     assert err <= 6e-2, err                                         # layer-normed outputs, bf16 storage between every operation in both
     assert torch.isfinite(outs[True]).all()
+
+
+def test_incremental_beam_search_equals_full_prefix_recompute(hip):
+    """Beam search with one decode step at a time (the persistent decoder kernel keeps every computed row's self-attention keys /
+    values in its per-layer pools; a hypothesis attends its ancestors' slots) against the reference's form (decode.py:62-66: every
+    step recomputes the whole prefix of every hypothesis), bf16, d_model = 512: same n-best token lists, scores within bf16 noise
+    (the keys are summed in slot order instead of (hypothesis, position) order)."""
+    import bist_amd.model.decode as D
+    from bist_amd.model.decode import beam_search_decode
+    M, Batch = hip
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=3, nb_venc_blocks=3, nb_cenc_blocks=3)
+    V, C = 300, 256
+    model, _ = build_model(M, cfg, V, C, torch.bfloat16)
+    outs = {}
+    for seed in (31, 32):
+        ob = O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=seed)
+        for incr in (False, True):
+            D.INCREMENTAL = incr
+            try:
+                with torch.no_grad():
+                    for _ in range(2):                 # second turn: replayed graphs, pools reused
+                        hyps, best = beam_search_decode(model, to_batch(Batch, ob, torch.bfloat16), 12, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID,
+                                                        beam=5, penalty=1.0, nbest=5, train_args=_args(cfg))
+            finally:
+                D.INCREMENTAL = True
+            outs[(seed, incr)] = hyps
+        a, b = outs[(seed, False)], outs[(seed, True)]
+        assert len(a) == len(b) and len(a) > 0
+        assert [list(map(int, x[0])) for x in a] == [list(map(int, x[0])) for x in b], seed
+        assert max(abs(float(x[1]) - float(y[1])) for x, y in zip(a, b)) <= 5e-2, seed
+    store = model.__dict__.get("_bist_step_graphs", {})
+    assert any(k[0] == "incr" for k in store if isinstance(k, tuple)), "the incremental step graphs were not used"
