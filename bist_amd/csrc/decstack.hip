@@ -82,8 +82,11 @@ __device__ __forceinline__ float rows_sum(float v) {
 // key / value caches are never written inside the launch and use plain loads.
 typedef __attribute__((address_space(1))) unsigned long long gu64;       // shared words and payload: GLOBAL accesses, never flat
 typedef __attribute__((address_space(1))) unsigned gu32;
-__device__ __forceinline__ void st8(void* p, uint2 v) {
-  __hip_atomic_store((gu64*)p, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// wt = false (all 32 workgroups verified to sit on ONE XCD, see the kernel): a plain store -- the XCD's L2 is the common point of its
+// CUs, the line stays there for the readers' sc1 (L1-bypassing) loads instead of going out to memory and coming back
+__device__ __forceinline__ void st8(void* p, uint2 v, bool wt) {
+  if (wt) __hip_atomic_store((gu64*)p, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *(gu64*)p = ((unsigned long long)v.y << 32) | v.x;
 }
 // sc1 loads (L2-served, never from this CU's L1): EVERY load of handed-off bytes is one of these, so no acquire fence either
 __device__ __forceinline__ uint4 ld16(const void* base, long byte_off) {          // base wave-uniform
@@ -266,7 +269,7 @@ __device__ __forceinline__ void reduce_tiles(f32x4 (&acc)[4][4], char* part, int
 // fetched as 4-byte words (two channels of one key); otherwise transposed V^T [512][LkP] (the per-turn memories), 8-byte loads.
 template <bool VROW>
 __device__ __forceinline__ void core_unit(const bf16_t* Q, const bf16_t* K, const bf16_t* VT, const unsigned char* mask, int mrs, int Lk, int LkP,
-                                          bf16_t* ctx, int R, int head, int mt, int w, int x, int kg) {
+                                          bf16_t* ctx, int R, int head, int mt, int w, int x, int kg, bool wt) {
   const int KT = LkP >> 4;                                  // key tiles (2 or 4)
   const int row = 16 * mt + x, rowc = min(row, R - 1);
   uint4 qf[2], kf[2][4];
@@ -337,7 +340,7 @@ __device__ __forceinline__ void core_unit(const bf16_t* Q, const bf16_t* K, cons
                                 pack2(s[2 * j + 1][0] * inv, s[2 * j + 1][1] * inv), pack2(s[2 * j + 1][2] * inv, s[2 * j + 1][3] * inv));
     o = mfma16(vf, pf, o);                                  // O^T[channel 4lg+r][row x]
   }
-  if (row < R) st8(ctx + (long)row * D + head * 64 + 16 * w + 4 * kg, make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3])));
+  if (row < R) st8(ctx + (long)row * D + head * 64 + 16 * w + 4 * kg, make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3])), wt);
 }
 
 __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
@@ -345,7 +348,17 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
   char* img = smem;                       // [64][1024 B]
   char* part = smem + 64 * 1024;          // 4 waves x 16 (tile, row tile) x 64 lanes x 16 B
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kg = lane >> 4;
-  const int wg = blockIdx.x, R = a.R, RP = (R + 15) & ~15, MTR = RP >> 4;
+  // The grid is 8 x NWG blocks of which every 8th works: blocks are dealt round-robin over the 8 XCDs (observed, not promised), so
+  // the NWG workers land on ONE XCD and can hand data over through its L2.  That is VERIFIED at run time (each worker publishes its
+  // HW_REG_XCC_ID before the first barrier); until then, and for good if the ids differ, payload stores are write-through (wt).
+  if (blockIdx.x & 7) return;
+  const int wg = blockIdx.x >> 3, R = a.R, RP = (R + 15) & ~15, MTR = RP >> 4;
+  bool wt = true;
+  __shared__ unsigned same_xcd;
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 15u;          // HW_REG_XCC_ID[3:0]
+    __hip_atomic_fetch_or((gu32*)a.sync + 2, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   unsigned phase = 0;
   int nst = 0;
 #define STAMP() do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && nst < 128) a.stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
   // row-major bf16 store of a reduced tile: lane (x = row, lg = kg) holds columns col0 + 4*kg .. +3
   auto store_rows = [&](bf16_t* out, int ld, int col0, int mt, const float (&v)[4]) {
     const int row = 16 * mt + x;
-    if (row < R) st8(out + (long)row * ld + col0 + 4 * kg, make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3])));
+    if (row < R) st8(out + (long)row * ld + col0 + 4 * kg, make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3])), wt);
   };
   auto bias4 = [&](const bf16_t* b, int col0, float (&bv)[4]) {
     const uint2 q = *reinterpret_cast<const uint2*>(b + col0 + 4 * kg);
@@ -411,13 +424,19 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
         });
       }
       grid_barrier(a.sync, ++phase * NWG, a.dbg);
+      if (phase == 1) {                    // every worker's XCC id is in: one bit set = one XCD = plain payload stores from here on
+        if (tid == 0) same_xcd = __builtin_popcount(__hip_atomic_load((gu32*)a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
+        __syncthreads();
+        wt = !(same_xcd && !(a.dbg & 4));
+        if (tid == 0 && wg == 0) __hip_atomic_store((gu32*)a.sync + 5, wt ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (readable: which mode ran)
+      }
       STAMP();
       // ---------------- C(j): the attention core, one (head, 16-row tile) unit per workgroup ----------------
       if (j < 4) {
         const int head = wg & 7, mt = wg >> 3;
         if (mt < MTR) {
-          if (j == 0) core_unit<true>(a.qbuf, a.kcache + (long)l * (64 * D), a.vcache + (long)l * (64 * D), a.smask, a.LkS, a.slot0 + R, a.LkS, ctx, R, head, mt, w, x, kg);
-          else core_unit<false>(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], 0, Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, head, mt, w, x, kg);
+          if (j == 0) core_unit<true>(a.qbuf, a.kcache + (long)l * (64 * D), a.vcache + (long)l * (64 * D), a.smask, a.LkS, a.slot0 + R, a.LkS, ctx, R, head, mt, w, x, kg, wt);
+          else core_unit<false>(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], 0, Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, head, mt, w, x, kg, wt);
         }
         grid_barrier(a.sync, ++phase * NWG, a.dbg);
         STAMP();
@@ -458,6 +477,7 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
     if (__hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NWG - 1) {
       __hip_atomic_store(sync + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -489,7 +509,7 @@ extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, 
             (bf16_t*)vcache, slot0, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, nullptr};
   if (const char* e = getenv("BIST_DECSTACK_DBG")) a.dbg = atoi(e);
   if (const char* e = getenv("BIST_DECSTACK_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10));
-  hipLaunchKernelGGL(decstack_kernel, dim3(NWG), dim3(NT), 128 * 1024, st, a);
+  hipLaunchKernelGGL(decstack_kernel, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
   BIST_LAUNCH_CHECK("bist_decoder_stack_fwd");
   return BIST_OK;
 }
