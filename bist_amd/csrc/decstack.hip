@@ -125,15 +125,15 @@ __device__ __forceinline__ uint4 img_frag(const char* img, int mt, int ks, int x
   return *reinterpret_cast<const uint4*>(img + (mt * 16 + x) * 1024 + (((4 * ks + kg) ^ x) << 4));
 }
 
-// LN_s(x) of all rows into the image (rows >= R zero): wave w takes rows 16w .. 16w+15, sixteen lanes per row (32 channels each), four
-// rows per pass; all 16 row loads of a lane are in flight together
+// LN_s(x) of all rows into the image (rows >= R zero): the RP padded rows are dealt evenly to the four waves (RP / 4 each), sixteen lanes
+// per row (32 channels each), four rows per pass; all row loads of a lane are in flight together
 __device__ __forceinline__ void layernorm_to_image(const bf16_t* x, const bf16_t* ga, const bf16_t* gb, char* img, int R, int RP, int w, int lane) {
-  if (w * 16 >= RP) return;
-  const int sub = lane & 15, rq = lane >> 4;
+  const int sub = lane & 15, rq = lane >> 4, MTR = RP >> 4, row0 = w * (RP >> 2);
   uint4 q[4][4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int row = w * 16 + 4 * p + rq;
+    if (p >= MTR) break;
+    const int row = row0 + 4 * p + rq;
 #pragma unroll
     for (int c = 0; c < 4; ++c) q[p][c] = ld16(x, (long)min(row, R - 1) * (D * 2) + (sub * 4 + c) * 16);
   }
@@ -142,7 +142,8 @@ __device__ __forceinline__ void layernorm_to_image(const bf16_t* x, const bf16_t
   for (int c = 0; c < 4; ++c) { qa[c] = reinterpret_cast<const uint4*>(ga)[sub * 4 + c]; qb[c] = reinterpret_cast<const uint4*>(gb)[sub * 4 + c]; }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int row = w * 16 + 4 * p + rq;
+    if (p >= MTR) break;
+    const int row = row0 + 4 * p + rq;
     const bool live = row < R;
     float v[32];
     float sum = 0.f;

@@ -275,7 +275,9 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
         ft = model.encode(batch)
     # the hypotheses' token prefixes live on the HOST (the reference keeps them as device tensors and pays two tiny device
     # launches per candidate: decode.py:88-99); one [n, Lt] copy per step carries them to the device
-    hyplist = [([], 0.0, torch.full((1, 1), start_symbol, dtype=torch.long))]
+    # a hypothesis = (tokens after <sos>, log-prob, pool slots of its prefix rows); its token prefix is [<sos>] + tokens (the reference
+    # carries it as a device tensor `st`, decode.py:56,92,98: two tiny launches per candidate)
+    hyplist = [([], 0.0, ())]
     best_state, comp_hyplist = None, []
     rows_cache = {}
     dec = getattr(model, "mutlimodal_decoder", None)
@@ -283,7 +285,6 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
     # kernel's self-attention pools; a hypothesis carries the slots of its prefix (``_bist_slots`` on its token tensor)
     incremental = bool(use_graphs and INCREMENTAL and lp_first is not None and max_len * beam <= 64 and dec is not None
                        and getattr(dec, "FUSED_DECODE", False) and Fn.FUSED_DECODE and ft.get("_bist_pool_ready", False))
-    hyplist[0][2]._bist_slots = ()
     for l in range(max_len):
         new_hyplist, argmin = [], 0
         lp_rows = lp_first if l == 0 else None
@@ -292,17 +293,19 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
         elif BATCH_HYPOTHESES and len(hyplist) > 1 and "_bist_reasoning" in ft:
             n = len(hyplist)
             bn, fn = _turn_for_rows(batch, ft, n, rows_cache)
-            trg = torch.cat([st for _, _, st in hyplist], dim=0)
-            if incremental and all(len(getattr(st, "_bist_slots", ())) == l for _, _, st in hyplist):
+            if incremental and all(len(slots) == l for _, _, slots in hyplist):
                 slot0 = l * beam
                 mask_np = np.zeros((n, 32 if slot0 + n <= 32 else 64), dtype=np.uint8)
-                for j, (_, _, st) in enumerate(hyplist):
-                    mask_np[j, list(st._bist_slots) + [slot0 + j]] = 1
-                lp_rows = _graph_step_incr(model, bn, fn, trg[:, -1:], l, slot0, mask_np, train_args)     # [n, 1, V]
+                for j, (_, _, slots) in enumerate(hyplist):
+                    mask_np[j, list(slots) + [slot0 + j]] = 1
+                last = torch.tensor([[out[-1]] for out, _, _ in hyplist], dtype=torch.long)
+                lp_rows = _graph_step_incr(model, bn, fn, last, l, slot0, mask_np, train_args)             # [n, 1, V]
             elif use_graphs:
                 incremental = False              # (the pools no longer hold every hypothesis's prefix)
+                trg = torch.tensor([[start_symbol] + [int(t) for t in out] for out, _, _ in hyplist], dtype=torch.long)
                 lp_rows = _graph_step(model, bn, fn, trg, train_args)                        # [n, 1, V]
             else:
+                trg = torch.tensor([[start_symbol] + [int(t) for t in out] for out, _, _ in hyplist], dtype=torch.long)
                 trg = trg.to(dev)
                 bn.trg = trg
                 bn.trg_mask = subsequent_mask(trg.size(1), dev)
@@ -311,11 +314,12 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
                 step["decoded_text"] = f2["decoded_text"][:, -1:].contiguous()
                 step["encoded_tgt"] = f2["encoded_tgt"][:, -1:].contiguous()
                 lp_rows = model.generator(step, bn, train_args).float().cpu().numpy()    # [n, 1, V]
-        for idx, (out, lp, st) in enumerate(hyplist):
-            own_slots = tuple(getattr(st, "_bist_slots", ())) + (l * beam + idx,)       # the rows of this hypothesis's prefix, this step's included
+        for idx, (out, lp, slots) in enumerate(hyplist):
+            own_slots = slots + (l * beam + idx,)       # the rows of this hypothesis's prefix, this step's included
             if lp_rows is not None:
                 lp_vec = np.squeeze(lp_rows[idx:idx + 1] + lp)
             else:
+                st = torch.tensor([[start_symbol] + [int(t) for t in out]], dtype=torch.long)
                 batch.trg = st.to(dev)
                 batch.trg_mask = subsequent_mask(st.size(1), dev)
                 ft = model.decode(batch, ft)
@@ -335,16 +339,12 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
                 new_lp = lp_vec[o]
                 if len(new_hyplist) == beam:
                     if new_hyplist[argmin][1] < new_lp:
-                        new_st = torch.cat([st, torch.full((1, 1), int(o), dtype=torch.long)], dim=1)
-                        new_st._bist_slots = own_slots
-                        new_hyplist[argmin] = (out + [o], new_lp, new_st)
+                        new_hyplist[argmin] = (out + [o], new_lp, own_slots)
                         argmin = min(enumerate(new_hyplist), key=lambda e: e[1][1])[0]
                     else:
                         break
                 else:
-                    new_st = torch.cat([st, torch.full((1, 1), int(o), dtype=torch.long)], dim=1)
-                    new_st._bist_slots = own_slots
-                    new_hyplist.append((out + [o], new_lp, new_st))
+                    new_hyplist.append((out + [o], new_lp, own_slots))
                     if len(new_hyplist) == beam:
                         argmin = min(enumerate(new_hyplist), key=lambda e: e[1][1])[0]
         hyplist = new_hyplist
