@@ -41,6 +41,7 @@ def _turn_for_rows(batch, ft, n, cache):
         f["_bist_reasoning"] = [{k: _rows(v, n) for k, v in layer.items()} for layer in ft["_bist_reasoning"]]
         if "_bist_turn" in ft:
             f["_bist_turn"] = ft["_bist_turn"]
+        f["_bist_shared_rows"] = True          # every row is the same dialogue (the decoder's persistent kernel relies on it)
         hit = cache[n] = (b, f)
     return hit
 
@@ -58,7 +59,8 @@ class _TurnBuffers:
         for name in ("query", "his", "cap", "query_mask", "his_mask", "cap_mask"):
             v = getattr(bn, name, None)
             setattr(self.b, name, v.clone() if v is not None else None)
-        self.f = {k: v.clone() for k, v in fn.items() if k not in ("_bist_reasoning", "_bist_turn")}
+        self.f = {k: v.clone() for k, v in fn.items() if torch.is_tensor(v)}
+        self.f["_bist_shared_rows"] = True
         self.f["_bist_reasoning"] = [{k: v.clone() for k, v in layer.items()} for layer in fn["_bist_reasoning"]]
         self.loaded = None               # the (bn, fn) pair currently held
 
@@ -71,7 +73,7 @@ class _TurnBuffers:
             if v is not None:
                 dsts.append(getattr(self.b, name)); srcs.append(v)
         for k, v in fn.items():
-            if k not in ("_bist_reasoning", "_bist_turn"):
+            if torch.is_tensor(v):
                 dsts.append(self.f[k]); srcs.append(v)
         for dst, src in zip(self.f["_bist_reasoning"], fn["_bist_reasoning"]):
             for k, v in src.items():

@@ -137,6 +137,9 @@ class MultimodalDecoder8(nn.Module):
         if not (self.v_N > 0 and self.c_N > 0 and getattr(a, "enc_vc_combine", "none") != "none"):
             return False                     # the layer must be the four-attention form of decoder.py:27-29
         n, Lt, d = x.shape
+        # the kernel reads ONE dialogue's memories for all rows: a single dialogue, or rows that decode.py replicated from one
+        if not (ft["encoded_his"].shape[0] == 1 or ft.get("_bist_shared_rows", False)):
+            return False
         Lk = max(ft["encoded_his"].shape[1], ft["encoded_query"].shape[1])
         return ops.decoder_stack_ok(n * Lt, d, self.layers[0].attn[0].h, Lk, x.dtype) and len(self.layers[0].attn) == 4
 
