@@ -319,3 +319,35 @@ def test_incremental_beam_search_equals_full_prefix_recompute(hip):
         assert max(abs(float(x[1]) - float(y[1])) for x, y in zip(a, b)) <= 5e-2, seed
     store = model.__dict__.get("_bist_step_graphs", {})
     assert any(k[0] == "incr" for k in store if isinstance(k, tuple)), "the incremental step graphs were not used"
+
+
+def test_beam_search_turns_of_different_dialogue_lengths_do_not_share_state(hip):
+    """Turns of two dialogue geometries in alternation (A, B, A, B): the persistent decoder kernel's per-geometry key / value caches,
+    descriptors, self-attention pools and the captured step graphs must each serve their own turn.  Every turn equals the same turn
+    decoded with the layer-by-layer decoder and full-prefix steps."""
+    import bist_amd.model.decode as D
+    from bist_amd import functional as Fn
+    from bist_amd.model.decode import beam_search_decode
+    M, Batch = hip
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    V, C = 300, 256
+    model, _ = build_model(M, cfg, V, C, torch.bfloat16)
+    dialogues = [O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=41), O.det_batch(1, 8, 9, C, 12, 45, 10, 12, V, seed=42),
+                 O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=43), O.det_batch(1, 8, 9, C, 12, 45, 10, 12, V, seed=44)]
+
+    def turn(ob):
+        with torch.no_grad():
+            return beam_search_decode(model, to_batch(Batch, ob, torch.bfloat16), 12, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID, beam=5,
+                                      penalty=1.0, nbest=5, train_args=_args(cfg))[0]
+    fast = [turn(ob) for ob in dialogues] + [turn(dialogues[0])]
+    Fn.FUSED_DECODE, D.INCREMENTAL = False, False
+    model.__dict__.pop("_bist_step_graphs", None); model.__dict__.pop("_bist_step_graphs_key", None)
+    try:
+        slow = [turn(ob) for ob in dialogues] + [turn(dialogues[0])]
+    finally:
+        Fn.FUSED_DECODE, D.INCREMENTAL = True, True
+        model.__dict__.pop("_bist_step_graphs", None); model.__dict__.pop("_bist_step_graphs_key", None)
+    for i, (a, b) in enumerate(zip(fast, slow)):
+        assert [list(map(int, x[0])) for x in a] == [list(map(int, x[0])) for x in b], i
+        assert max(abs(float(x[1]) - float(y[1])) for x, y in zip(a, b)) <= 5e-2, i
+    assert [list(map(int, x[0])) for x in fast[0]] == [list(map(int, x[0])) for x in fast[4]]
