@@ -352,6 +352,8 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
   // The grid is 8 x NWG blocks of which every 8th works: blocks are dealt round-robin over the 8 XCDs (observed, not promised), so
   // the NWG workers land on ONE XCD and can hand data over through its L2.  That is VERIFIED at run time (each worker publishes its
   // HW_REG_XCC_ID before the first barrier); until then, and for good if the ids differ, payload stores are write-through (wt).
+  if ((a.dbg & 8) && threadIdx.x == 0)      // development: the XCC ids of ALL 256 blocks, or-ed into sync[6] (8 XCDs -> 0xff)
+    __hip_atomic_fetch_or((gu32*)a.sync + 6, 1u << (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (blockIdx.x & 7) return;
   const int wg = blockIdx.x >> 3, R = a.R, RP = (R + 15) & ~15, MTR = RP >> 4;
   bool wt = true;
