@@ -114,6 +114,7 @@ SIGNATURES = {
     "bist_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _I32, _F, _I32, _I32, _P]),
     "bist_noam_hyper": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "bist_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _P]),
+    "bist_text_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     "bist_noam_hyper_pending": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "bist_adam_apply_dev": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _P]),
     "bist_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _P]),

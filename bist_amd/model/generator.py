@@ -65,6 +65,9 @@ def _text_vector(p: Tensor, enc: Tensor) -> Tensor:
     """sum_t p[b,i,t] * enc[b,t,:]  (generator.py:117-118) as a batched GEMM; p f32 [B,Lt,L]."""
     B, Lt, L = p.shape
     d = enc.shape[-1]
+    if not torch.is_grad_enabled() and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and enc.is_contiguous() \
+            and d % (8 if enc.dtype == torch.bfloat16 else 4) == 0 and d <= 1024:
+        return ops.text_vector(p, enc)           # inference: one launch instead of a cast and a fallback-path GEMM (K = L is unaligned)
     return Fn.bmm_nn(Fn.cast(p, enc.dtype), enc)
 
 

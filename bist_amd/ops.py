@@ -456,6 +456,19 @@ def embed_pe(ids: Tensor, lut: Tensor, pe: Tensor, out: Optional[Tensor] = None,
     return out
 
 
+def text_vector(p: Tensor, enc: Tensor) -> Tensor:
+    """sum_t p[b,i,t] * enc[b,t,:] (generator.py:117-118), inference: p f32 [B,Lt,L], enc [B,L,d] -> [B,Lt,d] in enc's dtype."""
+    _dev(p, enc)
+    B, Lt, L = p.shape
+    d = enc.shape[-1]
+    if p.dtype != torch.float32 or enc.shape[0] != B or enc.shape[1] != L or not p.is_contiguous() or not enc.is_contiguous():
+        raise ValueError("bist_amd.text_vector: bad operands")
+    out = torch.empty((B, Lt, d), device=enc.device, dtype=enc.dtype)
+    check(lib.bist_text_vector_fwd(p.data_ptr(), enc.data_ptr(), out.data_ptr(), B * Lt, Lt, L, d, dtype_code(enc.dtype), _stream()),
+          "bist_text_vector_fwd")
+    return out
+
+
 def temporal_mask(fts: Tensor) -> Tensor:
     """(fts.sum(2).sum(-1) != 0).unsqueeze(-2) of data/dataset.py:79, computed on the device."""
     _dev(fts)

@@ -423,6 +423,10 @@ int bist_pointer_mix_bwd(const float* logits, const float* switch_logits, int32_
                          const int64_t* const* ptr_text, const int32_t* ptr_len, const float* out, const float* dout,
                          float* dlogits, float* dswitch_logits, float* const* dptr_p, int64_t rows, int32_t Lt, int32_t V,
                          int32_t sigmoid_switch, void* stream);
+/* The pointer generator's text vector (generator.py:117-118), inference: out[row, :] = sum_t p[row, t] * enc[row / Lt, t, :]
+ * (p f32 [rows][L], enc [rows / Lt][L][d], out [rows][d] in dtype); training uses the batched bist_gemm (it needs the backward products). */
+int bist_text_vector_fwd(const float* p, const void* enc, void* out, int64_t rows, int32_t Lt, int32_t L, int32_t d, int32_t dtype,
+                         void* stream);
 int bist_log_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int32_t V, void* stream);
 /* dlogp[row,v] = -smoothed_target[row,v] * gout[0] / denom[0]  (gout, denom: device scalars).     */
 int bist_label_smoothing_bwd(const int64_t* target, const float* gout, const int64_t* denom, float* dlogp, int64_t rows,

@@ -587,3 +587,30 @@ def test_gemm_256_tile_launch_sheds_its_underfilled_last_round():
     err = (y[rows].double() - want).abs().max().item()
     assert err <= 2e-2 * max(1.0, want.abs().max().item()), err
     assert torch.isfinite(y.float()).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_text_vector_and_pointer_scatter_with_repeated_ids(dtype):
+    """bist_text_vector_fwd against an fp64 einsum, and the pointer generator's scatter (bist_pointer_mix_fwd) with token ids that repeat
+    inside a source and across sources against a plain index_add reference."""
+    from bist_amd import ops
+    torch.manual_seed(11)
+    B, Lt, L, d, V = 3, 4, 37, 512, 200
+    p = torch.softmax(torch.randn(B, Lt, L), -1).cuda()
+    enc = torch.randn(B, L, d).cuda().to(dtype)
+    got = ops.text_vector(p, enc).double().cpu()
+    want = torch.einsum("bil,bld->bid", p.double().cpu(), enc.double().cpu())
+    assert (got - want).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 1e-5)
+    # scatter: two sources, ids drawn from a small set so that they repeat
+    logits = torch.randn(B * Lt, V).cuda()
+    sw = torch.randn(B * Lt, 3).cuda()
+    ps = [torch.softmax(torch.randn(B, Lt, L_), -1).cuda() for L_ in (L, 19)]
+    texts = [torch.randint(0, 12, (B, L_)).cuda() for L_ in (L, 19)]
+    out = ops.pointer_mix(logits, sw, ps, texts, Lt).double().cpu()
+    s = torch.softmax(sw.double().cpu(), -1)
+    mix = s[:, 2:3] * torch.softmax(logits.double().cpu(), -1)
+    for j in range(2):
+        pj = ps[j].double().cpu().reshape(B * Lt, -1)
+        ids = texts[j].cpu().repeat_interleave(Lt, dim=0)
+        mix = mix.scatter_add(1, ids, s[:, j:j + 1] * pj)
+    assert (out - mix.log()).abs().max().item() <= 1e-5
