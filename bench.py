@@ -325,7 +325,7 @@ def main():
                     res[name] = min(ts)
                 finally:
                     MultimodalDecoder8.REASONING_CACHE = True
-        return {"what": "beam_search_decode turn, B=1 beam=5 maxlen=12 (BASELINE configs[4]), hipGraph replay per (rows, prefix length)", "ms_per_turn": res["cached"],
+        return {"what": "beam_search_decode turn, B=1 beam=5 maxlen=12 (BASELINE configs[4]), one decode step at a time through the persistent decoder kernel, one hipGraph replay per (rows, position)", "ms_per_turn": res["cached"],
                 "ms_per_turn_reasoning_recomputed": res["recompute"]}
 
     decode = decode_turn_ms() if (rank == 0 and not a.no_decode) else None
