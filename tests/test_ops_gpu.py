@@ -614,3 +614,32 @@ def test_text_vector_and_pointer_scatter_with_repeated_ids(dtype):
         ids = texts[j].cpu().repeat_interleave(Lt, dim=0)
         mix = mix.scatter_add(1, ids, s[:, j:j + 1] * pj)
     assert (out - mix.log()).abs().max().item() <= 1e-5
+
+
+def test_new_entry_points_refuse_calls_outside_their_envelope():
+    """bist_decoder_stack_fwd (slots beyond the pool, LkS not 32 / 64), bist_gemm with a LayerNorm prologue outside bist_gemm_ln_ok,
+    bist_adam_apply_dev with a range that is not a multiple of 4: BIST_EINVAL and a message, no launch."""
+    import ctypes as C
+    from bist_amd import ops
+    from bist_amd._lib import lib
+    z = lambda *s, dt=torch.bfloat16: torch.zeros(*s, device="cuda", dtype=dt)
+    bufs = {"x0": z(64, 512), "x1": z(64, 512), "q": z(64, 512), "kc": z(1, 64, 512), "vc": z(1, 64, 512), "h": z(64, 2048),
+            "sync": z(8, dt=torch.int32)}
+    desc = z(int(lib.bist_decoder_layer_desc_bytes()), dt=torch.uint8)
+    st = torch.cuda.current_stream().cuda_stream
+    def stack(R, LkS, slot0):
+        return lib.bist_decoder_stack_fwd(desc.data_ptr(), 1, bufs["x0"].data_ptr(), bufs["x0"].data_ptr(), bufs["x1"].data_ptr(), bufs["q"].data_ptr(),
+                                          bufs["kc"].data_ptr(), bufs["vc"].data_ptr(), bufs["h"].data_ptr(), z(64, 64, dt=torch.uint8).data_ptr(),
+                                          R, LkS, slot0, bufs["sync"].data_ptr(), 1, st)
+    assert stack(5, 64, 60) != 0 and b"slot" in lib.bist_last_error()          # slots 60..64 leave the pool
+    assert stack(5, 48, 0) != 0                                                  # LkS must be 32 or 64
+    assert stack(40, 32, 0) != 0                                                 # more rows than key slots
+    # LayerNorm prologue with K != 512
+    x, w, y = z(64, 256), z(512, 256), z(64, 512)
+    g = ops.gemm_desc(x, w, y, M=64, N=512, K=256, a_rs=256, b_rs=256, ldc=512)
+    a = z(256)
+    g.ln_gain, g.ln_offset, g.ln_eps = a.data_ptr(), a.data_ptr(), 1e-6
+    assert lib.bist_gemm_ln_ok(C.byref(g)) == 0 and lib.bist_gemm(C.byref(g), st) != 0
+    f = lambda n: torch.zeros(n, device="cuda")
+    assert lib.bist_adam_apply_dev(f(8).data_ptr(), f(8).data_ptr(), f(8).data_ptr(), f(8).data_ptr(), None, 6, f(8).data_ptr(), 0.9, 0.98, 1e-9, 0, 0, st) != 0
+    torch.cuda.synchronize()
