@@ -31,7 +31,7 @@ class BistGemm(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("hint", C.c_int32), ("reserved", C.c_int32),
         ("ln_gain", C.c_void_p), ("ln_offset", C.c_void_p), ("ln_out", C.c_void_p), ("ln_ld", C.c_int64), ("ln_eps", C.c_float),
-        ("reserved2", C.c_int32),
+        ("ln_mode", C.c_int32),
     ]
 
 

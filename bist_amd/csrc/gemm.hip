@@ -50,6 +50,7 @@ struct GemmK {   // device-side argument block (by value)
   int dbg;                           // BIST_GEMM_DBG ablation aid (0 in production): 1 exit at entry, 2 skip the K loop, 3 skip the epilogue
   // LayerNorm prologue (gemm_t64_pre_kernel, K = 512 bf16): A rows are normalised in LDS before the products and written to ln_out
   const char* ln_a; const char* ln_b; char* ln_out; long ln_ld; float ln_eps;
+  int ln_mode;                       // 0: LayerNorm of the A rows (prologue); 1: LayerNorm of the OUTPUT rows (epilogue of the 256-tile kernel, N = 512)
 };
 
 template <typename T> struct Mma;
@@ -1215,6 +1216,128 @@ __global__ __launch_bounds__(NTHREADS) void gemm_t64_pair_kernel(const GemmK g1,
 //   * fragment reads are inline asm (the compiler adds no waits of its own), barriers are raw s_barrier;
 //   * the epilogue stores straight from the accumulators (frag_out).
 // ---------------------------------------------------------------------------------------------
+// LayerNorm EPILOGUE of the 256-tile kernel (N = 512 = two column tiles, bf16 output): C = LayerNorm(act(alpha A.B^T + bias)) with the
+// reference's LayerNorm (modules.py:28-31) over the 512 columns of a row, i.e. `self.in_norm(F.relu(self.W(fts)))` of VidEncoder8
+// (encoder.py:75-81) in ONE launch instead of a GEMM plus a 2 x M x 512 x 2-byte LayerNorm pass.  A row's statistics need both column
+// tiles: the two workgroups of a row block exchange their per-row (sum, sum of squares) of 256 columns through the workspace
+// (write-through stores, a flag each, sc1 loads -- placement-independent; each resets the flag it polled, so the header is zero again
+// when the launch ends).  One pass: var = (sum v^2 - 512 mean^2) / 511 in fp32 (post-ReLU activations of O(1): no cancellation to
+// speak of).  A bounded spin: if the partner never arrives, word WS_HEADER - 1 of the header is set (sticky) and the rows are
+// normalised with this tile's statistics alone.
+template <int FR>
+__device__ __forceinline__ void frag_out_ln(const GemmK& g, f32x4 (&acc)[FR][4], char* lds, int tm, int tn, int m0, int n0, int wr, int wc, int lane, int tid) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  typedef __attribute__((address_space(1))) unsigned gu32;
+  const int lr = lane & 15, lg = lane >> 4;
+  constexpr int WROWS = FR * 16;
+  const bf16_t* bias = reinterpret_cast<const bf16_t*>(g.bias);
+  const bool relu = g.act == BIST_ACT_RELU;
+  float2* part = reinterpret_cast<float2*>(lds);              // [2 * WROWS rows][4 wave columns]
+  float2* stats = part + 2 * WROWS * 4;                       // [2 * WROWS]: (mean, 1 / (std + eps))
+  // 1. alpha, bias, activation in place; 2. this wave's per-row partial sums over its 64 columns
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + lg * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      const uint2 q = *reinterpret_cast<const uint2*>(bias + n);
+      bv[0] = __builtin_bit_cast(float, q.x << 16); bv[1] = __builtin_bit_cast(float, q.x & 0xffff0000u);
+      bv[2] = __builtin_bit_cast(float, q.y << 16); bv[3] = __builtin_bit_cast(float, q.y & 0xffff0000u);
+    }
+#pragma unroll
+    for (int i = 0; i < FR; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] * g.alpha + bv[r];
+        acc[i][j][r] = relu ? fmaxf(v, 0.f) : v;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < FR; ++i) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (lg == 0) part[(wr * WROWS + i * 16 + lr) * 4 + wc] = make_float2(s1, s2);
+  }
+  __syncthreads();
+  // 3. this tile's sums to the partner, the partner's to us
+  float* ws = g.ws;
+  gu32* flag_mine = (gu32*)(ws) + (tm * 2 + tn);
+  gu32* flag_other = (gu32*)(ws) + (tm * 2 + (tn ^ 1));
+  gu64* x_mine = (gu64*)(ws + WS_HEADER) + (long)(tm * 2 + tn) * (2 * WROWS);
+  gu64* x_other = (gu64*)(ws + WS_HEADER) + (long)(tm * 2 + (tn ^ 1)) * (2 * WROWS);
+  float S1 = 0.f, S2 = 0.f;
+  if (tid < 2 * WROWS) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const float2 q = part[tid * 4 + c]; S1 += q.x; S2 += q.y; }
+    __hip_atomic_store(x_mine + tid, ((unsigned long long)__builtin_bit_cast(unsigned, S2) << 32) | __builtin_bit_cast(unsigned, S1),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int partner_ok;
+  if (tid == 0) {
+    __hip_atomic_store(flag_mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    bool ok = true;
+    while (__hip_atomic_load(flag_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 21)) { ok = false; __hip_atomic_store((gu32*)ws + (WS_HEADER - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    if (ok) __hip_atomic_store(flag_other, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // nobody else reads the flag we polled
+    partner_ok = ok;
+  }
+  __syncthreads();
+  if (tid < 2 * WROWS) {
+    float n_cols = 256.f;
+    if (partner_ok) {
+      const unsigned long long q = __hip_atomic_load(x_other + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      S1 += __builtin_bit_cast(float, (unsigned)q); S2 += __builtin_bit_cast(float, (unsigned)(q >> 32));
+      n_cols = 512.f;
+    }
+    const float mean = S1 / n_cols;
+    const float var = fmaxf(S2 - n_cols * mean * mean, 0.f) / (n_cols - 1.f);
+    stats[tid] = make_float2(mean, 1.f / (sqrtf(var) + g.ln_eps));
+  }
+  __syncthreads();
+  // 4. normalise and store (the 16-byte row pieces of frag_rows)
+  const bf16_t* ga = reinterpret_cast<const bf16_t*>(g.ln_a);
+  const bf16_t* gb = reinterpret_cast<const bf16_t*>(g.ln_b);
+  bf16_t* Cz = reinterpret_cast<bf16_t*>(g.C);
+  const int cofs = (lg & 1) * 16 + (lg >> 1) * 8;
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    const int n = n0 + wc * 64 + jp * 32 + cofs;
+    const uint4 qa = *reinterpret_cast<const uint4*>(ga + n), qb = *reinterpret_cast<const uint4*>(gb + n);
+    const unsigned a4[4] = {qa.x, qa.y, qa.z, qa.w}, b4[4] = {qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+    for (int i = 0; i < FR; ++i) {
+      const int rl = wr * WROWS + i * 16 + lr;
+      const float2 st = stats[rl];
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = acc[i][2 * jp][r], b = acc[i][2 * jp + 1][r];
+        swap16(a, b);
+        v[r] = a; v[4 + r] = b;
+      }
+      unsigned o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y0 = __builtin_bit_cast(float, a4[e] << 16) * (v[2 * e] - st.x) * st.y + __builtin_bit_cast(float, b4[e] << 16);
+        const float y1 = __builtin_bit_cast(float, a4[e] & 0xffff0000u) * (v[2 * e + 1] - st.x) * st.y + __builtin_bit_cast(float, b4[e] & 0xffff0000u);
+        const bf16_t l16 = from_f<bf16_t>(y0), h16 = from_f<bf16_t>(y1);
+        o4[e] = (unsigned)__builtin_bit_cast(unsigned short, l16) | ((unsigned)__builtin_bit_cast(unsigned short, h16) << 16);
+      }
+      *reinterpret_cast<uint4*>(Cz + (long)(m0 + rl) * g.ldc + n) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    }
+  }
+}
+
 constexpr int BIG = 256;
 constexpr int HALF_BYTES = 128 * ROW_BYTES;          // 16 KiB
 constexpr int KT_BYTES = 4 * HALF_BYTES;             // one K tile: Aq0 | Bq0 | Bq1 | Aq1
@@ -1348,6 +1471,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmK g) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();            // the extra barrier of the staggered group
   if constexpr (V == 1) { stamp[2] = wall_clock64(); cyc0 = clock64() - cyc0; stamp[4] = stamp[2]; }
+  if constexpr (FR == 8 && V == 0 && sizeof(TO) == 2) {
+    if (g.ln_mode == 1) {                              // LayerNorm epilogue (the launcher checked the envelope: whole tiles, N = 512, no dropout / residual)
+      __syncthreads();                                 // every wave is done with the operand stages
+      frag_out_ln<FR>(g, acc, lds, tm, tn, m0, n0, wr, wc, lane, tid);
+      return;
+    }
+  }
   frag_out<T, TO, FR, 4>(g, acc, z1, z2, m0 + wr * WROWS, n0 + wc * 64, lane);
   if constexpr (V == 1) {
     stamp[5] = wall_clock64();
@@ -1680,7 +1810,7 @@ Plan make_plan(const BistGemm* g) {
 // The LayerNorm prologue exists in gemm_t64_pre_kernel<NK = 8> only: bf16, K = 512, A rows K-contiguous and 16-byte aligned, unbatched,
 // a launch of at most 256 64x64 tiles (one per CU), N >= 512 so that column tiles 0..7 exist to write ln_out.
 bool ln_fusable(const BistGemm* g, const Plan& p) {
-  if (!(g->ln_gain && g->ln_offset)) return false;
+  if (!(g->ln_gain && g->ln_offset) || g->ln_mode != 0) return false;
   static const int off = [] { const char* e = getenv("BIST_GEMM_NO_LN"); return e ? atoi(e) : 0; }();      // tuning aid
   const long t64s = (long)((g->M + 63) / 64) * ((g->N + 63) / 64);
   return !off && g->in_dtype == BIST_BF16 && g->K == 512 && g->batch1 == 1 && g->batch2 == 1 && p.fast && p.t64 && !p.atr && p.split == 1 &&
@@ -1688,7 +1818,21 @@ bool ln_fusable(const BistGemm* g, const Plan& p) {
          (!g->ln_out || (((uintptr_t)g->ln_out % 16 == 0) && g->ln_ld % 8 == 0 && g->ln_ld >= 512));
 }
 
+// The LayerNorm EPILOGUE exists in the 256-tile kernel only: bf16 in and out, N = 512 (two column tiles), whole 256-row tiles, unbatched,
+// K-contiguous operands, no dropout / residual, a workspace for the exchange of the row statistics (header flags: at most 512 row blocks).
+bool ln_epilogue_ok(const BistGemm* g, const Plan& p) {
+  if (!(g->ln_gain && g->ln_offset) || g->ln_mode != 1) return false;
+  static const int off = [] { const char* e = getenv("BIST_GEMM_NO_LN"); return e ? atoi(e) : 0; }();
+  const long blocks = g->M / 256;
+  return !off && g->in_dtype == BIST_BF16 && g->out_dtype == BIST_BF16 && g->N == 512 && g->M % 256 == 0 && blocks >= 1 && 2 * blocks < WS_HEADER - 1 &&
+         g->batch1 == 1 && g->batch2 == 1 && p.fast && !p.atr && !p.btr && g->K % 64 == 0 && g->K >= 128 && g->drop_p == 0.f && !g->residual &&
+         g->ldc % 8 == 0 && ((uintptr_t)g->C % 16 == 0) && ((uintptr_t)g->ln_gain % 16 == 0) && ((uintptr_t)g->ln_offset % 16 == 0) &&
+         (!g->bias || (uintptr_t)g->bias % 8 == 0) && g->workspace &&
+         (size_t)g->workspace_bytes >= WS_HEADER_BYTES + (size_t)blocks * 2 * 256 * 8;
+}
+
 bool use_tile256(const BistGemm* g, const Plan& p) {
+  if (g->ln_gain && g->ln_mode == 1) return ln_epilogue_ok(g, p);
   if (g->ln_gain) return false;
   if (g->in_dtype != BIST_BF16) return false;
   const long big_tiles = (long)((g->M + BIG - 1) / BIG) * ((g->N + BIG - 1) / BIG) * g->batch1 * g->batch2;
@@ -1700,7 +1844,10 @@ bool use_tile256(const BistGemm* g, const Plan& p) {
 
 template <typename T, typename TO>
 int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
-  if (k.ln_a && !ln_fusable(g, make_plan(g))) { bist_set_error("bist_gemm: LayerNorm prologue outside its envelope (bist_gemm_ln_ok)"); return BIST_EINVAL; }
+  if (k.ln_a && !(k.ln_mode == 1 ? ln_epilogue_ok(g, make_plan(g)) : ln_fusable(g, make_plan(g)))) {
+    bist_set_error("bist_gemm: LayerNorm %s outside its envelope (bist_gemm_ln_ok)", k.ln_mode == 1 ? "epilogue" : "prologue");
+    return BIST_EINVAL;
+  }
   if (const int sk = skinny_kind(g)) return launch_skinny<T, TO>(g, k, sk, st);
   const Plan p = make_plan(g);
   k.split_k = p.split;
@@ -1723,10 +1870,11 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
       const long pad8 = (long)((g->M + 255) / 256) * 256, pad5 = (long)((g->M + 159) / 160) * 160;
       const bool stamps = (g->hint & 15) == BIST_GEMM_TILE256 && (g->hint >> 4) == 1;       // development aid (FR = 8 only)
       int fr = (!stamps && pad5 < pad8) ? 5 : 8;
+      if (k.ln_mode == 1) fr = 8;                      // the LayerNorm epilogue is built for 256-row tiles
       static const int force_fr = [] { const char* e = getenv("BIST_GEMM_BIG_FR"); return e ? atoi(e) : 0; }();      // tuning aid
-      if (!stamps && force_fr >= 5 && force_fr <= 8) fr = force_fr;
+      if (!stamps && force_fr >= 5 && force_fr <= 8 && k.ln_mode != 1) fr = force_fr;
       k.tiles_m = (g->M + 32 * fr - 1) / (32 * fr); k.tiles_n = (g->N + BIG - 1) / BIG;
-      k.split_k = 1; k.ws = nullptr;
+      k.split_k = 1; k.ws = k.ln_mode == 1 ? (float*)g->workspace : nullptr;
       // Wave quantisation: one tile per CU per round, so 784 tiles (P0 at B = 64: 392 row blocks x 2) are 3 full rounds plus a
       // fourth with 16 of 256 CUs busy.  When at least two rounds are full and the last one would be less than 1/8 full, its row
       // blocks leave this launch and go through bist_gemm as a product of their own (few rows: finer tiles / split K fill the
@@ -1745,7 +1893,11 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
         if (g->residual) tail.residual = (const char*)g->residual + rows_main * g->ldr * so;
         tail.M = g->M - (int)rows_main;
         tail.hint = 0;
+        tail.ln_gain = tail.ln_offset = nullptr; tail.ln_out = nullptr; tail.ln_mode = 0;
         if (const int rc = bist_gemm(&tail, (void*)st)) return rc;
+        if (k.ln_mode == 1) {                          // the shed rows get their LayerNorm as a (small) launch of its own, in place
+          if (const int rc = bist_layernorm_fwd(tail.C, g->ln_gain, g->ln_offset, tail.C, tail.M, g->N, g->ldc, g->ldc, g->ln_eps, BIST_BF16, (void*)st)) return rc;
+        }
         k.M = (int)rows_main;
         k.tiles_m -= tail_blocks;
       }
@@ -1828,6 +1980,7 @@ int launch(const BistGemm* g, GemmK& k, hipStream_t st) {
 extern "C" int bist_gemm_ln_ok(const BistGemm* g) {
   if (!g || !g->ln_gain) return 0;
   const Plan p = make_plan(g);
+  if (g->ln_mode == 1) return ln_epilogue_ok(g, p) ? 1 : 0;
   static const int no_pre = [] { const char* e = getenv("BIST_GEMM_NO_PRE"); return e ? atoi(e) : 0; }();
   return ln_fusable(g, p) && !no_pre ? 1 : 0;
 }
@@ -1867,6 +2020,8 @@ int fill_gemmk(const BistGemm* g, GemmK& k) {
   k.split_k = 1; k.ws = nullptr;
   BIST_REQUIRE((g->ln_gain == nullptr) == (g->ln_offset == nullptr), "bist_gemm: LayerNorm prologue needs gain and offset");
   k.ln_a = (const char*)g->ln_gain; k.ln_b = (const char*)g->ln_offset; k.ln_out = (char*)g->ln_out; k.ln_ld = g->ln_ld; k.ln_eps = g->ln_eps;
+  k.ln_mode = g->ln_gain ? g->ln_mode : 0;
+  BIST_REQUIRE(k.ln_mode == 0 || k.ln_mode == 1, "bist_gemm: ln_mode must be 0 (prologue) or 1 (epilogue)");
   { static const int dbg = [] { const char* e = getenv("BIST_GEMM_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
   {
     const long so = g->out_dtype == BIST_BF16 ? 2 : 4;

@@ -84,8 +84,15 @@ class VidEncoder8(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record()
                 ft["_bist_pre_vid"] = ev
-            act = Fn.linear(fts.reshape(B * T * S, C), self.W.weight, self.W.bias, act=Fn.ACT_RELU)
-            ft["spatiotemporal_ft"] = self.in_norm(act).view(B, T, S, -1)
+            if not torch.is_grad_enabled() and fts.is_cuda:
+                # inference: LayerNorm(ReLU(W fts + b)) as ONE launch where the product's LayerNorm epilogue covers the shape (no
+                # separate pass over the [B*T*S, 512] activations); training keeps both tensors for the backward pass
+                n = self.in_norm
+                y = ops.linear(fts.reshape(B * T * S, C), self.W.weight, self.W.bias, act=Fn.ACT_RELU, ln_out=(n.a_2, n.b_2, n.eps))
+                ft["spatiotemporal_ft"] = y.view(B, T, S, -1)
+            else:
+                act = Fn.linear(fts.reshape(B * T * S, C), self.W.weight, self.W.bias, act=Fn.ACT_RELU)
+                ft["spatiotemporal_ft"] = self.in_norm(act).view(B, T, S, -1)
         return ft
 
 

@@ -171,8 +171,11 @@ GEMM_TIMING_SHAPE = None  # optional (M,N,K): only launches of this shape are br
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE, residual: Optional[Tensor] = None,
            res_map: Tuple[int, int] = (0, 0), alpha: float = 1.0, out: Optional[Tensor] = None,
            out_dtype: Optional[torch.dtype] = None, accumulate: bool = False, drop_p: float = 0.0, drop_seed: int = 0,
-           ln=None) -> Tensor:
+           ln=None, ln_out=None) -> Tensor:
     """y = act(alpha * x.W^T + bias) (+ residual): nn.Linear on the MFMA GEMM.
+    ``ln_out`` = (gain, offset, eps): y = LayerNorm(act(alpha x.W^T + bias)) over the N = 512 output columns in the same launch (the
+    LayerNorm EPILOGUE of bist_gemm, ln_mode = 1: VidEncoder8's in_norm(relu(W fts))) when inside its envelope, else a LayerNorm launch
+    after the product.
     ``ln`` (or the tag ``x._bist_ln``): x is a PENDING LayerNorm output (layernorm(lazy=True)): the product is taken of the
     un-normalised rows with the LayerNorm as the GEMM's prologue, which also fills x.
 
@@ -197,6 +200,16 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = AC
     r2 = None
     if residual is not None:
         r2 = residual.reshape(-1, N) if residual.dim() != 2 else residual
+    if ln_out is not None:
+        ga, gb, eps = ln_out
+        g = gemm_desc(x2, w, o2, M=M, N=N, K=K, a_rs=x2.stride(0), b_rs=w.stride(0), ldc=o2.stride(0), bias=bias, alpha=alpha, act=act)
+        g.ln_gain, g.ln_offset, g.ln_eps, g.ln_mode = ga.data_ptr(), gb.data_ptr(), eps, 1
+        if residual is None and drop_p == 0 and LN_EPILOGUE and lib.bist_gemm_ln_ok(C.byref(g)):
+            check(lib.bist_gemm(C.byref(g), _stream()), "bist_gemm")
+            return out
+        gemm(x2, w, o2, M=M, N=N, K=K, a_rs=x2.stride(0), b_rs=w.stride(0), ldc=o2.stride(0), bias=bias,
+             residual=r2, ldr=r2.stride(0) if r2 is not None else 0, alpha=alpha, act=act, res_map=res_map, drop_p=drop_p, drop_seed=drop_seed)
+        return layernorm(o2, ga, gb, eps, out=o2)
     if ln is not None:
         xp, ga, gb, eps = ln
         g = gemm_desc(xp, w, o2, M=M, N=N, K=K, a_rs=xp.stride(0), b_rs=w.stride(0), ldc=o2.stride(0), bias=bias,
@@ -218,6 +231,11 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = AC
 # fused kernel waits for all of its K tiles before it can normalise (no product under the loads) and that costs what the saved launch
 # boundary (~1.2 us) gains.  Not adopted: opt-in with BIST_LAZY_LN=1.
 LAZY_LN = os.environ.get("BIST_LAZY_LN", "0") != "0"
+# LayerNorm as the EPILOGUE of the input projection (bist_gemm ln_mode = 1: the two column-tile workgroups of a row block exchange row
+# statistics): saves the 227 MB LayerNorm pass of the B = 64 region but measured 0.766 / 0.764 ms against 0.754 / 0.748 ms with the pass
+# as its own launch (B = 16: 0.285 / 0.283 vs 0.289 / 0.273) -- the pair hand-shake and the epilogue arithmetic at the end of every
+# round cost more than the streaming pass.  Opt-in with BIST_LN_EPILOGUE=1.
+LN_EPILOGUE = os.environ.get("BIST_LN_EPILOGUE", "0") != "0"
 
 
 def ln_lazy_ok(x: Tensor, a: Tensor, b: Tensor) -> bool:

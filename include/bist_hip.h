@@ -122,7 +122,11 @@ typedef struct BistGemm {
   void* ln_out;
   int64_t ln_ld;
   float ln_eps;
-  int32_t reserved2;
+  /* ln_mode = 1: the LayerNorm is applied to the OUTPUT rows instead -- C = LayerNorm(act(alpha A.B^T + bias)) over the N = 512
+   * columns, the `self.in_norm(F.relu(self.W(fts)))` of VidEncoder8 (model/encoder.py:75-81) as one launch (256-tile kernel: the
+   * two column-tile workgroups of a row block exchange their row statistics through `workspace`).  Envelope (bist_gemm_ln_ok): bf16,
+   * N = 512, M a multiple of 256, K-contiguous operands, no dropout / residual, workspace >= 4 KiB + M * 16 bytes; ln_out unused. */
+  int32_t ln_mode;
 } BistGemm;
 int bist_gemm_ln_ok(const BistGemm* g);       /* 1 if bist_gemm(g) will run g's LayerNorm prologue */
 #define BIST_GEMM_TILE256 2

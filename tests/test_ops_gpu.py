@@ -643,3 +643,32 @@ def test_new_entry_points_refuse_calls_outside_their_envelope():
     f = lambda n: torch.zeros(n, device="cuda")
     assert lib.bist_adam_apply_dev(f(8).data_ptr(), f(8).data_ptr(), f(8).data_ptr(), f(8).data_ptr(), None, 6, f(8).data_ptr(), 0.9, 0.98, 1e-9, 0, 0, st) != 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,K", [(25088, 2048), (100352, 2048), (1024, 512)])
+def test_layernorm_epilogue_of_the_256_tile_product(M, K, monkeypatch):
+    """LayerNorm(ReLU(x.W^T + b)) over N = 512 columns as ONE launch (BistGemm.ln_mode = 1: the two column-tile workgroups of a row
+    block exchange their row statistics) against the product followed by bist_layernorm_fwd -- VidEncoder8's input projection at
+    B = 16 and B = 64 (the latter also sheds its under-filled last round, whose rows get a LayerNorm launch of their own)."""
+    import ctypes as C
+    from bist_amd import ops
+    from bist_amd._lib import lib
+    monkeypatch.setattr(ops, "LN_EPILOGUE", True)          # (opt-in: BIST_LN_EPILOGUE=1)
+    torch.manual_seed(M % 1000 + K)
+    x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(512, K, device="cuda") * (1.0 / K ** 0.5)).bfloat16()
+    bias = (torch.randn(512, device="cuda") * 0.1).bfloat16()
+    a = (1 + 0.2 * torch.randn(512, device="cuda")).bfloat16()
+    b = (0.1 * torch.randn(512, device="cuda")).bfloat16()
+    want = ops.layernorm(ops.linear(x, w, bias, act=ops.ACT_RELU), a, b, 1e-6)
+    y = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
+    g = ops.gemm_desc(x, w, y, M=M, N=512, K=K, a_rs=K, b_rs=K, ldc=512, bias=bias, act=ops.ACT_RELU)
+    g.ln_gain, g.ln_offset, g.ln_eps, g.ln_mode = a.data_ptr(), b.data_ptr(), 1e-6, 1
+    assert lib.bist_gemm_ln_ok(C.byref(g)) == 1
+    got = ops.linear(x, w, bias, act=ops.ACT_RELU, ln_out=(a, b, 1e-6))
+    torch.cuda.synchronize()
+    d = (got.float() - want.float()).abs()
+    # same values up to the rounding of the bf16 activations the separate LayerNorm reads (the epilogue normalises the fp32 sums)
+    assert bool((d <= 2 ** -5 * torch.clamp(want.float().abs(), min=1.0)).all()) and d.mean().item() <= 4e-3, (d.max().item(), d.mean().item())
+    ws = ops._workspace(x.device)
+    assert int(ws.view(torch.int32)[:1024].abs().max().item()) == 0, "exchange flags / error word must be zero after the launch"
