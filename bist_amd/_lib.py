@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libbist_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GATE = 0, 1, 2
 # kernel families of bist_launch_count (include/bist_hip.h: BIST_K_*)
-K_ST1_MFMA_FWD, K_ST1_MFMA_BWD, K_ST1_VALU, K_ST2_MFMA_FWD, K_ST2_MFMA_BWD, K_ST2_VALU, K_MHA_FWD, K_MHA_BWD_MFMA, K_MHA_BWD_VALU, K_ST1_FUSED = range(10)
+K_ST1_MFMA_FWD, K_ST1_MFMA_BWD, K_ST1_VALU, K_ST2_MFMA_FWD, K_ST2_MFMA_BWD, K_ST2_VALU, K_MHA_FWD, K_MHA_BWD_MFMA, K_MHA_BWD_VALU, K_ST1_FUSED, K_DECSTACK = range(11)
 
 
 class BistGemm(C.Structure):
@@ -32,6 +32,7 @@ class BistGemm(C.Structure):
         ("hint", C.c_int32), ("reserved", C.c_int32),
         ("ln_gain", C.c_void_p), ("ln_offset", C.c_void_p), ("ln_out", C.c_void_p), ("ln_ld", C.c_int64), ("ln_eps", C.c_float),
         ("ln_mode", C.c_int32),
+        ("bias_bs1", C.c_int64),
     ]
 
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "bist_device_ok": (C.c_int, []),
     "bist_launch_count": (C.c_int64, [_I32]),
     "bist_launch_count_reset": (None, []),
+    "bist_dev_set_stamps": (C.c_int, [_I32, _P]),
     "bist_gemm": (C.c_int, [C.POINTER(BistGemm), _P]),
     "bist_gemm_pair": (C.c_int, [C.POINTER(BistGemm), C.POINTER(BistGemm), _P]),
     "bist_gemm_is_fast": (C.c_int, [C.POINTER(BistGemm)]),

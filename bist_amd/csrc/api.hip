@@ -1,6 +1,7 @@
 // Library-wide plumbing: version, error string, device probe.
 #include "common.hpp"
 #include <string.h>
+#include <stdlib.h>
 #include <atomic>
 
 namespace {
@@ -21,7 +22,24 @@ void bist_count_launch(int family) { if (family >= 0 && family < BIST_K_COUNT) g
 extern "C" int64_t bist_launch_count(int32_t family) { return family >= 0 && family < BIST_K_COUNT ? (int64_t)g_launches[family].load() : -1; }
 extern "C" void bist_launch_count_reset(void) { for (auto& c : g_launches) c.store(0); }
 
-extern "C" int bist_version(void) { return 100; }   // 0.1.0
+// ---- development hooks ---------------------------------------------------------------------------------------------------
+// In-kernel s_memtime stamp buffers of the fused stage-1 kernel (which = 0) and the persistent decoder kernel (which = 1): set by
+// an explicit call that hands over a device buffer the CALLER owns (scripts/stamp_*.py); null in production.  The ablation bits
+// (BIST_ST1F_DBG / BIST_DECSTACK_DBG) are read from the environment once per process.
+namespace { std::atomic<unsigned long long*> g_stamps[2]; }
+unsigned long long* bist_dev_stamps(int which) { return (which == 0 || which == 1) ? g_stamps[which].load(std::memory_order_relaxed) : nullptr; }
+int bist_dev_dbg(int which) {
+  static const int st1f = [] { const char* e = getenv("BIST_ST1F_DBG"); return e ? atoi(e) : 0; }();
+  static const int dec = [] { const char* e = getenv("BIST_DECSTACK_DBG"); return e ? atoi(e) : 0; }();
+  return which == 0 ? st1f : which == 1 ? dec : 0;
+}
+extern "C" int bist_dev_set_stamps(int32_t which, void* device_buffer) {
+  BIST_REQUIRE(which == 0 || which == 1, "bist_dev_set_stamps: which = 0 (fused stage 1) or 1 (decoder stack)");
+  g_stamps[which].store(reinterpret_cast<unsigned long long*>(device_buffer), std::memory_order_relaxed);
+  return BIST_OK;
+}
+
+extern "C" int bist_version(void) { return 101; }   // 0.1.1
 
 extern "C" const char* bist_last_error(void) { return g_err; }
 

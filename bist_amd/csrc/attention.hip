@@ -289,7 +289,7 @@ extern "C" int bist_st_stage1_pv_fwd(const void* scores, const void* V, const ui
     const int r = bist_st1_mfma(scores, sc_dtype == BIST_F32, V, tmask, O, nullptr, nullptr, 0, nullptr, B, T, S, Lq, h, dk, ldv, 0,
                                 direction, 0, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
-    if (r < 0) { bist_set_error("bist_st_stage1_pv_fwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+    if (r < 0) return BIST_ELAUNCH;      // (the matrix-core launcher left the reason in bist_last_error)
   }
   bist_count_launch(BIST_K_ST1_VALU);
   const int G = direction == 0 ? S : T, Kn = direction == 0 ? T : S;
@@ -324,7 +324,7 @@ extern "C" int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t*
   if (dtype == BIST_BF16 && !getenv("BIST_ST2_VALU")) {          // matrix-core path (attention_mfma.hip)
     const int r = bist_st2_mfma(q2f, Y, gmask, PY, nullptr, nullptr, nullptr, rowsum, nullptr, B, G, Lq, h, d, 0, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
-    if (r < 0) { bist_set_error("bist_st_stage2_fwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+    if (r < 0) return BIST_ELAUNCH;      // (the matrix-core launcher left the reason in bist_last_error)
   }
   bist_count_launch(BIST_K_ST2_VALU);
   const size_t lds = ((size_t)h * d + (size_t)h * G) * sizeof(float);

@@ -333,7 +333,7 @@ extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, co
     const int r = bist_mha_bwd_mfma(Q, K, V, mask, dO, dP_ext, dQ, dK, dV, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs,
                                     lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
-    if (r < 0) { bist_set_error("bist_mha_core_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+    if (r < 0) return BIST_ELAUNCH;      // (the matrix-core launcher left the reason in bist_last_error)
   }
   bist_count_launch(BIST_K_MHA_BWD_VALU);
   const size_t lds = (size_t)2 * Lq * Lk * sizeof(float);
@@ -365,7 +365,7 @@ extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const u
     const int r = bist_st1_mfma(scores, 1, V, tmask, nullptr, dO, dscores, dsc_bf16, dV, B, T, S, Lq, h, dk, ldv, lddv, direction, 1, dr,
                                 (hipStream_t)stream);
     if (r == 1) return BIST_OK;
-    if (r < 0) { bist_set_error("bist_st_stage1_pv_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+    if (r < 0) return BIST_ELAUNCH;      // (the matrix-core launcher left the reason in bist_last_error)
   }
   bist_count_launch(BIST_K_ST1_VALU);
   const int G = direction == 0 ? S : T, Kn = direction == 0 ? T : S;
@@ -395,7 +395,7 @@ extern "C" int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t*
   if (dtype == BIST_BF16 && !getenv("BIST_ST2_VALU")) {          // matrix-core path (attention_mfma.hip)
     const int r = bist_st2_mfma(q2f, Y, gmask, nullptr, dPY, dq2f, dY, nullptr, d_rowsum, B, G, Lq, h, d, 1, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
-    if (r < 0) { bist_set_error("bist_st_stage2_bwd: MFMA kernel launch failed"); return BIST_ELAUNCH; }
+    if (r < 0) return BIST_ELAUNCH;      // (the matrix-core launcher left the reason in bist_last_error)
   }
   bist_count_launch(BIST_K_ST2_VALU);
   const size_t lds = ((size_t)2 * h * d + (size_t)2 * h * G) * sizeof(float);

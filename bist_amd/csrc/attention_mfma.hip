@@ -17,6 +17,14 @@
 
 namespace {
 
+// 1 = launched; -1 = the launch failed (reason left in bist_last_error)
+inline int launched(const char* name) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 1;
+  bist_set_error("%s: launch failed: %s", name, hipGetErrorString(e));
+  return -1;
+}
+
 constexpr float MASK_FILL = -1e9f;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -312,16 +320,12 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
 
 template <typename TS, int KSTEPS, bool BWD>
 int launch_one(const St1Args& a, int B, size_t lds, hipStream_t st) {
-  static bool attr_set = false;       // allow > 64 KiB of dynamic LDS once per instantiation
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&st1_mfma_kernel<TS, KSTEPS, BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  BIST_LDS_OPTIN((&st1_mfma_kernel<TS, KSTEPS, BWD>), 160 * 1024, "bist_st_stage1_pv (matrix-core kernel)", -1);      // > 64 KiB of dynamic LDS
   const int G = a.dir == 0 ? a.S : a.T;
   dim3 grid((unsigned)((G + a.Gc - 1) / a.Gc), (unsigned)a.h, (unsigned)B);
   hipLaunchKernelGGL((st1_mfma_kernel<TS, KSTEPS, BWD>), grid, dim3(256), lds, st, a);
   bist_count_launch(BWD ? BIST_K_ST1_MFMA_BWD : BIST_K_ST1_MFMA_FWD);
-  return hipGetLastError() == hipSuccess ? 1 : -1;
+  return launched("st1_mfma_kernel");
 }
 
 // =====================================================================================================
@@ -747,7 +751,7 @@ int bist_mha_bwd_mfma(const void* Q, const void* K, const void* V, const unsigne
                Lq, Lk, h, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, drop, dk / 64};
   hipLaunchKernelGGL(mha_bwd_mfma_kernel, dim3((unsigned)h, (unsigned)N), dim3(256), 0, st, a);
   bist_count_launch(BIST_K_MHA_BWD_MFMA);
-  return hipGetLastError() == hipSuccess ? 1 : -1;
+  return launched("mha_bwd_mfma_kernel");
 }
 
 // returns 1 if launched, 0 if outside the envelope, -1 on launch error
@@ -762,15 +766,14 @@ int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, vo
   dim3 grid((unsigned)Lq, (unsigned)B);
 #define ST2_GO(BWD_, GB_)                                                                                                  \
   do {                                                                                                                     \
-    static bool attr = false;                                                                                              \
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&st2_mfma_kernel<BWD_, GB_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    BIST_LDS_OPTIN((&st2_mfma_kernel<BWD_, GB_>), 160 * 1024, "bist_st_stage2 (matrix-core kernel)", -1);                  \
     hipLaunchKernelGGL((st2_mfma_kernel<BWD_, GB_>), grid, dim3(256), lds, st, a);                                         \
   } while (0)
   if (bwd) { if (gb == 2) ST2_GO(true, 2); else ST2_GO(true, 1); }
   else { if (gb == 2) ST2_GO(false, 2); else ST2_GO(false, 1); }
 #undef ST2_GO
   bist_count_launch(bwd ? BIST_K_ST2_MFMA_BWD : BIST_K_ST2_MFMA_FWD);
-  return hipGetLastError() == hipSuccess ? 1 : -1;
+  return launched("st2_mfma_kernel");
 }
 
 // returns 1 if launched, 0 if the shape is outside this kernel's envelope (caller falls back), -1 on launch error

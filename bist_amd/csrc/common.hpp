@@ -33,6 +33,29 @@ void bist_count_launch(int family);       // BIST_K_* launch counters (api.hip)
     }                                                                        \
   } while (0)
 
+// Per-device, once-per-kernel opt-in to more than 64 KiB of dynamic LDS.  `static` at the expansion site: one flag word per kernel
+// instantiation, one bit per device ordinal (a process that drives several GPUs sets the attribute on each).  A refusal surfaces
+// HERE as an error return instead of as a launch failure far from its cause.
+#define BIST_LDS_OPTIN(kernel_, bytes_, name_, failret_)                                                                     \
+  do {                                                                                                                       \
+    static unsigned long long done__ = 0ULL;                                                                                 \
+    int dev__ = 0;                                                                                                           \
+    if (hipGetDevice(&dev__) != hipSuccess) dev__ = 0;                                                                       \
+    if (!(dev__ >= 0 && dev__ < 64 && ((done__ >> dev__) & 1ULL))) {                                                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes_)) != hipSuccess) { \
+        (void)hipGetLastError();                                                                                             \
+        bist_set_error("%s: cannot reserve %d bytes of dynamic LDS on device %d", name_, (int)(bytes_), dev__);               \
+        return failret_;                                                                                                     \
+      }                                                                                                                      \
+      if (dev__ >= 0 && dev__ < 64) done__ |= 1ULL << dev__;                                                                 \
+    }                                                                                                                        \
+  } while (0)
+
+// Development hooks (api.hip): in-kernel stamp buffers are handed over by an explicit call (bist_dev_set_stamps), never parsed
+// from the environment; the ablation bits are read from the environment ONCE.
+unsigned long long* bist_dev_stamps(int which);      // which: 0 = st1_fused, 1 = decstack; null unless set
+int bist_dev_dbg(int which);
+
 // MFMA implementation of the stage-1 core (attention_mfma.hip): 1 = launched, 0 = shape outside its envelope, -1 = error
 struct DropArg;
 int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsigned char* tmask, void* O, const void* dO,

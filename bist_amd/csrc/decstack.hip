@@ -487,8 +487,24 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
 
 }  // namespace
 
+// The kernel's NWG workers (every 8th block of the grid, i.e. one XCD; each holds 128 KiB of LDS = one per CU) must be resident
+// TOGETHER or its grid barriers time out: the current device needs at least NWG CUs per XCD (8 XCDs) and 128 KiB of opt-in LDS per
+// workgroup.  Queried once per device ordinal.
+static int bist_decoder_stack_device_ok(void) {
+  static signed char ok[64] = {0};            // 0 unknown, 1 yes, -1 no
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64 && ok[dev] != 0) return ok[dev] > 0;
+  hipDeviceProp_t p;
+  int good = 0;
+  if (hipGetDeviceProperties(&p, dev) == hipSuccess)
+    good = p.multiProcessorCount >= 8 * NWG && (long)p.sharedMemPerBlockOptin >= 128L * 1024;
+  if (dev >= 0 && dev < 64) ok[dev] = good ? 1 : -1;
+  return good;
+}
+
 extern "C" int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk_max, int32_t dtype) {
-  return dtype == BIST_BF16 && d == D && h == H && R >= 1 && R <= 64 && Lk_max >= 1 && Lk_max <= 64;
+  return dtype == BIST_BF16 && d == D && h == H && R >= 1 && R <= 64 && Lk_max >= 1 && Lk_max <= 64 && bist_decoder_stack_device_ok();
 }
 
 extern "C" int64_t bist_decoder_layer_desc_bytes(void) { return (int64_t)sizeof(DecLayerDev); }
@@ -500,19 +516,14 @@ extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, 
   BIST_REQUIRE(dtype == BIST_BF16 && n_layers >= 1 && R >= 1 && R <= 64 && slot0 >= 0 && slot0 + R <= 64 && LkS >= slot0 + R && LkS <= 64 && LkS % 32 == 0,
                "bist_decoder_stack_fwd: bf16, 1..64 rows, slots slot0 .. slot0 + R - 1 inside the LkS (32 or 64) key slots");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decstack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
-      bist_set_error("bist_decoder_stack_fwd: cannot reserve 128 KiB of LDS");
-      return BIST_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  BIST_REQUIRE(bist_decoder_stack_device_ok(), "bist_decoder_stack_fwd: this device cannot keep the kernel's %d workgroups resident on one XCD", NWG);
+  BIST_LDS_OPTIN(&decstack_kernel, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
   DecArgs a{(const DecLayerDev*)layers_dev, n_layers, (const bf16_t*)x_in, {(bf16_t*)xbuf0, (bf16_t*)xbuf1}, (bf16_t*)qbuf, (bf16_t*)kcache,
             (bf16_t*)vcache, slot0, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, nullptr};
-  if (const char* e = getenv("BIST_DECSTACK_DBG")) a.dbg = atoi(e);
-  if (const char* e = getenv("BIST_DECSTACK_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10));
+  a.dbg = bist_dev_dbg(1);
+  a.stamps = bist_dev_stamps(1);
   hipLaunchKernelGGL(decstack_kernel, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
   BIST_LAUNCH_CHECK("bist_decoder_stack_fwd");
+  bist_count_launch(BIST_K_DECSTACK);
   return BIST_OK;
 }

@@ -41,7 +41,7 @@ struct GemmK {   // device-side argument block (by value)
   int M, N, K;
   long a_rs, a_ks, b_rs, b_ks, ldc, ldr;
   int batch2;
-  long a_bs1, a_bs2, b_bs1, b_bs2, c_bs1, c_bs2, r_bs1, r_bs2, bias_bs2;
+  long a_bs1, a_bs2, b_bs1, b_bs2, c_bs1, c_bs2, r_bs1, r_bs2, bias_bs1, bias_bs2;
   float alpha; int act; int res_outer, res_inner;
   float drop_p; unsigned long long drop_seed; const unsigned long long* drop_ctr;
   int tiles_m, tiles_n;
@@ -223,7 +223,7 @@ struct RowOut {
   bool relu, dropping, gate;
   __device__ __forceinline__ RowOut(const GemmK& g_, int z1, int z2, unsigned long long zoff_) : g(g_), zoff(zoff_) {
     C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
-    bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
+    bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z1 * g.bias_bs1 + z2 * g.bias_bs2 : nullptr;
     res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
     relu = g.act == BIST_ACT_RELU;
     gate = g.act == BIST_ACT_GATE;
@@ -470,7 +470,7 @@ __device__ __forceinline__ void stream_out(const GemmK& g, const char* lds_lo, c
   const TO* res = nullptr;
   if constexpr (!SPLIT) {
     if (g.bias) {
-      const T* bias = reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 + n;
+      const T* bias = reinterpret_cast<const T*>(g.bias) + z1 * g.bias_bs1 + z2 * g.bias_bs2 + n;
 #pragma unroll
       for (int e = 0; e < VW; ++e) if (n + e < g.N) bv[e] = to_f(bias[e]);
     }
@@ -1504,7 +1504,7 @@ __global__ void splitk_reduce_kernel(const GemmK g, long total) {
   float acc = 0.f;
   for (int s = 0; s < g.split_k; ++s) acc += W[(long)s * mn];
   TO* C = reinterpret_cast<TO*>(g.C) + z1 * g.c_bs1 + z2 * g.c_bs2;
-  const T* bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z2 * g.bias_bs2 : nullptr;
+  const T* bias = g.bias ? reinterpret_cast<const T*>(g.bias) + z1 * g.bias_bs1 + z2 * g.bias_bs2 : nullptr;
   const TO* res = g.residual ? reinterpret_cast<const TO*>(g.residual) + z1 * g.r_bs1 + z2 * g.r_bs2 : nullptr;
   const float bv = bias ? to_f(bias[n]) : 0.f;
   C[(long)m * g.ldc + n] = from_f<TO>(epilogue_value<T, TO>(g, acc, bv, res, m, n, (unsigned long long)zlin * mn));
@@ -2013,7 +2013,7 @@ int fill_gemmk(const BistGemm* g, GemmK& k) {
   k.a_rs = g->a_rs; k.a_ks = g->a_ks; k.b_rs = g->b_rs; k.b_ks = g->b_ks; k.ldc = g->ldc; k.ldr = g->ldr;
   k.batch2 = g->batch2;
   k.a_bs1 = g->a_bs1; k.a_bs2 = g->a_bs2; k.b_bs1 = g->b_bs1; k.b_bs2 = g->b_bs2;
-  k.c_bs1 = g->c_bs1; k.c_bs2 = g->c_bs2; k.r_bs1 = g->r_bs1; k.r_bs2 = g->r_bs2; k.bias_bs2 = g->bias_bs2;
+  k.c_bs1 = g->c_bs1; k.c_bs2 = g->c_bs2; k.r_bs1 = g->r_bs1; k.r_bs2 = g->r_bs2; k.bias_bs1 = g->bias_bs1; k.bias_bs2 = g->bias_bs2;
   k.alpha = g->alpha; k.act = g->act; k.res_outer = g->res_outer; k.res_inner = g->res_inner;
   k.drop_p = g->drop_p; k.drop_seed = g->drop_seed; k.drop_ctr = (const unsigned long long*)g->drop_ctr;
   k.tiles_m = (g->M + BM - 1) / BM; k.tiles_n = (g->N + BN - 1) / BN;

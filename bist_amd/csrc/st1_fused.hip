@@ -441,15 +441,7 @@ __global__ void pack_frag_rows_kernel(const bf16_t* __restrict__ W, bf16_t* __re
 
 template <int KT, int MT4>
 int launch(const St1F& a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&st1_fused_kernel<KT, MT4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            MT * 16 * 1024) != hipSuccess) {
-      bist_set_error("bist_st_stage1_fused_fwd: cannot reserve %d bytes of LDS", MT * 16 * 1024);
-      return BIST_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  BIST_LDS_OPTIN((&st1_fused_kernel<KT, MT4>), MT * 16 * 1024, "bist_st_stage1_fused_fwd", BIST_ELAUNCH);
   hipLaunchKernelGGL((st1_fused_kernel<KT, MT4>), dim3((unsigned)(a.B * a.cpc)), dim3(512), MT * 16 * 1024, st, a);
   BIST_LAUNCH_CHECK("bist_st_stage1_fused_fwd");
   bist_count_launch(BIST_K_ST1_FUSED);
@@ -487,8 +479,8 @@ extern "C" int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const u
   const int KT = K <= 32 ? 2 : K <= 64 ? 4 : 8, NG = MT / KT;
   St1F a{(const bf16_t*)qf, (const bf16_t*)vft, kmask, (const bf16_t*)Wv, (const bf16_t*)bv, (const bf16_t*)Wo, (const bf16_t*)bo,
          (const bf16_t*)xres, (bf16_t*)Y, B, T, S, Lq, direction, (G + NG - 1) / NG, nullptr, 0};
-  if (const char* e = getenv("BIST_ST1F_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10));
-  if (const char* e = getenv("BIST_ST1F_DBG")) a.dbg = atoi(e);
+  a.stamps = bist_dev_stamps(0);
+  a.dbg = bist_dev_dbg(0);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int need = (NG * Lq + 15) / 16;          // 16-row tiles of the output projection
   if (KT == 2) return need <= 5 ? launch<2, 5>(a, st) : launch<2, 8>(a, st);

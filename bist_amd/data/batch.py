@@ -16,7 +16,9 @@ PAD = 1  # '<blank>' (data/data_handler.py:23; collate pads with 1, dataset.py:1
 
 def subsequent_mask(size: int, device=None) -> torch.Tensor:
     """[1,size,size] bool, True where a position may be attended (data/data_utils.py:14-18)."""
-    return torch.ones(1, size, size, dtype=torch.bool, device=device).tril_()
+    m = torch.ones(1, size, size, dtype=torch.bool, device=device).tril_()
+    m._bist_causal = size          # content tag: consumers may cache what they derive from a pure causal mask by its size alone
+    return m
 
 
 class Batch:

@@ -240,17 +240,24 @@ class MultimodalDecoder8(nn.Module):
         return raw
 
     def _self_mask(self, st, b, n: int, Lt: int, LkS: int):
-        """[n*Lt, LkS] uint8: row (j,t) attends key (j',t') iff j' == j and trg_mask[j or 0][t][t'] (dataset.py:101-105)."""
+        """[n*Lt, LkS] uint8: row (j,t) attends key (j',t') iff j' == j and trg_mask[j or 0][t][t'] (dataset.py:101-105).
+        Pure causal target masks (data.batch.subsequent_mask tags them; every beam-search step has one) are cached by CONTENT --
+        (rows, prefix length, slots) -- and never evicted or replaced: captured step graphs of several dialogue geometries share
+        (n, Lt) and bake the buffer's address, so one buffer per key must live as long as the decoder.  Any other target mask is
+        built per call (during a capture it then comes from, and lives with, that graph's own memory pool)."""
         tm = b.trg_mask
-        key = (n, Lt, LkS, tm.data_ptr(), tm._version, tuple(tm.shape))
-        hit = st["masks"].get(key[:3])
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        causal = getattr(tm, "_bist_causal", None) == Lt and tuple(tm.shape[-2:]) == (Lt, Lt)
+        key = (n, Lt, LkS, tm.device)
+        if causal:
+            hit = st["masks"].get(key)
+            if hit is not None:
+                return hit
         m = torch.zeros(n * Lt, LkS, device=tm.device, dtype=torch.uint8)
         blk = tm.to(torch.uint8).expand(n, Lt, Lt)
         for j in range(n):
             m[j * Lt:(j + 1) * Lt, j * Lt:(j + 1) * Lt] = blk[j]
-        st["masks"][key[:3]] = (key, m)
+        if causal:
+            st["masks"][key] = m
         return m
 
     def check_decode_errors(self) -> None:

@@ -48,7 +48,7 @@ def gemm_desc(a: Tensor, b: Tensor, c: Tensor, *, M: int, N: int, K: int, a_rs: 
               a_ks: int = 1, b_ks: int = 1, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
               alpha: float = 1.0, act: int = ACT_NONE, batch: Tuple[int, int] = (1, 1),
               a_bs: Tuple[int, int] = (0, 0), b_bs: Tuple[int, int] = (0, 0), c_bs: Tuple[int, int] = (0, 0),
-              r_bs: Tuple[int, int] = (0, 0), bias_bs2: int = 0, res_map: Tuple[int, int] = (0, 0),
+              r_bs: Tuple[int, int] = (0, 0), bias_bs2: int = 0, bias_bs1: int = 0, res_map: Tuple[int, int] = (0, 0),
               a_off: int = 0, b_off: int = 0, c_off: int = 0, bias_off: int = 0, r_off: int = 0,
               drop_p: float = 0.0, drop_seed: int = 0) -> BistGemm:
     _dev(a, b, c, bias, residual)
@@ -69,6 +69,7 @@ def gemm_desc(a: Tensor, b: Tensor, c: Tensor, *, M: int, N: int, K: int, a_rs: 
     g.c_bs1, g.c_bs2 = c_bs
     g.r_bs1, g.r_bs2 = r_bs
     g.bias_bs2 = bias_bs2
+    g.bias_bs1 = bias_bs1
     g.alpha, g.act = alpha, act
     g.res_outer, g.res_inner = res_map
     g.in_dtype, g.out_dtype = dtype_code(a.dtype), dtype_code(c.dtype)

@@ -55,9 +55,14 @@ int bist_device_ok(void);
 #define BIST_K_MHA_BWD_MFMA 7
 #define BIST_K_MHA_BWD_VALU 8
 #define BIST_K_ST1_FUSED 9      /* bist_st_stage1_fused_fwd                                                  */
-#define BIST_K_COUNT 10
+#define BIST_K_DECSTACK 10      /* bist_decoder_stack_fwd (persistent decoder-stack kernel)                   */
+#define BIST_K_COUNT 11
 int64_t bist_launch_count(int32_t family);
 void bist_launch_count_reset(void);
+/* Development hook: hand the fused stage-1 kernel (which = 0) or the persistent decoder kernel (which = 1) a caller-owned DEVICE
+ * buffer for its in-kernel s_memtime stamps (8 / 128 uint64 per workgroup; see scripts/stamp_*.py), or NULL to switch them off.
+ * Production never calls it; nothing is read from the environment.                                                           */
+int bist_dev_set_stamps(int32_t which, void* device_buffer);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM  C[z] = epilogue( alpha * A[z] . B[z]^T )            (fp32 accumulate on the MFMA units)
@@ -127,6 +132,10 @@ typedef struct BistGemm {
    * two column-tile workgroups of a row block exchange their row statistics through `workspace`).  Envelope (bist_gemm_ln_ok): bf16,
    * N = 512, M a multiple of 256, K-contiguous operands, no dropout / residual, workspace >= 4 KiB + M * 16 bytes; ln_out unused. */
   int32_t ln_mode;
+  /* bias stride (elements) of the OUTER batch index z1 (bias_bs2 above is the inner one's): a product batched over two sets of
+   * weights -- the t2s and s2t instances of one sublayer (encoder.py:176,184: attn[0] / attn[3], ...), run as one launch -- reads
+   * set z1's bias at bias + z1 * bias_bs1.  (Appended in 0.1.1; 0 = one bias for every z1.)                                    */
+  int64_t bias_bs1;
 } BistGemm;
 int bist_gemm_ln_ok(const BistGemm* g);       /* 1 if bist_gemm(g) will run g's LayerNorm prologue */
 #define BIST_GEMM_TILE256 2

@@ -3,7 +3,8 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 stamps = torch.zeros(128, dtype=torch.int64, device="cuda")
-os.environ["BIST_DECSTACK_STAMPS"] = str(stamps.data_ptr())
+from bist_amd import _lib as _bl
+_bl.check(_bl.lib.bist_dev_set_stamps(1, stamps.data_ptr()), "bist_dev_set_stamps")      # explicit hand-over of a buffer this script owns
 import bench
 import bist_amd.model as M
 from bist_amd.model.decode import beam_search_decode

@@ -1,4 +1,4 @@
-"""Phase timeline of st1_fused_kernel from in-kernel s_memtime stamps (development aid; BIST_ST1F_STAMPS)."""
+"""Phase timeline of st1_fused_kernel from in-kernel s_memtime stamps (development aid; bist_dev_set_stamps)."""
 import os
 import sys
 
@@ -12,7 +12,8 @@ K = T if direction == 0 else S
 NG = 4 if K <= 32 else 2 if K <= 64 else 1
 nwg = B * ((G + NG - 1) // NG)
 stamps = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
-os.environ["BIST_ST1F_STAMPS"] = str(stamps.data_ptr())
+from bist_amd import _lib as _bl
+_bl.check(_bl.lib.bist_dev_set_stamps(0, stamps.data_ptr()), "bist_dev_set_stamps")      # explicit hand-over of a buffer this script owns
 from bist_amd import ops
 
 g = torch.Generator().manual_seed(0)

@@ -15,7 +15,8 @@ Capture-process-only shims (never shipped, the reference is not modified):
   * generator.py:66,113 / decode.py:63-65 hard-code ``.cuda()`` -> identity on
     this CPU-only box.
 
-usage:  python tests/golden/make_golden.py [g6]   (from the repo root; "g6" regenerates the full-size digests only)
+usage:  python tests/golden/make_golden.py [g6|g7|g8]   (from the repo root; "g6" regenerates the full-size digests only,
+        "g8" the teacher-forced decode-step log-probs of the full-size model only)
 """
 import argparse
 import json
@@ -262,11 +263,61 @@ def main_g6():
     np.savez_compressed(os.path.join(HERE, "g6_fullsize.npz"), **out)
 
 
+G8_ROWS, G8_STEPS, G8_TOPK, G8_SAMPLES = 5, 12, 16, 64
+
+
+def g8_sequences(vocab):
+    """Five forced responses of twelve tokens (ids 4 .. V-1: no <pad>/<sos>/<eos>/<unk>), one per hypothesis row."""
+    rs = np.random.RandomState(8008)
+    return rs.randint(4, vocab, size=(G8_ROWS, G8_STEPS)).astype(np.int64)
+
+
+def main_g8():
+    """The reference's decode STEP at d_model=512, L=6 (BASELINE configs[4]'s model): for five forced token sequences and every prefix
+    length 1..12 (decode.py:63-70: trg = <sos> + prefix, causal mask, model.decode, last position, generator), the log-prob row's
+    16 largest entries (ids + values) and its values at 64 fixed ids.  Pins the build's persistent decoder kernel (one decode step at
+    a time, self-attention pools, ancestry masks) to the reference at every position, not only through a short n-best list."""
+    from data.data_utils import subsequent_mask
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=6, nb_venc_blocks=6, nb_cenc_blocks=6)
+    dims = dict(FULL, T=32)
+    vocab = dims["V"]
+    model, sd = build(cfg, vocab, dims["C"])
+    ob1 = O.det_batch(1, dims["T"], dims["S"], dims["C"], dims["Lq"], dims["Lh"], dims["Lc"], dims["Lt"], vocab, seed=dims["seed"] + 1)
+    rb = ref_batch(ob1)
+    seqs = g8_sequences(vocab)
+    sample_ids = np.linspace(0, vocab - 1, G8_SAMPLES).astype(np.int64)
+    top_ids = np.zeros((G8_ROWS, G8_STEPS, G8_TOPK), dtype=np.int64)
+    top_val = np.zeros((G8_ROWS, G8_STEPS, G8_TOPK), dtype=np.float32)
+    samp = np.zeros((G8_ROWS, G8_STEPS, G8_SAMPLES), dtype=np.float32)
+    args = ref_args(cfg)
+    with torch.no_grad():
+        ft = model.encode(rb)
+        for j in range(G8_ROWS):
+            for l in range(G8_STEPS):
+                st = torch.tensor([[O.SOS_ID] + [int(t) for t in seqs[j, :l]]], dtype=torch.long)
+                rb.trg = st
+                rb.trg_mask = subsequent_mask(st.size(1)).long()
+                rb.trg_mean_mask = torch.ones(st.shape).long()
+                ft = model.decode(rb, ft)
+                ft["decoded_text"] = ft["decoded_text"][:, -1].unsqueeze(1)
+                ft["encoded_tgt"] = ft["encoded_tgt"][:, -1].unsqueeze(1)
+                lp = model.generator(ft, rb, args).reshape(-1).numpy()
+                order = np.argsort(lp)[::-1][:G8_TOPK]
+                top_ids[j, l], top_val[j, l], samp[j, l] = order, lp[order], lp[sample_ids]
+    out = {"seqs": seqs, "top_ids": top_ids, "top_val": top_val, "sample_ids": sample_ids, "sample_val": samp,
+           "cfg": np.asarray(json.dumps({"cfg": cfg.__dict__, "dims": dims}))}
+    np.savez_compressed(os.path.join(HERE, "g8_decode_steps.npz"), **out)
+
+
 def main():
     os.makedirs(HERE, exist_ok=True)
     if sys.argv[1:] == ["g6"]:                 # the full-size digests alone (the other fixtures are untouched)
         main_g6()
         print("g6_fullsize.npz", os.path.getsize(os.path.join(HERE, "g6_fullsize.npz")) // 1024, "KiB")
+        return
+    if sys.argv[1:] == ["g8"]:
+        main_g8()
+        print("g8_decode_steps.npz", os.path.getsize(os.path.join(HERE, "g8_decode_steps.npz")) // 1024, "KiB")
         return
     if sys.argv[1:] == ["g7"]:
         main_g7()
@@ -292,6 +343,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g5_beam.npz"), **out)
     main_g6()
     main_g7()
+    main_g8()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

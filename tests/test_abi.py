@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     import subprocess
     from bist_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    structs = {"BistGemm": ["a_rs", "alpha", "drop_seed", "workspace", "hint", "ln_gain", "ln_ld", "ln_eps"],
+    structs = {"BistGemm": ["a_rs", "alpha", "drop_seed", "workspace", "hint", "ln_gain", "ln_ld", "ln_eps", "ln_mode", "bias_bs1"],
                "BistDecLayer": ["Wqkv", "Wo", "cmask", "W1", "Lk", "LkP"], "BistDrop": ["seed", "ctr"]}
     src = ["#include <stdio.h>", "#include <stddef.h>", '#include "bist_hip.h"', "int main(void) {"]
     for st, fields in structs.items():
@@ -86,3 +86,17 @@ def test_reference_pickle_resolves_to_this_build_on_cpu(golden_dir):
     assert obj.generator.vocab_gen is obj.query_embed[0].lut.weight          # the shared embedding survives the pickle
     sub = obj.mutlimodal_decoder.v_layers[0].sublayer[0]
     assert sub.p == sub.dropout.p and obj.mutlimodal_decoder.v_layers[0].attn[0].keep_attn is False
+
+
+def test_no_spill_of_a_register_with_an_inline_asm_load_in_flight():
+    """The fused stage-1 kernel's inline-asm loads write registers the compiler does not track (counted waits): the ISA guard that
+    __graft_entry__.build() runs must pass for the sources as they are (a compiler update that starts spilling such a register
+    would corrupt results silently between GPU runs)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("/opt/rocm/bin/hipcc") is None:
+        pytest.skip("hipcc is not installed here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_spills.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("inline-asm load in flight: none") >= 5, r.stdout

@@ -321,10 +321,13 @@ def test_incremental_beam_search_equals_full_prefix_recompute(hip):
     assert any(k[0] == "incr" for k in store if isinstance(k, tuple)), "the incremental step graphs were not used"
 
 
-def test_beam_search_turns_of_different_dialogue_lengths_do_not_share_state(hip):
+@pytest.mark.parametrize("incremental", [True, False], ids=["incremental", "full_prefix"])
+def test_beam_search_turns_of_different_dialogue_lengths_do_not_share_state(hip, incremental):
     """Turns of two dialogue geometries in alternation (A, B, A, B): the persistent decoder kernel's per-geometry key / value caches,
     descriptors, self-attention pools and the captured step graphs must each serve their own turn.  Every turn equals the same turn
-    decoded with the layer-by-layer decoder and full-prefix steps."""
+    decoded with the layer-by-layer decoder and full-prefix steps.  full_prefix: the fused kernel on ALL prefix rows per step
+    (BIST_INCREMENTAL_DECODE=0): the step graphs of both geometries share (hypotheses, prefix length) and with it the block-diagonal
+    self-attention mask buffer -- replaying geometry A's graphs after geometry B's were captured must still read a live mask."""
     import bist_amd.model.decode as D
     from bist_amd import functional as Fn
     from bist_amd.model.decode import beam_search_decode
@@ -339,7 +342,18 @@ def test_beam_search_turns_of_different_dialogue_lengths_do_not_share_state(hip)
         with torch.no_grad():
             return beam_search_decode(model, to_batch(Batch, ob, torch.bfloat16), 12, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID, beam=5,
                                       penalty=1.0, nbest=5, train_args=_args(cfg))[0]
-    fast = [turn(ob) for ob in dialogues] + [turn(dialogues[0])]
+    model.__dict__.pop("_bist_step_graphs", None); model.__dict__.pop("_bist_step_graphs_key", None)
+    D.INCREMENTAL = incremental
+    try:
+        fast = [turn(ob) for ob in dialogues] + [turn(dialogues[0])]
+        if not incremental:
+            # allocations between the replays: a mask buffer freed by mistake would be recycled under the captured graphs
+            junk = [torch.randn(64, 64, device="cuda") for _ in range(64)]
+            again = turn(dialogues[0])
+            assert [list(map(int, x[0])) for x in again] == [list(map(int, x[0])) for x in fast[0]]
+            del junk
+    finally:
+        D.INCREMENTAL = True
     Fn.FUSED_DECODE, D.INCREMENTAL = False, False
     model.__dict__.pop("_bist_step_graphs", None); model.__dict__.pop("_bist_step_graphs_key", None)
     try:
@@ -376,3 +390,88 @@ def test_beam_search_on_length_buckets_gives_the_same_n_best(hip, golden_dir):
     for i, (toks, score) in enumerate(hyps):
         assert [int(t) for t in toks] == g[f"beam5_hyp{i}"].tolist(), f"hyp {i}"
         assert abs(float(score) - float(g[f"beam5_score{i}"])) < 1e-3
+
+
+def _counts():
+    from bist_amd import _lib
+    return {n: _lib.lib.bist_launch_count(getattr(_lib, n)) for n in dir(_lib) if n.startswith("K_")}
+
+
+def test_persistent_decoder_steps_match_the_reference_golden(hip, golden_dir):
+    """BASELINE configs[4]: the path the bench's `decode` line times -- bf16, d_model=512, L=6, the decoder layers of every decode
+    step as ONE persistent launch (bist_decoder_stack_fwd), one step at a time over the per-layer self-attention pools with ancestry
+    masks -- against the REFERENCE's own decode steps (tests/golden/g8_decode_steps.npz: model/decode.py:63-70 run at full size for
+    five forced token sequences, every prefix length 1..12).  Step l carries the five hypotheses' NEW tokens only; hypothesis j
+    attends slot 0 (<sos>, shared) and its own earlier slots.  bf16 bound: every sampled / top-16 log-prob within 8e-2 of the
+    reference's fp32 value (they are O(10)); the arg-max token identical wherever the reference's own top-2 margin exceeds 2 x that."""
+    import bist_amd.model.decode as D
+    from bist_amd import _lib
+    M, Batch = hip
+    g = np.load(os.path.join(golden_dir, "g8_decode_steps.npz"))
+    meta = json.loads(str(g["cfg"]))
+    cfg, dm = O.Cfg(**meta["cfg"]), meta["dims"]
+    model, _ = build_model(M, cfg, dm["V"], dm["C"], torch.bfloat16)
+    ob = O.det_batch(1, dm["T"], dm["S"], dm["C"], dm["Lq"], dm["Lh"], dm["Lc"], dm["Lt"], dm["V"], seed=dm["seed"] + 1)
+    b = to_batch(Batch, ob, torch.bfloat16)
+    seqs, sample_ids = g["seqs"], g["sample_ids"]
+    n, steps = seqs.shape
+    BOUND = 8e-2
+    worst, decided, agree = 0.0, 0, 0
+
+    def check(lp_row, j, l):
+        nonlocal worst, decided, agree
+        e = max(np.abs(lp_row[g["top_ids"][j, l]] - g["top_val"][j, l]).max(), np.abs(lp_row[sample_ids] - g["sample_val"][j, l]).max())
+        worst = max(worst, float(e))
+        if g["top_val"][j, l, 0] - g["top_val"][j, l, 1] > 2 * BOUND:
+            decided += 1
+            agree += int(lp_row.argmax()) == int(g["top_ids"][j, l, 0])
+
+    _lib.lib.bist_launch_count_reset()
+    model.__dict__.pop("_bist_step_graphs", None); model.__dict__.pop("_bist_step_graphs_key", None)
+    with torch.no_grad():
+        ft, lp0 = D._graph_first_step(model, b, O.SOS_ID, _args(cfg))
+        assert ft.get("_bist_pool_ready"), "the turn's first step did not run through the persistent decoder kernel"
+        for j in range(n):
+            check(lp0.reshape(-1), j, 0)
+        bn, fn = D._turn_for_rows(b, ft, n, {})
+        for l in range(1, steps):
+            slot0 = l * n
+            mask = np.zeros((n, 32 if slot0 + n <= 32 else 64), dtype=np.uint8)
+            for j in range(n):
+                mask[j, [0] + [k * n + j for k in range(1, l)] + [slot0 + j]] = 1
+            last = torch.from_numpy(seqs[:, l - 1:l].copy())
+            lp = D._graph_step_incr(model, bn, fn, last, l, slot0, mask, _args(cfg))
+            assert lp.shape[:2] == (n, 1)
+            for j in range(n):
+                check(lp[j, 0], j, l)
+        model.mutlimodal_decoder.check_decode_errors()
+    c = _counts()
+    assert c["K_DECSTACK"] >= 2 * steps - 1, c            # warm-up + capture of the first step and of each of the 11 incremental steps
+    assert worst <= BOUND, f"log-probs beyond the bf16 bound of the reference: {worst}"
+    assert decided >= 30 and agree == decided, (decided, agree)
+
+
+def test_bf16_persistent_decoder_beam_search_matches_the_full_size_reference_n_best(hip, golden_dir):
+    """The same production path end to end: bf16 beam search (beam 5, maxlen 12; fused decoder stack + incremental steps, asserted
+    through bist_launch_count) at d_model=512, L=6 on the G6 dialogue against the REFERENCE's n-best (g6_fullsize.npz T32_beam_*):
+    identical token lists, scores within the bf16 bound."""
+    from bist_amd import _lib
+    from bist_amd.model.decode import beam_search_decode
+    M, Batch = hip
+    g = np.load(os.path.join(golden_dir, "g6_fullsize.npz"))
+    meta = json.loads(str(g["T32_cfg"]))
+    cfg, dm = O.Cfg(**meta["cfg"]), meta["dims"]
+    model, _ = build_model(M, cfg, dm["V"], dm["C"], torch.bfloat16)
+    ob1 = O.det_batch(1, dm["T"], dm["S"], dm["C"], dm["Lq"], dm["Lh"], dm["Lc"], dm["Lt"], dm["V"], seed=dm["seed"] + 1)
+    _lib.lib.bist_launch_count_reset()
+    with torch.no_grad():
+        for _ in range(2):                   # the second turn replays the captured graphs
+            hyps, _best = beam_search_decode(model, to_batch(Batch, ob1, torch.bfloat16), 12, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID,
+                                             beam=meta["beam"], penalty=1.0, nbest=5, train_args=_args(cfg))
+    assert _counts()["K_DECSTACK"] >= 12, _counts()
+    store = model.__dict__.get("_bist_step_graphs", {})
+    assert any(k[0] == "incr" for k in store if isinstance(k, tuple)), "the incremental step graphs were not used"
+    assert len(hyps) == int(g["T32_beam_n"])
+    for i, (toks, score) in enumerate(hyps):
+        assert [int(t) for t in toks] == g[f"T32_beam_hyp{i}"].tolist(), (i, toks)
+        assert abs(float(score) - float(g[f"T32_beam_score{i}"])) <= 8e-2, (i, float(score), float(g[f"T32_beam_score{i}"]))

@@ -170,3 +170,27 @@ def test_oracle_matches_reference_at_full_size(golden_dir, tag):
     check_digest(_digest(logp), g[f"{tag}_dg_logp"], f"{tag} logp", 2e-4)
     assert np.array_equal(logp.argmax(-1).numpy(), g[f"{tag}_argmax"])
     assert np.abs(logp[0, 0].numpy() - g[f"{tag}_logp_row0"]).max() <= 2e-4
+
+
+def test_oracle_decode_steps_match_reference_at_full_size(golden_dir):
+    """tests/golden/g8_decode_steps.npz: the REFERENCE's decode step (decode.py:63-70) at d_model=512, L=6 for five forced token
+    sequences and every prefix length 1..12 -- the 16 largest log-probs (ids + values) and 64 sampled entries per step.  The oracle
+    is checked on a subset (two rows, three prefix lengths: each oracle decode re-runs the whole reasoning, like the reference)."""
+    g = np.load(os.path.join(golden_dir, "g8_decode_steps.npz"))
+    meta = json.loads(str(g["cfg"]))
+    cfg, dm = O.Cfg(**meta["cfg"]), meta["dims"]
+    sd = O.det_state(cfg, dm["V"], dm["C"])
+    b = O.det_batch(1, dm["T"], dm["S"], dm["C"], dm["Lq"], dm["Lh"], dm["Lc"], dm["Lt"], dm["V"], seed=dm["seed"] + 1)
+    seqs, sample_ids = g["seqs"], g["sample_ids"]
+    with torch.no_grad():
+        ft = O.mtn_encode(sd, cfg, b)
+        for j, l in ((0, 0), (0, 5), (0, 11), (3, 1), (3, 7), (3, 11)):
+            st = torch.tensor([[O.SOS_ID] + [int(t) for t in seqs[j, :l]]], dtype=torch.long)
+            b.trg, b.trg_mask = st, O.subsequent_mask(st.size(1))
+            ft = O.mtn_decode(sd, cfg, b, ft)
+            step = dict(ft)
+            step["decoded_text"], step["encoded_tgt"] = ft["decoded_text"][:, -1:], ft["encoded_tgt"][:, -1:]
+            lp = O.multi_pointer_generator(sd, cfg, step, b).reshape(-1).numpy()
+            assert np.abs(lp[g["top_ids"][j, l]] - g["top_val"][j, l]).max() <= 2e-4, (j, l)
+            assert np.abs(lp[sample_ids] - g["sample_val"][j, l]).max() <= 2e-4, (j, l)
+            assert int(lp.argmax()) == int(g["top_ids"][j, l, 0]), (j, l)
