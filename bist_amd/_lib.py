@@ -53,6 +53,15 @@ class BistLnGrad(C.Structure):
                 ("rows", C.c_int64), ("lddy", C.c_int64), ("ldx", C.c_int64), ("eps", C.c_float)]
 
 
+class BistLnSet(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p)]
+
+
+class BistLnBwdSet(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("a", C.c_void_p), ("dx", C.c_void_p), ("da", C.c_void_p), ("db", C.c_void_p),
+                ("dx_add", C.c_void_p), ("dz", C.c_void_p), ("drop_row0", C.c_uint64)]
+
+
 class BistColSum(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64), ("N", C.c_int32), ("ldx", C.c_int64)]
 
@@ -72,6 +81,10 @@ SIGNATURES = {
     "bist_gemm_is_fast": (C.c_int, [C.POINTER(BistGemm)]),
     "bist_gemm_ln_ok": (C.c_int, [C.POINTER(BistGemm)]),
     "bist_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I64, _I64, _F, _I32, _P]),
+    "bist_layernorm_fwd_multi": (C.c_int, [C.POINTER(BistLnSet), _I32, _I64, _I32, _I64, _I64, _F, _I32, _P]),
+    "bist_layernorm_bwd_multi": (C.c_int, [C.POINTER(BistLnBwdSet), _I32, _I64, _I32, _I64, _I64, _I64, _F, _I64, C.POINTER(BistDrop), _I32, _P]),
+    "bist_scaled_bias_fwd_z": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I32, _P]),
+    "bist_scaled_bias_bwd_z": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I32, _P]),
     "bist_mha_core_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32,
                                     _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.POINTER(BistDrop), _I32, _P]),
     "bist_st_stage1_pv_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, C.POINTER(BistDrop), _I32, _I32, _P]),

@@ -183,11 +183,22 @@ __global__ __launch_bounds__(256) void col_sum_multi_kernel(const ColSumBatch b)
 // LayerNorm backward (forward: y = a*(x-mean)/(std+eps)+b, std unbiased):
 //   g = dy*a;  dx_i = (g_i - mean(g))/s - xc_i * sum_j(g_j xc_j) / ((d-1) * std * s^2),  s = std+eps
 //   da += dy * xc/s ; db += dy          (fp32 atomics, one row per wave, 4 rows per block)
+// Several LayerNorm backward passes of one geometry in ONE launch (bist_layernorm_bwd_multi): set = blockIdx.y.  row0 = the set's first
+// row in the stacked tensor the dropout mask of dz is indexed by (the mask of the producing GEMM's epilogue runs over the stacked output).
+constexpr int LNB_SETS = 8;
+struct LnBwdSetsK {
+  const void* dy[LNB_SETS]; const void* x[LNB_SETS]; const void* a[LNB_SETS]; void* dx[LNB_SETS]; float* da[LNB_SETS]; float* db[LNB_SETS];
+  const void* add[LNB_SETS]; void* dz[LNB_SETS]; unsigned long long row0[LNB_SETS];
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
-                                                            T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
-                                                            long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
-                                                            const T* __restrict__ dx_add, long ldadd, T* __restrict__ dz, const DropArg zdrop) {
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LnBwdSetsK sets, long rows, int d, long lddy, long ldx, long lddx, float eps,
+                                                            int rows_per_wave, long ldadd, const DropArg zdrop) {
+  const int zs = blockIdx.y;
+  const T* __restrict__ dy = (const T*)sets.dy[zs]; const T* __restrict__ x = (const T*)sets.x[zs]; const T* __restrict__ a = (const T*)sets.a[zs];
+  T* __restrict__ dx = (T*)sets.dx[zs]; float* __restrict__ da = sets.da[zs]; float* __restrict__ db = sets.db[zs];
+  const T* __restrict__ dx_add = (const T*)sets.add[zs]; T* __restrict__ dz = (T*)sets.dz[zs];
+  const unsigned long long zrow0 = sets.row0[zs];
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long r0 = wave * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         const float add = dx_add ? to_f(dx_add[row * ldadd + c]) : 0.f;
         const T dxv = from_f<T>((gy * to_f(a[c]) - mg) * inv - xc * k2 + add);
         dxr[c] = dxv;
-        if (dz) dz[row * (long)d + c] = from_f<T>(to_f(dxv) * drop_mul(zkey, (unsigned long long)row * d + c, zdrop.p, zks));
+        if (dz) dz[row * (long)d + c] = from_f<T>(to_f(dxv) * drop_mul(zkey, (zrow0 + (unsigned long long)row) * d + c, zdrop.p, zks));
         pa[u] += gy * xc * inv;
         pb[u] += gy;
       }
@@ -247,7 +258,8 @@ __device__ __forceinline__ void layernorm_bwd_vec_body(const T* __restrict__ dy,
                                                        T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
                                                        long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
                                                        const T* __restrict__ dx_add, long ldadd, long blk, float (*red)[4][64 * NV * (16 / (int)sizeof(T))],
-                                                       T* __restrict__ dz = nullptr, const DropArg zdrop = DropArg{0.f, 0ULL, nullptr}) {
+                                                       T* __restrict__ dz = nullptr, const DropArg zdrop = DropArg{0.f, 0ULL, nullptr},
+                                                       unsigned long long zrow0 = 0ULL) {
   constexpr int E = 16 / (int)sizeof(T), NE = NV * E;
   const unsigned long long zkey = (DX && dz) ? zdrop.key() : 0ULL;
   const float zks = (DX && dz) ? zdrop.keep_scale() : 1.f;
@@ -310,7 +322,7 @@ __device__ __forceinline__ void layernorm_bwd_vec_body(const T* __restrict__ dy,
           T zo[E];
 #pragma unroll
           for (int e = 0; e < E; ++e)
-            zo[e] = from_f<T>(to_f(o[e]) * drop_mul(zkey, (unsigned long long)row * d + (j * 64 + lane) * E + e, zdrop.p, zks));
+            zo[e] = from_f<T>(to_f(o[e]) * drop_mul(zkey, (zrow0 + (unsigned long long)row) * d + (j * 64 + lane) * E + e, zdrop.p, zks));
           *reinterpret_cast<uint4*>(dz + row * (long)d + (j * 64 + lane) * E) = *reinterpret_cast<const uint4*>(zo);
         }
       }
@@ -330,13 +342,13 @@ __device__ __forceinline__ void layernorm_bwd_vec_body(const T* __restrict__ dy,
 }
 
 template <typename T, int NV, bool PARAMS>
-__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ a,
-                                                                T* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
-                                                                long rows, int d, long lddy, long ldx, long lddx, float eps, int rows_per_wave,
-                                                                const T* __restrict__ dx_add, long ldadd, T* __restrict__ dz, const DropArg zdrop) {
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const LnBwdSetsK sets, long rows, int d, long lddy, long ldx, long lddx, float eps,
+                                                                int rows_per_wave, long ldadd, const DropArg zdrop) {
   __shared__ float red[PARAMS ? 2 : 1][4][64 * NV * (16 / (int)sizeof(T))];
-  layernorm_bwd_vec_body<T, NV, true, PARAMS>(dy, x, a, dx, da, db, rows, d, lddy, ldx, lddx, eps, rows_per_wave, dx_add, ldadd,
-                                              (long)blockIdx.x, red, dz, zdrop);
+  const int zs = blockIdx.y;
+  layernorm_bwd_vec_body<T, NV, true, PARAMS>((const T*)sets.dy[zs], (const T*)sets.x[zs], (const T*)sets.a[zs], (T*)sets.dx[zs], sets.da[zs], sets.db[zs],
+                                              rows, d, lddy, ldx, lddx, eps, rows_per_wave, (const T*)sets.add[zs], ldadd,
+                                              (long)blockIdx.x, red, (T*)sets.dz[zs], zdrop, sets.row0[zs]);
 }
 
 // gain/offset gradients of many LayerNorms (one row width) in one launch: block -> job through the prefix table
@@ -373,21 +385,23 @@ __global__ void embed_bwd_kernel(const long* __restrict__ ids, const T* __restri
 // y = x + s[m, head] * bias  and its backward (the value bias of stage 2 under attention dropout, bist_hip.h)
 template <typename T>
 __global__ void scaled_bias_kernel(const T* __restrict__ x, const float* __restrict__ s, const T* __restrict__ bias, T* __restrict__ y,
-                                   long M, int h, int dk) {
+                                   long M, int h, int dk, long Mset, long bias_zs) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int d = h * dk;
   if (idx >= M * d) return;
   const long m = idx / d; const int c = (int)(idx % d);
-  y[idx] = from_f<T>(to_f(x[idx]) + s[m * h + c / dk] * to_f(bias[c]));
+  y[idx] = from_f<T>(to_f(x[idx]) + s[m * h + c / dk] * to_f(bias[(m / Mset) * bias_zs + c]));      // rows [z*Mset, (z+1)*Mset) use bias set z
 }
 // ds[m, head] = <dy[m, head, :], bias[head, :]>  and  dbias[head, c] += sum_m s[m, head] dy[m, head, c].
 // One wave per head per block of RPB rows: the wave walks its rows, keeps the dbias partial sums of its head in
 // registers (dk <= 256: up to 4 columns per lane) and issues ONE atomic per column per block (it was one per element).
 template <typename T>
 __global__ __launch_bounds__(256) void scaled_bias_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ s, const T* __restrict__ bias,
-                                                              float* __restrict__ ds, float* __restrict__ dbias, long M, int h, int dk, int rpb) {
+                                                              float* __restrict__ ds, float* __restrict__ dbias, long M, int h, int dk, int rpb,
+                                                              long Mset, long bias_zs, long dbias_zs) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long m0 = (long)blockIdx.x * rpb, m1 = min(M, m0 + rpb);
+  { const long z = m0 / Mset; bias += z * bias_zs; dbias += z * dbias_zs; }      // Mset % rpb == 0: a block's rows lie in one set
   for (int hh = w; hh < h; hh += 4) {
     float bv[4], part[4];
 #pragma unroll
@@ -649,39 +663,56 @@ extern "C" int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t
   return BIST_OK;
 }
 
-extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
-                                  int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
-                                  void* dz, const BistDrop* dz_drop, int32_t dtype, void* stream) {
-  BIST_REQUIRE(dy && x && a && dx && ((da != nullptr) == (db != nullptr)), "bist_layernorm_bwd: null pointer");
+extern "C" int bist_layernorm_bwd_multi(const BistLnBwdSet* sets, int32_t nsets, int64_t rows, int32_t d, int64_t lddy, int64_t ldx, int64_t lddx,
+                                        float eps, int64_t ldadd, const BistDrop* dz_drop, int32_t dtype, void* stream) {
+  BIST_REQUIRE(sets && nsets >= 1 && nsets <= LNB_SETS, "bist_layernorm_bwd_multi: 1..%d sets", LNB_SETS);
   BIST_REQUIRE(rows > 0 && d > 1 && d <= 2048, "bist_layernorm_bwd: bad shape rows=%ld d=%d", (long)rows, d);
   hipStream_t st = (hipStream_t)stream;
   const long sz = dtype == BIST_BF16 ? 2 : 4;
-  BIST_REQUIRE(!dx_add || ldadd >= d, "bist_layernorm_bwd: bad dx_add stride");
-  BIST_REQUIRE(!dz || (dz_drop && dz_drop->p > 0.f && dz_drop->p < 1.f), "bist_layernorm_bwd: dz needs a dropout spec");
-  const DropArg zd = make_drop(dz ? dz_drop : nullptr);
-  const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)a | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)dz) % 16 == 0) && (lddy * sz) % 16 == 0 &&
-                  (ldx * sz) % 16 == 0 && (lddx * sz) % 16 == 0 && (!dx_add || (ldadd * sz) % 16 == 0);
+  LnBwdSetsK k{};
+  bool any_dz = false, any_add = false, al = (lddy * sz) % 16 == 0 && (ldx * sz) % 16 == 0 && (lddx * sz) % 16 == 0;
+  const bool params = sets[0].da != nullptr;
+  for (int i = 0; i < nsets; ++i) {
+    const BistLnBwdSet& q = sets[i];
+    BIST_REQUIRE(q.dy && q.x && q.a && q.dx && ((q.da != nullptr) == (q.db != nullptr)), "bist_layernorm_bwd: null pointer (set %d)", i);
+    BIST_REQUIRE((q.da != nullptr) == params, "bist_layernorm_bwd_multi: every set or no set accumulates the parameter gradients");
+    k.dy[i] = q.dy; k.x[i] = q.x; k.a[i] = q.a; k.dx[i] = q.dx; k.da[i] = q.da; k.db[i] = q.db; k.add[i] = q.dx_add; k.dz[i] = q.dz; k.row0[i] = q.drop_row0;
+    any_dz = any_dz || q.dz; any_add = any_add || q.dx_add;
+    al = al && (((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.a | (uintptr_t)q.dx | (uintptr_t)q.dx_add | (uintptr_t)q.dz) % 16 == 0);
+  }
+  BIST_REQUIRE(!any_add || ldadd >= d, "bist_layernorm_bwd: bad dx_add stride");
+  BIST_REQUIRE(!any_dz || (dz_drop && dz_drop->p > 0.f && dz_drop->p < 1.f), "bist_layernorm_bwd: dz needs a dropout spec");
+  const DropArg zd = make_drop(any_dz ? dz_drop : nullptr);
+  al = al && (!any_add || (ldadd * sz) % 16 == 0);
   if (al && (d * sz) == 1024) {                   // d = 512 bf16 / 256 f32: one 16-byte vector per lane
-    int rpw2 = (int)((rows + 1023) / 1024);       // ~1024 waves: enough parallelism for dx, few atomics per column
+    int rpw2 = (int)((rows * nsets + 1023) / 1024);       // ~1024 waves: enough parallelism for dx, few atomics per column
     if (rpw2 < 2) rpw2 = 2;
-    const unsigned g2 = blocks_for(blocks_for(rows, rpw2), 4);
-#define LNV(TT, PP) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TT, 1, PP>), dim3(g2), dim3(256), 0, st, (const TT*)dy, (const TT*)x, (const TT*)a, \
-                                       (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw2, (const TT*)dx_add, (long)ldadd, (TT*)dz, zd)
-    if (dtype == BIST_BF16) { if (da) LNV(bf16_t, true); else LNV(bf16_t, false); }
-    else { if (da) LNV(float, true); else LNV(float, false); }
+    const dim3 g2(blocks_for(blocks_for(rows, rpw2), 4), (unsigned)nsets);
+#define LNV(TT, PP) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TT, 1, PP>), g2, dim3(256), 0, st, k, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, \
+                                       rpw2, (long)ldadd, zd)
+    if (dtype == BIST_BF16) { if (params) LNV(bf16_t, true); else LNV(bf16_t, false); }
+    else { if (params) LNV(float, true); else LNV(float, false); }
 #undef LNV
     BIST_LAUNCH_CHECK("bist_layernorm_bwd");
     return BIST_OK;
   }
-  BIST_REQUIRE(da != nullptr, "bist_layernorm_bwd: the dx-only form needs 1 KiB rows (d = 512 bf16 / 256 f32), 16-byte aligned");
-  int rpw = (int)((rows + 4095) / 4096);          // <= 4096 waves flush their partial sums
+  BIST_REQUIRE(params, "bist_layernorm_bwd: the dx-only form needs 1 KiB rows (d = 512 bf16 / 256 f32), 16-byte aligned");
+  int rpw = (int)((rows * nsets + 4095) / 4096);          // <= 4096 waves flush their partial sums
   if (rpw < 1) rpw = 1;
-  const unsigned g = blocks_for(blocks_for(rows, rpw), 4);
-#define L(TT, ...) hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, dim3(g), dim3(256), 0, st, (const TT*)dy, (const TT*)x, (const TT*)a, (TT*)dx, da, db, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw, (const TT*)dx_add, (long)ldadd, (TT*)dz, zd)
+  const dim3 g(blocks_for(blocks_for(rows, rpw), 4), (unsigned)nsets);
+#define L(TT, ...) hipLaunchKernelGGL(layernorm_bwd_kernel<TT>, g, dim3(256), 0, st, k, (long)rows, d, (long)lddy, (long)ldx, (long)lddx, eps, rpw, (long)ldadd, zd)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_layernorm_bwd");
   return BIST_OK;
+}
+
+extern "C" int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
+                                  int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
+                                  void* dz, const BistDrop* dz_drop, int32_t dtype, void* stream) {
+  BIST_REQUIRE(dy && x && a && dx && ((da != nullptr) == (db != nullptr)), "bist_layernorm_bwd: null pointer");
+  const BistLnBwdSet one{dy, x, a, dx, da, db, dx_add, dz, 0ULL};
+  return bist_layernorm_bwd_multi(&one, 1, rows, d, lddy, ldx, lddx, eps, ldadd, dz_drop, dtype, stream);
 }
 
 extern "C" int bist_layernorm_param_grad_multi(const BistLnGrad* jobs, int32_t njobs, int32_t d, int32_t dtype, void* stream) {
@@ -720,28 +751,39 @@ extern "C" int bist_layernorm_param_grad_multi(const BistLnGrad* jobs, int32_t n
   return BIST_OK;
 }
 
-extern "C" int bist_scaled_bias_fwd(const void* x, const float* s, const void* bias, void* y, int64_t M, int32_t h, int32_t dk,
-                                    int32_t dtype, void* stream) {
-  BIST_REQUIRE(x && s && bias && y && M > 0 && h > 0 && dk > 0, "bist_scaled_bias_fwd: bad argument");
+extern "C" int bist_scaled_bias_fwd_z(const void* x, const float* s, const void* bias, void* y, int64_t M, int32_t h, int32_t dk,
+                                      int32_t nsets, int64_t bias_zs, int32_t dtype, void* stream) {
+  BIST_REQUIRE(x && s && bias && y && M > 0 && h > 0 && dk > 0 && nsets >= 1 && M % nsets == 0, "bist_scaled_bias_fwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
-#define L(TT, ...) hipLaunchKernelGGL(scaled_bias_kernel<TT>, dim3(blocks_for(M * h * dk, 256)), dim3(256), 0, st, (const TT*)x, s, (const TT*)bias, (TT*)y, (long)M, h, dk)
+  const long Mset = M / nsets;
+#define L(TT, ...) hipLaunchKernelGGL(scaled_bias_kernel<TT>, dim3(blocks_for(M * h * dk, 256)), dim3(256), 0, st, (const TT*)x, s, (const TT*)bias, (TT*)y, (long)M, h, dk, Mset, (long)bias_zs)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_scaled_bias_fwd");
   return BIST_OK;
 }
+extern "C" int bist_scaled_bias_fwd(const void* x, const float* s, const void* bias, void* y, int64_t M, int32_t h, int32_t dk,
+                                    int32_t dtype, void* stream) {
+  return bist_scaled_bias_fwd_z(x, s, bias, y, M, h, dk, 1, 0, dtype, stream);
+}
 
-extern "C" int bist_scaled_bias_bwd(const void* dy, const float* s, const void* bias, float* ds, float* dbias, int64_t M, int32_t h,
-                                    int32_t dk, int32_t dtype, void* stream) {
-  BIST_REQUIRE(dy && s && bias && ds && dbias && M > 0 && h > 0 && dk > 0, "bist_scaled_bias_bwd: bad argument");
+extern "C" int bist_scaled_bias_bwd_z(const void* dy, const float* s, const void* bias, float* ds, float* dbias, int64_t M, int32_t h,
+                                      int32_t dk, int32_t nsets, int64_t bias_zs, int64_t dbias_zs, int32_t dtype, void* stream) {
+  BIST_REQUIRE(dy && s && bias && ds && dbias && M > 0 && h > 0 && dk > 0 && nsets >= 1 && M % nsets == 0, "bist_scaled_bias_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   BIST_REQUIRE(dk <= 256, "bist_scaled_bias_bwd: head width %d > 256", dk);
-  const int rpb = 4;                             // rows per block: M / 4 blocks, 4 atomics per column per 16 rows ... (M = 320: 80 blocks)
-#define L(TT, ...) hipLaunchKernelGGL(scaled_bias_bwd_kernel<TT>, dim3(blocks_for(M, rpb)), dim3(256), 0, st, (const TT*)dy, s, (const TT*)bias, ds, dbias, (long)M, h, dk, rpb)
+  const long Mset = M / nsets;
+  int rpb = 4;                                   // rows per block: M / 4 blocks, 4 atomics per column per 16 rows ... (M = 320: 80 blocks)
+  while (rpb > 1 && Mset % rpb != 0) rpb >>= 1;   // a block's rows must lie in one set
+#define L(TT, ...) hipLaunchKernelGGL(scaled_bias_bwd_kernel<TT>, dim3(blocks_for(M, rpb)), dim3(256), 0, st, (const TT*)dy, s, (const TT*)bias, ds, dbias, (long)M, h, dk, rpb, Mset, (long)bias_zs, (long)dbias_zs)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_scaled_bias_bwd");
   return BIST_OK;
+}
+extern "C" int bist_scaled_bias_bwd(const void* dy, const float* s, const void* bias, float* ds, float* dbias, int64_t M, int32_t h,
+                                    int32_t dk, int32_t dtype, void* stream) {
+  return bist_scaled_bias_bwd_z(dy, s, bias, ds, dbias, M, h, dk, 1, 0, 0, dtype, stream);
 }
 
 extern "C" int bist_embed_bwd(const int64_t* ids, const void* dy, float* dlut, int64_t rows, int32_t d, const BistDrop* drop,

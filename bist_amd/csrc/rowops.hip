@@ -8,9 +8,15 @@ namespace {
 // One 64-lane wave per row; the row is read three times (mean, centred sum of squares, output):
 // the second and third reads hit L1/L2.  Two-pass variance, like torch.std.
 // ---------------------------------------------------------------------------------------------
+// Several LayerNorms of one geometry in ONE launch (bist_layernorm_fwd_multi): set = blockIdx.y picks (rows in, gain, offset, rows out).
+// The t2s and s2t instances of a sublayer normalise same-shaped query tensors with different parameters (encoder.py:176,184).
+constexpr int LN_SETS = 8;
+struct LnSetsK { const void* x[LN_SETS]; const void* a[LN_SETS]; const void* b[LN_SETS]; void* y[LN_SETS]; };
+
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ b,
-                                                        T* __restrict__ y, long rows, int d, long ldx, long ldy, float eps) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnSetsK sets, long rows, int d, long ldx, long ldy, float eps) {
+  const T* __restrict__ x = (const T*)sets.x[blockIdx.y]; const T* __restrict__ a = (const T*)sets.a[blockIdx.y];
+  const T* __restrict__ b = (const T*)sets.b[blockIdx.y]; T* __restrict__ y = (T*)sets.y[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -30,8 +36,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // NV 16-byte vectors of the row, which is read from HBM exactly once and kept in registers for both
 // reductions (two-pass variance, like torch.std) and the output.
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ b,
-                                                            T* __restrict__ y, long rows, int d, long ldx, long ldy, float eps) {
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const LnSetsK sets, long rows, int d, long ldx, long ldy, float eps) {
+  const T* __restrict__ x = (const T*)sets.x[blockIdx.y]; const T* __restrict__ a = (const T*)sets.a[blockIdx.y];
+  const T* __restrict__ b = (const T*)sets.b[blockIdx.y]; T* __restrict__ y = (T*)sets.y[blockIdx.y];
   constexpr int E = 16 / (int)sizeof(T);             // elements per 16-byte vector
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -163,28 +170,40 @@ extern "C" int bist_add_dropout_fwd(const void* a, const void* b, void* out, int
   return BIST_OK;
 }
 
-extern "C" int bist_layernorm_fwd(const void* x, const void* a, const void* b, void* y, int64_t rows, int32_t d,
-                                  int64_t ldx, int64_t ldy, float eps, int32_t dtype, void* stream) {
-  BIST_REQUIRE(x && a && b && y, "bist_layernorm_fwd: null pointer");
+extern "C" int bist_layernorm_fwd_multi(const BistLnSet* sets, int32_t nsets, int64_t rows, int32_t d, int64_t ldx, int64_t ldy, float eps,
+                                        int32_t dtype, void* stream) {
+  BIST_REQUIRE(sets && nsets >= 1 && nsets <= LN_SETS, "bist_layernorm_fwd_multi: 1..%d sets", LN_SETS);
   BIST_REQUIRE(rows > 0 && d > 1 && ldx >= d && ldy >= d, "bist_layernorm_fwd: bad shape rows=%ld d=%d", (long)rows, d);
   hipStream_t st = (hipStream_t)stream;
-  const unsigned g = blocks_for(rows, 4);
   const long sz = dtype == BIST_BF16 ? 2 : 4;
-  const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)a | (uintptr_t)b) % 16 == 0) && (ldx * sz) % 16 == 0 && (ldy * sz) % 16 == 0;
+  LnSetsK k{};
+  bool al = (ldx * sz) % 16 == 0 && (ldy * sz) % 16 == 0;
+  for (int i = 0; i < nsets; ++i) {
+    BIST_REQUIRE(sets[i].x && sets[i].a && sets[i].b && sets[i].y, "bist_layernorm_fwd: null pointer (set %d)", i);
+    k.x[i] = sets[i].x; k.a[i] = sets[i].a; k.b[i] = sets[i].b; k.y[i] = sets[i].y;
+    al = al && (((uintptr_t)sets[i].x | (uintptr_t)sets[i].y | (uintptr_t)sets[i].a | (uintptr_t)sets[i].b) % 16 == 0);
+  }
+  const dim3 g(blocks_for(rows, 4), (unsigned)nsets);
   const long nv = (d * sz) % 1024 == 0 ? d * sz / 1024 : 0;     // 16-byte vectors per lane
   if (al && dtype == BIST_BF16 && nv == 1)
-    hipLaunchKernelGGL((layernorm_vec_kernel<bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, d, ldx, ldy, eps);
+    hipLaunchKernelGGL((layernorm_vec_kernel<bf16_t, 1>), g, dim3(256), 0, st, k, (long)rows, d, (long)ldx, (long)ldy, eps);
   else if (al && dtype == BIST_F32 && nv == 1)
-    hipLaunchKernelGGL((layernorm_vec_kernel<float, 1>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)b, (float*)y, rows, d, ldx, ldy, eps);
+    hipLaunchKernelGGL((layernorm_vec_kernel<float, 1>), g, dim3(256), 0, st, k, (long)rows, d, (long)ldx, (long)ldy, eps);
   else if (al && dtype == BIST_F32 && nv == 2)
-    hipLaunchKernelGGL((layernorm_vec_kernel<float, 2>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)b, (float*)y, rows, d, ldx, ldy, eps);
+    hipLaunchKernelGGL((layernorm_vec_kernel<float, 2>), g, dim3(256), 0, st, k, (long)rows, d, (long)ldx, (long)ldy, eps);
   else if (dtype == BIST_BF16)
-    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, d, ldx, ldy, eps);
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, g, dim3(256), 0, st, k, (long)rows, d, (long)ldx, (long)ldy, eps);
   else if (dtype == BIST_F32)
-    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)b, (float*)y, rows, d, ldx, ldy, eps);
+    hipLaunchKernelGGL(layernorm_kernel<float>, g, dim3(256), 0, st, k, (long)rows, d, (long)ldx, (long)ldy, eps);
   else { bist_set_error("bist_layernorm_fwd: bad dtype %d", dtype); return BIST_EINVAL; }
   BIST_LAUNCH_CHECK("bist_layernorm_fwd");
   return BIST_OK;
+}
+
+extern "C" int bist_layernorm_fwd(const void* x, const void* a, const void* b, void* y, int64_t rows, int32_t d,
+                                  int64_t ldx, int64_t ldy, float eps, int32_t dtype, void* stream) {
+  const BistLnSet one{x, a, b, y};
+  return bist_layernorm_fwd_multi(&one, 1, rows, d, ldx, ldy, eps, dtype, stream);
 }
 
 extern "C" int bist_embed_pe_fwd(const int64_t* ids, const void* lut, const float* pe, void* y, int64_t rows, int32_t L,

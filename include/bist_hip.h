@@ -162,6 +162,12 @@ int bist_gemm_is_fast(const BistGemm* g);
  * ------------------------------------------------------------------------------------------ */
 int bist_layernorm_fwd(const void* x, const void* a, const void* b, void* y, int64_t rows, int32_t d,
                        int64_t ldx, int64_t ldy, float eps, int32_t dtype, void* stream);
+/* Up to 8 LayerNorms of ONE geometry (rows, d, strides) in one launch: set i normalises rows x_i with (a_i, b_i) into y_i.  The t2s and
+ * s2t instances of a VidEncoderLayer4 sublayer (encoder.py:176 / :184, :121 / :148, ...) normalise same-shaped query tensors with
+ * different parameters: run together, the two directions' query-side chains are ONE sequence of launches instead of two.          */
+typedef struct BistLnSet { const void* x; const void* a; const void* b; void* y; } BistLnSet;
+int bist_layernorm_fwd_multi(const BistLnSet* sets, int32_t nsets, int64_t rows, int32_t d, int64_t ldx, int64_t ldy, float eps,
+                             int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dropout of attention probabilities in training (modules.py:62-63: p_attn = dropout(p_attn) after the
@@ -303,6 +309,12 @@ int bist_scaled_bias_fwd(const void* x, const float* s, const void* bias, void* 
 /* ds[m, hh] = sum_c dy[m, hh*dk+c] bias[hh*dk+c];  dbias[hh*dk+c] += sum_m s[m, hh] dy[m, hh*dk+c]  (f32 acc) */
 int bist_scaled_bias_bwd(const void* dy, const float* s, const void* bias, float* ds, float* dbias, int64_t M, int32_t h,
                          int32_t dk, int32_t dtype, void* stream);
+/* The same over `nsets` stacked row blocks of M / nsets rows: block z reads bias + z * bias_zs (and adds into dbias + z * dbias_zs) --
+ * the two directions' stage-2 value biases (attn[2] / attn[5]) in one launch.                                                     */
+int bist_scaled_bias_fwd_z(const void* x, const float* s, const void* bias, void* y, int64_t M, int32_t h, int32_t dk,
+                           int32_t nsets, int64_t bias_zs, int32_t dtype, void* stream);
+int bist_scaled_bias_bwd_z(const void* dy, const float* s, const void* bias, float* ds, float* dbias, int64_t M, int32_t h,
+                           int32_t dk, int32_t nsets, int64_t bias_zs, int64_t dbias_zs, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise helpers on the path.
@@ -399,6 +411,14 @@ int bist_col_sum_multi(const BistColSum* jobs, int32_t njobs, int32_t dtype, voi
 int bist_layernorm_bwd(const void* dy, const void* x, const void* a, void* dx, float* da, float* db, int64_t rows,
                        int32_t d, int64_t lddy, int64_t ldx, int64_t lddx, float eps, const void* dx_add, int64_t ldadd,
                        void* dz, const BistDrop* dz_drop, int32_t dtype, void* stream);
+/* Up to 8 LayerNorm backward passes of one geometry in one launch (see bist_layernorm_fwd_multi); every set or no set accumulates
+ * da / db.  drop_row0: the set's first row in the STACKED tensor its dz mask is indexed over, (drop_row0 + row) * d + col -- the mask
+ * index of a z-batched GEMM's dropout epilogue.                                                                                  */
+typedef struct BistLnBwdSet {
+  const void* dy; const void* x; const void* a; void* dx; float* da; float* db; const void* dx_add; void* dz; uint64_t drop_row0;
+} BistLnBwdSet;
+int bist_layernorm_bwd_multi(const BistLnBwdSet* sets, int32_t nsets, int64_t rows, int32_t d, int64_t lddy, int64_t ldx, int64_t lddx,
+                             float eps, int64_t ldadd, const BistDrop* dz_drop, int32_t dtype, void* stream);
 /* dz (nullable, [rows, d] contiguous) additionally receives dropout-mask(dz_drop) * dx with mask index row*d + col:
  * when x is the output of a GEMM with a dropout epilogue (x = drop(z) + res, modules.py:44), this is exactly the
  * gradient of z, and the GEMM's backward needs no separate masking pass.                                        */

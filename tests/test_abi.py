@@ -38,7 +38,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     from bist_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     structs = {"BistGemm": ["a_rs", "alpha", "drop_seed", "workspace", "hint", "ln_gain", "ln_ld", "ln_eps", "ln_mode", "bias_bs1"],
-               "BistDecLayer": ["Wqkv", "Wo", "cmask", "W1", "Lk", "LkP"], "BistDrop": ["seed", "ctr"]}
+               "BistDecLayer": ["Wqkv", "Wo", "cmask", "W1", "Lk", "LkP"], "BistDrop": ["seed", "ctr"],
+               "BistLnSet": ["a", "y"], "BistLnBwdSet": ["dx", "db", "dz", "drop_row0"]}
     src = ["#include <stdio.h>", "#include <stddef.h>", '#include "bist_hip.h"', "int main(void) {"]
     for st, fields in structs.items():
         src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
