@@ -32,6 +32,7 @@ class Batch:
         self.query, self.his, self.cap, self.trg, self.trg_y = query, his, cap, trg, trg_y
         self.fts = fts
         self.query_mask = (query != pad).unsqueeze(-2)              # dataset.py:66
+        self.query_mask2 = torch.cat([self.query_mask, self.query_mask], dim=0)   # the same mask for the stacked (t2s, s2t) batch of a reasoning layer
         self.his_mask = (his != pad).unsqueeze(-2)                  # dataset.py:67
         self.cap_mask = (cap != pad).unsqueeze(-2) if cap is not None else None   # dataset.py:92
         self.temporal_mask: Optional[torch.Tensor] = None           # dataset.py:79 (device-side, see below)
@@ -58,7 +59,7 @@ class Batch:
 
     def move_to_cuda(self):
         """dataset.py:107-127."""
-        for name in ("query", "his", "cap", "trg", "trg_y", "query_mask", "his_mask", "cap_mask", "trg_mask",
+        for name in ("query", "his", "cap", "trg", "trg_y", "query_mask", "query_mask2", "his_mask", "cap_mask", "trg_mask",
                      "trg_mean_mask", "fts", "temporal_mask"):
             v = getattr(self, name)
             if v is not None:

@@ -213,7 +213,7 @@ def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args)
     return out.cpu().numpy()
 
 
-_TURN_FIELDS = ("query", "his", "cap", "fts", "query_mask", "his_mask", "cap_mask", "temporal_mask")
+_TURN_FIELDS = ("query", "his", "cap", "fts", "query_mask", "query_mask2", "his_mask", "cap_mask", "temporal_mask")
 
 
 def _graph_first_step(model, batch, start_symbol, train_args):
@@ -286,6 +286,8 @@ def _bucketed(batch, pad_symbol):
             out = copy.copy(batch)
         setattr(out, name, torch.nn.functional.pad(v, (0, extra), value=pad_symbol))
         setattr(out, name + "_mask", torch.nn.functional.pad(getattr(batch, name + "_mask"), (0, extra), value=False))
+        if name == "query" and getattr(batch, "query_mask2", None) is not None:
+            out.query_mask2 = torch.cat([out.query_mask, out.query_mask], dim=0)
     return out if out is not None else batch
 
 

@@ -11,6 +11,7 @@ import ctypes as C
 
 from .. import functional as Fn
 from .. import ops
+from .. import zbatch as Z
 from .._lib import BistDecLayer, lib
 from .encoder import _cross_attention, _feed_forward, _self_attention
 from .modules import LayerNorm, SublayerConnection, clones
@@ -101,13 +102,18 @@ class MultimodalDecoder8(nn.Module):
             return
         if mode != "dyn":
             return
+        spare = ft.get("_bist_alias") or {}
+
+        def other(k):            # a second alias of ft[k] where the producer handed several out (one consumer each: no gradient accumulation pass)
+            lst = spare.get(k)
+            return lst.pop(0) if lst else ft[k]
         parts = [ft["encoded_query"]]
         if self.c_N > 0:
             parts.append(ft["cap_ft"])
         if args.t2s:
-            parts.append(ft["spatial_ft"])
+            parts.append(other("spatial_ft"))
         if args.s2t:
-            parts.append(ft["temporal_ft"])
+            parts.append(other("temporal_ft"))
         W, bias = self.vc_combine_W.weight, self.vc_combine_W.bias
         d = parts[0].shape[-1]
         if W.shape[1] != d * len(parts):
@@ -362,10 +368,20 @@ class MultimodalDecoder8(nn.Module):
                     ft["cap_ft"] = self.cap_out_norm(in_ft["cap"])                           # decoder.py:132
             if self.v_N > 0:
                 in_ft = self.v_layers[l](in_ft, ft, b)
-                if self.args.s2t:
-                    ft["temporal_ft"] = self.temporal_out_norm(in_ft["s2t"])                 # decoder.py:127
-                if self.args.t2s:
-                    ft["spatial_ft"] = self.spatial_out_norm(in_ft["t2s"])                   # :129
+                if "_z" in in_ft:
+                    # both directions came back stacked (bist_amd/zbatch.py): the two output norms as ONE launch; the stacked tensor
+                    # goes on to the next reasoning layer through the LayerNorm node (one consumer each, no accumulation pass)
+                    normed, in_ft["_z"] = Z.layernorm_res(in_ft["_z"], self.spatial_out_norm, self.temporal_out_norm)   # decoder.py:127,129
+                    last = l + 1 == len(self.layers)
+                    n_use = 2 + (1 if (last and torch.is_grad_enabled()) else 0)      # fusion logits, fusion sum (, auto-encoder loss)
+                    sp, tp = Z.unstack(normed, n_use, n_use)
+                    ft["spatial_ft"], ft["temporal_ft"] = sp[0], tp[0]
+                    ft["_bist_alias"] = {"spatial_ft": sp[1:], "temporal_ft": tp[1:]}
+                else:
+                    if self.args.s2t:
+                        ft["temporal_ft"] = self.temporal_out_norm(in_ft["s2t"])             # decoder.py:127
+                    if self.args.t2s:
+                        ft["spatial_ft"] = self.spatial_out_norm(in_ft["t2s"])               # :129
             if fork_cap:
                 main.wait_stream(side)
             elif self.c_N > 0:
@@ -395,6 +411,7 @@ class MultimodalDecoder8(nn.Module):
             x = self._decode_fused(b, ft, x)
             ft["_bist_fused_first"] = True       # (decode.py: position 0 of the turn is in the kernel's pools)
         ft.pop("_bist_vft_fan", None)
+        ft.pop("_bist_qmask2", None)
         ft.pop("_bist_vftp_fan", None)
         ft.pop("_bist_mem_fan", None)
         ft.pop("_bist_v_pre", None)

@@ -31,7 +31,8 @@ class Generator(nn.Module):
             self.shared_W = False
 
     def forward(self, ft, batch, args, ft_key="decoded_text"):
-        x = ft[ft_key]
+        spare = (ft.get("_bist_alias") or {}).get(ft_key)        # an alias of ft[ft_key] set aside for this consumer (one-pass gradient sum)
+        x = spare.pop(0) if spare else ft[ft_key]
         if self.shared_W:
             logits = Fn.linear(x, self.proj, None, out_dtype=torch.float32)
         else:

@@ -14,7 +14,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, BF16, F32, BistColSum, BistDrop, BistGemm, BistLnGrad, check, lib
+from ._lib import ACT_NONE, ACT_RELU, BF16, F32, BistColSum, BistDrop, BistGemm, BistLnBwdSet, BistLnGrad, BistLnSet, check, lib
 
 Tensor = torch.Tensor
 
@@ -280,6 +280,34 @@ def layernorm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6, out: Optional[
     return out
 
 
+def layernorm_multi(xs: Sequence[Tensor], gains: Sequence[Tensor], offsets: Sequence[Tensor], outs: Sequence[Tensor], eps: float = 1e-6) -> None:
+    """len(xs) LayerNorms of one geometry in ONE launch (bist_layernorm_fwd_multi): outs[i] = LN(xs[i]; gains[i], offsets[i]); every
+    xs[i] / outs[i] is [rows, d] with the same rows, d and row strides (the t2s and s2t instances of a sublayer's norm)."""
+    _dev(*xs, *gains, *offsets, *outs)
+    n = len(xs)
+    x0, o0 = xs[0], outs[0]
+    rows, d = x0.shape
+    for x, o in zip(xs, outs):
+        if x.shape != (rows, d) or o.shape != (rows, d) or x.stride() != x0.stride() or o.stride() != o0.stride() or x.stride(1) != 1 or o.stride(1) != 1 \
+                or x.dtype != x0.dtype or o.dtype != x0.dtype:
+            raise ValueError("bist_amd.layernorm_multi: the sets must share one geometry and dtype")
+    arr = (BistLnSet * n)()
+    for i in range(n):
+        arr[i].x, arr[i].a, arr[i].b, arr[i].y = xs[i].data_ptr(), gains[i].data_ptr(), offsets[i].data_ptr(), outs[i].data_ptr()
+    check(lib.bist_layernorm_fwd_multi(arr, n, rows, d, x0.stride(0), o0.stride(0), eps, dtype_code(x0.dtype), _stream()), "bist_layernorm_fwd_multi")
+
+
+def layernorm_bwd_multi(sets, rows: int, d: int, lddy: int, ldx: int, lddx: int, eps: float, ldadd: int, zdrop, dtype: torch.dtype) -> None:
+    """sets: list of (dy, x, a, dx, da or None, db or None, dx_add or None, dz or None, drop_row0) -- bist_layernorm_bwd_multi."""
+    n = len(sets)
+    arr = (BistLnBwdSet * n)()
+    for i, (dy, x, a, dx, da, db, add, dz, row0) in enumerate(sets):
+        _dev(dy, x, a, dx, da, db, add, dz)
+        arr[i].dy, arr[i].x, arr[i].a, arr[i].dx = dy.data_ptr(), x.data_ptr(), a.data_ptr(), dx.data_ptr()
+        arr[i].da, arr[i].db, arr[i].dx_add, arr[i].dz, arr[i].drop_row0 = _ptr(da), _ptr(db), _ptr(add), _ptr(dz), int(row0)
+    check(lib.bist_layernorm_bwd_multi(arr, n, rows, d, lddy, ldx, lddx, eps, ldadd, zdrop, dtype_code(dtype), _stream()), "bist_layernorm_bwd_multi")
+
+
 def drop_ref(drop):
     """(p, seed) or None -> BistDrop by reference (NULL when off); the device step counter rides along."""
     if drop is None or drop[0] <= 0.0:
@@ -458,6 +486,30 @@ def scaled_bias(x: Tensor, s: Tensor, bias: Tensor, h: int, out: Optional[Tensor
     check(lib.bist_scaled_bias_fwd(x2.data_ptr(), s.data_ptr(), bias.data_ptr(), out.data_ptr(), x2.shape[0], h, d // h,
                                    dtype_code(x.dtype), _stream()), "bist_scaled_bias_fwd")
     return out.view(x.shape)
+
+
+def scaled_bias_z(x: Tensor, s: Tensor, bias0: Tensor, bias_zs: int, h: int, nsets: int, out: Optional[Tensor] = None) -> Tensor:
+    """scaled_bias over `nsets` stacked row blocks, block z with the bias at bias0 + z * bias_zs elements (bist_scaled_bias_fwd_z)."""
+    _dev(x, s, bias0)
+    d = x.shape[-1]
+    x2 = x.reshape(-1, d)
+    if not x2.is_contiguous() or not s.is_contiguous() or s.dtype != torch.float32 or s.numel() != x2.shape[0] * h or x2.shape[0] % nsets:
+        raise ValueError("bist_amd.scaled_bias_z: bad operands")
+    if out is None:
+        out = torch.empty_like(x2)
+    check(lib.bist_scaled_bias_fwd_z(x2.data_ptr(), s.data_ptr(), bias0.data_ptr(), out.data_ptr(), x2.shape[0], h, d // h, nsets, bias_zs,
+                                     dtype_code(x.dtype), _stream()), "bist_scaled_bias_fwd_z")
+    return out.view(x.shape)
+
+
+def copy_into(dst: Tensor, src: Tensor) -> Tensor:
+    """dst <- src (same shape, dtype, both contiguous) as a one-operand bist_add_n launch: device-side data movement only."""
+    _dev(dst, src)
+    if dst.shape != src.shape or dst.dtype != src.dtype or not dst.is_contiguous() or not src.is_contiguous():
+        raise ValueError("bist_amd.copy_into: contiguous tensors of one shape and dtype")
+    arr = (C.c_void_p * 1)(src.data_ptr())
+    check(lib.bist_add_n(arr, 1, dst.data_ptr(), dst.numel(), dtype_code(dst.dtype), _stream()), "bist_add_n")
+    return dst
 
 
 def embed_pe(ids: Tensor, lut: Tensor, pe: Tensor, out: Optional[Tensor] = None, drop=None) -> Tensor:

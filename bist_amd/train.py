@@ -356,7 +356,7 @@ class Trainer:
         return terms
 
     # ---- hipGraph path: forward + backward + gradient fold captured once per batch geometry ----------------
-    _BATCH_FIELDS = ("query", "his", "cap", "trg", "trg_y", "fts", "query_mask", "his_mask", "cap_mask", "temporal_mask",
+    _BATCH_FIELDS = ("query", "his", "cap", "trg", "trg_y", "fts", "query_mask", "query_mask2", "his_mask", "cap_mask", "temporal_mask",
                      "trg_mask", "trg_mean_mask", "ntokens", "qntokens")
 
     def _shape_key(self, batch):
