@@ -564,7 +564,7 @@ class ZStage2Fn(Function):
             check(lib.bist_st_stage2_fwd(q5[z].data_ptr(), yc.data_ptr(), _ptr(mk), py[z].data_ptr(), rs[z].data_ptr() if rs is not None else None,
                                          B, y.shape[1], Lq, h, d, ops.drop_ref(drops[z]), dtype_code(y.dtype), _stream()), "bist_st_stage2_fwd")
         ctx.save_for_backward(q5, y0, y1, m8)
-        ctx.cfg = (h, drops)
+        ctx.cfg = (h, drops, tuple(q2f.shape))
         ctx.set_materialize_grads(False)
         if rs is None:
             ctx.mark_non_differentiable()
@@ -574,7 +574,7 @@ class ZStage2Fn(Function):
     @staticmethod
     def backward(ctx, dpy, drs):
         q5, y0, y1, m8 = ctx.saved_tensors
-        h, drops = ctx.cfg
+        h, drops, q_shape = ctx.cfg
         B, Lq, d = y0.shape[0], y0.shape[2], y0.shape[3]
         if dpy is None:
             dpy = torch.zeros(q5.shape, device=q5.device, dtype=q5.dtype)
@@ -592,4 +592,4 @@ class ZStage2Fn(Function):
                                          dq[z].data_ptr(), dy.data_ptr(), B, y.shape[1], Lq, h, d, ops.drop_ref(drops[z]), dtype_code(y.dtype),
                                          _stream()), "bist_st_stage2_bwd")
             dys.append(dy)
-        return dq, dys[0], dys[1], None, None, None
+        return dq.view(q_shape), dys[0], dys[1], None, None, None

@@ -118,7 +118,9 @@ def test_lockstep_layer_equals_two_chains_forward_and_gradients(hip, dtype, T):
     bad = {}
     for n in ga:
         a, b = ga[n].flatten().double(), gb[n].flatten().double()
-        scale = max(b.abs().max().item(), 1e-12)
+        if n.endswith("linears.1.bias") and b.abs().max().item() < 1e-4:
+            continue          # key biases: exactly zero gradient in exact arithmetic (softmax shift invariance), rounding noise in both forms
+        scale = max(b.abs().max().item(), 1e-6)
         rel = (a - b).abs().max().item() / scale
         if dtype == torch.float32:
             if rel > 2e-4:
