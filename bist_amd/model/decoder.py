@@ -349,11 +349,14 @@ class MultimodalDecoder8(nn.Module):
             fan = ft.get("_bist_vftp_fan") or ft["_bist_vft_fan"]
             va = fan.take()
             side_.wait_stream(main_)
+            both_v = Z.ENABLED                                    # lock-step layer: its stage-1 node consumes both on the main stream
+            vb = ft["_bist_vft_fan"].take() if both_v else None
             with torch.cuda.stream(side_):
-                v1 = self.v_layers[l].train_value(va, 1)          # t2s only: its consumer (and its gradient) live on the main stream;
-                ev = torch.cuda.Event()                           # an edge between two side streams crashes hipGraph capture
+                v1 = self.v_layers[l].train_value(va, 1)          # two-chain layer: t2s only -- its consumer (and its gradient) live on the main
+                v4 = self.v_layers[l].train_value(vb, 4) if both_v else None      # stream; an edge between two side streams crashes hipGraph capture
+                ev = torch.cuda.Event()
                 ev.record(side_)
-            ft["_bist_v_pre"] = (v1, None, ev)
+            ft["_bist_v_pre"] = (v1, v4, ev)
         Fn.param_gate(1)                     # deferred optimiser: layer 0's parameters (and everything outside the layer stacks) are final
         if values_ahead:
             issue_values(0)

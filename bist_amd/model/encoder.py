@@ -301,8 +301,25 @@ class VidEncoderLayer4(nn.Module):
         ctx, _ = Fn.mha_packed(qkv.view(2 * B, Lq, 3 * d), None, None, "qkv", self._mask2(b, ft, B), h, False, Fn.attn_drop(att[0]))
         x1 = Z.linear(ctx, (att[0].linears[3].weight, att[0].linears[3].bias), (att[3].linears[3].weight, att[3].linears[3].bias),
                       residual=xr, out_shape=(2, B, Lq, d), **Fn.drop_args(sub[0]))
-        # ---- A1 | A4: stage 1 --------------------------------------------------------------------------------------------
+        # ---- A1 | A4: stage 1; the query side of stage 2 (A2 | A5: LayerNorm, projection, fold -- it depends on x1 only) goes to a side
+        # stream and runs under the stage-1 launches -----------------------------------------------------------------------------
         xn1, xr1 = Z.layernorm_res(x1, sub[1].norm, sub[5].norm)
+        main = torch.cuda.current_stream()
+        side = Fn.side_stream(0) if (Fn.CONCURRENT and Z.DIR_STREAMS) else None
+
+        def stage2_query(xr_):
+            xn2_, xr2_ = Z.layernorm_res(xr_, sub[2].norm, sub[6].norm)
+            q2_ = Z.linear(xn2_, (att[2].linears[0].weight, att[2].linears[0].bias), (att[5].linears[0].weight, att[5].linears[0].bias))
+            return xr2_, Z.head_fold(q2_, att[2].linears[1].weight, att[5].linears[1].weight, h, 1.0 / math.sqrt(dk))
+        ev2 = None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                xr1b, q2f = stage2_query(xr1)
+                ev2 = torch.cuda.Event()
+                ev2.record(side)
+        else:
+            xr1b, q2f = stage2_query(xr1)
         q = Z.linear(xn1, (att[1].linears[0].weight, att[1].linears[0].bias), (att[4].linears[0].weight, att[4].linears[0].bias))
         qf = Z.head_fold(q, att[1].linears[1].weight, att[4].linears[1].weight, h, 1.0 / math.sqrt(dk)).view(2, B, Lq * h, d)
         fused = (Fn.FUSED_ST1 and not grad and all(ops.st_stage1_fused_ok(T, S, Lq, d, h, dr, vft.dtype) for dr in (0, 1)))
@@ -311,25 +328,24 @@ class VidEncoderLayer4(nn.Module):
             # direction in one launch (csrc/st1_fused.hip)
             y0 = self._stage1_fused(1, x1[0], qf[0], take0(), b.temporal_mask, 0)
             y1 = self._stage1_fused(4, x1[1], qf[1], take(), None, 1)
-            xr1b = xr1
+            xr2 = xr1b
         else:
             pre = ft.pop("_bist_v_pre", None)            # (v_t2s, v_s2t or None, event): projected ahead by the layer loop (decoder.py)
             vft0, vft1 = take0(), take()
             if pre is not None:
                 v0, v1, ev = pre
-                torch.cuda.current_stream().wait_event(ev)
+                main.wait_event(ev)
                 if v1 is None:
                     v1 = self.train_value(take(), 4)
             else:
                 v0, v1 = self.train_value(take0(), 1), self.train_value(take(), 4)
             cfg = (B, T, S, Lq, h, dk, permuted, (Fn.attn_drop(att[1]), Fn.attn_drop(att[4])),
                    tuple(((kw["drop_p"], kw["drop_seed"]) if kw else None) for kw in (Fn.drop_args(sub[1]), Fn.drop_args(sub[5]))))
-            y0, y1, xr1b = Z.ZStage1Fn.apply(qf, xr1, vft0, vft1, v0, v1, b.temporal_mask, att[1].linears[3].weight, att[1].linears[3].bias,
-                                             att[4].linears[3].weight, att[4].linears[3].bias, cfg)
+            y0, y1, xr2 = Z.ZStage1Fn.apply(qf, xr1b, vft0, vft1, v0, v1, b.temporal_mask, att[1].linears[3].weight, att[1].linears[3].bias,
+                                            att[4].linears[3].weight, att[4].linears[3].bias, cfg)
+        if ev2 is not None:
+            main.wait_event(ev2)
         # ---- A2 | A5: stage 2 --------------------------------------------------------------------------------------------
-        xn2, xr2 = Z.layernorm_res(xr1b, sub[2].norm, sub[6].norm)
-        q2 = Z.linear(xn2, (att[2].linears[0].weight, att[2].linears[0].bias), (att[5].linears[0].weight, att[5].linears[0].bias))
-        q2f = Z.head_fold(q2, att[2].linears[1].weight, att[5].linears[1].weight, h, 1.0 / math.sqrt(dk))
         py, rs = Z.ZStage2Fn.apply(q2f, y0, y1, b.temporal_mask, h, (Fn.attn_drop(att[2]), Fn.attn_drop(att[5])))
         wv2, wv5, bv2, bv5 = att[2].linears[2].weight, att[5].linears[2].weight, att[2].linears[2].bias, att[5].linears[2].bias
         if rs is None:

@@ -37,6 +37,29 @@ from .ops import _ptr, _stream, dtype_code
 Tensor = torch.Tensor
 
 ENABLED = os.environ.get("BIST_ZBATCH", "1") != "0"      # tuning aid: 0 = the two directions as two chains on two streams (round 2)
+# tuning aid: the per-direction launches of stage 1 / stage 2 (chip-filling kernels of 20-50 us with short tails) of the s2t direction on a
+# side stream beside the t2s direction's on the main stream; 0 = back to back on one stream
+DIR_STREAMS = os.environ.get("BIST_Z_DIR_STREAMS", "1") != "0"
+
+
+class _DirStreams:
+    """fork: the side stream waits for the main stream; `on(z)`: context of direction z's launches; join: main waits for side.
+    Every edge is main <-> side (an edge between two side streams crashes hipGraph capture in the HIP runtime)."""
+
+    def __init__(self, enabled: bool):
+        from . import functional as Fn
+        self.main = self.side = None
+        if enabled and DIR_STREAMS and Fn.CONCURRENT:
+            self.main, self.side = torch.cuda.current_stream(), Fn.side_stream(0)
+            self.side.wait_stream(self.main)
+
+    def on(self, z: int):
+        import contextlib
+        return torch.cuda.stream(self.side) if (z == 1 and self.side is not None) else contextlib.nullcontext()
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
 
 
 def zstride(p0: Tensor, p1: Tensor) -> int:
@@ -460,24 +483,36 @@ class ZStage1Fn(Function):
         qf3 = qf.reshape(2, B, Lq * h, d)
         x2 = x.reshape(2, B * Lq, d)
         ys, saved = [], []
-        for z, (vft, v, wo, bo) in enumerate(((vft0, v0, wo0, bo0), (vft1, v1, wo1, bo1))):
-            # geometry of this direction as the core sees it: permuted t2s = "s2t" over the region-major tensors + the frame mask
+        # Tensors that outlive this call (saved for backward / returned) are allocated HERE, on the calling stream's pool, before the
+        # fork: a block handed out under the side stream would return to the side stream's pool when freed and could be re-used by a
+        # later side-stream launch while a consumer on another stream still reads it.
+        geo = []
+        for z in range(2):
             direction = 1 if (z == 1 or permuted) else 0
             Tc, Sc = (S, T) if (z == 0 and permuted) else (T, S)
             G = Sc if direction == 0 else Tc
-            kmask = tmask if z == 0 else None
-            m8 = ag._mask_u8(kmask.reshape(B, -1)) if kmask is not None else None
+            geo.append((direction, Tc, Sc, G,
+                        torch.empty((B, Lq * h, Tc * Sc), device=qf.device, dtype=torch.float32),
+                        torch.empty((B, G, Lq, d), device=qf.device, dtype=qf.dtype),
+                        torch.empty((B * G * Lq, d), device=qf.device, dtype=qf.dtype)))
+        kmask8 = ag._mask_u8(tmask.reshape(B, -1)) if tmask is not None else None
+        ds = _DirStreams(qf.is_cuda)
+        for z, (vft, v, wo, bo) in enumerate(((vft0, v0, wo0, bo0), (vft1, v1, wo1, bo1))):
+          with ds.on(z):
+            # geometry of this direction as the core sees it: permuted t2s = "s2t" over the region-major tensors + the frame mask
+            direction, Tc, Sc, G, scores, o, y = geo[z]
+            m8 = kmask8 if z == 0 else None
             q3 = qf3[z]
             TS = Tc * Sc
-            scores = torch.empty((B, Lq * h, TS), device=qf.device, dtype=torch.float32)
             vf = vft.reshape(B, TS, d)
             ops.gemm(q3, vf, scores, M=Lq * h, N=TS, K=d, a_rs=q3.stride(1), b_rs=vf.stride(1), ldc=TS, batch=(B, 1),
                      a_bs=(q3.stride(0), 0), b_bs=(vf.stride(0), 0), c_bs=(Lq * h * TS, 0))
-            o = ops.st_stage1_pv(scores, v, m8, B=B, T=Tc, S=Sc, Lq=Lq, h=h, dk=dk, direction=direction, drop=adrop[z])
+            ops.st_stage1_pv(scores, v, m8, B=B, T=Tc, S=Sc, Lq=Lq, h=h, dk=dk, direction=direction, drop=adrop[z], out=o)
             sp, ss = sdrop[z] if sdrop[z] is not None else (0.0, 0)
-            y = ops.linear(o.view(B * G * Lq, d), wo, bo, residual=x2[z], res_map=(G * Lq, Lq), drop_p=sp, drop_seed=ss)
+            ops.linear(o.view(B * G * Lq, d), wo, bo, residual=x2[z], res_map=(G * Lq, Lq), drop_p=sp, drop_seed=ss, out=y)
             ys.append(y.view(B, G, Lq, d))
             saved += [scores, o, m8]
+        ds.join()
         ctx.save_for_backward(qf3, vft0, vft1, v0, v1, wo0, wo1, *saved)
         ctx.cfg = cfg
         ctx.bias = (bo0.dtype, tuple(x.shape))
@@ -496,43 +531,50 @@ class ZStage1Fn(Function):
         dqf = torch.empty(qf3.shape, device=dev, dtype=dt)
         dres = torch.empty((2, B * Lq, d), device=dev, dtype=dt)
         outs = {}
-        for z, (dy, vft, v, wo, scores, o, m8) in enumerate(((dy0, vft0, v0, wo0, sc0, o0, m80), (dy1, vft1, v1, wo1, sc1, o1, m81))):
-            direction = 1 if (z == 1 or permuted) else 0
+        pre = []                     # escaping tensors: allocated before the fork (see forward)
+        for z, (vft, v) in enumerate(((vft0, v0), (vft1, v1))):
             Tc, Sc = (S, T) if (z == 0 and permuted) else (T, S)
-            G = Sc if direction == 0 else Tc
-            TS = Tc * Sc
-            M = B * G * Lq
-            if dy is None:
-                dy = torch.zeros((M, d), device=dev, dtype=dt)
-            dy = dy.reshape(M, d)
-            if not dy.is_contiguous():
-                dy = dy.contiguous()
-            # gradient of the un-expanded query: the sum over the groups
-            check(lib.bist_group_sum(dy.data_ptr(), dres[z].data_ptr(), B, G, Lq * d, dtype_code(dt), _stream()), "bist_group_sum")
-            dzz = dy
-            if sdrop[z] is not None and sdrop[z][0] > 0:
-                dzz = torch.empty_like(dy)
-                check(lib.bist_epilogue_bwd(dy.data_ptr(), dy.data_ptr(), dzz.data_ptr(), M, d, d, d, d, ACT_NONE, sdrop[z][0], sdrop[z][1],
-                                            _ptr(ops.DROP_CTR), dtype_code(dt), _stream()), "bist_epilogue_bwd")
-            o2 = o.view(M, d)
-            do, dwo, dbo = ag._linear_grads(o2, wo, dzz, 1.0, ctx.w_dst[z], ctx.b_dst[z], bdt, True, ctx.needs_input_grad[7 + 2 * z],
-                                            ctx.needs_input_grad[8 + 2 * z])
-            direct16 = v.dtype == torch.bfloat16
-            dsc = torch.empty(scores.shape, device=dev, dtype=torch.bfloat16 if direct16 else scores.dtype)
-            dv = torch.empty((B, Tc, Sc, d), device=dev, dtype=v.dtype)
-            check(lib.bist_st_stage1_pv_bwd(scores.data_ptr(), v.data_ptr(), _ptr(m8), do.data_ptr(), dsc.data_ptr(), dtype_code(dsc.dtype),
-                                            dv.data_ptr(), B, Tc, Sc, Lq, h, dk, v.stride(-2), d, direction, ops.drop_ref(adrop[z]),
-                                            dtype_code(v.dtype), _stream()), "bist_st_stage1_pv_bwd")
-            g = dsc if dsc.dtype == dt else ops.cast(dsc, dt)
-            vf = vft.reshape(B, TS, d)
-            q3 = qf3[z]
-            R = Lq * h
-            ops.gemm(g, vf, dqf[z], M=R, N=d, K=TS, a_rs=TS, a_ks=1, b_rs=1, b_ks=vf.stride(1), ldc=d, batch=(B, 1),
-                     a_bs=(R * TS, 0), b_bs=(vf.stride(0), 0), c_bs=(R * d, 0))
-            dvft = torch.empty((B, TS, d), device=dev, dtype=vft.dtype)
-            ops.gemm(g, q3, dvft, M=TS, N=d, K=R, a_rs=1, a_ks=TS, b_rs=1, b_ks=q3.stride(1), ldc=d, batch=(B, 1),
-                     a_bs=(R * TS, 0), b_bs=(q3.stride(0), 0), c_bs=(TS * d, 0))
-            outs[z] = (dvft.view(vft.shape), dv, dwo, dbo)
+            pre.append((torch.empty((B, Tc, Sc, d), device=dev, dtype=v.dtype), torch.empty((B, Tc * Sc, d), device=dev, dtype=vft.dtype)))
+        direct = all(w is not None for w in ctx.w_dst) and all(b_ is not None for b_ in ctx.b_dst)
+        ds = _DirStreams(dev.type == "cuda" and direct)     # (fresh weight-gradient tensors would be allocated under the side stream)
+        for z, (dy, vft, v, wo, scores, o, m8) in enumerate(((dy0, vft0, v0, wo0, sc0, o0, m80), (dy1, vft1, v1, wo1, sc1, o1, m81))):
+          with ds.on(z):
+              direction = 1 if (z == 1 or permuted) else 0
+              Tc, Sc = (S, T) if (z == 0 and permuted) else (T, S)
+              G = Sc if direction == 0 else Tc
+              TS = Tc * Sc
+              M = B * G * Lq
+              dv, dvft = pre[z]
+              if dy is None:
+                  dy = torch.zeros((M, d), device=dev, dtype=dt)
+              dy = dy.reshape(M, d)
+              if not dy.is_contiguous():
+                  dy = dy.contiguous()
+              # gradient of the un-expanded query: the sum over the groups
+              check(lib.bist_group_sum(dy.data_ptr(), dres[z].data_ptr(), B, G, Lq * d, dtype_code(dt), _stream()), "bist_group_sum")
+              dzz = dy
+              if sdrop[z] is not None and sdrop[z][0] > 0:
+                  dzz = torch.empty_like(dy)
+                  check(lib.bist_epilogue_bwd(dy.data_ptr(), dy.data_ptr(), dzz.data_ptr(), M, d, d, d, d, ACT_NONE, sdrop[z][0], sdrop[z][1],
+                                              _ptr(ops.DROP_CTR), dtype_code(dt), _stream()), "bist_epilogue_bwd")
+              o2 = o.view(M, d)
+              do, dwo, dbo = ag._linear_grads(o2, wo, dzz, 1.0, ctx.w_dst[z], ctx.b_dst[z], bdt, True, ctx.needs_input_grad[7 + 2 * z],
+                                              ctx.needs_input_grad[8 + 2 * z])
+              direct16 = v.dtype == torch.bfloat16
+              dsc = torch.empty(scores.shape, device=dev, dtype=torch.bfloat16 if direct16 else scores.dtype)
+              check(lib.bist_st_stage1_pv_bwd(scores.data_ptr(), v.data_ptr(), _ptr(m8), do.data_ptr(), dsc.data_ptr(), dtype_code(dsc.dtype),
+                                              dv.data_ptr(), B, Tc, Sc, Lq, h, dk, v.stride(-2), d, direction, ops.drop_ref(adrop[z]),
+                                              dtype_code(v.dtype), _stream()), "bist_st_stage1_pv_bwd")
+              g = dsc if dsc.dtype == dt else ops.cast(dsc, dt)
+              vf = vft.reshape(B, TS, d)
+              q3 = qf3[z]
+              R = Lq * h
+              ops.gemm(g, vf, dqf[z], M=R, N=d, K=TS, a_rs=TS, a_ks=1, b_rs=1, b_ks=vf.stride(1), ldc=d, batch=(B, 1),
+                       a_bs=(R * TS, 0), b_bs=(vf.stride(0), 0), c_bs=(R * d, 0))
+              ops.gemm(g, q3, dvft, M=TS, N=d, K=R, a_rs=1, a_ks=TS, b_rs=1, b_ks=q3.stride(1), ldc=d, batch=(B, 1),
+                       a_bs=(R * TS, 0), b_bs=(q3.stride(0), 0), c_bs=(TS * d, 0))
+              outs[z] = (dvft.view(vft.shape), dv, dwo, dbo)
+        ds.join()
         if dxp is not None:          # the gradient that came back through x' (the sublayer input's next consumer)
             dxp2 = dxp.reshape(2, B * Lq, d)
             if not dxp2.is_contiguous():
@@ -559,10 +601,13 @@ class ZStage2Fn(Function):
         py = torch.empty((2, B, Lq, h, d), device=y0.device, dtype=y0.dtype)
         with_rs = any(dr is not None and dr[0] > 0 for dr in drops)
         rs = torch.empty((2, B, Lq, h), device=y0.device, dtype=torch.float32) if with_rs else None
+        ds = _DirStreams(y0.is_cuda)
         for z, (y, mk) in enumerate(((y0, None), (y1, m8))):
+          with ds.on(z):
             yc = y if y.is_contiguous() else y.contiguous()
             check(lib.bist_st_stage2_fwd(q5[z].data_ptr(), yc.data_ptr(), _ptr(mk), py[z].data_ptr(), rs[z].data_ptr() if rs is not None else None,
                                          B, y.shape[1], Lq, h, d, ops.drop_ref(drops[z]), dtype_code(y.dtype), _stream()), "bist_st_stage2_fwd")
+        ds.join()
         ctx.save_for_backward(q5, y0, y1, m8)
         ctx.cfg = (h, drops, tuple(q2f.shape))
         ctx.set_materialize_grads(False)
@@ -585,11 +630,15 @@ class ZStage2Fn(Function):
             drs = drs.reshape(2, B, Lq, h).contiguous().float()
         dq = torch.empty_like(q5)
         dys = []
+        ycs = [y if y.is_contiguous() else y.contiguous() for y in (y0, y1)]
+        pre = [torch.empty_like(yc) for yc in ycs]           # escaping tensors: allocated before the fork (see ZStage1Fn.forward)
+        ds = _DirStreams(y0.is_cuda)
         for z, (y, mk) in enumerate(((y0, None), (y1, m8))):
-            yc = y if y.is_contiguous() else y.contiguous()
-            dy = torch.empty_like(yc)
+          with ds.on(z):
+            yc, dy = ycs[z], pre[z]
             check(lib.bist_st_stage2_bwd(q5[z].data_ptr(), yc.data_ptr(), _ptr(mk), dpy[z].data_ptr(), drs[z].data_ptr() if drs is not None else None,
                                          dq[z].data_ptr(), dy.data_ptr(), B, y.shape[1], Lq, h, d, ops.drop_ref(drops[z]), dtype_code(y.dtype),
                                          _stream()), "bist_st_stage2_bwd")
             dys.append(dy)
+        ds.join()
         return dq.view(q_shape), dys[0], dys[1], None, None, None
