@@ -79,9 +79,11 @@ class VidEncoder8(nn.Module):
             if fts.dtype != self.W.weight.dtype:
                 fts = Fn.cast(fts, self.W.weight.dtype)
             B, T, S, C = fts.shape
-            if fts.is_cuda and not torch.is_grad_enabled():
+            if fts.is_cuda and not torch.is_grad_enabled() and not Z.ENABLED and Fn.CONCURRENT:
                 # inference: everything queued so far (the text encoders) is done at this point of the stream; the first reasoning
-                # layer forks its query-side chains from HERE, so that they run under the input projection instead of after it
+                # layer forks its query-side chains from HERE, so that they run under the input projection instead of after it.
+                # (Recorded ONLY when a layer will wait on it: an event recorded during a hipGraph capture and never waited on stays in
+                # the graph as an event-record node of an event object that dies with this call -- replays then crash in the runtime.)
                 ev = torch.cuda.Event()
                 ev.record()
                 ft["_bist_pre_vid"] = ev
@@ -448,6 +450,8 @@ class VidEncoderLayer4(nn.Module):
                 trace.update(s2t_self=x, s2t_stage1=y, s2t_stage2=z, s2t_ff=in_ft["s2t"])
 
         pre_vid = ft.pop("_bist_pre_vid", None)
+        if pre_vid is not None and not (concurrent and fused and Fn.EVAL_SCHED in (1, 2)):
+            torch.cuda.current_stream().wait_event(pre_vid)      # no schedule below waits on it: consume it here (see VidEncoder8.forward)
         if trace is not None and fused:
             fused = False                                # the traced form keeps every stage's output: separate launches
             v_t2s, v_s2t = self.value_projection(take())

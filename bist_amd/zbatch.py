@@ -36,10 +36,16 @@ from .ops import _ptr, _stream, dtype_code
 
 Tensor = torch.Tensor
 
-ENABLED = os.environ.get("BIST_ZBATCH", "1") != "0"      # tuning aid: 0 = the two directions as two chains on two streams (round 2)
-# tuning aid: the per-direction launches of stage 1 / stage 2 (chip-filling kernels of 20-50 us with short tails) of the s2t direction on a
-# side stream beside the t2s direction's on the main stream; 0 = back to back on one stream
-DIR_STREAMS = os.environ.get("BIST_Z_DIR_STREAMS", "1") != "0"
+# Measured (round 3, BASELINE configs[1], same box, `python bench.py`): the lock-step form is 1 143 launches and 14.1 ms of summed kernel
+# time per training step against 1 397 launches / 16.2-16.7 ms for the two-chain form -- and 12.1-12.4 ms per step against 11.7-11.8:
+# with both directions on ONE stream the two directions' chip-filling stage-1 launches run back to back, while the two-chain form
+# overlaps one direction's big launches with the other's small ones (1.38 kernels in flight on average against 1.16).  Under rocprofv3
+# (which serialises part of that overlap) the lock-step form is the faster one (13.7 vs 14.6 ms).  So it is OPT-IN: BIST_ZBATCH=1.
+ENABLED = os.environ.get("BIST_ZBATCH", "0") != "0"
+# tuning aid (lock-step form): the s2t direction's stage-1 / stage-2 launches on a side stream beside the t2s direction's, and the query side
+# of stage 2 under the stage-1 launches.  Measured 13.4 vs 12.35 ms per step: every fork / join is a cross-queue dependency in the replayed
+# hipGraph (~10 us on the critical path each), three per layer and pass cost more than the overlap returns.  Off by default.
+DIR_STREAMS = os.environ.get("BIST_Z_DIR_STREAMS", "0") != "0"
 
 
 class _DirStreams:

@@ -182,6 +182,7 @@ def test_z_linear_dropout_and_layernorm_handoff_against_torch(hip):
 def test_training_mode_lockstep_step_is_finite_and_changes_with_the_step_counter(hip):
     """train() mode (dropout at all four sites) through the lock-step layer under the Trainer's flat buffers: finite losses, and two
     steps on the same batch draw different dropout masks (the device step counter rides in every z-batched epilogue)."""
+    from bist_amd import zbatch as Z
     from bist_amd.train import Trainer
     M, Batch = hip
     cfg = O.Cfg(d_model=128, att_h=8, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2, dropout=0.1)
@@ -191,7 +192,12 @@ def test_training_mode_lockstep_step_is_finite_and_changes_with_the_step_counter
     tr = Trainer(model, _args(cfg), V, compute_dtype=torch.bfloat16, warmup=10, use_graph=False)
     ob = O.det_batch(4, 8, 49, C, 20, 30, 12, 10, V, seed=3)
     b = _batch(Batch, ob, torch.bfloat16)
-    l1 = {k: float(v) for k, v in tr.step(b).items()}
-    l2 = {k: float(v) for k, v in tr.step(b).items()}
+    old = Z.ENABLED
+    Z.ENABLED = True
+    try:
+        l1 = {k: float(v) for k, v in tr.step(b).items()}
+        l2 = {k: float(v) for k, v in tr.step(b).items()}
+    finally:
+        Z.ENABLED = old
     assert all(np.isfinite(v) for v in list(l1.values()) + list(l2.values())), (l1, l2)
     assert l1 != l2
