@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libbist_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GATE = 0, 1, 2
 # kernel families of bist_launch_count (include/bist_hip.h: BIST_K_*)
-K_ST1_MFMA_FWD, K_ST1_MFMA_BWD, K_ST1_VALU, K_ST2_MFMA_FWD, K_ST2_MFMA_BWD, K_ST2_VALU, K_MHA_FWD, K_MHA_BWD_MFMA, K_MHA_BWD_VALU, K_ST1_FUSED, K_DECSTACK = range(11)
+K_ST1_MFMA_FWD, K_ST1_MFMA_BWD, K_ST1_VALU, K_ST2_MFMA_FWD, K_ST2_MFMA_BWD, K_ST2_VALU, K_MHA_FWD, K_MHA_BWD_MFMA, K_MHA_BWD_VALU, K_ST1_FUSED, K_DECSTACK, K_ST1_FUSED_TRAIN, K_ST1_PBWD = range(13)
 
 
 class BistGemm(C.Structure):
@@ -89,8 +89,12 @@ SIGNATURES = {
                                     _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, C.POINTER(BistDrop), _I32, _P]),
     "bist_st_stage1_pv_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, C.POINTER(BistDrop), _I32, _I32, _P]),
     "bist_pack_frag_rows": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
+    "bist_pack_frag_rows_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I32, _I32, _I32, _I32, _P]),
     "bist_st_stage1_fused_ok": (C.c_int, [_I32] * 7),
     "bist_st_stage1_fused_fwd": (C.c_int, [_P] * 9 + [_I32] * 8 + [_P]),
+    "bist_st_stage1_fused_train_ok": (C.c_int, [_I32] * 7),
+    "bist_st_stage1_fused_train_fwd": (C.c_int, [_P] * 12 + [C.POINTER(BistDrop), C.POINTER(BistDrop)] + [_I32] * 8 + [_P]),
+    "bist_st_stage1_pv_bwd_p": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I32, _P] + [_I32] * 6 + [_I64, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_decoder_stack_ok": (C.c_int, [_I32] * 5),
     "bist_decoder_layer_desc_bytes": (C.c_int64, []),
     "bist_decoder_stack_fwd": (C.c_int, [_P, _I32] + [_P] * 8 + [_I32, _I32, _I32, _P, _I32, _P]),

@@ -700,6 +700,65 @@ class StStage1PvFn(Function):
         return dsc, dv, None, None, None, None
 
 
+class St1FusedTrainFn(Function):
+    """Stage 1 of one direction (A1 / A4), training: y = x + drop(W_o . MHA(LN(x), X_g, X_g) + b_o) on the expanded query, forward as ONE
+    launch (bist_st_stage1_fused_train_fwd: value projection, scores, masked softmax + dropout, P.V, output projection + dropout +
+    residual) that leaves V, the probabilities and the context rows behind for this backward -- the same kernels the unfused path runs:
+    group sum + dropout mask of dy, output projection dX / dW, bist_st_stage1_pv_bwd_p (probabilities instead of a score gather and a
+    softmax recompute), the two score-product gradients and the value projection's dX / dW.  No fp32 score tensor exists at any point.
+    vft_a / vft_b: two aliases of the video tensor (its gradient through the scores and through the value projection)."""
+
+    @staticmethod
+    def forward(ctx, qf, x, vft_a, vft_b, tmask, wv, bv, wo, bo, wv_frag, wo_frag, cfg):
+        h, direction, adrop, sdrop = cfg
+        B, T, S, d = vft_a.shape
+        K = T if direction == 0 else S
+        m8 = _mask_u8(tmask.reshape(B, K)) if tmask is not None else None
+        y, v, p, o = ops.st_stage1_fused_train(qf.reshape(B, -1, d), vft_a, m8, wv_frag, bv, wo_frag, bo, x, h=h, direction=direction,
+                                               attn_drop=adrop, sub_drop=sdrop)
+        ctx.save_for_backward(qf, vft_a, v, p, o, m8, wv, wo)
+        ctx.cfg = (cfg, tuple(x.shape), bv.dtype, tuple(qf.shape))
+        ctx.w_dst = (getattr(wv, "_grad_view", None), getattr(wo, "_grad_view", None))
+        ctx.b_dst = (getattr(bv, "_acc32", None), getattr(bo, "_acc32", None))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        qf, vft, v, p, o, m8, wv, wo = ctx.saved_tensors
+        (h, direction, adrop, sdrop), x_shape, bdt, qf_shape = ctx.cfg
+        B, T, S, d = vft.shape
+        dk = d // h
+        G = S if direction == 0 else T
+        Lq = x_shape[1]
+        M, TS, R = B * G * Lq, T * S, Lq * h
+        dev, dt = vft.device, vft.dtype
+        dy = dy.reshape(M, d)
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        dres = torch.empty((B * Lq, d), device=dev, dtype=dt)          # gradient of the un-expanded query: the sum over the groups
+        check(lib.bist_group_sum(dy.data_ptr(), dres.data_ptr(), B, G, Lq * d, dtype_code(dt), _stream()), "bist_group_sum")
+        dz = dy
+        if sdrop is not None and sdrop[0] > 0:
+            dz = torch.empty_like(dy)
+            check(lib.bist_epilogue_bwd(dy.data_ptr(), dy.data_ptr(), dz.data_ptr(), M, d, d, d, d, ACT_NONE, sdrop[0], sdrop[1] & 0xFFFFFFFFFFFFFFFF,
+                                        _ptr(ops.DROP_CTR), dtype_code(dt), _stream()), "bist_epilogue_bwd")
+        do, dwo, dbo = _linear_grads(o.view(M, d), wo, dz, 1.0, ctx.w_dst[1], ctx.b_dst[1], bdt, True, ctx.needs_input_grad[7], ctx.needs_input_grad[8])
+        dsc = torch.empty((B, R, TS), device=dev, dtype=dt)
+        dv = torch.empty((B, T, S, d), device=dev, dtype=dt)
+        check(lib.bist_st_stage1_pv_bwd_p(p.data_ptr(), p.shape[-1], v.data_ptr(), _ptr(m8), do.data_ptr(), dsc.data_ptr(), dtype_code(dt), dv.data_ptr(),
+                                          B, T, S, Lq, h, dk, d, d, direction, ops.drop_ref(adrop), dtype_code(dt), _stream()), "bist_st_stage1_pv_bwd_p")
+        q3, vf = qf.reshape(B, R, d), vft.reshape(B, TS, d)
+        dqf = torch.empty((B, R, d), device=dev, dtype=dt)
+        ops.gemm(dsc, vf, dqf, M=R, N=d, K=TS, a_rs=TS, a_ks=1, b_rs=1, b_ks=vf.stride(1), ldc=d, batch=(B, 1),
+                 a_bs=(R * TS, 0), b_bs=(vf.stride(0), 0), c_bs=(R * d, 0))
+        dvft_a = torch.empty((B, TS, d), device=dev, dtype=dt)
+        ops.gemm(dsc, q3, dvft_a, M=TS, N=d, K=R, a_rs=1, a_ks=TS, b_rs=1, b_ks=q3.stride(1), ldc=d, batch=(B, 1),
+                 a_bs=(R * TS, 0), b_bs=(q3.stride(0), 0), c_bs=(TS * d, 0))
+        dvft_b, dwv, dbv = _linear_grads(vft.view(B * TS, d), wv, dv.view(B * TS, d), 1.0, ctx.w_dst[0], ctx.b_dst[0], bdt, True,
+                                         ctx.needs_input_grad[5], ctx.needs_input_grad[6])
+        return (dqf.view(qf_shape), dres.view(x_shape), dvft_a.view(vft.shape), dvft_b.view(vft.shape), None, dwv, dbv, dwo, dbo, None, None, None)
+
+
 class StStage2Fn(Function):
     """(PY, rowsum): rowsum [B,Lq,h] f32 = sum_g P'[g] is only produced under dropout (None otherwise)."""
 

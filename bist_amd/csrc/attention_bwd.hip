@@ -385,6 +385,22 @@ extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const u
   return BIST_OK;
 }
 
+extern "C" int bist_st_stage1_pv_bwd_p(const float* P, int32_t KP, const void* V, const uint8_t* tmask, const void* dO, void* dscores,
+                                       int32_t dscores_dtype, void* dV, int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk,
+                                       int64_t ldv, int64_t lddv, int32_t direction, const BistDrop* drop, int32_t dtype, void* stream) {
+  BIST_REQUIRE(P && V && dO && dscores && dV, "bist_st_stage1_pv_bwd_p: null pointer");
+  BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_st_stage1_pv_bwd_p: drop p out of range");
+  BIST_REQUIRE(B > 0 && T > 0 && S > 0 && Lq > 0 && h > 0 && dk > 0 && (direction == 0 || direction == 1), "bist_st_stage1_pv_bwd_p: bad shape");
+  BIST_REQUIRE(dscores_dtype == BIST_F32 || dscores_dtype == BIST_BF16, "bist_st_stage1_pv_bwd_p: bad dscores dtype %d", (int)dscores_dtype);
+  BIST_REQUIRE(dtype == BIST_BF16 && KP >= (direction == 0 ? T : S), "bist_st_stage1_pv_bwd_p: bf16 only, KP >= keys");
+  const int r = bist_st1_mfma(P, 1, V, tmask, nullptr, dO, dscores, dscores_dtype == BIST_BF16, dV, B, T, S, Lq, h, dk, ldv, lddv, direction, 1,
+                              make_drop(drop), (hipStream_t)stream, KP);
+  if (r == 1) return BIST_OK;
+  if (r < 0) return BIST_ELAUNCH;
+  bist_set_error("bist_st_stage1_pv_bwd_p: shape outside the matrix-core kernel's envelope (dk = 64, Lq <= 32, keys <= 128)");
+  return BIST_EINVAL;
+}
+
 extern "C" int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t* gmask, const void* dPY, const float* d_rowsum,
                                   void* dq2f, void* dY, int32_t B, int32_t G, int32_t Lq, int32_t h, int32_t d, const BistDrop* drop,
                                   int32_t dtype, void* stream) {

@@ -54,6 +54,8 @@ struct St1Args {
   const bf16_t* dO; void* dscores; bf16_t* dV;   // backward (dscores f32, or bf16 when dsc_bf16)
   int T, S, Lq, h; long ldv, lddv; int dir, Gc;
   int dsc_bf16;
+  int p_kp;     // > 0 (backward): `scores` holds the PROBABILITIES before dropout as [B, G, h, Lq, p_kp] f32 (the fused training forward's
+                // side output): phases A and B are one contiguous read per (query row, group) instead of a score gather + softmax
   int dbg;      // timing ablation only (BIST_ST1_DBG): bit0 skip slab gather, bit1 skip softmax, bit2 skip phase C
   DropArg drop; // dropout of the probabilities: the slab keeps P, the bf16 image that feeds the MFMAs holds mask*P/(1-p)
 };
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
   const TS* sc = reinterpret_cast<const TS*>(a.scores) + (long)b * Lq * h * TS_;
   const unsigned char* mk = a.tmask ? a.tmask + (long)b * Kn : nullptr;      // key mask [B, K]
   // ---- A: score slab ---------------------------------------------------------------------------------------
-  if (a.dbg & 1) {
+  if ((a.dbg & 1) || a.p_kp > 0) {
   } else if (dir == 1) {
     // group = frame t, keys = regions: for a fixed query row the gc*S scores are ONE contiguous run -> 16-byte loads
     const int run = gc * Kn;
@@ -171,6 +173,25 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
       const bool act = r < rows;
       float* p = slab + (long)(act ? r : 0) * KP;
       float v[PER];
+      if (a.p_kp > 0) {
+        // the probabilities themselves: row (b, g, hh, i) of the saved tensor, keys part, part + 4, ... of this lane
+        if (act) {
+          const int i = r / gc, gl = r - i * gc;
+          const float* src = reinterpret_cast<const float*>(a.scores) + ((((long)b * G + (g0 + gl)) * h + hh) * Lq + i) * a.p_kp;
+          bf16_t* pi = pimg + ((long)gl * 32 + i) * KPAD;
+          const unsigned long long dbase = ((((unsigned long long)b * G + (g0 + gl)) * h + hh) * Lq + i) * Kn;
+#pragma unroll
+          for (int u = 0; u < PER; ++u) {
+            const int k = part + 4 * u;
+            if (k < Kn) {
+              const float q = src[k];
+              p[k] = q;
+              pi[k] = (bf16_t)(a.drop.p > 0.f ? q * drop_mul(dkey, dbase + k, a.drop.p, dks) : q);
+            }
+          }
+        }
+        continue;
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
@@ -324,7 +345,7 @@ int launch_one(const St1Args& a, int B, size_t lds, hipStream_t st) {
   const int G = a.dir == 0 ? a.S : a.T;
   dim3 grid((unsigned)((G + a.Gc - 1) / a.Gc), (unsigned)a.h, (unsigned)B);
   hipLaunchKernelGGL((st1_mfma_kernel<TS, KSTEPS, BWD>), grid, dim3(256), lds, st, a);
-  bist_count_launch(BWD ? BIST_K_ST1_MFMA_BWD : BIST_K_ST1_MFMA_FWD);
+  bist_count_launch(BWD ? (a.p_kp > 0 ? BIST_K_ST1_PBWD : BIST_K_ST1_MFMA_BWD) : BIST_K_ST1_MFMA_FWD);
   return launched("st1_mfma_kernel");
 }
 
@@ -779,7 +800,7 @@ int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, vo
 // returns 1 if launched, 0 if the shape is outside this kernel's envelope (caller falls back), -1 on launch error
 int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsigned char* tmask, void* O, const void* dO,
                   void* dscores, int dsc_bf16, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
-                  int bwd, const DropArg& drop, hipStream_t st) {
+                  int bwd, const DropArg& drop, hipStream_t st, int p_kp) {
   const int G = dir == 0 ? S : T, Kn = dir == 0 ? T : S;
   if (dk != 64 || Lq > 32 || Kn > 128 || (ldv % 8) != 0 || ((uintptr_t)V % 16) != 0) return 0;
   if (bwd && ((lddv % 8) != 0 || ((long)h * dk) % 8 != 0 || !sc_is_f32)) return 0;
@@ -797,7 +818,8 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
   const size_t lds = (size_t)(((long)Lq * Gc * (Kn + 1) * 4 + 15) / 16 * 16) + (size_t)Gc * 32 * kpad * 2 + (size_t)Gc * kpad * 64 * 2 +
                      (bwd ? (size_t)Gc * 32 * 64 * 2 : 0) + 16;
   static const int dbg = [] { const char* e = getenv("BIST_ST1_DBG"); return e ? atoi(e) : 0; }();
-  St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc, dsc_bf16, dbg, drop};
+  if (p_kp > 0 && (!bwd || !sc_is_f32 || p_kp < Kn)) return 0;
+  St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc, dsc_bf16, p_kp, dbg, drop};
 #define GO(TS_, KS_)                                                                   \
   return bwd ? launch_one<TS_, KS_, true>(a, B, lds, st) : launch_one<TS_, KS_, false>(a, B, lds, st)
   if (sc_is_f32) {

@@ -60,7 +60,7 @@ int bist_dev_dbg(int which);
 struct DropArg;
 int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsigned char* tmask, void* O, const void* dO,
                   void* dscores, int dsc_bf16, void* dV, int B, int T, int S, int Lq, int h, int dk, long ldv, long lddv, int dir,
-                  int bwd, const DropArg& drop, hipStream_t st);
+                  int bwd, const DropArg& drop, hipStream_t st, int p_kp = 0);
 
 int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, void* PY, const void* dPY, void* dq2f, void* dY,
                   float* rowsum, const float* d_rowsum, int B, int G, int Lq, int h, int d, int bwd, const DropArg& drop, hipStream_t st);

@@ -38,6 +38,14 @@ struct St1F {
   int B, T, S, Lq, dir, cpc;     // cpc = chunks per clip
   unsigned long long* stamps;    // BIST_ST1F_STAMPS (development): per workgroup 8 s_memtime stamps at the phase boundaries, or null
   int dbg;                       // BIST_ST1F_DBG timing ablation (0 in production): bit0/1/2 no weight loads in step 1/2/4, bit3 no X DMA, bit4 skip step 3
+  // TRAINING form (bist_st_stage1_fused_train_fwd): what the backward pass needs leaves the kernel as side outputs, and the two dropouts
+  // of the sublayer (attention probabilities modules.py:62-63, sublayer output modules.py:44) are applied in place
+  bf16_t* Vout;                  // [B,T,S,d]  V = X W_v^T + b_v   (what bist_st_stage1_pv_bwd reads)
+  float* Pout;                   // [B,G,h,Lq,KP] probabilities BEFORE dropout, KP = keys rounded up to 4 (bist_st_stage1_pv_bwd_p)
+  bf16_t* Oout;                  // [B,G,Lq,d] head-concatenated context = the output projection's input (its weight gradient)
+  int KP;
+  DropArg adrop;                 // attention-probability dropout, element index ((((b G + g) h + hh) Lq + i) K + key
+  DropArg sdrop;                 // sublayer-output dropout, element index (row of Y) * d + column
 };
 
 __device__ uint4 g_zero_line;      // 16 zero bytes: DMA source of every padding row
@@ -142,7 +150,7 @@ struct Chunk { int b, g0, ng, w, lane; };
 
 // The work of one chunk with MTA active key tiles (NGA = MTA / KT groups) and MT4A row tiles in the output projection.  The full
 // chunk is <KT, 8, MT4>; the last chunk of a clip (G % NG groups) runs the smallest instantiation that holds it.
-template <int KT, int MTA, int MT4A>
+template <int KT, int MTA, int MT4A, bool TRAIN = false>
 __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* smem) {
   constexpr int NGA = MTA / KT;
   const int w = c.w, lane = c.lane, b = c.b, g0 = c.g0, ng = c.ng;
@@ -263,8 +271,11 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
   // softmax of every (group, query row) over the group's keys, in registers, BEFORE the barrier: the two waves of a SIMD do not
   // finish steps 1-2 together, and this vector work of the first runs under the matrix work of the second
   uint4 pf[NGA][2][KT / 2];
+  float rsum[TRAIN ? NGA : 1][2];                // TRAIN: sum of the KEPT (dropped-out, rescaled) probabilities of this lane's query rows
   if (!(a.dbg & 16)) {
     const bool plain = repl == 0;            // per lane; uniform in the common case (no padding keys, nothing masked)
+    const unsigned long long akey = (TRAIN && a.adrop.p > 0.f) ? a.adrop.key() : 0ULL;
+    const float aks = (TRAIN && a.adrop.p > 0.f) ? a.adrop.keep_scale() : 1.f;
 #pragma unroll
     for (int gl = 0; gl < NGA; ++gl)
 #pragma unroll
@@ -287,16 +298,77 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
 #pragma unroll
           for (int r = 0; r < 4; ++r) { sv[kt][r] = __expf(sv[kt][r] - mx); den += sv[kt][r]; }
         const float inv = 1.f / rows_sum(den);
+        if constexpr (TRAIN) {
+          const int i = it * 16 + x;
+          const bool live = gl < ng && i < Lq;
+          // probabilities before dropout, row (b, g, hh, i) of Pout: this lane's keys 16 kt + 4 kg + r are 4 consecutive floats
+          const long prow = ((((long)b * G + g0 + gl) * H + w) * Lq + i);
+          float kept = 0.f;
 #pragma unroll
-        for (int k2 = 0; k2 < KT / 2; ++k2)
-          pf[gl][it][k2] = make_uint4(pack2(sv[2 * k2][0] * inv, sv[2 * k2][1] * inv), pack2(sv[2 * k2][2] * inv, sv[2 * k2][3] * inv),
-                                      pack2(sv[2 * k2 + 1][0] * inv, sv[2 * k2 + 1][1] * inv), pack2(sv[2 * k2 + 1][2] * inv, sv[2 * k2 + 1][3] * inv));
+          for (int kt = 0; kt < KT; ++kt) {
+            const int kk0 = 16 * kt + 4 * kg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sv[kt][r] *= inv;
+            if (live && kk0 < a.KP) *reinterpret_cast<float4*>(a.Pout + prow * a.KP + kk0) = make_float4(sv[kt][0], sv[kt][1], sv[kt][2], sv[kt][3]);
+            if (a.adrop.p > 0.f) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sv[kt][r] *= drop_mul(akey, (unsigned long long)prow * K + kk0 + r, a.adrop.p, aks);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kept += sv[kt][r];
+          }
+          rsum[gl][it] = rows_sum(kept);
+#pragma unroll
+          for (int k2 = 0; k2 < KT / 2; ++k2)
+            pf[gl][it][k2] = make_uint4(pack2(sv[2 * k2][0], sv[2 * k2][1]), pack2(sv[2 * k2][2], sv[2 * k2][3]),
+                                        pack2(sv[2 * k2 + 1][0], sv[2 * k2 + 1][1]), pack2(sv[2 * k2 + 1][2], sv[2 * k2 + 1][3]));
+        } else {
+#pragma unroll
+          for (int k2 = 0; k2 < KT / 2; ++k2)
+            pf[gl][it][k2] = make_uint4(pack2(sv[2 * k2][0] * inv, sv[2 * k2][1] * inv), pack2(sv[2 * k2][2] * inv, sv[2 * k2][3] * inv),
+                                        pack2(sv[2 * k2 + 1][0] * inv, sv[2 * k2 + 1][1] * inv), pack2(sv[2 * k2 + 1][2] * inv, sv[2 * k2 + 1][3] * inv));
+        }
       }
   }
   STAMP(3);
   __syncthreads();          // every wave is done with the X image: it becomes the context image
   STAMP(4);
 
+  if constexpr (TRAIN) {
+    // V side output.  vpk holds V (without its bias) as packed bf16 in MFMA-fragment order -- lane (x, kg): channel 16 nt + x of keys
+    // 16 mt + 4 kg + r.  Each wave turns its [32 keys][64 channels] pieces into 128-byte rows through a 4 KiB staging tile of its own in
+    // the part of the dead X image that the context rows (NGA * Lq <= 96 rows) do not use, and stores them 16 bytes per lane.
+    char* stg = smem + 96 * 1024 + w * 4096;
+    float bvx[4];                                // value bias of this lane's channel 16 nt + x
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bvx[nt] = (float)a.bv[w * 64 + nt * 16 + x];
+#pragma unroll
+    for (int p = 0; p < MTA / 2; ++p) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const uint4 q = vpk[p][nt];
+        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {             // j = 4 * (tile parity) + r
+          const float val = ((j & 1) ? bf_hi(u[j >> 1]) : bf_lo(u[j >> 1])) + bvx[nt];
+          const int kl = (j >> 2) * 16 + 4 * kg + (j & 3);
+          *reinterpret_cast<bf16_t*>(stg + kl * 128 + (nt * 16 + x) * 2) = (bf16_t)val;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int kl = q4 * 8 + (lane >> 3), r = p * 32 + kl;          // key row of the chunk image
+        const int gl = r / (16 * KT), kk = r % (16 * KT);
+        const uint4 row = *reinterpret_cast<const uint4*>(stg + kl * 128 + (lane & 7) * 16);
+        if (gl < ng && kk < K) {
+          const int t = a.dir == 0 ? kk : g0 + gl, sI = a.dir == 0 ? g0 + gl : kk;
+          *reinterpret_cast<uint4*>(a.Vout + (((long)b * T_ + t) * S_ + sI) * D + w * 64 + (lane & 7) * 8) = row;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
   // ---- 3. context rows: O^T = V^T . P^T per group, + b_v, as bf16 rows (g, i) of the context image ------------------------------
 #pragma unroll
   for (int gl = 0; gl < NGA; ++gl) {
@@ -312,14 +384,24 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
         const int i = it * 16 + x;
         if (i < Lq) {
           const int row = gl * Lq + i;
+          const float bs = TRAIN ? rsum[TRAIN ? gl : 0][it] : 1.f;      // dropped probabilities do not sum to one: P'(V + b) = P'V + rowsum(P') b
           char* dst = smem + row * 1024 + ((((c0 >> 3)) ^ (row & 15)) << 4) + (kg & 1) * 8;
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o[0] + bvf[nt][0], o[1] + bvf[nt][1]), pack2(o[2] + bvf[nt][2], o[3] + bvf[nt][3]));
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o[0] + bs * bvf[nt][0], o[1] + bs * bvf[nt][1]), pack2(o[2] + bs * bvf[nt][2], o[3] + bs * bvf[nt][3]));
         }
       }
     }
   }
   __syncthreads();
   STAMP(5);
+  if constexpr (TRAIN) {
+    // the context rows (g, i) as they lie in the image (16-byte chunks swizzled by row & 15) -> Oout [B, G, Lq, d], one 1-KiB row per wave step
+    const int rows_o = ng * Lq;
+    for (int row = w; row < rows_o; row += 8) {
+      const int gl = row / Lq, i = row - gl * Lq;
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + row * 1024 + ((lane ^ (row & 15)) << 4));
+      *reinterpret_cast<uint4*>(a.Oout + (((long)b * G + g0 + gl) * Lq + i) * D + lane * 8) = v;
+    }
+  }
 
   // ---- 4. Y = ctx . W_o^T + b_o + x ----------------------------------------------------------------------------
   {
@@ -386,10 +468,25 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
         }
         uint4 xq;
         if constexpr (PRE) xq = xr[mt][jp]; else xq = *reinterpret_cast<const uint4*>(a.xres + xoff[mt] + jp * 32);
-        const uint4 o = make_uint4(pack2(v[0] + bf_lo(bq.x) + bf_lo(xq.x), v[1] + bf_hi(bq.x) + bf_hi(xq.x)),
-                                   pack2(v[2] + bf_lo(bq.y) + bf_lo(xq.y), v[3] + bf_hi(bq.y) + bf_hi(xq.y)),
-                                   pack2(v[4] + bf_lo(bq.z) + bf_lo(xq.z), v[5] + bf_hi(bq.z) + bf_hi(xq.z)),
-                                   pack2(v[6] + bf_lo(bq.w) + bf_lo(xq.w), v[7] + bf_hi(bq.w) + bf_hi(xq.w)));
+        const float bb[8] = {bf_lo(bq.x), bf_hi(bq.x), bf_lo(bq.y), bf_hi(bq.y), bf_lo(bq.z), bf_hi(bq.z), bf_lo(bq.w), bf_hi(bq.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bb[e];
+        if constexpr (TRAIN) {
+          if (a.sdrop.p > 0.f) {               // y = x + dropout(W_o ctx + b_o): mask index = (row of Y) * d + column, as in the GEMM epilogue
+            const unsigned long long i4 = (unsigned long long)(yoff[mt] + jp * 32) >> 2;
+            const uint32_t thr = drop_threshold(a.sdrop.p);
+            const float ks = a.sdrop.keep_scale();
+            const unsigned long long skey = a.sdrop.key();
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+              const uint64_t bits = drop_bits4(skey, i4 + q4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[4 * q4 + e] = drop_keep_of(bits, e, thr) ? v[4 * q4 + e] * ks : 0.f;
+            }
+          }
+        }
+        const uint4 o = make_uint4(pack2(v[0] + bf_lo(xq.x), v[1] + bf_hi(xq.x)), pack2(v[2] + bf_lo(xq.y), v[3] + bf_hi(xq.y)),
+                                   pack2(v[4] + bf_lo(xq.z), v[5] + bf_hi(xq.z)), pack2(v[6] + bf_lo(xq.w), v[7] + bf_hi(xq.w)));
         if (mt * 16 + x < rows) *reinterpret_cast<uint4*>(a.Y + yoff[mt] + jp * 32) = o;
       }
     }
@@ -397,7 +494,7 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
   STAMP(7);
 }
 
-template <int KT, int MT4>
+template <int KT, int MT4, bool TRAIN = false>
 __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
   constexpr int NG = MT / KT;
   constexpr int LQC = MT4 * 16 / NG;                    // the query-length class of this instantiation (20 or 32 rows per group)
@@ -418,12 +515,12 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
   }
   c.lane = threadIdx.x & 63; c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if constexpr (KT == 2) {
-    if (c.ng == 1) { chunk_body<2, 2, (LQC + 15) / 16>(a, c, smem); return; }
-    if (c.ng == 2) { chunk_body<2, 4, (2 * LQC + 15) / 16>(a, c, smem); return; }
+    if (c.ng == 1) { chunk_body<2, 2, (LQC + 15) / 16, TRAIN>(a, c, smem); return; }
+    if (c.ng == 2) { chunk_body<2, 4, (2 * LQC + 15) / 16, TRAIN>(a, c, smem); return; }
   } else if constexpr (KT == 4) {
-    if (c.ng == 1) { chunk_body<4, 4, (LQC + 15) / 16>(a, c, smem); return; }
+    if (c.ng == 1) { chunk_body<4, 4, (LQC + 15) / 16, TRAIN>(a, c, smem); return; }
   }
-  chunk_body<KT, MT, MT4>(a, c, smem);
+  chunk_body<KT, MT, MT4, TRAIN>(a, c, smem);
 }
 
 // W [rows][cols] row-major -> fragment order [rows/16][cols/64][2][64 lanes][8]: lane (x = lane & 15, kg = lane >> 4) of block
@@ -439,12 +536,28 @@ __global__ void pack_frag_rows_kernel(const bf16_t* __restrict__ W, bf16_t* __re
   reinterpret_cast<uint4*>(out)[piece] = *reinterpret_cast<const uint4*>(src);
 }
 
-template <int KT, int MT4>
+// several same-sized weights in one launch (the training step re-packs the value / output projections of every reasoning layer)
+constexpr int PACK_MAX = 32;
+struct PackSets { const bf16_t* src[PACK_MAX]; bf16_t* dst[PACK_MAX]; };
+__global__ void pack_frag_rows_multi_kernel(const PackSets sets, int rows, int cols) {
+  const long piece = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kps = cols >> 6;
+  if (piece >= (long)rows * cols / 8) return;
+  const bf16_t* W = sets.src[blockIdx.y];
+  bf16_t* out = sets.dst[blockIdx.y];
+  const int lane = piece & 63, e = (piece >> 6) & 1;
+  const long blk = piece >> 7;
+  const int kp = blk % kps, nt = blk / kps;
+  const bf16_t* src = W + (long)(16 * nt + (lane & 15)) * cols + 64 * kp + 16 * (lane >> 4) + 8 * e;
+  reinterpret_cast<uint4*>(out)[piece] = *reinterpret_cast<const uint4*>(src);
+}
+
+template <int KT, int MT4, bool TRAIN = false>
 int launch(const St1F& a, hipStream_t st) {
-  BIST_LDS_OPTIN((&st1_fused_kernel<KT, MT4>), MT * 16 * 1024, "bist_st_stage1_fused_fwd", BIST_ELAUNCH);
-  hipLaunchKernelGGL((st1_fused_kernel<KT, MT4>), dim3((unsigned)(a.B * a.cpc)), dim3(512), MT * 16 * 1024, st, a);
+  BIST_LDS_OPTIN((&st1_fused_kernel<KT, MT4, TRAIN>), MT * 16 * 1024, "bist_st_stage1_fused_fwd", BIST_ELAUNCH);
+  hipLaunchKernelGGL((st1_fused_kernel<KT, MT4, TRAIN>), dim3((unsigned)(a.B * a.cpc)), dim3(512), MT * 16 * 1024, st, a);
   BIST_LAUNCH_CHECK("bist_st_stage1_fused_fwd");
-  bist_count_launch(BIST_K_ST1_FUSED);
+  bist_count_launch(TRAIN ? BIST_K_ST1_FUSED_TRAIN : BIST_K_ST1_FUSED);
   return BIST_OK;
 }
 
@@ -461,29 +574,75 @@ extern "C" int bist_pack_frag_rows(const void* W, void* out, int32_t rows, int32
   return BIST_OK;
 }
 
+extern "C" int bist_pack_frag_rows_multi(const void* const* Ws, void* const* outs, int32_t n, int32_t rows, int32_t cols, int32_t dtype, void* stream) {
+  BIST_REQUIRE(Ws && outs && n >= 1 && n <= PACK_MAX && rows > 0 && cols > 0, "bist_pack_frag_rows_multi: 1..%d matrices", PACK_MAX);
+  BIST_REQUIRE(dtype == BIST_BF16 && rows % 16 == 0 && cols % 64 == 0, "bist_pack_frag_rows_multi: bf16 [rows %% 16 == 0][cols %% 64 == 0] only");
+  PackSets k{};
+  for (int i = 0; i < n; ++i) {
+    BIST_REQUIRE(Ws[i] && outs[i] && Ws[i] != outs[i] && ((reinterpret_cast<uintptr_t>(Ws[i]) | reinterpret_cast<uintptr_t>(outs[i])) & 15) == 0,
+                 "bist_pack_frag_rows_multi: matrix %d null, in place or not 16-byte aligned", i);
+    k.src[i] = (const bf16_t*)Ws[i]; k.dst[i] = (bf16_t*)outs[i];
+  }
+  const long pieces = (long)rows * cols / 8;
+  hipLaunchKernelGGL(pack_frag_rows_multi_kernel, dim3((unsigned)((pieces + 255) / 256), (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), k, rows, cols);
+  BIST_LAUNCH_CHECK("bist_pack_frag_rows_multi");
+  return BIST_OK;
+}
+
 extern "C" int bist_st_stage1_fused_ok(int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype) {
   const int K = direction == 0 ? T : S;
   return dtype == BIST_BF16 && d == D && h == H && Lq >= 1 && Lq <= 32 && K >= 1 && K <= 128 && T >= 1 && S >= 1 &&
          (direction == 0 || direction == 1);
 }
 
-extern "C" int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv,
-                                        const void* Wo, const void* bo, const void* xres, void* Y, int32_t B, int32_t T, int32_t S,
-                                        int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream) {
-  BIST_REQUIRE(qf && vft && Wv && bv && Wo && bo && xres && Y && B > 0, "bist_st_stage1_fused_fwd: null pointer or empty batch");
-  BIST_REQUIRE(bist_st_stage1_fused_ok(T, S, Lq, d, h, direction, dtype),
-               "bist_st_stage1_fused_fwd: shape outside the kernel's envelope (bf16, d=512, h=8, Lq<=32, keys<=128)");
-  const void* ptrs[] = {qf, vft, Wv, bv, Wo, bo, xres, Y};
-  for (const void* p : ptrs) BIST_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, "bist_st_stage1_fused_fwd: operands must be 16-byte aligned");
+namespace {
+int fused_common(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv, const void* Wo, const void* bo,
+                 const void* xres, void* Y, int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype,
+                 void* Vout, float* Pout, void* Oout, const BistDrop* attn_drop, const BistDrop* sub_drop, bool train, void* stream) {
+  const char* who = train ? "bist_st_stage1_fused_train_fwd" : "bist_st_stage1_fused_fwd";
+  BIST_REQUIRE(qf && vft && Wv && bv && Wo && bo && xres && Y && B > 0, "%s: null pointer or empty batch", who);
+  BIST_REQUIRE(bist_st_stage1_fused_ok(T, S, Lq, d, h, direction, dtype), "%s: shape outside the kernel's envelope (bf16, d=512, h=8, Lq<=32, keys<=128)", who);
+  const void* ptrs[] = {qf, vft, Wv, bv, Wo, bo, xres, Y, Vout, Pout, Oout};
+  for (const void* p : ptrs) BIST_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, "%s: operands must be 16-byte aligned", who);
   const int K = direction == 0 ? T : S, G = direction == 0 ? S : T;
   const int KT = K <= 32 ? 2 : K <= 64 ? 4 : 8, NG = MT / KT;
   St1F a{(const bf16_t*)qf, (const bf16_t*)vft, kmask, (const bf16_t*)Wv, (const bf16_t*)bv, (const bf16_t*)Wo, (const bf16_t*)bo,
-         (const bf16_t*)xres, (bf16_t*)Y, B, T, S, Lq, direction, (G + NG - 1) / NG, nullptr, 0};
+         (const bf16_t*)xres, (bf16_t*)Y, B, T, S, Lq, direction, (G + NG - 1) / NG, nullptr, 0,
+         (bf16_t*)Vout, Pout, (bf16_t*)Oout, (K + 3) / 4 * 4, make_drop(attn_drop), make_drop(sub_drop)};
   a.stamps = bist_dev_stamps(0);
   a.dbg = bist_dev_dbg(0);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int need = (NG * Lq + 15) / 16;          // 16-row tiles of the output projection
+  if (train) {
+    BIST_REQUIRE(Vout && Pout && Oout, "%s: null side output", who);
+    BIST_REQUIRE(bist_st_stage1_fused_train_ok(T, S, Lq, d, h, direction, dtype), "%s: the staging tiles of the value rows need NG * Lq <= 96 context rows", who);
+    BIST_REQUIRE((!attn_drop || (attn_drop->p >= 0.f && attn_drop->p < 1.f)) && (!sub_drop || (sub_drop->p >= 0.f && sub_drop->p < 1.f)), "%s: drop p out of range", who);
+    if (KT == 2) return need <= 5 ? launch<2, 5, true>(a, st) : launch<2, 8, true>(a, st);
+    if (KT == 4) return need <= 3 ? launch<4, 3, true>(a, st) : launch<4, 4, true>(a, st);
+    return launch<8, 2, true>(a, st);
+  }
   if (KT == 2) return need <= 5 ? launch<2, 5>(a, st) : launch<2, 8>(a, st);
   if (KT == 4) return need <= 3 ? launch<4, 3>(a, st) : launch<4, 4>(a, st);
   return launch<8, 2>(a, st);
+}
+}  // namespace
+
+extern "C" int bist_st_stage1_fused_train_ok(int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype) {
+  if (!bist_st_stage1_fused_ok(T, S, Lq, d, h, direction, dtype)) return 0;
+  const int K = direction == 0 ? T : S;
+  const int KT = K <= 32 ? 2 : K <= 64 ? 4 : 8, NG = MT / KT;
+  return NG * Lq <= 96;
+}
+
+extern "C" int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv,
+                                        const void* Wo, const void* bo, const void* xres, void* Y, int32_t B, int32_t T, int32_t S,
+                                        int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream) {
+  return fused_common(qf, vft, kmask, Wv, bv, Wo, bo, xres, Y, B, T, S, Lq, d, h, direction, dtype, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
+}
+
+extern "C" int bist_st_stage1_fused_train_fwd(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv,
+                                              const void* Wo, const void* bo, const void* xres, void* Y, void* Vout, float* Pout, void* Oout,
+                                              const BistDrop* attn_drop, const BistDrop* sub_drop, int32_t B, int32_t T, int32_t S,
+                                              int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream) {
+  return fused_common(qf, vft, kmask, Wv, bv, Wo, bo, xres, Y, B, T, S, Lq, d, h, direction, dtype, Vout, Pout, Oout, attn_drop, sub_drop, true, stream);
 }

@@ -108,6 +108,16 @@ def st_stage1_pv(scores, v, tmask, *, B, T, S, Lq, h, dk, direction, drop=None):
     return ops.st_stage1_pv(scores, v, tmask, B=B, T=T, S=S, Lq=Lq, h=h, dk=dk, direction=direction, drop=drop)
 
 
+FUSED_TRAIN = os.environ.get("BIST_FUSED_TRAIN", "1") != "0"      # tuning aid: 0 = the training forward of stage 1 as four launches (value / score products, core, output projection)
+
+
+def st_stage1_fused_train(qf, x, vft_a, vft_b, tmask, attn, frag, *, h, direction, attn_drop=None, sub_drop=None):
+    """Training stage 1 of one direction as one launch forward (autograd.St1FusedTrainFn); attn: the MultiHeadedAttention holding
+    linears[2] (values) and linears[3] (output); frag = (W_v, W_o) in fragment order."""
+    return ag.St1FusedTrainFn.apply(qf, x, vft_a, vft_b, tmask, attn.linears[2].weight, attn.linears[2].bias, attn.linears[3].weight,
+                                    attn.linears[3].bias, frag[0], frag[1], (h, direction, attn_drop, sub_drop))
+
+
 def st_stage2(q2f, y, gmask, *, h, drop=None):
     """(PY, rowsum or None); rowsum only under dropout -- scale the value bias with it (scaled_bias)."""
     if _grad():

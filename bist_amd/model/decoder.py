@@ -320,11 +320,30 @@ class MultimodalDecoder8(nn.Module):
         cache = [] if use_cache else None
         q = ft["encoded_query"]
         in_ft = {"t2s": q, "s2t": q, "audio": q, "cap": q}
+        fused_train = False
         if self.v_N > 0 and "spatiotemporal_ft" in ft:
             # training: the video tensor feeds 4 products per reasoning layer (2 score products, 2 value projections); their [B*T*S, d] gradients are summed in one pass
             L = len(self.layers)
             both = getattr(self.args, "t2s", 1) and getattr(self.args, "s2t", 1)
-            if (torch.is_grad_enabled() and both and Fn.PERMUTED_T2S and ft["spatiotemporal_ft"].requires_grad
+            vft_ = ft["spatiotemporal_ft"]
+            a0 = self.v_layers[0].attn[0]
+            fused_train = bool(torch.is_grad_enabled() and both and Fn.FUSED_TRAIN and not Z.ENABLED and vft_.is_cuda and vft_.dim() == 4 and vft_.is_contiguous()
+                               and q.dtype == vft_.dtype and len(self.v_layers[0].attn) == 6
+                               and all(ops.st_stage1_fused_train_ok(vft_.shape[1], vft_.shape[2], q.shape[1], vft_.shape[3], a0.h, dr, vft_.dtype) for dr in (0, 1)))
+            if fused_train:
+                # stage 1 of both directions as ONE launch each (csrc/st1_fused.hip, training form): no value projections of their own, no
+                # score tensors, no region-major copy.  Per layer the video tensor has four readers (per direction: the fused launch's
+                # rows and the value projection's weight-gradient / dX products of its backward).  The value / output projection weights
+                # of all layers go to fragment order in ONE launch, into buffers that keep their addresses (hipGraph replays re-run it).
+                ft["_bist_fused_train"] = True
+                ft["_bist_vft_fan"] = Fn.Fan(vft_, 4 * L)
+                ws, outs = [], []
+                for vl in self.v_layers[:L]:
+                    for ai in (1, 4):
+                        ws += [vl.attn[ai].linears[2].weight.detach(), vl.attn[ai].linears[3].weight.detach()]
+                        outs += vl.frag_train(ai)
+                ops.pack_frag_rows_multi(ws, outs)
+            elif (torch.is_grad_enabled() and both and Fn.PERMUTED_T2S and ft["spatiotemporal_ft"].requires_grad
                     and ft["spatiotemporal_ft"].shape[1] >= 64):      # from 64 frames: 21.9 vs 22.3 ms at T = 128; 11.8 vs 11.7 ms at T = 32
                 # t2s works on a region-major copy of the video tensor (made once, shared by all layers): contiguous score
                 # runs and value tiles in its stage-1 core instead of 16-byte pieces (Fn.permute_ts)
@@ -341,7 +360,7 @@ class MultimodalDecoder8(nn.Module):
         # Training: the value projections of layer l+1 (two big GEMMs that depend on the video tensor only) are issued on the
         # caption stream ahead of decoder layer l, and awaited through an event just before the stage-1 cores; their
         # backward products then run on that stream under the small-kernel chains of the two directions.
-        values_ahead = (torch.is_grad_enabled() and self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda and Fn.VALUES_AHEAD
+        values_ahead = (torch.is_grad_enabled() and not fused_train and self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda and Fn.VALUES_AHEAD
                         and getattr(self.args, "t2s", 1) and getattr(self.args, "s2t", 1) and "_bist_vft_fan" in ft)
 
         def issue_values(l):
@@ -414,6 +433,7 @@ class MultimodalDecoder8(nn.Module):
             x = self._decode_fused(b, ft, x)
             ft["_bist_fused_first"] = True       # (decode.py: position 0 of the turn is in the kernel's pools)
         ft.pop("_bist_vft_fan", None)
+        ft.pop("_bist_fused_train", None)
         ft.pop("_bist_qmask2", None)
         ft.pop("_bist_vftp_fan", None)
         ft.pop("_bist_mem_fan", None)

@@ -138,8 +138,21 @@ class VidEncoderLayer4(nn.Module):
                                       "(decoder.py:123-124 overwrites the video tensor)" % args.enc_st_combine)
 
     # -- stage 1 ------------------------------------------------------------------------------
+    def frag_train(self, ai: int):
+        """(W_v, W_o) of attention `ai` in MFMA-fragment order for the TRAINING launches: persistent buffers (captured hipGraphs hold
+        their addresses) that the layer loop refreshes once per forward pass, all layers in one launch (decoder.py)."""
+        bufs = self.__dict__.setdefault("_frag_train", {})
+        out = []
+        for j in (2, 3):
+            w = self.attn[ai].linears[j].weight
+            b_ = bufs.get((ai, j))
+            if b_ is None or b_.device != w.device or b_.dtype != w.dtype or b_.shape != w.shape:
+                b_ = bufs[(ai, j)] = torch.empty(w.shape, device=w.device, dtype=w.dtype)
+            out.append(b_)
+        return out
+
     def _stage1(self, ai: int, si: int, x: Tensor, vft: Tensor, v: Tensor, tmask: Optional[Tensor], direction: int,
-                permuted: bool = False) -> Tensor:
+                permuted: bool = False, train_fused: Optional[Tensor] = None) -> Tensor:
         """A1 (direction 0, encoder.py:110-123) / A4 (direction 1, encoder.py:142-150) -> [B,G,Lq,d].
         permuted (t2s only): vft and v are region-major [B,S,T,*] (Fn.permute_ts): the step is then the s2t form with the two
         axes exchanged plus the frame mask -- contiguous score runs and value tiles instead of 16-byte pieces."""
@@ -151,6 +164,11 @@ class VidEncoderLayer4(nn.Module):
         xn, xr = sub.norm.with_residual(x, lazy=True)
         q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)                           # [B*Lq, d]
         qf = Fn.head_fold(q, attn.linears[1].weight, h, 1.0 / math.sqrt(dk)).view(B, Lq * h, d)   # rows (i, hh)
+        if train_fused is not None:      # training: the same single launch, with the dropouts and the side outputs the backward pass reads
+            adrop = Fn.attn_drop(attn)            # (seeds drawn in the order of the unfused path: probabilities, then sublayer output)
+            kw = Fn.drop_args(sub)
+            return Fn.st_stage1_fused_train(qf, xr, vft, train_fused, tmask, attn, self.frag_train(ai), h=h, direction=direction,
+                                            attn_drop=adrop, sub_drop=(kw["drop_p"], kw["drop_seed"]) if kw else None)
         if v is None:           # inference: value projection, scores, softmax, P.V, output projection and residual in one launch
             wv, wo = self._frag_weights(ai)
             return ops.st_stage1_fused(qf, vft, tmask, wv, attn.linears[2].bias, wo, attn.linears[3].bias, x, h=h, direction=direction)
@@ -393,7 +411,8 @@ class VidEncoderLayer4(nn.Module):
         def branch_v(ai):
             return self.train_value(take_t2s() if ai == 1 else take(), ai)
 
-        per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V and "_bist_v_pre" not in ft
+        train_fused = bool(ft.get("_bist_fused_train")) and torch.is_grad_enabled() and t2s_on and s2t_on
+        per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V and "_bist_v_pre" not in ft and not train_fused
         v_t2s = v_s2t = None
         pre = ft.pop("_bist_v_pre", None)                  # (v_t2s, v_s2t, event): projected ahead by the layer loop (decoder.py)
         self._v_event = None
@@ -403,7 +422,7 @@ class VidEncoderLayer4(nn.Module):
         fused = (Fn.FUSED_ST1 and not torch.is_grad_enabled() and vft.is_cuda and pre is None
                  and all(ops.st_stage1_fused_ok(T_, S_, x0.shape[1], d_, self.attn[0].h, dr, vft.dtype)
                          for dr, on in ((0, t2s_on), (1, s2t_on)) if on))
-        if fused:
+        if fused or train_fused:
             pass
         elif pre is not None:
             v_t2s, v_s2t, ev = pre
@@ -435,7 +454,7 @@ class VidEncoderLayer4(nn.Module):
         def t2s_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
             y = self._stage1(ai + 1, si + 1, x, vft_t2s, branch_v(ai + 1) if per_branch_v else v_t2s, b.temporal_mask, 0,
-                             permuted=permuted)                                                  # A1
+                             permuted=permuted, train_fused=take() if train_fused else None)     # A1
             z = self._stage2(ai + 2, si + 2, x, y, None)                                          # A2
             in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
             if trace is not None:
@@ -443,7 +462,8 @@ class VidEncoderLayer4(nn.Module):
 
         def s2t_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
-            y = self._stage1(ai + 1, si + 1, x, vft_s2t, branch_v(ai + 1) if per_branch_v else v_s2t, None, 1)              # A4
+            y = self._stage1(ai + 1, si + 1, x, vft_s2t, branch_v(ai + 1) if per_branch_v else v_s2t, None, 1,
+                             train_fused=take() if train_fused else None)                        # A4
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
             if trace is not None:

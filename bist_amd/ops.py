@@ -400,6 +400,50 @@ def pack_frag_rows(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def pack_frag_rows_multi(ws: Sequence[Tensor], outs: Sequence[Tensor]) -> None:
+    """pack_frag_rows of up to 32 same-sized weights in one launch (bist_pack_frag_rows_multi); outs keep their addresses."""
+    _dev(*ws, *outs)
+    n = len(ws)
+    for w, o in zip(ws, outs):
+        if w.shape != ws[0].shape or o.shape != w.shape or not w.is_contiguous() or not o.is_contiguous() or w.dtype != ws[0].dtype or o.dtype != w.dtype:
+            raise ValueError("bist_amd.pack_frag_rows_multi: contiguous matrices of one shape and dtype")
+    for o0 in range(0, n, 32):
+        part_w, part_o = ws[o0:o0 + 32], outs[o0:o0 + 32]
+        a = (C.c_void_p * len(part_w))(*[w.data_ptr() for w in part_w])
+        b = (C.c_void_p * len(part_w))(*[o.data_ptr() for o in part_o])
+        check(lib.bist_pack_frag_rows_multi(a, b, len(part_w), ws[0].shape[0], ws[0].shape[1], dtype_code(ws[0].dtype), _stream()),
+              "bist_pack_frag_rows_multi")
+
+
+def st_stage1_fused_train_ok(T: int, S: int, Lq: int, d: int, h: int, direction: int, dtype: torch.dtype) -> bool:
+    return dtype in _DT and bool(lib.bist_st_stage1_fused_train_ok(T, S, Lq, d, h, direction, _DT[dtype]))
+
+
+def st_stage1_fused_train(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: Tensor, bv: Tensor, wo: Tensor, bo: Tensor, xres: Tensor, *,
+                          h: int, direction: int, attn_drop=None, sub_drop=None):
+    """Stage 1 of one direction in one launch, TRAINING form (bist_st_stage1_fused_train_fwd): -> (Y [B,G,Lq,d], V [B,T,S,d],
+    P [B,G,h,Lq,KP] f32 probabilities before dropout, O [B,G,Lq,d] context rows); wv / wo in fragment order; kmask uint8 [B,K] or None."""
+    _dev(qf, vft, kmask, wv, bv, wo, bo, xres)
+    B, T, S, d = vft.shape
+    Lq = xres.shape[1]
+    G, K = (S, T) if direction == 0 else (T, S)
+    for t_ in (qf, vft, wv, bv, wo, bo, xres):
+        if not t_.is_contiguous() or t_.dtype != vft.dtype:
+            raise ValueError("bist_amd.st_stage1_fused_train: operands must be contiguous and of one dtype")
+    if qf.numel() != B * Lq * h * d or wv.shape != (d, d) or wo.shape != (d, d) or xres.shape != (B, Lq, d):
+        raise ValueError("bist_amd.st_stage1_fused_train: operand shapes do not match [B,T,S,d] / Lq / h")
+    KP = (K + 3) // 4 * 4
+    y = torch.empty((B, G, Lq, d), device=vft.device, dtype=vft.dtype)
+    v = torch.empty((B, T, S, d), device=vft.device, dtype=vft.dtype)
+    p = torch.empty((B, G, h, Lq, KP), device=vft.device, dtype=torch.float32)
+    o = torch.empty((B, G, Lq, d), device=vft.device, dtype=vft.dtype)
+    check(lib.bist_st_stage1_fused_train_fwd(qf.data_ptr(), vft.data_ptr(), _ptr(kmask), wv.data_ptr(), bv.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                                             xres.data_ptr(), y.data_ptr(), v.data_ptr(), p.data_ptr(), o.data_ptr(), drop_ref(attn_drop),
+                                             drop_ref(sub_drop), B, T, S, Lq, d, h, direction, dtype_code(vft.dtype), _stream()),
+          "bist_st_stage1_fused_train_fwd")
+    return y, v, p, o
+
+
 def st_stage1_fused(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: Tensor, bv: Tensor, wo: Tensor, bo: Tensor,
                     xres: Tensor, *, h: int, direction: int, out: Optional[Tensor] = None) -> Tensor:
     """Stage 1 of one direction in one launch (inference form): qf [B, Lq*h, d] folded query, vft [B,T,S,d], kmask [B,K] or

@@ -56,7 +56,9 @@ int bist_device_ok(void);
 #define BIST_K_MHA_BWD_VALU 8
 #define BIST_K_ST1_FUSED 9      /* bist_st_stage1_fused_fwd                                                  */
 #define BIST_K_DECSTACK 10      /* bist_decoder_stack_fwd (persistent decoder-stack kernel)                   */
-#define BIST_K_COUNT 11
+#define BIST_K_ST1_FUSED_TRAIN 11   /* bist_st_stage1_fused_train_fwd                                        */
+#define BIST_K_ST1_PBWD 12      /* bist_st_stage1_pv_bwd_p (backward core fed with the saved probabilities)  */
+#define BIST_K_COUNT 13
 int64_t bist_launch_count(int32_t family);
 void bist_launch_count_reset(void);
 /* Development hook: hand the fused stage-1 kernel (which = 0) or the persistent decoder kernel (which = 1) a caller-owned DEVICE
@@ -240,10 +242,28 @@ int bist_st_stage1_pv_fwd(const void* scores, const void* V, const uint8_t* tmas
  * [rows/16][cols/64][2][64][8]: the 16 bytes lane (x, kg) feeds a v_mfma_f32_16x16x32_bf16 for row tile nt, k-step pair kp, parity
  * e are W[16*nt + x][64*kp + 16*kg + 8*e .. +7], and one wave load of a block reads 1 KiB contiguously.                       */
 int bist_pack_frag_rows(const void* W, void* out, int32_t rows, int32_t cols, int32_t dtype, void* stream);
+/* n <= 32 matrices of one size in ONE launch (host arrays of device pointers): a training step re-packs the value / output projection
+ * weights of every reasoning layer after the optimiser moved them.                                                             */
+int bist_pack_frag_rows_multi(const void* const* Ws, void* const* outs, int32_t n, int32_t rows, int32_t cols, int32_t dtype, void* stream);
 int bist_st_stage1_fused_ok(int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype);
 int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv,
                              const void* Wo, const void* bo, const void* xres, void* Y, int32_t B, int32_t T, int32_t S,
                              int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream);
+/* The TRAINING form of the same launch: the sublayer's two dropouts are applied in the kernel -- attn_drop on the probabilities
+ * (modules.py:62-63; mask index ((((b*G + g)*h + hh)*Lq + i)*K + key, as bist_st_stage1_pv_fwd; the value bias is then scaled by the
+ * kept probabilities' row sum) and sub_drop on W_o ctx + b_o before the residual (modules.py:44; mask index (row of Y)*d + column,
+ * as bist_gemm's epilogue) -- and what the backward pass needs leaves as side outputs:
+ *   Vout [B,T,S,d]        V = X W_v^T + b_v (the operand of bist_st_stage1_pv_bwd_p and of the value projection's weight gradient),
+ *   Pout [B,G,h,Lq,KP]    f32 probabilities BEFORE dropout, KP = K rounded up to a multiple of 4 (padding zero),
+ *   Oout [B,G,Lq,d]       the head-concatenated context (the output projection's input).
+ * Against the unfused training forward (value GEMM, score GEMM, softmax + P.V core, output projection: four launches, fp32 scores
+ * written and re-read) this is one launch and no score tensor.  bist_st_stage1_fused_train_ok: the envelope of the inference form
+ * and at most 96 context rows per workgroup (groups per workgroup x Lq; Lq <= 24 at <= 32 keys).                              */
+int bist_st_stage1_fused_train_ok(int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype);
+int bist_st_stage1_fused_train_fwd(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv,
+                                   const void* Wo, const void* bo, const void* xres, void* Y, void* Vout, float* Pout, void* Oout,
+                                   const BistDrop* attn_drop, const BistDrop* sub_drop, int32_t B, int32_t T, int32_t S,
+                                   int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The response-decoder stack of one beam-search step as ONE persistent launch (inference; bf16, d = 512, h = 8, R <= 64 rows).
@@ -445,6 +465,11 @@ int bist_mha_core_bwd(const void* Q, const void* K, const void* V, const uint8_t
                       int64_t mask_bs, int64_t mask_qs, float scale, const BistDrop* drop, int32_t dtype, void* stream);
 /* dscores ([B,Lq*h,T*S] in dscores_dtype: BIST_F32, or BIST_BF16 when the score products' backward takes bf16 operands --
  * saves the f32 -> bf16 pass over 4*B*Lq*h*T*S bytes) and dV ([B,T,S,*], row stride lddv) of bist_st_stage1_pv_fwd.        */
+/* The same backward fed with the probabilities the fused training forward saved (P [B,G,h,Lq,KP] f32, before dropout) instead of the
+ * raw scores: no score gather, no softmax recompute.  bf16, matrix-core kernel only (dk = 64, Lq <= 32, keys <= 128).            */
+int bist_st_stage1_pv_bwd_p(const float* P, int32_t KP, const void* V, const uint8_t* tmask, const void* dO, void* dscores,
+                            int32_t dscores_dtype, void* dV, int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk,
+                            int64_t ldv, int64_t lddv, int32_t direction, const BistDrop* drop, int32_t dtype, void* stream);
 int bist_st_stage1_pv_bwd(const float* scores, const void* V, const uint8_t* tmask, const void* dO, void* dscores, int32_t dscores_dtype, void* dV,
                           int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t h, int32_t dk, int64_t ldv, int64_t lddv,
                           int32_t direction, const BistDrop* drop, int32_t dtype, void* stream);

@@ -112,7 +112,8 @@ def test_inference_path_matches_oracle(prod):
 
 def test_training_path_matches_oracle_forward_losses_and_gradients(prod):
     """Autograd on (eval mode: dropout off, as in the oracle): the forward goes through the kernels the bench's training step runs
-    (separate stage-1 launches with st1_mfma, st2_mfma), the backward through st1/st2 backward and mha_bwd_mfma."""
+    (stage 1 as the fused training launch bist_st_stage1_fused_train_fwd, st2_mfma), the backward through bist_st_stage1_pv_bwd_p, the
+    stage-2 backward and mha_bwd_mfma."""
     from bist_amd import _lib
     from bist_amd.model.label_smoothing import LabelSmoothing
     from bist_amd.model.optimize import SimpleLossCompute
@@ -127,8 +128,11 @@ def test_training_path_matches_oracle_forward_losses_and_gradients(prod):
     total.backward()
     torch.cuda.synchronize()
     c = _counts()
-    assert c["K_ST1_MFMA_FWD"] == 4 and c["K_ST1_MFMA_BWD"] == 4 and c["K_ST2_MFMA_FWD"] == 4 and c["K_ST2_MFMA_BWD"] == 4, c
-    assert c["K_MHA_BWD_MFMA"] > 0 and c["K_ST1_VALU"] == 0 and c["K_ST2_VALU"] == 0 and c["K_MHA_BWD_VALU"] == 0 and c["K_ST1_FUSED"] == 0, c
+    # stage 1: forward = the fused TRAINING launch (one per direction and layer), backward = the matrix-core core fed with its saved
+    # probabilities; stage 2 and the small attentions on their matrix-core kernels; never the fp32 VALU fallbacks
+    assert c["K_ST1_FUSED_TRAIN"] == 4 and c["K_ST1_PBWD"] == 4 and c["K_ST2_MFMA_FWD"] == 4 and c["K_ST2_MFMA_BWD"] == 4, c
+    assert c["K_ST1_MFMA_FWD"] == 0 and c["K_ST1_MFMA_BWD"] == 0 and c["K_ST1_FUSED"] == 0, c
+    assert c["K_MHA_BWD_MFMA"] > 0 and c["K_ST1_VALU"] == 0 and c["K_ST2_VALU"] == 0 and c["K_MHA_BWD_VALU"] == 0, c
     _check_forward({k: v for k, v in ft.items()}, logp, p, f"training forward T={p['T']}")
     for name, val in terms.items():
         ref = p["losses"][name]
