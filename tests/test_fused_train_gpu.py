@@ -80,7 +80,7 @@ def test_fused_training_forward_matches_the_unfused_kernels(direction, T, S, Lq,
     assert (y.float() - y_ref.float()).abs().max().item() <= 1.2e-1, "outputs (the sublayer dropout masks of the two paths must coincide)"
     if drop:      # the masks really dropped something, and identically: zeros of drop(W_o ctx + b_o) sit at the same places
         za, zb = (y.float() - x.float().view(B, 1, Lq, d)) == 0, (y_ref.float() - x.float().view(B, 1, Lq, d)) == 0
-        assert 0.05 < za.float().mean().item() < 0.15 and (za == zb).float().mean().item() > 0.999
+        assert 0.05 < za.float().mean().item() < 0.15 and (za == zb).float().mean().item() > 0.99      # (bf16: x + tiny rounds to x in either path)
 
 
 @pytest.mark.parametrize("direction,T,S", [(0, 32, 49), (1, 32, 49), (0, 128, 9)])
