@@ -709,14 +709,15 @@ class St1FusedTrainFn(Function):
     vft_a / vft_b: two aliases of the video tensor (its gradient through the scores and through the value projection)."""
 
     @staticmethod
-    def forward(ctx, qf, x, vft_a, vft_b, tmask, wv, bv, wo, bo, wv_frag, wo_frag, cfg):
+    def forward(ctx, qf, x, vft_a, vft_b, v_in, tmask, wv, bv, wo, bo, wv_frag, wo_frag, cfg):
         h, direction, adrop, sdrop = cfg
         B, T, S, d = vft_a.shape
         K = T if direction == 0 else S
         m8 = _mask_u8(tmask.reshape(B, K)) if tmask is not None else None
         y, v, p, o = ops.st_stage1_fused_train(qf.reshape(B, -1, d), vft_a, m8, wv_frag, bv, wo_frag, bo, x, h=h, direction=direction,
-                                               attn_drop=adrop, sub_drop=sdrop)
-        ctx.save_for_backward(qf, vft_a, v, p, o, m8, wv, wo)
+                                               attn_drop=adrop, sub_drop=sdrop, want_v=v_in is None)
+        ctx.own_v = v_in is None
+        ctx.save_for_backward(qf, vft_a, v if v_in is None else v_in, p, o, m8, wv, wo)
         ctx.cfg = (cfg, tuple(x.shape), bv.dtype, tuple(qf.shape))
         ctx.w_dst = (getattr(wv, "_grad_view", None), getattr(wo, "_grad_view", None))
         ctx.b_dst = (getattr(bv, "_acc32", None), getattr(bo, "_acc32", None))
@@ -742,11 +743,11 @@ class St1FusedTrainFn(Function):
             dz = torch.empty_like(dy)
             check(lib.bist_epilogue_bwd(dy.data_ptr(), dy.data_ptr(), dz.data_ptr(), M, d, d, d, d, ACT_NONE, sdrop[0], sdrop[1] & 0xFFFFFFFFFFFFFFFF,
                                         _ptr(ops.DROP_CTR), dtype_code(dt), _stream()), "bist_epilogue_bwd")
-        do, dwo, dbo = _linear_grads(o.view(M, d), wo, dz, 1.0, ctx.w_dst[1], ctx.b_dst[1], bdt, True, ctx.needs_input_grad[7], ctx.needs_input_grad[8])
+        do, dwo, dbo = _linear_grads(o.view(M, d), wo, dz, 1.0, ctx.w_dst[1], ctx.b_dst[1], bdt, True, ctx.needs_input_grad[8], ctx.needs_input_grad[9])
         dsc = torch.empty((B, R, TS), device=dev, dtype=dt)
         dv = torch.empty((B, T, S, d), device=dev, dtype=dt)
         check(lib.bist_st_stage1_pv_bwd_p(p.data_ptr(), p.shape[-1], v.data_ptr(), _ptr(m8), do.data_ptr(), dsc.data_ptr(), dtype_code(dt), dv.data_ptr(),
-                                          B, T, S, Lq, h, dk, d, d, direction, ops.drop_ref(adrop), dtype_code(dt), _stream()), "bist_st_stage1_pv_bwd_p")
+                                          B, T, S, Lq, h, dk, v.stride(-2), d, direction, ops.drop_ref(adrop), dtype_code(dt), _stream()), "bist_st_stage1_pv_bwd_p")
         q3, vf = qf.reshape(B, R, d), vft.reshape(B, TS, d)
         dqf = torch.empty((B, R, d), device=dev, dtype=dt)
         ops.gemm(dsc, vf, dqf, M=R, N=d, K=TS, a_rs=TS, a_ks=1, b_rs=1, b_ks=vf.stride(1), ldc=d, batch=(B, 1),
@@ -754,9 +755,11 @@ class St1FusedTrainFn(Function):
         dvft_a = torch.empty((B, TS, d), device=dev, dtype=dt)
         ops.gemm(dsc, q3, dvft_a, M=TS, N=d, K=R, a_rs=1, a_ks=TS, b_rs=1, b_ks=q3.stride(1), ldc=d, batch=(B, 1),
                  a_bs=(R * TS, 0), b_bs=(q3.stride(0), 0), c_bs=(TS * d, 0))
+        if not ctx.own_v:            # the value projection is a product of its own (another stream): its backward takes dV from here
+            return (dqf.view(qf_shape), dres.view(x_shape), dvft_a.view(vft.shape), None, dv, None, None, None, dwo, dbo, None, None, None)
         dvft_b, dwv, dbv = _linear_grads(vft.view(B * TS, d), wv, dv.view(B * TS, d), 1.0, ctx.w_dst[0], ctx.b_dst[0], bdt, True,
-                                         ctx.needs_input_grad[5], ctx.needs_input_grad[6])
-        return (dqf.view(qf_shape), dres.view(x_shape), dvft_a.view(vft.shape), dvft_b.view(vft.shape), None, dwv, dbv, dwo, dbo, None, None, None)
+                                         ctx.needs_input_grad[6], ctx.needs_input_grad[7])
+        return (dqf.view(qf_shape), dres.view(x_shape), dvft_a.view(vft.shape), dvft_b.view(vft.shape), None, None, dwv, dbv, dwo, dbo, None, None, None)
 
 
 class StStage2Fn(Function):

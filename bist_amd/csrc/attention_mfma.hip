@@ -167,31 +167,34 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
   const float dks = a.drop.p > 0.f ? a.drop.keep_scale() : 1.f;
   {
     constexpr int PER = (KPAD + 3) / 4;              // keys per lane (k = part, part+4, ...)
-    const int rows = (a.dbg & 2) ? 0 : Lq * gc;
+    if (a.p_kp > 0) {
+      // the probabilities themselves (before dropout), saved by the fused training forward as [B, G, h, Lq, p_kp] f32: the [Lq][p_kp]
+      // block of a (group, head) is contiguous -- 16 bytes per lane, straight into the slab and (with the dropout mask) the bf16 image
+      const int kp4 = a.p_kp >> 2;
+      for (int e = tid; e < gc * Lq * kp4; e += 256) {
+        const int gl = e / (Lq * kp4), rem = e - gl * (Lq * kp4), i = rem / kp4, k0 = (rem - i * kp4) * 4;
+        const float4 q4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.scores) +
+                                                            ((((long)b * G + (g0 + gl)) * h + hh) * Lq + i) * a.p_kp + k0);
+        const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
+        float* p = slab + ((long)i * gc + gl) * KP;
+        bf16_t* pi = pimg + ((long)gl * 32 + i) * KPAD;
+        const unsigned long long dbase = ((((unsigned long long)b * G + (g0 + gl)) * h + hh) * Lq + i) * Kn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + j;
+          if (k < Kn) {
+            p[k] = qv[j];
+            pi[k] = (bf16_t)(a.drop.p > 0.f ? qv[j] * drop_mul(dkey, dbase + k, a.drop.p, dks) : qv[j]);
+          }
+        }
+      }
+    }
+    const int rows = ((a.dbg & 2) || a.p_kp > 0) ? 0 : Lq * gc;
     for (int r0 = 0; r0 < rows; r0 += 64) {
       const int r = r0 + (tid >> 2), part = tid & 3;
       const bool act = r < rows;
       float* p = slab + (long)(act ? r : 0) * KP;
       float v[PER];
-      if (a.p_kp > 0) {
-        // the probabilities themselves: row (b, g, hh, i) of the saved tensor, keys part, part + 4, ... of this lane
-        if (act) {
-          const int i = r / gc, gl = r - i * gc;
-          const float* src = reinterpret_cast<const float*>(a.scores) + ((((long)b * G + (g0 + gl)) * h + hh) * Lq + i) * a.p_kp;
-          bf16_t* pi = pimg + ((long)gl * 32 + i) * KPAD;
-          const unsigned long long dbase = ((((unsigned long long)b * G + (g0 + gl)) * h + hh) * Lq + i) * Kn;
-#pragma unroll
-          for (int u = 0; u < PER; ++u) {
-            const int k = part + 4 * u;
-            if (k < Kn) {
-              const float q = src[k];
-              p[k] = q;
-              pi[k] = (bf16_t)(a.drop.p > 0.f ? q * drop_mul(dkey, dbase + k, a.drop.p, dks) : q);
-            }
-          }
-        }
-        continue;
-      }
       float mx = -INFINITY;
 #pragma unroll
       for (int u = 0; u < PER; ++u) {

@@ -334,8 +334,8 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
   __syncthreads();          // every wave is done with the X image: it becomes the context image
   STAMP(4);
 
-  if constexpr (TRAIN) {
-    // V side output.  vpk holds V (without its bias) as packed bf16 in MFMA-fragment order -- lane (x, kg): channel 16 nt + x of keys
+  if (TRAIN && a.Vout != nullptr) {
+    // V side output (skipped when the caller keeps a value projection of its own).  vpk holds V (without its bias) as packed bf16 in MFMA-fragment order -- lane (x, kg): channel 16 nt + x of keys
     // 16 mt + 4 kg + r.  Each wave turns its [32 keys][64 channels] pieces into 128-byte rows through a 4 KiB staging tile of its own in
     // the part of the dead X image that the context rows (NGA * Lq <= 96 rows) do not use, and stores them 16 bytes per lane.
     char* stg = smem + 96 * 1024 + w * 4096;
@@ -614,7 +614,7 @@ int fused_common(const void* qf, const void* vft, const uint8_t* kmask, const vo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int need = (NG * Lq + 15) / 16;          // 16-row tiles of the output projection
   if (train) {
-    BIST_REQUIRE(Vout && Pout && Oout, "%s: null side output", who);
+    BIST_REQUIRE(Pout && Oout, "%s: null side output", who);
     BIST_REQUIRE(bist_st_stage1_fused_train_ok(T, S, Lq, d, h, direction, dtype), "%s: the staging tiles of the value rows need NG * Lq <= 96 context rows", who);
     BIST_REQUIRE((!attn_drop || (attn_drop->p >= 0.f && attn_drop->p < 1.f)) && (!sub_drop || (sub_drop->p >= 0.f && sub_drop->p < 1.f)), "%s: drop p out of range", who);
     if (KT == 2) return need <= 5 ? launch<2, 5, true>(a, st) : launch<2, 8, true>(a, st);

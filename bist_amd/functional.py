@@ -111,10 +111,18 @@ def st_stage1_pv(scores, v, tmask, *, B, T, S, Lq, h, dk, direction, drop=None):
 FUSED_TRAIN = os.environ.get("BIST_FUSED_TRAIN", "1") != "0"      # tuning aid: 0 = the training forward of stage 1 as four launches (value / score products, core, output projection)
 
 
-def st_stage1_fused_train(qf, x, vft_a, vft_b, tmask, attn, frag, *, h, direction, attn_drop=None, sub_drop=None):
+# The fused training launch with the value projection kept as a product of its OWN (0, default) or computed and saved by the launch (1).
+# Measured at BASELINE configs[1] (round 3): with the launch's own values the value projection's two backward products move from a side
+# stream onto each direction's critical chain, and the step is SLOWER than the four-launch form (13.0 vs 11.8 ms) although 1.5 ms of
+# kernel time are gone; kept off the chains the fused launch only shortens them.
+FUSED_TRAIN_OWN_V = os.environ.get("BIST_FUSED_TRAIN_OWN_V", "0") != "0"
+
+
+def st_stage1_fused_train(qf, x, vft_a, vft_b, tmask, attn, frag, *, h, direction, attn_drop=None, sub_drop=None, v=None):
     """Training stage 1 of one direction as one launch forward (autograd.St1FusedTrainFn); attn: the MultiHeadedAttention holding
-    linears[2] (values) and linears[3] (output); frag = (W_v, W_o) in fragment order."""
-    return ag.St1FusedTrainFn.apply(qf, x, vft_a, vft_b, tmask, attn.linears[2].weight, attn.linears[2].bias, attn.linears[3].weight,
+    linears[2] (values) and linears[3] (output); frag = (W_v, W_o) in fragment order; v: the value projection when the caller runs it
+    as a product of its own (vft_b is then unused)."""
+    return ag.St1FusedTrainFn.apply(qf, x, vft_a, vft_b, v, tmask, attn.linears[2].weight, attn.linears[2].bias, attn.linears[3].weight,
                                     attn.linears[3].bias, frag[0], frag[1], (h, direction, attn_drop, sub_drop))
 
 

@@ -167,8 +167,14 @@ class VidEncoderLayer4(nn.Module):
         if train_fused is not None:      # training: the same single launch, with the dropouts and the side outputs the backward pass reads
             adrop = Fn.attn_drop(attn)            # (seeds drawn in the order of the unfused path: probabilities, then sublayer output)
             kw = Fn.drop_args(sub)
-            return Fn.st_stage1_fused_train(qf, xr, vft, train_fused, tmask, attn, self.frag_train(ai), h=h, direction=direction,
-                                            attn_drop=adrop, sub_drop=(kw["drop_p"], kw["drop_seed"]) if kw else None)
+            v_ready = self.__dict__.get("_v_ready")
+            if v is not None and v_ready is not None:
+                torch.cuda.current_stream().wait_stream(v_ready)
+            v_event = self.__dict__.get("_v_event")
+            if v is not None and v_event is not None:
+                torch.cuda.current_stream().wait_event(v_event)
+            return Fn.st_stage1_fused_train(qf, xr, vft, train_fused if v is None else None, tmask, attn, self.frag_train(ai), h=h, direction=direction,
+                                            attn_drop=adrop, sub_drop=(kw["drop_p"], kw["drop_seed"]) if kw else None, v=v)
         if v is None:           # inference: value projection, scores, softmax, P.V, output projection and residual in one launch
             wv, wo = self._frag_weights(ai)
             return ops.st_stage1_fused(qf, vft, tmask, wv, attn.linears[2].bias, wo, attn.linears[3].bias, x, h=h, direction=direction)
@@ -412,7 +418,8 @@ class VidEncoderLayer4(nn.Module):
             return self.train_value(take_t2s() if ai == 1 else take(), ai)
 
         train_fused = bool(ft.get("_bist_fused_train")) and torch.is_grad_enabled() and t2s_on and s2t_on
-        per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V and "_bist_v_pre" not in ft and not train_fused
+        own_v = train_fused and Fn.FUSED_TRAIN_OWN_V
+        per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V and "_bist_v_pre" not in ft and not own_v
         v_t2s = v_s2t = None
         pre = ft.pop("_bist_v_pre", None)                  # (v_t2s, v_s2t, event): projected ahead by the layer loop (decoder.py)
         self._v_event = None
@@ -422,7 +429,7 @@ class VidEncoderLayer4(nn.Module):
         fused = (Fn.FUSED_ST1 and not torch.is_grad_enabled() and vft.is_cuda and pre is None
                  and all(ops.st_stage1_fused_ok(T_, S_, x0.shape[1], d_, self.attn[0].h, dr, vft.dtype)
                          for dr, on in ((0, t2s_on), (1, s2t_on)) if on))
-        if fused or train_fused:
+        if fused or own_v:
             pass
         elif pre is not None:
             v_t2s, v_s2t, ev = pre
@@ -454,7 +461,7 @@ class VidEncoderLayer4(nn.Module):
         def t2s_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
             y = self._stage1(ai + 1, si + 1, x, vft_t2s, branch_v(ai + 1) if per_branch_v else v_t2s, b.temporal_mask, 0,
-                             permuted=permuted, train_fused=take() if train_fused else None)     # A1
+                             permuted=permuted, train_fused=(take() if own_v else True) if train_fused else None)     # A1
             z = self._stage2(ai + 2, si + 2, x, y, None)                                          # A2
             in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
             if trace is not None:
@@ -463,7 +470,7 @@ class VidEncoderLayer4(nn.Module):
         def s2t_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
             y = self._stage1(ai + 1, si + 1, x, vft_s2t, branch_v(ai + 1) if per_branch_v else v_s2t, None, 1,
-                             train_fused=take() if train_fused else None)                        # A4
+                             train_fused=(take() if own_v else True) if train_fused else None)    # A4
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
             if trace is not None:

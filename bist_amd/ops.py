@@ -420,7 +420,7 @@ def st_stage1_fused_train_ok(T: int, S: int, Lq: int, d: int, h: int, direction:
 
 
 def st_stage1_fused_train(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: Tensor, bv: Tensor, wo: Tensor, bo: Tensor, xres: Tensor, *,
-                          h: int, direction: int, attn_drop=None, sub_drop=None):
+                          h: int, direction: int, attn_drop=None, sub_drop=None, want_v: bool = True):
     """Stage 1 of one direction in one launch, TRAINING form (bist_st_stage1_fused_train_fwd): -> (Y [B,G,Lq,d], V [B,T,S,d],
     P [B,G,h,Lq,KP] f32 probabilities before dropout, O [B,G,Lq,d] context rows); wv / wo in fragment order; kmask uint8 [B,K] or None."""
     _dev(qf, vft, kmask, wv, bv, wo, bo, xres)
@@ -434,11 +434,11 @@ def st_stage1_fused_train(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: 
         raise ValueError("bist_amd.st_stage1_fused_train: operand shapes do not match [B,T,S,d] / Lq / h")
     KP = (K + 3) // 4 * 4
     y = torch.empty((B, G, Lq, d), device=vft.device, dtype=vft.dtype)
-    v = torch.empty((B, T, S, d), device=vft.device, dtype=vft.dtype)
+    v = torch.empty((B, T, S, d), device=vft.device, dtype=vft.dtype) if want_v else None
     p = torch.empty((B, G, h, Lq, KP), device=vft.device, dtype=torch.float32)
     o = torch.empty((B, G, Lq, d), device=vft.device, dtype=vft.dtype)
     check(lib.bist_st_stage1_fused_train_fwd(qf.data_ptr(), vft.data_ptr(), _ptr(kmask), wv.data_ptr(), bv.data_ptr(), wo.data_ptr(), bo.data_ptr(),
-                                             xres.data_ptr(), y.data_ptr(), v.data_ptr(), p.data_ptr(), o.data_ptr(), drop_ref(attn_drop),
+                                             xres.data_ptr(), y.data_ptr(), _ptr(v), p.data_ptr(), o.data_ptr(), drop_ref(attn_drop),
                                              drop_ref(sub_drop), B, T, S, Lq, d, h, direction, dtype_code(vft.dtype), _stream()),
           "bist_st_stage1_fused_train_fwd")
     return y, v, p, o

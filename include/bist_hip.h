@@ -253,7 +253,9 @@ int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const uint8_t* kma
  * (modules.py:62-63; mask index ((((b*G + g)*h + hh)*Lq + i)*K + key, as bist_st_stage1_pv_fwd; the value bias is then scaled by the
  * kept probabilities' row sum) and sub_drop on W_o ctx + b_o before the residual (modules.py:44; mask index (row of Y)*d + column,
  * as bist_gemm's epilogue) -- and what the backward pass needs leaves as side outputs:
- *   Vout [B,T,S,d]        V = X W_v^T + b_v (the operand of bist_st_stage1_pv_bwd_p and of the value projection's weight gradient),
+ *   Vout [B,T,S,d]        V = X W_v^T + b_v (the operand of bist_st_stage1_pv_bwd_p and of the value projection's weight gradient);
+ *                         NULL when the caller runs the value projection as a product of its own (on another stream, off the
+ *                         critical chain of the direction) and only wants the probabilities and the context rows from here,
  *   Pout [B,G,h,Lq,KP]    f32 probabilities BEFORE dropout, KP = K rounded up to a multiple of 4 (padding zero),
  *   Oout [B,G,Lq,d]       the head-concatenated context (the output projection's input).
  * Against the unfused training forward (value GEMM, score GEMM, softmax + P.V core, output projection: four launches, fp32 scores

@@ -83,8 +83,9 @@ def test_fused_training_forward_matches_the_unfused_kernels(direction, T, S, Lq,
         assert 0.05 < za.float().mean().item() < 0.15 and (za == zb).float().mean().item() > 0.99      # (bf16: x + tiny rounds to x in either path)
 
 
+@pytest.mark.parametrize("own_v", [True, False], ids=["own_values", "values_given"])
 @pytest.mark.parametrize("direction,T,S", [(0, 32, 49), (1, 32, 49), (0, 128, 9)])
-def test_fused_training_node_gradients_match_the_unfused_autograd_path(direction, T, S):
+def test_fused_training_node_gradients_match_the_unfused_autograd_path(direction, T, S, own_v):
     """St1FusedTrainFn (one launch forward; backward on the saved V / probabilities / context) against the four-node unfused path
     (value projection, score product, softmax + P.V core, output projection) under autograd, both dropouts on, same seeds."""
     from bist_amd import functional as Fn, ops
@@ -109,7 +110,11 @@ def test_fused_training_node_gradients_match_the_unfused_autograd_path(direction
         attn.zero_grad(set_to_none=True)
         if fused:
             frag = (ops.pack_frag_rows(attn.linears[2].weight.detach()), ops.pack_frag_rows(attn.linears[3].weight.detach()))
-            y = Fn.st_stage1_fused_train(q_, x_, v_, v_, tmask, attn, frag, h=h, direction=direction, attn_drop=adrop, sub_drop=sdrop)
+            if own_v:       # the launch projects (and saves) the values itself
+                y = Fn.st_stage1_fused_train(q_, x_, v_, v_, tmask, attn, frag, h=h, direction=direction, attn_drop=adrop, sub_drop=sdrop)
+            else:           # the value projection stays a product of its own (the default: it runs off the direction's chain)
+                val = Fn.linear(v_.view(B * T * S, d), attn.linears[2].weight, attn.linears[2].bias).view(B, T, S, d)
+                y = Fn.st_stage1_fused_train(q_, x_, v_, None, tmask, attn, frag, h=h, direction=direction, attn_drop=adrop, sub_drop=sdrop, v=val)
         else:
             val = Fn.linear(v_.view(B * T * S, d), attn.linears[2].weight, attn.linears[2].bias).view(B, T, S, d)
             sc = Fn.st_scores(q_, v_.view(B, T * S, d))
