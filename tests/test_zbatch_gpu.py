@@ -83,7 +83,7 @@ def test_lockstep_layer_equals_two_chains_forward_and_gradients(hip, dtype, T):
     """Autograd on, dropout off: the same model, batch and loss through the lock-step form and through the two-chain form.  The two run
     the same kernels on the same rows (batched by direction or not), so the outputs agree to rounding of the few re-ordered sums and
     every parameter gradient agrees closely; bf16 at d_model=512 runs the production kernels (T=64: the region-major t2s form)."""
-    from bist_amd import zbatch as Z
+    from bist_amd import functional as Fn, zbatch as Z
     from bist_amd.model.label_smoothing import LabelSmoothing
     from bist_amd.model.optimize import SimpleLossCompute
     M, Batch = hip
@@ -96,7 +96,8 @@ def test_lockstep_layer_equals_two_chains_forward_and_gradients(hip, dtype, T):
     model, _ = _model(M, cfg, V, C, dtype)
     lc = SimpleLossCompute(model.generator, model.ae_generator, LabelSmoothing(V, O.PAD_ID, 0.1), None, args=_args(cfg))
     res = {}
-    old = Z.ENABLED
+    old, old_f = Z.ENABLED, Fn.FUSED_TRAIN
+    Fn.FUSED_TRAIN = False       # both forms on the SAME stage-1 kernels (the four-launch training forward): what differs is the batching by direction
     try:
         for z in (True, False):
             Z.ENABLED = z
@@ -108,8 +109,8 @@ def test_lockstep_layer_equals_two_chains_forward_and_gradients(hip, dtype, T):
             res[z] = ({k: ft[k].detach().float().cpu() for k in ("temporal_ft", "spatial_ft", "encoded_ft", "decoded_text")}, logp.detach().float().cpu(),
                       {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None})
     finally:
-        Z.ENABLED = old
-    tol = 2e-5 if dtype == torch.float32 else 6e-2      # (bf16: the two-chain form's stage 1 is the fused training launch, other kernels than the lock-step form's)
+        Z.ENABLED, Fn.FUSED_TRAIN = old, old_f
+    tol = 2e-5 if dtype == torch.float32 else 4e-2
     for k in res[True][0]:
         assert (res[True][0][k] - res[False][0][k]).abs().max().item() <= tol, k
     assert (res[True][1] - res[False][1]).abs().max().item() <= (1e-4 if dtype == torch.float32 else 6e-2)
