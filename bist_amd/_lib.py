@@ -95,6 +95,7 @@ SIGNATURES = {
     "bist_st_stage1_fused_train_ok": (C.c_int, [_I32] * 7),
     "bist_st_stage1_fused_train_fwd": (C.c_int, [_P] * 12 + [C.POINTER(BistDrop), C.POINTER(BistDrop)] + [_I32] * 8 + [_P]),
     "bist_st_stage1_pv_bwd_p": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I32, _P] + [_I32] * 6 + [_I64, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),
+    "bist_beam_step": (C.c_int, [_P] * 14 + [_I32] * 10 + [_F, _P]),
     "bist_decoder_stack_ok": (C.c_int, [_I32] * 5),
     "bist_decoder_layer_desc_bytes": (C.c_int64, []),
     "bist_decoder_stack_fwd": (C.c_int, [_P, _I32] + [_P] * 8 + [_I32, _I32, _I32, _P, _I32, _P]),

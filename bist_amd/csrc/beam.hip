@@ -1,0 +1,157 @@
+// Beam-search bookkeeping of one decode step on the device (reference: model/decode.py:59-99).
+//
+// The reference copies every hypothesis's log-prob row [V] to the host (decode.py:71, one synchronisation per hypothesis and step),
+// argsorts it with numpy and runs the beam update in Python.  Here a step's update is two small launches and NO host round trip:
+//   beam_topk_kernel    one workgroup per hypothesis row: lp_vec = logp[row] + lp[row] (decode.py:72, the same f32 addition), its
+//                       KC = beam + 2 largest entries in descending order (value, token id) and lp_vec[<eos>] -- the loop of
+//                       decode.py:79-97 takes at most `beam` candidates per row and skips at most two symbols;
+//   beam_select_kernel  one thread: decode.py:74-97 literally -- the completed-hypothesis score of every row (from min_len on), then
+//                       the rows in order, their candidates in descending order, into a list of at most `beam` entries with
+//                       replace-the-minimum (first minimal index, strict comparisons) and the early break; it writes the next step's
+//                       inputs in place (token per surviving hypothesis, its running score, its ancestry mask over the decoder
+//                       kernel's self-attention slots) and the step's record (parent row, token, score) for the host to rebuild the
+//                       token lists from at the END of the turn.
+// numpy's argsort orders equal values by its sort's internals, so whenever the KC + 1 largest values of a row are not all distinct
+// (or a value is NaN, or fewer than `beam` hypotheses survive) a sticky flag is raised and the caller repeats the turn on the host
+// path: the n-best lists are the reference's in every case.
+#include "common.hpp"
+
+namespace {
+
+constexpr int KC_MAX = 16;
+
+struct BeamArgs {
+  const float* logp;         // [n, V] log-probs of this step's rows
+  float* lp;                 // [beam] running scores: read for this step's rows, rewritten for the next step's
+  long* tok;                 // [beam] next step's input tokens
+  unsigned char* mask64;     // [beam, 64] ancestry masks over the decoder kernel's slots (read: this step's, written: next step's)
+  unsigned char* mask_out;   // [beam, LkS_next] the next step's mask in the width its launch reads (32 or 64)
+  float* cand_val; int* cand_idx; float* eos_val;      // scratch [n, KC], [n, KC], [n]
+  int* rec_parent; int* rec_token; float* rec_score; float* rec_comp; int* rec_n;      // records [max_len, beam] ..., rows per step [max_len]
+  int* flag;                 // sticky: 1 ties, 2 NaN, 4 fewer than beam survivors
+  int n, V, beam, KC, step, min_len, unk, eos, dec_eos, slot0_next, LkS_next;
+  float penalty;
+};
+
+__global__ __launch_bounds__(256) void beam_topk_kernel(const BeamArgs a) {
+  __shared__ float sval[256];
+  __shared__ int sidx[256];
+  __shared__ int scnt[256];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* lr = a.logp + (long)row * a.V;
+  const float base = a.lp[row];
+  constexpr int PER = 16;                              // V <= 4096
+  float v[PER];
+  bool nan = false;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid + 256 * u;
+    v[u] = i < a.V ? lr[i] + base : -INFINITY;
+    nan |= (v[u] != v[u]);
+  }
+  if (tid == 0) a.eos_val[row] = lr[a.eos] + base;
+  float last = INFINITY;
+  for (int k = 0; k <= a.KC; ++k) {                    // KC + 1 rounds: the extra one only checks distinctness
+    float best = -INFINITY; int bi = 0x7fffffff, cnt = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + 256 * u;
+      if (v[u] > best) { best = v[u]; bi = i; cnt = 1; }
+      else if (v[u] == best && v[u] > -INFINITY) { ++cnt; }
+    }
+    sval[tid] = best; sidx[tid] = bi; scnt[tid] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        const float o = sval[tid + s];
+        if (o > sval[tid]) { sval[tid] = o; sidx[tid] = sidx[tid + s]; scnt[tid] = scnt[tid + s]; }
+        else if (o == sval[tid] && o > -INFINITY) { scnt[tid] += scnt[tid + s]; sidx[tid] = min(sidx[tid], sidx[tid + s]); }
+      }
+      __syncthreads();
+    }
+    const float bv = sval[0]; const int bidx = sidx[0], bc = scnt[0];
+    if (tid == 0) {
+      if (bc > 1 || bv == last) atomicOr(a.flag, 1);
+      if (k < a.KC) { a.cand_val[row * a.KC + k] = bv; a.cand_idx[row * a.KC + k] = bv > -INFINITY ? bidx : -1; }
+    }
+    last = bv;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) if (tid + 256 * u == bidx) v[u] = -INFINITY;
+    __syncthreads();
+  }
+  if (nan) atomicOr(a.flag, 2);
+}
+
+__global__ void beam_select_kernel(const BeamArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = a.n, beam = a.beam, KC = a.KC, l = a.step;
+  a.rec_n[l] = n;
+  int cnt = 0, argmin = 0;
+  int parent[KC_MAX], token[KC_MAX];
+  float score[KC_MAX];
+  for (int idx = 0; idx < n; ++idx) {
+    // completed hypothesis of this row (decode.py:74-78): len(out) = l tokens so far
+    a.rec_comp[l * beam + idx] = l >= a.min_len ? a.eos_val[idx] + a.penalty * (float)(l + 1) : -INFINITY;
+    for (int c = 0; c < KC; ++c) {
+      const int o = a.cand_idx[idx * KC + c];
+      if (o < 0) break;
+      if (o == a.unk || (!a.dec_eos && o == a.eos)) continue;
+      const float new_lp = a.cand_val[idx * KC + c];
+      if (cnt == beam) {
+        if (score[argmin] < new_lp) {
+          parent[argmin] = idx; token[argmin] = o; score[argmin] = new_lp;
+          argmin = 0;
+          for (int j = 1; j < beam; ++j) if (score[j] < score[argmin]) argmin = j;       // first minimal index
+        } else {
+          break;
+        }
+      } else {
+        parent[cnt] = idx; token[cnt] = o; score[cnt] = new_lp; ++cnt;
+        if (cnt == beam) {
+          argmin = 0;
+          for (int j = 1; j < beam; ++j) if (score[j] < score[argmin]) argmin = j;
+        }
+      }
+    }
+  }
+  if (cnt < beam) atomicOr(a.flag, 4);
+  // next step's inputs: token, running score, ancestry mask (the parent's slots and the hypothesis's own new slot)
+  unsigned char nm[KC_MAX][64];
+  for (int j = 0; j < cnt; ++j) {
+    for (int s = 0; s < 64; ++s) nm[j][s] = a.mask64[parent[j] * 64 + s];
+    const int own = a.slot0_next + j;
+    if (own < 64) nm[j][own] = 1;
+  }
+  for (int j = 0; j < beam; ++j) {
+    const bool live = j < cnt;
+    a.rec_parent[l * beam + j] = live ? parent[j] : -1;
+    a.rec_token[l * beam + j] = live ? token[j] : -1;
+    a.rec_score[l * beam + j] = live ? score[j] : -INFINITY;
+    a.tok[j] = live ? (long)token[j] : 0L;
+    a.lp[j] = live ? score[j] : 0.f;
+    for (int s = 0; s < 64; ++s) a.mask64[j * 64 + s] = live ? nm[j][s] : (unsigned char)(s == 0);
+    if (a.mask_out)
+      for (int s = 0; s < a.LkS_next; ++s) a.mask_out[j * a.LkS_next + s] = live ? nm[j][s] : (unsigned char)(s == 0);
+  }
+}
+
+}  // namespace
+
+extern "C" int bist_beam_step(const float* logp, float* lp, int64_t* tok, uint8_t* mask64, uint8_t* mask_out, float* cand_val, int32_t* cand_idx,
+                              float* eos_val, int32_t* rec_parent, int32_t* rec_token, float* rec_score, float* rec_comp, int32_t* rec_n,
+                              int32_t* flag, int32_t n, int32_t V, int32_t beam, int32_t step, int32_t min_len, int32_t unk, int32_t eos,
+                              int32_t dec_eos, int32_t slot0_next, int32_t LkS_next, float penalty, void* stream) {
+  BIST_REQUIRE(logp && lp && tok && mask64 && cand_val && cand_idx && eos_val && rec_parent && rec_token && rec_score && rec_comp && rec_n && flag,
+               "bist_beam_step: null pointer");
+  BIST_REQUIRE(n >= 1 && n <= beam && beam >= 1 && beam + 2 <= KC_MAX && V >= 1 && V <= 4096 && step >= 0 && eos >= 0 && eos < V,
+               "bist_beam_step: 1 <= n <= beam <= %d, V <= 4096", KC_MAX - 2);
+  BIST_REQUIRE(LkS_next == 0 || ((LkS_next == 32 || LkS_next == 64) && mask_out), "bist_beam_step: the next step's mask is 32 or 64 slots wide");
+  BeamArgs a{logp, lp, (long*)tok, mask64, LkS_next ? mask_out : nullptr, cand_val, cand_idx, eos_val, rec_parent, rec_token, rec_score, rec_comp, rec_n,
+             flag, n, V, beam, beam + 2, step, min_len, unk, eos, dec_eos, slot0_next, LkS_next, penalty};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(beam_topk_kernel, dim3((unsigned)n), dim3(256), 0, st, a);
+  BIST_LAUNCH_CHECK("bist_beam_step (top-k)");
+  hipLaunchKernelGGL(beam_select_kernel, dim3(1), dim3(64), 0, st, a);
+  BIST_LAUNCH_CHECK("bist_beam_step (select)");
+  return BIST_OK;
+}

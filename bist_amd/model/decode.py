@@ -167,14 +167,16 @@ def _graph_step(model, bn, fn, trg, train_args):
 INCREMENTAL = os.environ.get("BIST_INCREMENTAL_DECODE", "1") != "0"      # tuning aid: 0 = every step recomputes all prefix rows, like the reference
 
 
-def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args):
+def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args, shared=None):
     """One decode step for the NEW position only (``pos``) of n hypotheses: the decoder stack's persistent kernel appends the rows'
     self-attention keys / values to its per-layer pools at slots slot0 .. and attends, per hypothesis, the slots named by mask_np
     [n, LkS] (its ancestors' rows from the earlier steps and its own).  The decoder is causal, so the earlier positions' rows are
-    what a recompute of the whole prefix (decode.py:62-66) would produce again.  One hipGraph per (n, pos)."""
+    what a recompute of the whole prefix (decode.py:62-66) would produce again.  One hipGraph per (n, pos).
+    shared = (tokens [n,1] int64, mask [n,LkS] uint8) device tensors: the graph reads THESE (the device-side beam update of the
+    previous step has written them, bist_beam_step) and the call returns the log-probs as a DEVICE tensor -- no host round trip."""
     dev = bn.query.device
-    n = new_tokens.shape[0]
-    LkS = mask_np.shape[1]
+    n = shared[0].shape[0] if shared is not None else new_tokens.shape[0]
+    LkS = shared[1].shape[1] if shared is not None else mask_np.shape[1]
     geom = (n, tuple(bn.query.shape), tuple(bn.his.shape), None if bn.cap is None else tuple(bn.cap.shape), fn["encoded_query"].dtype,
             len(fn["_bist_reasoning"]))
     store = model.__dict__.setdefault("_bist_step_graphs", {})
@@ -182,11 +184,11 @@ def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args)
     if tb is None:
         tb = store[("turn",) + geom] = _TurnBuffers(bn, fn, getattr(model, "mutlimodal_decoder", None))
     tb.load(bn, fn)
-    key = ("incr", pos, slot0, LkS) + geom
+    key = ("incr", pos, slot0, LkS, None if shared is None else (shared[0].data_ptr(), shared[1].data_ptr())) + geom
     g = store.get(key)
     if g is None:
-        strg = torch.zeros((n, 1), dtype=torch.long, device=dev)
-        smask = torch.zeros((n, LkS), dtype=torch.uint8, device=dev)
+        strg = shared[0] if shared is not None else torch.zeros((n, 1), dtype=torch.long, device=dev)
+        smask = shared[1] if shared is not None else torch.zeros((n, LkS), dtype=torch.uint8, device=dev)
         sb = types.SimpleNamespace(**vars(tb.b))
         sb.trg, sb.trg_mask = strg, None
 
@@ -195,8 +197,9 @@ def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args)
             f["_bist_incr"] = (slot0, smask)
             f2 = model.decode(sb, f, pos)
             return model.generator(f2, sb, train_args).float()
-        strg.copy_(new_tokens)
-        smask.copy_(torch.from_numpy(mask_np))
+        if shared is None:
+            strg.copy_(new_tokens)
+            smask.copy_(torch.from_numpy(mask_np))
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -207,16 +210,17 @@ def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args)
             out = run()
         g = store[key] = (graph, strg, smask, out)
     graph, strg, smask, out = g
-    strg.copy_(new_tokens)
-    smask.copy_(torch.from_numpy(mask_np))
+    if shared is None:
+        strg.copy_(new_tokens)
+        smask.copy_(torch.from_numpy(mask_np))
     graph.replay()
-    return out.cpu().numpy()
+    return out if shared is not None else out.cpu().numpy()
 
 
 _TURN_FIELDS = ("query", "his", "cap", "fts", "query_mask", "query_mask2", "his_mask", "cap_mask", "temporal_mask")
 
 
-def _graph_first_step(model, batch, start_symbol, train_args):
+def _graph_first_step(model, batch, start_symbol, train_args, host=True):
     """model.encode + the first decode step (prefix = <sos>) of a turn, replayed from one hipGraph per dialogue geometry:
     ~1000 launches of reasoning at B=1 are launch-bound when issued from Python.  Returns (ft, log-probs [1,1,V] numpy);
     ft (encoded text, per-layer reasoning) lives in the graph's static outputs until the next turn of this geometry."""
@@ -263,7 +267,94 @@ def _graph_first_step(model, batch, start_symbol, train_args):
     if hasattr(dec, "select_decode_cache"):
         # True: the replayed first step ran the decoder layers through the persistent kernel (position 0 sits in slot 0 of its pools)
         ft["_bist_pool_ready"] = bool(g[4]) and dec.select_decode_cache(ft, ft["_bist_turn"])
-    return ft, out.cpu().numpy()
+    return ft, (out.cpu().numpy() if host else out)
+
+
+DEVICE_BEAM = os.environ.get("BIST_DEVICE_BEAM", "1") != "0"      # tuning aid: 0 = the beam update of every step on the host (one D2H + sync per step, like the reference)
+
+
+class _BeamState:
+    """Device buffers of the device-side beam update (bist_beam_step), one set per (model, beam, max_len): next-step tokens and masks
+    (the static inputs of the incremental step graphs), running scores, per-step records, the sticky fallback flag."""
+
+    def __init__(self, dev, beam, max_len):
+        z = lambda *shape, dt: torch.zeros(*shape, device=dev, dtype=dt)
+        self.beam, self.max_len = beam, max_len
+        self.lp = z(beam, dt=torch.float32)
+        self.tok = z(beam, 1, dt=torch.long)
+        self.mask64 = z(beam, 64, dt=torch.uint8)
+        self.mask = {32: z(beam, 32, dt=torch.uint8), 64: z(beam, 64, dt=torch.uint8)}
+        kc = beam + 2
+        self.cand_val, self.cand_idx, self.eos_val = z(beam, kc, dt=torch.float32), z(beam, kc, dt=torch.int32), z(beam, dt=torch.float32)
+        # records in ONE buffer (one copy to the host per turn): parent | token | rows | flag (int32), then score | completed (f32 viewed)
+        n = max_len * beam
+        self.rec_i = z(2 * n + max_len + 1, dt=torch.int32)
+        self.rec_f = z(2 * n, dt=torch.float32)
+        self.parent, self.token = self.rec_i[:n], self.rec_i[n:2 * n]
+        self.rows, self.flag = self.rec_i[2 * n:2 * n + max_len], self.rec_i[2 * n + max_len:]
+        self.score, self.comp = self.rec_f[:n], self.rec_f[n:]
+        self.init = torch.zeros(beam, 64, dtype=torch.uint8)
+        self.init[0, 0] = 1                      # the turn's first row attends slot 0 (<sos>)
+        self.init = self.init.to(dev)
+
+    def reset(self):
+        self.lp.zero_()
+        self.flag.zero_()
+        self.mask64.copy_(self.init)
+
+    def step(self, logp, n, step, min_len, unk, eos, dec_eos, penalty, slot0_next, LkS_next):
+        from .. import _lib
+        from ..ops import _stream
+        V = logp.shape[-1]
+        lg = logp.reshape(-1, V)
+        mo = self.mask[LkS_next] if LkS_next else None
+        _lib.check(_lib.lib.bist_beam_step(lg.data_ptr(), self.lp.data_ptr(), self.tok.data_ptr(), self.mask64.data_ptr(),
+                                           mo.data_ptr() if mo is not None else None, self.cand_val.data_ptr(), self.cand_idx.data_ptr(),
+                                           self.eos_val.data_ptr(), self.parent.data_ptr(), self.token.data_ptr(), self.score.data_ptr(),
+                                           self.comp.data_ptr(), self.rows.data_ptr(), self.flag.data_ptr(), n, V, self.beam, step, min_len, unk, eos,
+                                           1 if dec_eos else 0, slot0_next, LkS_next, float(penalty), _stream()), "bist_beam_step")
+
+
+def _device_beam_turn(model, batch, ft, out0, max_len, unk_symbol, end_symbol, beam, penalty, nbest, min_len, train_args, dec_eos):
+    """The beam loop of decode.py:59-99 with the update of every step on the device: twelve graph replays and twenty-four small
+    launches queued back to back, ONE copy of the step records to the host at the end.  Returns None when the device flagged a
+    case it does not decide like numpy (ties among a row's largest values, NaN, too few candidates): the caller re-runs the turn
+    on the host path."""
+    dev = batch.query.device
+    key = ("beam_state", beam, max_len, dev)
+    store = model.__dict__.setdefault("_bist_step_graphs", {})
+    bs = store.get(key)
+    if bs is None:
+        bs = store[key] = _BeamState(dev, beam, max_len)
+    bs.reset()
+    lks = lambda slot0: 32 if slot0 + beam <= 32 else 64
+    bs.step(out0, 1, 0, min_len, unk_symbol, end_symbol, dec_eos, penalty, beam, lks(beam) if max_len > 1 else 0)
+    if max_len > 1:
+        bn, fn = _turn_for_rows(batch, ft, beam, {})
+    for l in range(1, max_len):
+        slot0 = l * beam
+        out = _graph_step_incr(model, bn, fn, None, l, slot0, None, train_args, shared=(bs.tok, bs.mask[lks(slot0)]))
+        nxt = (l + 1) * beam
+        bs.step(out, beam, l, min_len, unk_symbol, end_symbol, dec_eos, penalty, nxt, lks(nxt) if l + 1 < max_len else 0)
+    rec_i, rec_f = bs.rec_i.cpu().numpy(), bs.rec_f.cpu().numpy()          # the turn's only synchronisation
+    n = max_len * beam
+    if int(rec_i[2 * n + max_len]) != 0:
+        return None
+    parent, token, rows = rec_i[:n].reshape(max_len, beam), rec_i[n:2 * n].reshape(max_len, beam), rec_i[2 * n:2 * n + max_len]
+    comp = rec_f[n:].reshape(max_len, beam)
+    comp_hyplist, best_state = [], None
+    cur = [[]]
+    for l in range(max_len):
+        if l >= min_len:
+            for idx in range(int(rows[l])):
+                new_lp = comp[l, idx]
+                comp_hyplist.append((cur[idx], new_lp))
+                if best_state is None or best_state < new_lp:
+                    best_state = new_lp
+        cur = [cur[int(parent[l, j])] + [int(token[l, j])] for j in range(beam) if parent[l, j] >= 0]
+    if comp_hyplist:
+        return sorted(comp_hyplist, key=lambda e: -e[1])[:nbest], best_state
+    return [([], 0)], None
 
 
 BUCKET = int(os.environ.get("BIST_DECODE_BUCKET", "0"))      # 0 / 1 = off (default: at the bench geometry (20, 60, 25) -> (24, 64, 32) costs 0.8 ms per turn)
@@ -300,7 +391,17 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
         batch = _bucketed(batch, pad_symbol)
     lp_first = None
     if use_graphs:
-        ft, lp_first = _graph_first_step(model, batch, start_symbol, train_args)
+        dec0 = getattr(model, "mutlimodal_decoder", None)
+        want_dev = (DEVICE_BEAM and INCREMENTAL and max_len * beam <= 64 and beam + 2 <= 16 and dec0 is not None
+                    and getattr(dec0, "FUSED_DECODE", False) and Fn.FUSED_DECODE and min_len >= 0)
+        ft, out0 = _graph_first_step(model, batch, start_symbol, train_args, host=not want_dev)
+        if want_dev and ft.get("_bist_pool_ready", False) and out0.shape[-1] <= 4096 and out0.shape[-1] >= beam + 3:
+            res = _device_beam_turn(model, batch, ft, out0, max_len, unk_symbol, end_symbol, beam, penalty, nbest, min_len, train_args, dec_eos)
+            if res is not None:
+                dec0.check_decode_errors()
+                return res
+            # (ties / NaN / too few candidates: decided on the host exactly like the reference, from the same first step)
+        lp_first = out0.cpu().numpy() if want_dev else out0
     else:
         ft = model.encode(batch)
     # the hypotheses' token prefixes live on the HOST (the reference keeps them as device tensors and pays two tiny device

@@ -268,6 +268,24 @@ int bist_st_stage1_fused_train_fwd(const void* qf, const void* vft, const uint8_
                                    int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Beam-search bookkeeping of one decode step ON THE DEVICE (model/decode.py:59-99; the reference copies every hypothesis's
+ * log-prob row to the host -- decode.py:71, a synchronisation per hypothesis and step -- and runs numpy argsort + the beam update in
+ * Python).  Two small launches: per row the beam + 2 largest entries of lp_vec = logp[row] + lp[row] (decode.py:72) and lp_vec[eos];
+ * then decode.py:74-97 literally on one thread (completed-hypothesis scores from min_len on; rows in order, candidates descending,
+ * replace-the-minimum with the first minimal index, early break), which rewrites IN PLACE the next step's inputs -- tok [beam] int64
+ * tokens, lp [beam] running scores, mask64 [beam,64] ancestry masks over the decoder kernel's self-attention slots (hypothesis j of
+ * the next step owns slot slot0_next + j), mask_out [beam,LkS_next] the same mask in the width the next launch reads (LkS_next = 0:
+ * last step) -- and the step's record rec_*[step*beam + j] (parent row, token, score; rec_comp[step*beam + row] completed score,
+ * rec_n[step] rows) from which the host rebuilds the token lists once per turn.  flag (sticky int32): 1 = the beam + 3 largest values
+ * of a row are not all distinct (numpy orders ties by its sort's internals), 2 = NaN, 4 = fewer than beam survivors: the caller
+ * repeats the turn on the host path, so the n-best lists are the reference's in every case.  n <= beam <= 14, V <= 4096.
+ * ------------------------------------------------------------------------------------------ */
+int bist_beam_step(const float* logp, float* lp, int64_t* tok, uint8_t* mask64, uint8_t* mask_out, float* cand_val, int32_t* cand_idx,
+                   float* eos_val, int32_t* rec_parent, int32_t* rec_token, float* rec_score, float* rec_comp, int32_t* rec_n,
+                   int32_t* flag, int32_t n, int32_t V, int32_t beam, int32_t step, int32_t min_len, int32_t unk, int32_t eos,
+                   int32_t dec_eos, int32_t slot0_next, int32_t LkS_next, float penalty, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * The response-decoder stack of one beam-search step as ONE persistent launch (inference; bf16, d = 512, h = 8, R <= 64 rows).
  * Replaces, for all layers of MultimodalDecoder8's loop (model/decoder.py:114-182, reasoning results cached per turn), the
  * MultimodalDecoderLayer12.forward of decoder.py:20-60 with enc_vc_combine != 'none': causal self-attention, attention to the

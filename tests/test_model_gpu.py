@@ -475,3 +475,36 @@ def test_bf16_persistent_decoder_beam_search_matches_the_full_size_reference_n_b
     for i, (toks, score) in enumerate(hyps):
         assert [int(t) for t in toks] == g[f"T32_beam_hyp{i}"].tolist(), (i, toks)
         assert abs(float(score) - float(g[f"T32_beam_score{i}"])) <= 8e-2, (i, float(score), float(g[f"T32_beam_score{i}"]))
+
+
+def test_device_side_beam_update_equals_the_host_beam_loop(hip):
+    """The beam bookkeeping of decode.py:72-99 on the device (bist_beam_step: per-row top-(beam+2) of logp + lp, the replace-the-minimum
+    list with the reference's visiting order, ancestry masks, step records; one copy to the host per TURN) against the same loop on the
+    host (one copy and one synchronisation per STEP, numpy argsort order) -- same graphs, same log-probs: identical n-best token lists
+    and bit-identical scores, beam 5 / maxlen 12 and beam 3 / maxlen 7, several dialogues, repeated turns (replayed graphs)."""
+    import bist_amd.model.decode as D
+    from bist_amd.model.decode import beam_search_decode
+    M, Batch = hip
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    V, C = 300, 256
+    model, _ = build_model(M, cfg, V, C, torch.bfloat16)
+    for beam, maxlen in ((5, 12), (3, 7)):
+        for seed in (51, 52, 53):
+            ob = O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=seed)
+            outs = {}
+            for dev_beam in (True, False):
+                D.DEVICE_BEAM = dev_beam
+                try:
+                    with torch.no_grad():
+                        for _ in range(2):
+                            hyps, best = beam_search_decode(model, to_batch(Batch, ob, torch.bfloat16), maxlen, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID,
+                                                            beam=beam, penalty=1.0, nbest=5, train_args=_args(cfg))
+                finally:
+                    D.DEVICE_BEAM = True
+                outs[dev_beam] = (hyps, best)
+            a, b = outs[True], outs[False]
+            assert [list(map(int, x[0])) for x in a[0]] == [list(map(int, x[0])) for x in b[0]], (beam, seed)
+            assert all(float(x[1]) == float(y[1]) for x, y in zip(a[0], b[0])), (beam, seed, a[0], b[0])
+            assert float(a[1]) == float(b[1])
+    store = model.__dict__.get("_bist_step_graphs", {})
+    assert any(isinstance(k, tuple) and k[0] == "beam_state" for k in store), "the device-side beam path was not taken"
