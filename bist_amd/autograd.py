@@ -721,10 +721,11 @@ class St1FusedTrainFn(Function):
         ctx.cfg = (cfg, tuple(x.shape), bv.dtype, tuple(qf.shape))
         ctx.w_dst = (getattr(wv, "_grad_view", None), getattr(wo, "_grad_view", None))
         ctx.b_dst = (getattr(bv, "_acc32", None), getattr(bo, "_acc32", None))
-        return y
+        ctx.set_materialize_grads(False)
+        return y, x          # x again for its next consumer (stage 2's sublayer): that gradient comes back here and is folded into the group sum
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxp):
         qf, vft, v, p, o, m8, wv, wo = ctx.saved_tensors
         (h, direction, adrop, sdrop), x_shape, bdt, qf_shape = ctx.cfg
         B, T, S, d = vft.shape
@@ -733,11 +734,17 @@ class St1FusedTrainFn(Function):
         Lq = x_shape[1]
         M, TS, R = B * G * Lq, T * S, Lq * h
         dev, dt = vft.device, vft.dtype
+        if dy is None:
+            dy = torch.zeros((M, d), device=dev, dtype=dt)
         dy = dy.reshape(M, d)
         if not dy.is_contiguous():
             dy = dy.contiguous()
-        dres = torch.empty((B * Lq, d), device=dev, dtype=dt)          # gradient of the un-expanded query: the sum over the groups
-        check(lib.bist_group_sum(dy.data_ptr(), dres.data_ptr(), B, G, Lq * d, dtype_code(dt), _stream()), "bist_group_sum")
+        if dxp is not None:
+            dxp = dxp.reshape(B * Lq, d)
+            if not dxp.is_contiguous() or dxp.dtype != dt:
+                dxp = dxp.to(dt).contiguous()
+        dres = torch.empty((B * Lq, d), device=dev, dtype=dt)          # gradient of the un-expanded query: the sum over the groups (+ its other gradient)
+        check(lib.bist_group_sum_add(dy.data_ptr(), _ptr(dxp), dres.data_ptr(), B, G, Lq * d, dtype_code(dt), _stream()), "bist_group_sum_add")
         dz = dy
         if sdrop is not None and sdrop[0] > 0:
             dz = torch.empty_like(dy)

@@ -75,19 +75,20 @@ __global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(const T* __restri
 
 // out[b, i, :] = sum_g x[b, g, i, :]   (gradient of the expanded-query residual of stage 1)
 template <typename T>
-__global__ void group_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int G, long inner, long total) {
+__global__ void group_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int G, long inner, long total, const T* __restrict__ add) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const long b = idx / inner, r = idx % inner;
   const T* p = x + b * G * inner + r;
-  float acc = 0.f;
+  float acc = add ? to_f(add[idx]) : 0.f;
   for (int g = 0; g < G; ++g) acc += to_f(p[(long)g * inner]);
   out[idx] = from_f<T>(acc);
 }
 
 // the same with 16 bytes per thread (inner % E == 0, aligned): G independent 16-byte loads per thread
 template <typename T>
-__global__ __launch_bounds__(256) void group_sum_vec_kernel(const T* __restrict__ x, T* __restrict__ out, int G, long inner, long total) {
+__global__ __launch_bounds__(256) void group_sum_vec_kernel(const T* __restrict__ x, T* __restrict__ out, int G, long inner, long total,
+                                                            const T* __restrict__ add) {
   constexpr int E = 16 / (int)sizeof(T);
   const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * E;
   if (idx >= total) return;
@@ -96,6 +97,12 @@ __global__ __launch_bounds__(256) void group_sum_vec_kernel(const T* __restrict_
   float acc[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  if (add) {
+    T v[E];
+    *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(add + idx);
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = to_f(v[e]);
+  }
 #pragma unroll 4
   for (int g = 0; g < G; ++g) {
     T v[E];
@@ -599,22 +606,25 @@ extern "C" int bist_epilogue_bwd(const void* dy, const void* y, void* dz, int64_
   return BIST_OK;
 }
 
-extern "C" int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream) {
+extern "C" int bist_group_sum_add(const void* x, const void* add, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream) {
   BIST_REQUIRE(x && out && B > 0 && G > 0 && inner > 0, "bist_group_sum: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const long total = B * inner;
   const long gsz = dtype == BIST_BF16 ? 2 : 4, ge = 16 / gsz;
-  if ((dtype == BIST_BF16 || dtype == BIST_F32) && inner % ge == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0) {
-    if (dtype == BIST_BF16) hipLaunchKernelGGL(group_sum_vec_kernel<bf16_t>, dim3(blocks_for(total / ge, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, G, (long)inner, total);
-    else hipLaunchKernelGGL(group_sum_vec_kernel<float>, dim3(blocks_for(total / ge, 256)), dim3(256), 0, st, (const float*)x, (float*)out, G, (long)inner, total);
+  if ((dtype == BIST_BF16 || dtype == BIST_F32) && inner % ge == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)add % 16) == 0) {
+    if (dtype == BIST_BF16) hipLaunchKernelGGL(group_sum_vec_kernel<bf16_t>, dim3(blocks_for(total / ge, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, G, (long)inner, total, (const bf16_t*)add);
+    else hipLaunchKernelGGL(group_sum_vec_kernel<float>, dim3(blocks_for(total / ge, 256)), dim3(256), 0, st, (const float*)x, (float*)out, G, (long)inner, total, (const float*)add);
     BIST_LAUNCH_CHECK("bist_group_sum");
     return BIST_OK;
   }
-#define L(TT, ...) hipLaunchKernelGGL(group_sum_kernel<TT>, dim3(blocks_for(total, 256)), dim3(256), 0, st, (const TT*)x, (TT*)out, G, (long)inner, total)
+#define L(TT, ...) hipLaunchKernelGGL(group_sum_kernel<TT>, dim3(blocks_for(total, 256)), dim3(256), 0, st, (const TT*)x, (TT*)out, G, (long)inner, total, (const TT*)add)
   DISPATCH_T(dtype, L, 0)
 #undef L
   BIST_LAUNCH_CHECK("bist_group_sum");
   return BIST_OK;
+}
+extern "C" int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream) {
+  return bist_group_sum_add(x, nullptr, out, B, G, inner, dtype, stream);
 }
 
 extern "C" int bist_col_sum_acc(const void* x, float* out, int64_t M, int32_t N, int64_t ldx, int32_t dtype, void* stream) {

@@ -121,7 +121,7 @@ FUSED_TRAIN_OWN_V = os.environ.get("BIST_FUSED_TRAIN_OWN_V", "0") != "0"
 def st_stage1_fused_train(qf, x, vft_a, vft_b, tmask, attn, frag, *, h, direction, attn_drop=None, sub_drop=None, v=None):
     """Training stage 1 of one direction as one launch forward (autograd.St1FusedTrainFn); attn: the MultiHeadedAttention holding
     linears[2] (values) and linears[3] (output); frag = (W_v, W_o) in fragment order; v: the value projection when the caller runs it
-    as a product of its own (vft_b is then unused)."""
+    as a product of its own (vft_b is then unused).  -> (y [B,G,Lq,d], x' = x again for its next consumer)"""
     return ag.St1FusedTrainFn.apply(qf, x, vft_a, vft_b, v, tmask, attn.linears[2].weight, attn.linears[2].bias, attn.linears[3].weight,
                                     attn.linears[3].bias, frag[0], frag[1], (h, direction, attn_drop, sub_drop))
 
@@ -179,6 +179,20 @@ class Fan:
 
     def take(self):
         return next(self._it, self.x)
+
+
+def fan_take(ft, key):
+    """The next alias of ft[key] when the layer loop set a fan up for it (training: every consumer gets an alias of its own and the
+    gradients are summed in ONE bist_add_n launch by FanOutFn instead of pairwise by autograd), else ft[key] itself."""
+    fans = ft.get("_bist_fans")
+    f = fans.get(key) if fans else None
+    return f.take() if f is not None else ft[key]
+
+
+def fan_set(ft, key, n: int):
+    """ft[key] will be read by up to n consumers (unused aliases cost nothing)."""
+    if _grad() and ft.get(key) is not None and ft[key].requires_grad and ft[key].is_cuda:
+        ft.setdefault("_bist_fans", {})[key] = Fan(ft[key], n)
 
 
 def cast(x, dtype):

@@ -33,9 +33,7 @@ class MultimodalDecoderLayer12(nn.Module):
 
     def forward(self, b, ft, x):
         a, s, args = self.attn, self.sublayer, self.args
-        fans = ft.get("_bist_mem_fan") or {}             # training: per-layer aliases of the encoded texts (one-pass gradient sum)
-        his = fans["encoded_his"].take() if "encoded_his" in fans else ft["encoded_his"]
-        qry = fans["encoded_query"].take() if "encoded_query" in fans else ft["encoded_query"]
+        his, qry = Fn.fan_take(ft, "encoded_his"), Fn.fan_take(ft, "encoded_query")     # training: per-consumer aliases of the encoded texts (one-pass gradient sum)
         x = _self_attention(s[0], a[0], x, b.trg_mask)                                   # decoder.py:21
         x = _cross_attention(s[1], a[1], x, his, b.his_mask)                             # :22
         x = _cross_attention(s[2], a[2], x, qry, b.query_mask)                           # :23
@@ -107,7 +105,7 @@ class MultimodalDecoder8(nn.Module):
         def other(k):            # a second alias of ft[k] where the producer handed several out (one consumer each: no gradient accumulation pass)
             lst = spare.get(k)
             return lst.pop(0) if lst else ft[k]
-        parts = [ft["encoded_query"]]
+        parts = [Fn.fan_take(ft, "encoded_query")]
         if self.c_N > 0:
             parts.append(ft["cap_ft"])
         if args.t2s:
@@ -318,8 +316,16 @@ class MultimodalDecoder8(nn.Module):
             ft["decoded_text"] = self.norm(x)
             return ft
         cache = [] if use_cache else None
+        if torch.is_grad_enabled():
+            # every reader of an encoded text gets an alias of its own (FanOutFn: ONE bist_add_n launch sums their gradients; autograd's own
+            # accumulation is a pairwise elementwise launch per extra reader): the query feeds the three reasoning chains, every layer's
+            # fusion logits and decoder layer, and two readers per pointer attention; the caption every caption layer and its pointer
+            L_ = len(self.layers)
+            Fn.fan_set(ft, "encoded_query", 3 + 2 * L_ + 2)
+            Fn.fan_set(ft, "encoded_his", L_ + 2)
+            Fn.fan_set(ft, "encoded_cap", L_ + 2)
         q = ft["encoded_query"]
-        in_ft = {"t2s": q, "s2t": q, "audio": q, "cap": q}
+        in_ft = {"t2s": Fn.fan_take(ft, "encoded_query"), "s2t": Fn.fan_take(ft, "encoded_query"), "audio": q, "cap": Fn.fan_take(ft, "encoded_query")}
         fused_train = False
         if self.v_N > 0 and "spatiotemporal_ft" in ft:
             # training: the video tensor feeds 4 products per reasoning layer (2 score products, 2 value projections); their [B*T*S, d] gradients are summed in one pass
@@ -351,8 +357,6 @@ class MultimodalDecoder8(nn.Module):
                 ft["_bist_vftp_fan"] = Fn.Fan(Fn.permute_ts(ft["_bist_vft_fan"].take()), 2 * L)
             else:
                 ft["_bist_vft_fan"] = Fn.Fan(ft["spatiotemporal_ft"], 4 * L)
-        if torch.is_grad_enabled():
-            ft["_bist_mem_fan"] = {k: Fn.Fan(ft[k], len(self.layers)) for k in ("encoded_his", "encoded_query") if k in ft}
         dec_pending = None
         # inference with the reasoning cache: the decoder layers run AFTER the reasoning layers, as the persistent launch of later decode
         # steps (bist_decoder_stack_fwd) -- which also leaves this call's self-attention keys / values in the per-layer pools
@@ -387,7 +391,7 @@ class MultimodalDecoder8(nn.Module):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     in_ft = self.c_layers[l](in_ft, ft, b)
-                    ft["cap_ft"] = self.cap_out_norm(in_ft["cap"])                           # decoder.py:132
+                    ft["cap_ft"], in_ft["cap"] = Fn.layernorm_res(in_ft["cap"], self.cap_out_norm.a_2, self.cap_out_norm.b_2, self.cap_out_norm.eps)                           # decoder.py:132
             if self.v_N > 0:
                 in_ft = self.v_layers[l](in_ft, ft, b)
                 if "_z" in in_ft:
@@ -403,12 +407,16 @@ class MultimodalDecoder8(nn.Module):
                     if self.args.s2t:
                         ft["temporal_ft"] = self.temporal_out_norm(in_ft["s2t"])             # decoder.py:127
                     if self.args.t2s:
-                        ft["spatial_ft"] = self.spatial_out_norm(in_ft["t2s"])               # :129
+                        # the t2s stream goes on to the next layer THROUGH the norm's node (its gradient is added inside the norm's backward
+                        # kernel instead of by an accumulation launch); the s2t stream is not chained: its norm runs on the main stream, its
+                        # next layer on a side stream, and the chain would put two cross-stream hops per layer on that direction's backward
+                        n_ = self.spatial_out_norm
+                        ft["spatial_ft"], in_ft["t2s"] = Fn.layernorm_res(in_ft["t2s"], n_.a_2, n_.b_2, n_.eps)      # :129
             if fork_cap:
                 main.wait_stream(side)
             elif self.c_N > 0:
                 in_ft = self.c_layers[l](in_ft, ft, b)
-                ft["cap_ft"] = self.cap_out_norm(in_ft["cap"])                               # :132
+                ft["cap_ft"], in_ft["cap"] = Fn.layernorm_res(in_ft["cap"], self.cap_out_norm.a_2, self.cap_out_norm.b_2, self.cap_out_norm.eps)                               # :132
             self._fuse(ft)
             if cache is not None:
                 cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})
@@ -436,10 +444,11 @@ class MultimodalDecoder8(nn.Module):
         ft.pop("_bist_fused_train", None)
         ft.pop("_bist_qmask2", None)
         ft.pop("_bist_vftp_fan", None)
-        ft.pop("_bist_mem_fan", None)
         ft.pop("_bist_v_pre", None)
         ft.pop("_bist_pre_vid", None)
         if cache is not None:
             ft["_bist_reasoning"] = cache
         ft["decoded_text"] = self.norm(x)                                                    # :185
+        if torch.is_grad_enabled():
+            Fn.fan_set(ft, "decoded_text", 5)          # vocabulary logits, switch logits, one query projection per pointer attention
         return ft

@@ -173,8 +173,10 @@ class VidEncoderLayer4(nn.Module):
             v_event = self.__dict__.get("_v_event")
             if v is not None and v_event is not None:
                 torch.cuda.current_stream().wait_event(v_event)
-            return Fn.st_stage1_fused_train(qf, xr, vft, train_fused if v is None else None, tmask, attn, self.frag_train(ai), h=h, direction=direction,
-                                            attn_drop=adrop, sub_drop=(kw["drop_p"], kw["drop_seed"]) if kw else None, v=v)
+            y, xnext = Fn.st_stage1_fused_train(qf, xr, vft, train_fused if v is None else None, tmask, attn, self.frag_train(ai), h=h, direction=direction,
+                                                attn_drop=adrop, sub_drop=(kw["drop_p"], kw["drop_seed"]) if kw else None, v=v)
+            self.__dict__["_x_next"] = xnext       # x again, for stage 2 (one consumer per tensor: no accumulation launch by autograd)
+            return y
         if v is None:           # inference: value projection, scores, softmax, P.V, output projection and residual in one launch
             wv, wo = self._frag_weights(ai)
             return ops.st_stage1_fused(qf, vft, tmask, wv, attn.linears[2].bias, wo, attn.linears[3].bias, x, h=h, direction=direction)
@@ -462,6 +464,7 @@ class VidEncoderLayer4(nn.Module):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
             y = self._stage1(ai + 1, si + 1, x, vft_t2s, branch_v(ai + 1) if per_branch_v else v_t2s, b.temporal_mask, 0,
                              permuted=permuted, train_fused=(take() if own_v else True) if train_fused else None)     # A1
+            x = self.__dict__.pop("_x_next", x)
             z = self._stage2(ai + 2, si + 2, x, y, None)                                          # A2
             in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
             if trace is not None:
@@ -471,6 +474,7 @@ class VidEncoderLayer4(nn.Module):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
             y = self._stage1(ai + 1, si + 1, x, vft_s2t, branch_v(ai + 1) if per_branch_v else v_s2t, None, 1,
                              train_fused=(take() if own_v else True) if train_fused else None)    # A4
+            x = self.__dict__.pop("_x_next", x)
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
             if trace is not None:
@@ -564,7 +568,7 @@ class CapEncoderLayer(nn.Module):
 
     def forward(self, in_ft, ft, b):
         c = _self_attention(self.sublayer[0], self.attn[0], in_ft["cap"], b.query_mask)
-        c = _cross_attention(self.sublayer[1], self.attn[1], c, ft["encoded_cap"], b.cap_mask)
+        c = _cross_attention(self.sublayer[1], self.attn[1], c, Fn.fan_take(ft, "encoded_cap"), b.cap_mask)
         in_ft["cap"] = _feed_forward(self.sublayer[2], self.ff, c)
         return in_ft
 

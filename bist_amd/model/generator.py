@@ -41,12 +41,14 @@ class Generator(nn.Module):
 
 
 def _pointer_source(name: str, ft: Dict[str, Tensor], batch):
+    """(token ids, (encoded text for the key projection, the same for the text vector), mask): the two readers of the encoded text get
+    an alias each when the layer loop set a fan up (one-pass gradient sum)."""
     if name == "query":
-        return batch.query, ft["encoded_query"], batch.query_mask
+        return batch.query, (Fn.fan_take(ft, "encoded_query"), Fn.fan_take(ft, "encoded_query")), batch.query_mask
     if name == "his":
-        return batch.his, ft["encoded_his"], batch.his_mask
+        return batch.his, (Fn.fan_take(ft, "encoded_his"), Fn.fan_take(ft, "encoded_his")), batch.his_mask
     if name == "cap":
-        return batch.cap, ft["encoded_cap"], batch.cap_mask
+        return batch.cap, (Fn.fan_take(ft, "encoded_cap"), Fn.fan_take(ft, "encoded_cap")), batch.cap_mask
     raise ValueError("unknown pointer source %r" % name)
 
 
@@ -97,12 +99,12 @@ class PointerGenerator(nn.Module):
         B, Lt, d = x.shape
         if args.ptr_ft == "query+cap":
             raise NotImplementedError("ptr_ft='query+cap' is outside the hot path")
-        text, enc, mask = _pointer_source(args.ptr_ft, ft, batch)
+        text, (enc_k, enc_v), mask = _pointer_source(args.ptr_ft, ft, batch)
         if args.mask_unk:
             mask = mask & (text != UNK).unsqueeze(-2)
-        logits = Fn.linear(x, self.vocab_gen, None, out_dtype=torch.float32)
-        p = _pointer_probs(self.pointer_attn, x, enc, mask)
-        sw = _switch_logits(self.pointer_gen_W, [x, _text_vector(p, enc), ft["encoded_tgt"]])    # generator.py:71
+        logits = Fn.linear(Fn.fan_take(ft, "decoded_text"), self.vocab_gen, None, out_dtype=torch.float32)
+        p = _pointer_probs(self.pointer_attn, Fn.fan_take(ft, "decoded_text"), enc_k, mask)
+        sw = _switch_logits(self.pointer_gen_W, [Fn.fan_take(ft, "decoded_text"), _text_vector(p, enc_v), ft["encoded_tgt"]])    # generator.py:71
         return Fn.pointer_mix(logits, sw, [p], [text], Lt, sigmoid_switch=True).view(B, Lt, -1)
 
 
@@ -120,14 +122,14 @@ class MultiPointerGenerator(nn.Module):
     def forward(self, ft, batch, args):
         x = ft["decoded_text"]
         B, Lt, d = x.shape
-        logits = Fn.linear(x, self.vocab_gen, None, out_dtype=torch.float32)
-        ps, texts, vec = [], [], [x, ft["encoded_tgt"]]                                   # generator.py:92
+        logits = Fn.linear(Fn.fan_take(ft, "decoded_text"), self.vocab_gen, None, out_dtype=torch.float32)
+        ps, texts, vec = [], [], [Fn.fan_take(ft, "decoded_text"), ft["encoded_tgt"]]     # generator.py:92
         for idx, name in enumerate(args.ptr_ft.split(",")):
-            text, enc, mask = _pointer_source(name, ft, batch)
+            text, (enc_k, enc_v), mask = _pointer_source(name, ft, batch)
             if args.mask_unk:
                 mask = mask & (text != UNK).unsqueeze(-2)                                 # generator.py:106-107
-            p = _pointer_probs(self.pointer_attn[idx], x, enc, mask)
+            p = _pointer_probs(self.pointer_attn[idx], Fn.fan_take(ft, "decoded_text"), enc_k, mask)
             ps.append(p); texts.append(text)
-            vec.append(_text_vector(p, enc))
+            vec.append(_text_vector(p, enc_v))
         sw = _switch_logits(self.pointer_gen_W, vec)
         return Fn.pointer_mix(logits, sw, ps, texts, Lt).view(B, Lt, -1)

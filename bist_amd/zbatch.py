@@ -537,6 +537,11 @@ class ZStage1Fn(Function):
         dqf = torch.empty(qf3.shape, device=dev, dtype=dt)
         dres = torch.empty((2, B * Lq, d), device=dev, dtype=dt)
         outs = {}
+        dxp2 = None
+        if dxp is not None:          # the gradient that came back through x' (the sublayer input's next consumer)
+            dxp2 = dxp.reshape(2, B * Lq, d)
+            if not dxp2.is_contiguous():
+                dxp2 = dxp2.contiguous()
         pre = []                     # escaping tensors: allocated before the fork (see forward)
         for z, (vft, v) in enumerate(((vft0, v0), (vft1, v1))):
             Tc, Sc = (S, T) if (z == 0 and permuted) else (T, S)
@@ -556,8 +561,9 @@ class ZStage1Fn(Function):
               dy = dy.reshape(M, d)
               if not dy.is_contiguous():
                   dy = dy.contiguous()
-              # gradient of the un-expanded query: the sum over the groups
-              check(lib.bist_group_sum(dy.data_ptr(), dres[z].data_ptr(), B, G, Lq * d, dtype_code(dt), _stream()), "bist_group_sum")
+              # gradient of the un-expanded query: the sum over the groups (+ the gradient that came back through x')
+              check(lib.bist_group_sum_add(dy.data_ptr(), dxp2[z].data_ptr() if dxp2 is not None else None, dres[z].data_ptr(), B, G, Lq * d,
+                                           dtype_code(dt), _stream()), "bist_group_sum_add")
               dzz = dy
               if sdrop[z] is not None and sdrop[z][0] > 0:
                   dzz = torch.empty_like(dy)
@@ -581,11 +587,6 @@ class ZStage1Fn(Function):
                        a_bs=(R * TS, 0), b_bs=(q3.stride(0), 0), c_bs=(TS * d, 0))
               outs[z] = (dvft.view(vft.shape), dv, dwo, dbo)
         ds.join()
-        if dxp is not None:          # the gradient that came back through x' (the sublayer input's next consumer)
-            dxp2 = dxp.reshape(2, B * Lq, d)
-            if not dxp2.is_contiguous():
-                dxp2 = dxp2.contiguous()
-            dres = ops.add_n([dres, dxp2])
         return (dqf.view(2, B, Lq * h, d), dres.view(x_shape), outs[0][0], outs[1][0], outs[0][1], outs[1][1], None,
                 outs[0][2], outs[0][3], outs[1][2], outs[1][3], None)
 

@@ -436,6 +436,9 @@ int bist_epilogue_bwd(const void* dy, const void* y, void* dz, int64_t M, int32_
                       void* stream);
 /* out[b, r] = sum_g x[b, g, r]  (r < inner): gradient of the un-expanded query of stage 1.       */
 int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream);
+/* out[b, r] = add[b, r] + sum_g x[b, g, r]: the same with a second gradient of the un-expanded query (the one that arrives through its
+ * next consumer, stage 2's sublayer) folded in, so that autograd launches no accumulation of its own.  add nullable.          */
+int bist_group_sum_add(const void* x, const void* add, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream);
 /* out[n] += sum_m x[m, n]  (bias gradient, fp32 accumulator).                                    */
 int bist_col_sum_acc(const void* x, float* out, int64_t M, int32_t N, int64_t ldx, int32_t dtype, void* stream);
 /* Several bias gradients in one launch (the trainer queues the weight-gradient GEMMs' dz operands of a

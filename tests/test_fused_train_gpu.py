@@ -111,10 +111,10 @@ def test_fused_training_node_gradients_match_the_unfused_autograd_path(direction
         if fused:
             frag = (ops.pack_frag_rows(attn.linears[2].weight.detach()), ops.pack_frag_rows(attn.linears[3].weight.detach()))
             if own_v:       # the launch projects (and saves) the values itself
-                y = Fn.st_stage1_fused_train(q_, x_, v_, v_, tmask, attn, frag, h=h, direction=direction, attn_drop=adrop, sub_drop=sdrop)
+                y, _x2 = Fn.st_stage1_fused_train(q_, x_, v_, v_, tmask, attn, frag, h=h, direction=direction, attn_drop=adrop, sub_drop=sdrop)
             else:           # the value projection stays a product of its own (the default: it runs off the direction's chain)
                 val = Fn.linear(v_.view(B * T * S, d), attn.linears[2].weight, attn.linears[2].bias).view(B, T, S, d)
-                y = Fn.st_stage1_fused_train(q_, x_, v_, None, tmask, attn, frag, h=h, direction=direction, attn_drop=adrop, sub_drop=sdrop, v=val)
+                y, _x2 = Fn.st_stage1_fused_train(q_, x_, v_, None, tmask, attn, frag, h=h, direction=direction, attn_drop=adrop, sub_drop=sdrop, v=val)
         else:
             val = Fn.linear(v_.view(B * T * S, d), attn.linears[2].weight, attn.linears[2].bias).view(B, T, S, d)
             sc = Fn.st_scores(q_, v_.view(B, T * S, d))
