@@ -530,6 +530,69 @@ class FuseFn(Function):
         return (dscore, *dxs)
 
 
+class FuseDynFn(Function):
+    """The dynamic modality fusion of decoder.py:142-159 as ONE autograd node: score = cat(parts) W^T + b through per-part column blocks
+    (never the concat), out = sum_j softmax(score)[..., j] xs[j] with xs = parts[xs_idx[j]].  Every modality tensor feeds both the score
+    product and the weighted sum; as separate nodes that is two gradients per tensor and an accumulation launch by autograd for each
+    (three tensors x six layers).  Here the gradient of the weighted sum rides as the residual operand of the score product's dX launch."""
+
+    @staticmethod
+    def forward(ctx, W, bias, xs_idx, *parts):
+        d = parts[0].shape[-1]
+        p2 = [p.reshape(-1, d) for p in parts]
+        p2 = [p if p.is_contiguous() else p.contiguous() for p in p2]
+        score = None
+        for j, pj in enumerate(p2):                      # concat order of the reference: query, cap, spatial, temporal
+            score = ops.linear(pj, W[:, j * d:(j + 1) * d], bias if j == 0 else None, out=score, accumulate=j > 0)
+        xs = [p2[k] for k in xs_idx]
+        out = ops.fuse_modalities(score, xs)
+        ctx.save_for_backward(W, score, *p2)
+        ctx.cfg = (tuple(xs_idx), [tuple(p.shape) for p in parts], bias.dtype if bias is not None else None)
+        ctx.w_dst, ctx.b_dst = getattr(W, "_grad_view", None), (getattr(bias, "_acc32", None) if bias is not None else None)
+        return out.view(parts[0].shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        W, score, *p2 = ctx.saved_tensors
+        xs_idx, shapes, bdt = ctx.cfg
+        n, d = score.shape[-1], p2[0].shape[-1]
+        M = p2[0].shape[0]
+        dout = dout.reshape(M, d)
+        if not dout.is_contiguous():
+            dout = dout.contiguous()
+        xs = [p2[k] for k in xs_idx]
+        dscore = torch.empty_like(score)
+        dxs = [torch.empty_like(x) for x in xs]
+        xa = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        da = (C.c_void_p * n)(*[x.data_ptr() for x in dxs])
+        check(lib.bist_fuse_modalities_bwd(score.data_ptr(), xa, dout.data_ptr(), dscore.data_ptr(), da, M, n, d, dtype_code(score.dtype), _stream()),
+              "bist_fuse_modalities_bwd")
+        from_sum = {k: dxs[j] for j, k in enumerate(xs_idx)}
+        gw = ctx.w_dst
+        dW = None if gw is not None else torch.empty(W.shape, device=W.device, dtype=W.dtype)
+        grads = []
+        for j, pj in enumerate(p2):
+            Wj = W[:, j * d:(j + 1) * d]
+            dpj = torch.empty((M, d), device=pj.device, dtype=pj.dtype)
+            res = from_sum.get(j)
+            g_dx = ops.gemm_desc(dscore, Wj, dpj, M=M, N=d, K=n, a_rs=n, a_ks=1, b_rs=1, b_ks=Wj.stride(0), ldc=d, residual=res, ldr=d if res is not None else 0)
+            check(lib.bist_gemm(C.byref(g_dx), _stream()), "bist_gemm")
+            dst = gw[:, j * d:(j + 1) * d] if gw is not None else dW[:, j * d:(j + 1) * d]
+            g_dw = ops.gemm_desc(dscore, pj, dst, M=n, N=d, K=M, a_rs=1, a_ks=n, b_rs=1, b_ks=pj.stride(0), ldc=dst.stride(0),
+                                 residual=dst if gw is not None else None, ldr=dst.stride(0) if gw is not None else 0)
+            check(lib.bist_gemm(C.byref(g_dw), _stream()), "bist_gemm")
+            grads.append(dpj.view(shapes[j]))
+        db = None
+        if bdt is not None:
+            acc = ctx.b_dst if ctx.b_dst is not None else _f32_zeros((n,), dscore)
+            if ctx.b_dst is not None and ops.COLSUM_QUEUE is not None:
+                ops.COLSUM_QUEUE.append((dscore, acc, M, n))
+            else:
+                check(lib.bist_col_sum_acc(dscore.data_ptr(), acc.data_ptr(), M, n, n, dtype_code(dscore.dtype), _stream()), "bist_col_sum_acc")
+            db = None if ctx.b_dst is not None else _to_dtype_from_f32(acc, bdt)
+        return (dW, db, None, *grads)
+
+
 class AddFn(Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -154,6 +154,11 @@ def fuse_modalities(score, xs: Sequence[Tensor]):
     return ag.FuseFn.apply(score, *xs) if _grad() else ops.fuse_modalities(score, xs)
 
 
+def fuse_dyn(W, bias, parts, xs_idx):
+    """softmax(cat(parts) W^T + bias)-weighted sum of parts[xs_idx[j]] (decoder.py:142-159) as one autograd node (autograd.FuseDynFn)."""
+    return ag.FuseDynFn.apply(W, bias, tuple(xs_idx), *parts)
+
+
 def add(a, b):
     if _grad() and (a.requires_grad or b.requires_grad):
         return ag.AddFn.apply(a, b)

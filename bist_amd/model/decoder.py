@@ -116,6 +116,12 @@ class MultimodalDecoder8(nn.Module):
         d = parts[0].shape[-1]
         if W.shape[1] != d * len(parts):
             raise ValueError("vc_combine_W does not match the enabled modalities")
+        if (torch.is_grad_enabled() and self.c_N > 0 and args.t2s and args.s2t and parts[0].is_cuda and not spare
+                and all(p.is_contiguous() for p in parts)):
+            # training: the fusion logits and the weighted sum as ONE autograd node -- every modality tensor has one consumer here instead of
+            # two (autograd.FuseDynFn); parts = [query, cap, spatial, temporal], score column j -> temporal, spatial, cap (decoder.py:156-159)
+            ft["encoded_ft"] = Fn.fuse_dyn(W, bias, parts, (3, 2, 1))
+            return
         score = None
         for j, p in enumerate(parts):                      # concat order: query, cap, spatial, temporal
             score = Fn.linear(p, Fn.column_block(W, j, d), bias if j == 0 else None, out=score, accumulate=j > 0)
@@ -393,8 +399,13 @@ class MultimodalDecoder8(nn.Module):
                     in_ft = self.c_layers[l](in_ft, ft, b)
                     ft["cap_ft"], in_ft["cap"] = Fn.layernorm_res(in_ft["cap"], self.cap_out_norm.a_2, self.cap_out_norm.b_2, self.cap_out_norm.eps)                           # decoder.py:132
             if self.v_N > 0:
+                if torch.is_grad_enabled():
+                    ft["_bist_out_norms"] = (self.spatial_out_norm, self.temporal_out_norm)
                 in_ft = self.v_layers[l](in_ft, ft, b)
-                if "_z" in in_ft:
+                ft.pop("_bist_out_norms", None)
+                if in_ft.pop("_norms_done", False):
+                    pass                              # the layer applied the two output norms at the end of its direction chains (encoder.py)
+                elif "_z" in in_ft:
                     # both directions came back stacked (bist_amd/zbatch.py): the two output norms as ONE launch; the stacked tensor
                     # goes on to the next reasoning layer through the LayerNorm node (one consumer each, no accumulation pass)
                     normed, in_ft["_z"] = Z.layernorm_res(in_ft["_z"], self.spatial_out_norm, self.temporal_out_norm)   # decoder.py:127,129

@@ -459,6 +459,10 @@ class VidEncoderLayer4(nn.Module):
         self._v_ready = v_stream
 
         trace = self.__dict__.get("_bist_trace")      # debug hook: per-stage outputs (tests compare them with the reference's sublayer outputs)
+        # training: (spatial_out_norm, temporal_out_norm) of the layer loop (decoder.py:127,129), applied at the end of each direction's chain on
+        # that chain's stream; the stream then reaches the next layer THROUGH the norm's autograd node (the next layer's gradient is added
+        # inside the norm's backward kernel: one consumer per tensor, and the s2t chain's backward never leaves its stream)
+        out_norms = ft.get("_bist_out_norms") if (torch.is_grad_enabled() and t2s_on and s2t_on) else None
 
         def t2s_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
@@ -469,6 +473,8 @@ class VidEncoderLayer4(nn.Module):
             in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
             if trace is not None:
                 trace.update(t2s_self=x, t2s_stage1=y, t2s_stage2=z, t2s_ff=in_ft["t2s"])
+            if out_norms is not None:       # the layer loop's output norm of this stream, here on ITS stream; the stream goes on through the norm's node
+                ft["spatial_ft"], in_ft["t2s"] = Fn.layernorm_res(in_ft["t2s"], out_norms[0].a_2, out_norms[0].b_2, out_norms[0].eps)
 
         def s2t_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
@@ -479,6 +485,8 @@ class VidEncoderLayer4(nn.Module):
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
             if trace is not None:
                 trace.update(s2t_self=x, s2t_stage1=y, s2t_stage2=z, s2t_ff=in_ft["s2t"])
+            if out_norms is not None:
+                ft["temporal_ft"], in_ft["s2t"] = Fn.layernorm_res(in_ft["s2t"], out_norms[1].a_2, out_norms[1].b_2, out_norms[1].eps)
 
         pre_vid = ft.pop("_bist_pre_vid", None)
         if pre_vid is not None and not (concurrent and fused and Fn.EVAL_SCHED in (1, 2)):
@@ -546,6 +554,8 @@ class VidEncoderLayer4(nn.Module):
                 main.wait_stream(v_stream)
             self._v_ready = None
             self._v_event = None
+            if out_norms is not None:
+                in_ft["_norms_done"] = True
         else:
             ai = si = fi = 0
             if t2s_on:
@@ -553,6 +563,8 @@ class VidEncoderLayer4(nn.Module):
                 ai, si, fi = ai + 3, si + 4, fi + 1
             if s2t_on:
                 s2t_branch(ai, si, fi)
+            if out_norms is not None:
+                in_ft["_norms_done"] = True
         return in_ft
 
 
