@@ -117,6 +117,7 @@ SIGNATURES = {
     "bist_epilogue_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _I64, _I32, _F, C.c_uint64, _P, _I32, _P]),
     "bist_group_sum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
     "bist_group_sum_add": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I32, _P]),
+    "bist_group_sum_mask": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I64, C.POINTER(BistDrop), _I32, _P]),
     "bist_col_sum_acc": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P]),
     "bist_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _I64, _I64, _F, _P, _I64, _P, C.POINTER(BistDrop), _I32, _P]),
     "bist_col_sum_multi": (C.c_int, [C.POINTER(BistColSum), _I32, _I32, _P]),

@@ -642,6 +642,7 @@ class FanOutFn(Function):
     @staticmethod
     def forward(ctx, x, n):
         ctx.n = n
+        ctx.set_materialize_grads(False)        # aliases nobody read carry no gradient: None, not a zero tensor autograd would fill and we would sum
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
@@ -807,12 +808,17 @@ class St1FusedTrainFn(Function):
             if not dxp.is_contiguous() or dxp.dtype != dt:
                 dxp = dxp.to(dt).contiguous()
         dres = torch.empty((B * Lq, d), device=dev, dtype=dt)          # gradient of the un-expanded query: the sum over the groups (+ its other gradient)
-        check(lib.bist_group_sum_add(dy.data_ptr(), _ptr(dxp), dres.data_ptr(), B, G, Lq * d, dtype_code(dt), _stream()), "bist_group_sum_add")
         dz = dy
-        if sdrop is not None and sdrop[0] > 0:
-            dz = torch.empty_like(dy)
-            check(lib.bist_epilogue_bwd(dy.data_ptr(), dy.data_ptr(), dz.data_ptr(), M, d, d, d, d, ACT_NONE, sdrop[0], sdrop[1] & 0xFFFFFFFFFFFFFFFF,
-                                        _ptr(ops.DROP_CTR), dtype_code(dt), _stream()), "bist_epilogue_bwd")
+        if sdrop is not None and sdrop[0] > 0 and (Lq * d * dy.element_size()) % 16 == 0 and dy.data_ptr() % 16 == 0 and (dxp is None or dxp.data_ptr() % 16 == 0):
+            dz = torch.empty_like(dy)                                   # ... and the dropout-masked gradient, in the same pass over dy
+            check(lib.bist_group_sum_mask(dy.data_ptr(), _ptr(dxp), dres.data_ptr(), dz.data_ptr(), B, G, Lq * d, ops.drop_ref(sdrop), dtype_code(dt), _stream()),
+                  "bist_group_sum_mask")
+        else:
+            check(lib.bist_group_sum_add(dy.data_ptr(), _ptr(dxp), dres.data_ptr(), B, G, Lq * d, dtype_code(dt), _stream()), "bist_group_sum_add")
+            if sdrop is not None and sdrop[0] > 0:
+                dz = torch.empty_like(dy)
+                check(lib.bist_epilogue_bwd(dy.data_ptr(), dy.data_ptr(), dz.data_ptr(), M, d, d, d, d, ACT_NONE, sdrop[0], sdrop[1] & 0xFFFFFFFFFFFFFFFF,
+                                            _ptr(ops.DROP_CTR), dtype_code(dt), _stream()), "bist_epilogue_bwd")
         do, dwo, dbo = _linear_grads(o.view(M, d), wo, dz, 1.0, ctx.w_dst[1], ctx.b_dst[1], bdt, True, ctx.needs_input_grad[8], ctx.needs_input_grad[9])
         dsc = torch.empty((B, R, TS), device=dev, dtype=dt)
         dv = torch.empty((B, T, S, d), device=dev, dtype=dt)

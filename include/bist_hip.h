@@ -439,6 +439,11 @@ int bist_group_sum(const void* x, void* out, int64_t B, int32_t G, int64_t inner
 /* out[b, r] = add[b, r] + sum_g x[b, g, r]: the same with a second gradient of the un-expanded query (the one that arrives through its
  * next consumer, stage 2's sublayer) folded in, so that autograd launches no accumulation of its own.  add nullable.          */
 int bist_group_sum_add(const void* x, const void* add, void* out, int64_t B, int32_t G, int64_t inner, int32_t dtype, void* stream);
+/* The same pass also writes dz[b, g, r] = dropout-mask(drop) * x[b, g, r] / (1 - p), mask index = the element's flat index: with x = dY of
+ * the stage-1 sublayer (Y = query expanded over the groups + drop(W_o ctx + b_o), encoder.py:121,148 + modules.py:44) these are the
+ * gradient of the un-expanded query and the masked gradient the output projection's backward products read -- dY is read once.   */
+int bist_group_sum_mask(const void* x, const void* add, void* out, void* dz, int64_t B, int32_t G, int64_t inner, const BistDrop* drop,
+                        int32_t dtype, void* stream);
 /* out[n] += sum_m x[m, n]  (bias gradient, fp32 accumulator).                                    */
 int bist_col_sum_acc(const void* x, float* out, int64_t M, int32_t N, int64_t ldx, int32_t dtype, void* stream);
 /* Several bias gradients in one launch (the trainer queues the weight-gradient GEMMs' dz operands of a
