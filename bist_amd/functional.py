@@ -111,11 +111,12 @@ def st_stage1_pv(scores, v, tmask, *, B, T, S, Lq, h, dk, direction, drop=None):
 FUSED_TRAIN = os.environ.get("BIST_FUSED_TRAIN", "1") != "0"      # tuning aid: 0 = the training forward of stage 1 as four launches (value / score products, core, output projection)
 
 
-# The fused training launch with the value projection kept as a product of its OWN (0, default) or computed and saved by the launch (1).
-# Measured at BASELINE configs[1] (round 3): with the launch's own values the value projection's two backward products move from a side
-# stream onto each direction's critical chain, and the step is SLOWER than the four-launch form (13.0 vs 11.8 ms) although 1.5 ms of
-# kernel time are gone; kept off the chains the fused launch only shortens them.
-FUSED_TRAIN_OWN_V = os.environ.get("BIST_FUSED_TRAIN_OWN_V", "0") != "0"
+# Who projects the values of the fused training launch: 0 = a product of its own per direction (t2s: ahead on the caption stream, s2t: on
+# the main stream, as in the four-launch form); 1 = the launch itself, both directions (the value projection's two backward products then
+# sit on each direction's critical chain: measured 13.0 vs 11.8 ms per step at BASELINE configs[1], although 1.5 ms of kernel time are
+# gone); 2 = the launch itself for the s2t direction only -- that direction's value products leave the MAIN stream (which carries the
+# longer t2s chain: 49 groups against 32) for the shorter s2t chain's own stream.
+FUSED_TRAIN_OWN_V = int(os.environ.get("BIST_FUSED_TRAIN_OWN_V", "2"))
 
 
 def st_stage1_fused_train(qf, x, vft_a, vft_b, tmask, attn, frag, *, h, direction, attn_drop=None, sub_drop=None, v=None):

@@ -420,7 +420,8 @@ class VidEncoderLayer4(nn.Module):
             return self.train_value(take_t2s() if ai == 1 else take(), ai)
 
         train_fused = bool(ft.get("_bist_fused_train")) and torch.is_grad_enabled() and t2s_on and s2t_on
-        own_v = train_fused and Fn.FUSED_TRAIN_OWN_V
+        own_v = train_fused and Fn.FUSED_TRAIN_OWN_V == 1                 # both directions' values projected (and saved) by the fused launch
+        own_v_s2t = train_fused and Fn.FUSED_TRAIN_OWN_V in (1, 2)        # ... the s2t direction's
         per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V and "_bist_v_pre" not in ft and not own_v
         v_t2s = v_s2t = None
         pre = ft.pop("_bist_v_pre", None)                  # (v_t2s, v_s2t, event): projected ahead by the layer loop (decoder.py)
@@ -436,14 +437,15 @@ class VidEncoderLayer4(nn.Module):
         elif pre is not None:
             v_t2s, v_s2t, ev = pre
             main.wait_event(ev) if main is not None else torch.cuda.current_stream().wait_event(ev)
-            if v_s2t is None:
+            if v_s2t is None and not own_v_s2t:
                 v_s2t = self.train_value(take(), 4)
         elif per_branch_v:
             # training: one value GEMM per direction (each dV is a whole tensor), issued INSIDE its branch, so that the
             # projection and its two backward products run on that branch's stream
             pass
         elif torch.is_grad_enabled() and t2s_on and s2t_on:
-            v_t2s, v_s2t = self.train_value(take_t2s(), 1), self.train_value(take(), 4)
+            v_t2s = self.train_value(take_t2s(), 1)
+            v_s2t = None if own_v_s2t else self.train_value(take(), 4)
         elif concurrent:
             # (inference only: under autograd a third forked stream makes hipGraph capture of the training step crash in
             # the HIP runtime -- also with every side stream joined explicitly after backward)
@@ -479,7 +481,7 @@ class VidEncoderLayer4(nn.Module):
         def s2t_branch(ai, si, fi):
             x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
             y = self._stage1(ai + 1, si + 1, x, vft_s2t, branch_v(ai + 1) if per_branch_v else v_s2t, None, 1,
-                             train_fused=(take() if own_v else True) if train_fused else None)    # A4
+                             train_fused=(take() if own_v_s2t else True) if train_fused else None)    # A4
             x = self.__dict__.pop("_x_next", x)
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
             in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
