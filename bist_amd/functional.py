@@ -115,8 +115,13 @@ FUSED_TRAIN = os.environ.get("BIST_FUSED_TRAIN", "1") != "0"      # tuning aid: 
 # the main stream, as in the four-launch form); 1 = the launch itself, both directions (the value projection's two backward products then
 # sit on each direction's critical chain: measured 13.0 vs 11.8 ms per step at BASELINE configs[1], although 1.5 ms of kernel time are
 # gone); 2 = the launch itself for the s2t direction only -- that direction's value products leave the MAIN stream (which carries the
-# longer t2s chain: 49 groups against 32) for the shorter s2t chain's own stream.
-FUSED_TRAIN_OWN_V = int(os.environ.get("BIST_FUSED_TRAIN_OWN_V", "2"))
+# longer t2s chain: 49 groups against 32) for the shorter s2t chain's own stream: measured 18.8 vs 19.7 ms per step at T = 128 but
+# 10.02 vs 9.88 ms at T = 32, so -1 (default) = mode 2 from 64 frames, mode 0 below.
+FUSED_TRAIN_OWN_V = int(os.environ.get("BIST_FUSED_TRAIN_OWN_V", "-1"))
+
+
+def fused_train_own_v(T: int) -> int:
+    return FUSED_TRAIN_OWN_V if FUSED_TRAIN_OWN_V >= 0 else (2 if T >= 64 else 0)
 
 
 def st_stage1_fused_train(qf, x, vft_a, vft_b, tmask, attn, frag, *, h, direction, attn_drop=None, sub_drop=None, v=None):

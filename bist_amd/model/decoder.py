@@ -370,7 +370,7 @@ class MultimodalDecoder8(nn.Module):
         # Training: the value projections of layer l+1 (two big GEMMs that depend on the video tensor only) are issued on the
         # caption stream ahead of decoder layer l, and awaited through an event just before the stage-1 cores; their
         # backward products then run on that stream under the small-kernel chains of the two directions.
-        values_ahead = (torch.is_grad_enabled() and not (fused_train and Fn.FUSED_TRAIN_OWN_V == 1) and self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda and Fn.VALUES_AHEAD
+        values_ahead = (torch.is_grad_enabled() and not (fused_train and Fn.fused_train_own_v(ft["spatiotemporal_ft"].shape[1]) == 1) and self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda and Fn.VALUES_AHEAD
                         and getattr(self.args, "t2s", 1) and getattr(self.args, "s2t", 1) and "_bist_vft_fan" in ft)
 
         def issue_values(l):

@@ -420,8 +420,9 @@ class VidEncoderLayer4(nn.Module):
             return self.train_value(take_t2s() if ai == 1 else take(), ai)
 
         train_fused = bool(ft.get("_bist_fused_train")) and torch.is_grad_enabled() and t2s_on and s2t_on
-        own_v = train_fused and Fn.FUSED_TRAIN_OWN_V == 1                 # both directions' values projected (and saved) by the fused launch
-        own_v_s2t = train_fused and Fn.FUSED_TRAIN_OWN_V in (1, 2)        # ... the s2t direction's
+        own_mode = Fn.fused_train_own_v(vft.shape[1])
+        own_v = train_fused and own_mode == 1                 # both directions' values projected (and saved) by the fused launch
+        own_v_s2t = train_fused and own_mode in (1, 2)        # ... the s2t direction's
         per_branch_v = torch.is_grad_enabled() and t2s_on and s2t_on and Fn.BRANCH_V and "_bist_v_pre" not in ft and not own_v
         v_t2s = v_s2t = None
         pre = ft.pop("_bist_v_pre", None)                  # (v_t2s, v_s2t, event): projected ahead by the layer loop (decoder.py)
