@@ -648,6 +648,10 @@ class FanOutFn(Function):
     @staticmethod
     def backward(ctx, *grads):
         gs = [g for g in grads if g is not None]
+        for g in gs:                          # a gradient finished on another stream than its node's carries the event to wait on
+            ev = getattr(g, "_bist_ready", None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
         if not gs:
             return None, None
         if len(gs) == 1:
@@ -774,7 +778,7 @@ class St1FusedTrainFn(Function):
 
     @staticmethod
     def forward(ctx, qf, x, vft_a, vft_b, v_in, tmask, wv, bv, wo, bo, wv_frag, wo_frag, cfg):
-        h, direction, adrop, sdrop = cfg
+        h, direction, adrop, sdrop = cfg[:4]
         B, T, S, d = vft_a.shape
         K = T if direction == 0 else S
         m8 = _mask_u8(tmask.reshape(B, K)) if tmask is not None else None
@@ -791,7 +795,9 @@ class St1FusedTrainFn(Function):
     @staticmethod
     def backward(ctx, dy, dxp):
         qf, vft, v, p, o, m8, wv, wo = ctx.saved_tensors
-        (h, direction, adrop, sdrop), x_shape, bdt, qf_shape = ctx.cfg
+        cfg_, x_shape, bdt, qf_shape = ctx.cfg
+        h, direction, adrop, sdrop = cfg_[:4]
+        offload = bool(cfg_[4]) if len(cfg_) > 4 else False
         B, T, S, d = vft.shape
         dk = d // h
         G = S if direction == 0 else T
@@ -819,7 +825,22 @@ class St1FusedTrainFn(Function):
                 dz = torch.empty_like(dy)
                 check(lib.bist_epilogue_bwd(dy.data_ptr(), dy.data_ptr(), dz.data_ptr(), M, d, d, d, d, ACT_NONE, sdrop[0], sdrop[1] & 0xFFFFFFFFFFFFFFFF,
                                             _ptr(ops.DROP_CTR), dtype_code(dt), _stream()), "bist_epilogue_bwd")
-        do, dwo, dbo = _linear_grads(o.view(M, d), wo, dz, 1.0, ctx.w_dst[1], ctx.b_dst[1], bdt, True, ctx.needs_input_grad[8], ctx.needs_input_grad[9])
+        # Off the chain (offload: this direction runs on the MAIN stream of a several-stream step and the trainer owns the weight gradients):
+        # the output projection's weight gradient and the video tensor's gradient through the scores are not inputs of anything on this
+        # direction's chain -- they go to the caption / decoder stream; the video gradient carries the event its consumer (the one-pass sum of
+        # the video tensor's gradients, FanOutFn) waits on, the weight gradient is joined with every side stream at the end of the backward pass.
+        side = None
+        if offload and ctx.w_dst[1] is not None and ctx.b_dst[1] is not None and dev.type == "cuda":
+            from . import functional as Fn_
+            if Fn_.CONCURRENT:
+                side = Fn_.side_stream(1)
+        o2 = o.view(M, d)
+        dvft_a = torch.empty((B, TS, d), device=dev, dtype=dt)          # (escapes: allocated on this stream's pool)
+        if side is None:
+            do, dwo, dbo = _linear_grads(o2, wo, dz, 1.0, ctx.w_dst[1], ctx.b_dst[1], bdt, True, ctx.needs_input_grad[8], ctx.needs_input_grad[9])
+        else:
+            do, _, _ = _linear_grads(o2, wo, dz, 1.0, None, None, None, True, False, False)
+            dwo = dbo = None
         dsc = torch.empty((B, R, TS), device=dev, dtype=dt)
         dv = torch.empty((B, T, S, d), device=dev, dtype=dt)
         check(lib.bist_st_stage1_pv_bwd_p(p.data_ptr(), p.shape[-1], v.data_ptr(), _ptr(m8), do.data_ptr(), dsc.data_ptr(), dtype_code(dt), dv.data_ptr(),
@@ -828,14 +849,31 @@ class St1FusedTrainFn(Function):
         dqf = torch.empty((B, R, d), device=dev, dtype=dt)
         ops.gemm(dsc, vf, dqf, M=R, N=d, K=TS, a_rs=TS, a_ks=1, b_rs=1, b_ks=vf.stride(1), ldc=d, batch=(B, 1),
                  a_bs=(R * TS, 0), b_bs=(vf.stride(0), 0), c_bs=(R * d, 0))
-        dvft_a = torch.empty((B, TS, d), device=dev, dtype=dt)
-        ops.gemm(dsc, q3, dvft_a, M=TS, N=d, K=R, a_rs=1, a_ks=TS, b_rs=1, b_ks=q3.stride(1), ldc=d, batch=(B, 1),
-                 a_bs=(R * TS, 0), b_bs=(q3.stride(0), 0), c_bs=(TS * d, 0))
+
+        def video_grad():
+            ops.gemm(dsc, q3, dvft_a, M=TS, N=d, K=R, a_rs=1, a_ks=TS, b_rs=1, b_ks=q3.stride(1), ldc=d, batch=(B, 1),
+                     a_bs=(R * TS, 0), b_bs=(q3.stride(0), 0), c_bs=(TS * d, 0))
+        if side is None:
+            video_grad()
+        else:
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            for t_ in (dz, o2, dsc, q3, dvft_a):
+                t_.record_stream(side)              # read / written by the side stream after this call has released them
+            with torch.cuda.stream(side):
+                _linear_grads(o2, wo, dz, 1.0, ctx.w_dst[1], ctx.b_dst[1], bdt, False, True, ctx.needs_input_grad[9])
+                video_grad()
+                ev = torch.cuda.Event()
+                ev.record(side)
+            dvft_a._bist_ready = ev
+        gva = dvft_a.view(vft.shape)
+        if getattr(dvft_a, "_bist_ready", None) is not None:
+            gva._bist_ready = dvft_a._bist_ready
         if not ctx.own_v:            # the value projection is a product of its own (another stream): its backward takes dV from here
-            return (dqf.view(qf_shape), dres.view(x_shape), dvft_a.view(vft.shape), None, dv, None, None, None, dwo, dbo, None, None, None)
+            return (dqf.view(qf_shape), dres.view(x_shape), gva, None, dv, None, None, None, dwo, dbo, None, None, None)
         dvft_b, dwv, dbv = _linear_grads(vft.view(B * TS, d), wv, dv.view(B * TS, d), 1.0, ctx.w_dst[0], ctx.b_dst[0], bdt, True,
                                          ctx.needs_input_grad[6], ctx.needs_input_grad[7])
-        return (dqf.view(qf_shape), dres.view(x_shape), dvft_a.view(vft.shape), dvft_b.view(vft.shape), None, None, dwv, dbv, dwo, dbo, None, None, None)
+        return (dqf.view(qf_shape), dres.view(x_shape), gva, dvft_b.view(vft.shape), None, None, dwv, dbv, dwo, dbo, None, None, None)
 
 
 class StStage2Fn(Function):

@@ -124,12 +124,15 @@ def fused_train_own_v(T: int) -> int:
     return FUSED_TRAIN_OWN_V if FUSED_TRAIN_OWN_V >= 0 else (2 if T >= 64 else 0)
 
 
-def st_stage1_fused_train(qf, x, vft_a, vft_b, tmask, attn, frag, *, h, direction, attn_drop=None, sub_drop=None, v=None):
+OFFLOAD_T2S = os.environ.get("BIST_OFFLOAD_T2S", "1") != "0"      # tuning aid: t2s stage-1 backward products that feed nothing on its chain go to the caption / decoder stream
+
+
+def st_stage1_fused_train(qf, x, vft_a, vft_b, tmask, attn, frag, *, h, direction, attn_drop=None, sub_drop=None, v=None, offload=False):
     """Training stage 1 of one direction as one launch forward (autograd.St1FusedTrainFn); attn: the MultiHeadedAttention holding
     linears[2] (values) and linears[3] (output); frag = (W_v, W_o) in fragment order; v: the value projection when the caller runs it
     as a product of its own (vft_b is then unused).  -> (y [B,G,Lq,d], x' = x again for its next consumer)"""
     return ag.St1FusedTrainFn.apply(qf, x, vft_a, vft_b, v, tmask, attn.linears[2].weight, attn.linears[2].bias, attn.linears[3].weight,
-                                    attn.linears[3].bias, frag[0], frag[1], (h, direction, attn_drop, sub_drop))
+                                    attn.linears[3].bias, frag[0], frag[1], (h, direction, attn_drop, sub_drop, bool(offload and OFFLOAD_T2S)))
 
 
 def st_stage2(q2f, y, gmask, *, h, drop=None):

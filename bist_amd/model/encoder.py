@@ -174,7 +174,8 @@ class VidEncoderLayer4(nn.Module):
             if v is not None and v_event is not None:
                 torch.cuda.current_stream().wait_event(v_event)
             y, xnext = Fn.st_stage1_fused_train(qf, xr, vft, train_fused if v is None else None, tmask, attn, self.frag_train(ai), h=h, direction=direction,
-                                                attn_drop=adrop, sub_drop=(kw["drop_p"], kw["drop_seed"]) if kw else None, v=v)
+                                                attn_drop=adrop, sub_drop=(kw["drop_p"], kw["drop_seed"]) if kw else None, v=v,
+                                                offload=direction == 0 and bool(self.__dict__.get("_offload_main")))
             self.__dict__["_x_next"] = xnext       # x again, for stage 2 (one consumer per tensor: no accumulation launch by autograd)
             return y
         if v is None:           # inference: value projection, scores, softmax, P.V, output projection and residual in one launch
@@ -551,7 +552,11 @@ class VidEncoderLayer4(nn.Module):
             side.wait_stream(main)                    # fork: the two directions share only read-only inputs
             with torch.cuda.stream(side):
                 s2t_branch(3, 4, 1)
-            t2s_branch(0, 0, 0)
+            self.__dict__["_offload_main"] = True     # the t2s chain runs on the main stream: its off-chain backward products may leave it
+            try:
+                t2s_branch(0, 0, 0)
+            finally:
+                self.__dict__["_offload_main"] = False
             main.wait_stream(side)                    # join
             if v_stream is not None:
                 main.wait_stream(v_stream)
