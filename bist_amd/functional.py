@@ -124,7 +124,11 @@ def fused_train_own_v(T: int) -> int:
     return FUSED_TRAIN_OWN_V if FUSED_TRAIN_OWN_V >= 0 else (2 if T >= 64 else 0)
 
 
-OFFLOAD_T2S = os.environ.get("BIST_OFFLOAD_T2S", "1") != "0"      # tuning aid: t2s stage-1 backward products that feed nothing on its chain go to the caption / decoder stream
+# tuning aid: 1 = the t2s stage-1 backward products that feed nothing on its chain (output projection's weight gradient, video gradient through
+# the scores: 54 us per layer) go to the caption / decoder stream, their consumer waiting on an event.  Measured 11.57 vs 9.94 ms per step
+# (T = 128: 20.9 vs 18.8): a fork per layer and six extra event waits cost far more than the launches they move -- every cross-stream
+# dependency of the replayed hipGraph is paid on the critical path.  Off.
+OFFLOAD_T2S = os.environ.get("BIST_OFFLOAD_T2S", "0") != "0"
 
 
 def st_stage1_fused_train(qf, x, vft_a, vft_b, tmask, attn, frag, *, h, direction, attn_drop=None, sub_drop=None, v=None, offload=False):
