@@ -377,9 +377,7 @@ class MultimodalDecoder8(nn.Module):
             main_, side_ = torch.cuda.current_stream(), Fn.side_stream(1)
             fan = ft.get("_bist_vftp_fan") or ft["_bist_vft_fan"]
             va = fan.take()
-            if l == 0:
-                side_.wait_stream(main_)     # (later layers: the stream is already ordered after the input projection -- every cross-stream
-                                             #  dependency of the replayed step is paid on its critical path, so none is issued that orders nothing)
+            side_.wait_stream(main_)
             both_v = Z.ENABLED                                    # lock-step layer: its stage-1 node consumes both on the main stream
             vb = ft["_bist_vft_fan"].take() if both_v else None
             with torch.cuda.stream(side_):
@@ -396,8 +394,7 @@ class MultimodalDecoder8(nn.Module):
             fork_cap = self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda
             if fork_cap:                     # the caption reasoning layer is independent of the visual one
                 main, side = torch.cuda.current_stream(), Fn.side_stream(1)
-                if l == 0 or not (torch.is_grad_enabled() and Fn.PIPELINE_DECODER):
-                    side.wait_stream(main)   # (training, later layers: this stream's last work -- decoder layer l - 1 -- already waited for the main stream)
+                side.wait_stream(main)
                 with torch.cuda.stream(side):
                     in_ft = self.c_layers[l](in_ft, ft, b)
                     ft["cap_ft"], in_ft["cap"] = Fn.layernorm_res(in_ft["cap"], self.cap_out_norm.a_2, self.cap_out_norm.b_2, self.cap_out_norm.eps)                           # decoder.py:132
