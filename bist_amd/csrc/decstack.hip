@@ -49,6 +49,7 @@ struct DecArgs {
                                  // [4] STICKY error flag (a barrier timed out)
   int dbg;                       // BIST_DECSTACK_DBG (development): 1 = agent-scope acquire after every barrier
   unsigned long long* stamps;    // BIST_DECSTACK_STAMPS (development): s_memtime stamps of workgroup 0 in layer 0, or null
+  float* pbuf;                   // head-local form: per-head partial output projections, f32 [2][8 heads][16 rows][512]
 };
 
 __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
@@ -485,6 +486,242 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
   }
 }
 
+// =====================================================================================================================
+// Head-local form for R <= 16 rows (one decode step at a time: R = hypotheses): SIX grid barriers per layer instead of fourteen.
+// The column-split form above needs three barriers per attention sublayer because every product's columns are dealt to the 32
+// workgroups: projection -> (barrier) -> per-head core -> (barrier) -> output projection -> (barrier) -> next LayerNorm.  With one
+// 16-row tile there are only 8 core units anyway, so here workgroup hh < 8 OWNS head hh through a whole attention sublayer:
+//     x <- x + b_o + sum of the previous sublayer's 8 per-head partial outputs     (every workgroup, redundantly; x lives in LDS)
+//     LN(x) -> q_hh (+ k_hh, v_hh of the new rows for the self-attention) -> core of head hh -> ctx_hh [R x 64]
+//     partial output projection  Y_hh = ctx_hh . W_o[:, 64 hh .. 64 hh + 63]^T  [R x 512] (K = 64), f32, to pbuf       -> ONE barrier
+// and the sum over the heads happens at the head of the next phase.  The feed-forward block keeps its two column-split phases (all
+// 32 workgroups: 64 hidden columns each, then 16 output columns each over K = 2048).  Hand-offs inside a workgroup (q, k / v rows,
+// context rows) go through L2 as in the column-split form: store, drain, workgroup barrier, sc1 load.
+// =====================================================================================================================
+__device__ __forceinline__ void st16f(float* p, const f32x4& v, bool wt) {
+  st8(p, make_uint2(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1])), wt);
+  st8(p + 2, make_uint2(__builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])), wt);
+}
+
+// LN of the R <= 16 rows held in LDS (xs: [16][512] bf16, linear) into the swizzled image rows 0..15 (rows >= R zero): four rows per wave
+__device__ __forceinline__ void layernorm_lds_to_image(const char* xs, const bf16_t* ga, const bf16_t* gb, char* img, int R, int w, int lane) {
+  const int sub = lane & 15, rq = lane >> 4, row = w * 4 + rq;
+  const bool live = row < R;
+  uint4 q[4], qa[4], qb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    q[c] = *reinterpret_cast<const uint4*>(xs + min(row, R - 1) * 1024 + (sub * 4 + c) * 16);
+    qa[c] = reinterpret_cast<const uint4*>(ga)[sub * 4 + c]; qb[c] = reinterpret_cast<const uint4*>(gb)[sub * 4 + c];
+  }
+  float v[32];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t u[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[c * 8 + 2 * e] = bf_lo(u[e]); v[c * 8 + 2 * e + 1] = bf_hi(u[e]); sum += v[c * 8 + 2 * e] + v[c * 8 + 2 * e + 1]; }
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum * (1.f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 32; ++e) { const float dlt = v[e] - mean; ss += dlt * dlt; }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+  const float inv = 1.f / (sqrtf(ss * (1.f / (D - 1))) + 1e-6f);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t ua[4] = {qa[c].x, qa[c].y, qa[c].z, qa[c].w}, ub[4] = {qb[c].x, qb[c].y, qb[c].z, qb[c].w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float y0 = live ? bf_lo(ua[e]) * (v[c * 8 + 2 * e] - mean) * inv + bf_lo(ub[e]) : 0.f;
+      const float y1 = live ? bf_hi(ua[e]) * (v[c * 8 + 2 * e + 1] - mean) * inv + bf_hi(ub[e]) : 0.f;
+      o[e] = pack2(y0, y1);
+    }
+    *reinterpret_cast<uint4*>(img_at(img, row, sub * 4 + c)) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ __launch_bounds__(NT, 1) void decstack_head_kernel(const DecArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* img = smem;                       // image rows 0..15 [16][1024 B]
+  char* xs = smem + 16 * 1024;            // the residual stream of the R rows, bf16 [16][512] linear (every workgroup keeps its own copy)
+  char* part = smem + 64 * 1024;          // reduce_tiles scratch
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kg = lane >> 4;
+  if (blockIdx.x & 7) return;
+  const int wg = blockIdx.x >> 3, R = a.R;
+  const bool headwg = wg < H;
+  const int hh = wg & 7;
+  bool wt = true;
+  __shared__ unsigned same_xcd;
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 15u;
+    __hip_atomic_fetch_or((gu32*)a.sync + 2, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  unsigned phase = 0;
+  bf16_t* const ctx = a.hbuf;                                   // context rows [16][512] (attention sublayers); hidden rows in the FFN
+  bf16_t* const xout = a.xbuf[(5 * a.nl - 1) & 1];              // the buffer the caller reads the result from; written once per layer
+  uint4 wr[16];
+  f32x4 acc[4][4];
+  auto a_img = [&](int mt, int ks) { return img_frag(img, mt, ks, x, kg); };
+  auto bias4 = [&](const bf16_t* b, int col0, float (&bv)[4]) {
+    const uint2 q = *reinterpret_cast<const uint2*>(b + col0 + 4 * kg);
+    bv[0] = bf_lo(q.x); bv[1] = bf_hi(q.x); bv[2] = bf_lo(q.y); bv[3] = bf_hi(q.y);
+  };
+  auto store_rows = [&](bf16_t* out, int ld, int col0, const float (&v)[4]) {          // lane (x = row, kg): columns col0 + 4 kg ..
+    if (x < R) st8(out + (long)x * ld + col0 + 4 * kg, make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3])), wt);
+  };
+  // x rows into LDS: from global bf16 rows (mode 0) or x += bias + the 8 per-head partials of the previous sublayer (mode 1).  Thread
+  // (half = tid >> 7, c4 = tid & 127) walks rows half, half + 2, ..: 4 consecutive columns each.
+  auto load_x = [&](const bf16_t* src) {
+    for (int row = tid >> 7; row < R; row += 2) {
+      const int c = (tid & 127) * 4;
+      const uint2 q = ld8(src + (long)row * D + c);
+      *reinterpret_cast<uint2*>(xs + row * 1024 + c * 2) = q;
+    }
+  };
+  auto add_partials = [&](const float* P, const bf16_t* bo) {
+    const int c = (tid & 127) * 4;
+    const uint2 bq = *reinterpret_cast<const uint2*>(bo + c);
+    for (int row = tid >> 7; row < R; row += 2) {
+      uint4 pq[H];
+#pragma unroll
+      for (int p = 0; p < H; ++p) pq[p] = ld16(P, ((long)(p * 16 + row) * D + c) * 4);
+      const uint2 xo = *reinterpret_cast<const uint2*>(xs + row * 1024 + c * 2);
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < H; ++p) {
+        s4[0] += __builtin_bit_cast(float, pq[p].x); s4[1] += __builtin_bit_cast(float, pq[p].y);
+        s4[2] += __builtin_bit_cast(float, pq[p].z); s4[3] += __builtin_bit_cast(float, pq[p].w);
+      }
+      *reinterpret_cast<uint2*>(xs + row * 1024 + c * 2) =
+          make_uint2(pack2(s4[0] + bf_lo(bq.x) + bf_lo(xo.x), s4[1] + bf_hi(bq.x) + bf_hi(xo.x)),
+                     pack2(s4[2] + bf_lo(bq.y) + bf_lo(xo.y), s4[3] + bf_hi(bq.y) + bf_hi(xo.y)));
+    }
+  };
+  // this wave's 8 column tiles (16 (8 w + t) ..) x 2 k-steps of W_o's column block of head hh: lane (x, kg) holds W_o[col][64 hh + 32 ks + 8 kg ..]
+  auto load_wo = [&](const bf16_t* Wo) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        wr[t * 2 + ks] = *reinterpret_cast<const uint4*>(Wo + (long)(16 * (8 * w + t) + x) * D + hh * 64 + 32 * ks + 8 * kg);
+  };
+  auto head_sync = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
+
+  if (headwg) load_w<4, 4>(wr, a.layers[0].Wqkv, D, hh * 64, w, x, kg);                  // q rows of head hh, first layer
+  load_x(a.x_in);
+  __syncthreads();
+  int pb = 0;                                                   // partial buffer this phase WRITES
+#pragma unroll 1
+  for (int l = 0; l < a.nl; ++l) {
+    const DecLayerDev* Lp = a.layers + l;
+    if (l > 0) { load_x(xout); __syncthreads(); }
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {          // attention sublayers: 0 causal self-attention, 1..3 history / query / fused modalities
+      if (j > 0) { add_partials(a.pbuf + (long)(pb ^ 1) * (H * 16 * D), Lp->bo[j - 1]); __syncthreads(); }
+      float* const Pw = a.pbuf + (long)pb * (H * 16 * D) + (long)hh * (16 * D);
+      if (headwg) {
+        layernorm_lds_to_image(xs, Lp->ln_a[j], Lp->ln_b[j], img, R, w, lane);
+        __syncthreads();
+        if (j == 0) {
+          bf16_t* const kc = a.kcache + (long)l * (64 * D) + (long)a.slot0 * D;
+          bf16_t* const vc = a.vcache + (long)l * (64 * D) + (long)a.slot0 * D;
+#pragma unroll 1
+          for (int part3 = 0; part3 < 3; ++part3) {               // q, k, v rows of head hh in the packed [q; k; v] projection
+            partial_product<4, 4>(acc, wr, a_img, 1, w);
+            if (part3 < 2) load_w<4, 4>(wr, Lp->Wqkv, D, (part3 + 1) * D + hh * 64, w, x, kg);
+            bf16_t* dst = part3 == 0 ? a.qbuf : (part3 == 1 ? kc : vc);
+            const bf16_t* bqkv = Lp->bqkv + part3 * D;
+            reduce_tiles<4>(acc, part, 1, w, lane, [&](int t, int mt, const f32x4& v) {
+              const int col0 = hh * 64 + 16 * t;
+              float bv[4]; bias4(bqkv, col0, bv);
+              const float o[4] = {v[0] + bv[0], v[1] + bv[1], v[2] + bv[2], v[3] + bv[3]};
+              store_rows(dst, D, col0, o);
+            });
+          }
+        } else {
+          partial_product<4, 4>(acc, wr, a_img, 1, w);
+          const bf16_t* bq = Lp->bq[j - 1];
+          reduce_tiles<4>(acc, part, 1, w, lane, [&](int t, int mt, const f32x4& v) {
+            const int col0 = hh * 64 + 16 * t;
+            float bv[4]; bias4(bq, col0, bv);
+            const float o[4] = {v[0] + bv[0], v[1] + bv[1], v[2] + bv[2], v[3] + bv[3]};
+            store_rows(a.qbuf, D, col0, o);
+          });
+        }
+        load_wo(Lp->Wo[j]);                                        // flies under the core
+        head_sync();                                               // q (and this step's k / v rows) are in L2
+        if (j == 0) core_unit<true>(a.qbuf, a.kcache + (long)l * (64 * D), a.vcache + (long)l * (64 * D), a.smask, a.LkS, a.slot0 + R, a.LkS, ctx, R, hh, 0, w, x, kg, wt);
+        else core_unit<false>(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], 0, Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, hh, 0, w, x, kg, wt);
+        head_sync();                                               // the context rows of head hh are in L2
+        {
+          const int rowc = min(x, R - 1);
+          const uint4 c0 = ld16(ctx, ((long)rowc * D + hh * 64 + 8 * kg) * 2), c1 = ld16(ctx, ((long)rowc * D + hh * 64 + 32 + 8 * kg) * 2);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            o = mfma16(wr[t * 2], c0, o);
+            o = mfma16(wr[t * 2 + 1], c1, o);                      // Y_hh^T[col 4kg + r of tile][row x]
+            if (x < R) st16f(Pw + (long)x * D + 16 * (8 * w + t) + 4 * kg, o, wt);
+          }
+        }
+        if (j < 3) load_w<4, 4>(wr, Lp->Wq[j], D, hh * 64, w, x, kg);      // the next sublayer's query rows of head hh fly over the barrier
+      }
+      if (j == 3) load_w<4, 4>(wr, Lp->W1, D, wg * 64, w, x, kg);          // (every workgroup) the feed-forward block's first product
+      grid_barrier(a.sync, ++phase * NWG, a.dbg);
+      if (phase == 1) {
+        if (tid == 0) same_xcd = __builtin_popcount(__hip_atomic_load((gu32*)a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
+        __syncthreads();
+        wt = !(same_xcd && !(a.dbg & 4));
+        if (tid == 0 && wg == 0) __hip_atomic_store((gu32*)a.sync + 5, wt ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      pb ^= 1;
+    }
+    // ---------------- feed-forward block: hidden columns 64 wg .. (barrier), output columns 16 wg .. (barrier) ----------------
+    add_partials(a.pbuf + (long)(pb ^ 1) * (H * 16 * D), Lp->bo[3]);
+    __syncthreads();
+    layernorm_lds_to_image(xs, Lp->ln_a[4], Lp->ln_b[4], img, R, w, lane);
+    __syncthreads();
+    partial_product<4, 4>(acc, wr, a_img, 1, w);
+    load_w<1, 16>(wr, Lp->W2, 4 * D, wg * 16, w, x, kg);
+    {
+      const bf16_t* b1 = Lp->b1;
+      reduce_tiles<4>(acc, part, 1, w, lane, [&](int t, int mt, const f32x4& v) {
+        const int col0 = wg * 64 + 16 * t;
+        float bv[4]; bias4(b1, col0, bv);
+        const float o[4] = {fmaxf(v[0] + bv[0], 0.f), fmaxf(v[1] + bv[1], 0.f), fmaxf(v[2] + bv[2], 0.f), fmaxf(v[3] + bv[3], 0.f)};
+        store_rows(a.hbuf, 4 * D, col0, o);
+      });
+    }
+    grid_barrier(a.sync, ++phase * NWG, a.dbg);
+    {
+      auto a_glob = [&](int mt, int ks) { return ld16(a.hbuf, ((long)min(x, R - 1) * (4 * D) + 32 * ks + 8 * kg) * 2); };
+      partial_product_glob<16, true>(acc, wr, a_glob, 1, w);
+      if (headwg && l + 1 < a.nl) load_w<4, 4>(wr, Lp[1].Wqkv, D, hh * 64, w, x, kg);
+      const bf16_t* b2 = Lp->b2;
+      reduce_tiles<1>(acc, part, 1, w, lane, [&](int t, int mt, const f32x4& v) {
+        const int col0 = wg * 16, row = min(x, R - 1);
+        float bv[4]; bias4(b2, col0, bv);
+        const uint2 xr = *reinterpret_cast<const uint2*>(xs + row * 1024 + (col0 + 4 * kg) * 2);
+        const float o[4] = {v[0] + bv[0] + bf_lo(xr.x), v[1] + bv[1] + bf_hi(xr.x), v[2] + bv[2] + bf_lo(xr.y), v[3] + bv[3] + bf_hi(xr.y)};
+        store_rows(xout, D, col0, o);
+      });
+    }
+    grid_barrier(a.sync, ++phase * NWG, a.dbg);
+  }
+  if (tid == 0) {
+    gu32* sync = (gu32*)a.sync;
+    if (__hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NWG - 1) {
+      __hip_atomic_store(sync + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 }  // namespace
 
 // The kernel's NWG workers (every 8th block of the grid, i.e. one XCD; each holds 128 KiB of LDS = one per CU) must be resident
@@ -511,18 +748,26 @@ extern "C" int64_t bist_decoder_layer_desc_bytes(void) { return (int64_t)sizeof(
 
 extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, const void* x_in, void* xbuf0, void* xbuf1, void* qbuf,
                                       void* kcache, void* vcache, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, int32_t slot0,
-                                      void* sync, int32_t dtype, void* stream) {
+                                      void* sync, float* pbuf, int32_t dtype, void* stream) {
   BIST_REQUIRE(layers_dev && x_in && xbuf0 && xbuf1 && qbuf && kcache && vcache && hbuf && self_mask && sync, "bist_decoder_stack_fwd: null pointer");
   BIST_REQUIRE(dtype == BIST_BF16 && n_layers >= 1 && R >= 1 && R <= 64 && slot0 >= 0 && slot0 + R <= 64 && LkS >= slot0 + R && LkS <= 64 && LkS % 32 == 0,
                "bist_decoder_stack_fwd: bf16, 1..64 rows, slots slot0 .. slot0 + R - 1 inside the LkS (32 or 64) key slots");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   BIST_REQUIRE(bist_decoder_stack_device_ok(), "bist_decoder_stack_fwd: this device cannot keep the kernel's %d workgroups resident on one XCD", NWG);
-  BIST_LDS_OPTIN(&decstack_kernel, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
   DecArgs a{(const DecLayerDev*)layers_dev, n_layers, (const bf16_t*)x_in, {(bf16_t*)xbuf0, (bf16_t*)xbuf1}, (bf16_t*)qbuf, (bf16_t*)kcache,
-            (bf16_t*)vcache, slot0, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, nullptr};
+            (bf16_t*)vcache, slot0, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, nullptr, pbuf};
   a.dbg = bist_dev_dbg(1);
   a.stamps = bist_dev_stamps(1);
-  hipLaunchKernelGGL(decstack_kernel, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
+  // one 16-row tile (a decode step at a time: R = hypotheses) and a partial buffer: the head-local form, 6 grid barriers per layer instead of 14
+  static const int colsplit = [] { const char* e = getenv("BIST_DECSTACK_COLSPLIT"); return e ? atoi(e) : 0; }();      // tuning aid
+  if (R <= 16 && pbuf && !colsplit) {
+    BIST_REQUIRE((reinterpret_cast<uintptr_t>(pbuf) & 15) == 0, "bist_decoder_stack_fwd: pbuf must be 16-byte aligned");
+    BIST_LDS_OPTIN(&decstack_head_kernel, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
+    hipLaunchKernelGGL(decstack_head_kernel, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
+  } else {
+    BIST_LDS_OPTIN(&decstack_kernel, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
+    hipLaunchKernelGGL(decstack_kernel, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
+  }
   BIST_LAUNCH_CHECK("bist_decoder_stack_fwd");
   bist_count_launch(BIST_K_DECSTACK);
   return BIST_OK;

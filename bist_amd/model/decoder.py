@@ -161,7 +161,8 @@ class MultimodalDecoder8(nn.Module):
             z = lambda *shape, dt=dtype: torch.zeros(*shape, device=dev, dtype=dt)
             nl = len(self.layers)
             st = {"x0": z(64, 512), "x1": z(64, 512), "q": z(64, 512), "kc": z(nl, 64, 512), "vc": z(nl, 64, 512), "h": z(64, 2048),
-                  "sync": z(8, dt=torch.int32), "masks": {}, "kv": None}
+                  "sync": z(8, dt=torch.int32), "masks": {}, "kv": None,
+                  "p": z(2, 8, 16, 512, dt=torch.float32)}       # per-head partial output projections of the head-local form (R <= 16 rows)
             self.__dict__["_bist_dec_state"] = st
         return st
 

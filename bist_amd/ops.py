@@ -491,7 +491,7 @@ def decoder_stack(desc: Tensor, n_layers: int, x_in: Tensor, bufs: dict, self_ma
         raise ValueError("bist_amd.decoder_stack: caches / mask do not fit the call")
     check(lib.bist_decoder_stack_fwd(desc.data_ptr(), n_layers, x_in.data_ptr(), bufs["x0"].data_ptr(), bufs["x1"].data_ptr(),
                                      bufs["q"].data_ptr(), bufs["kc"].data_ptr(), bufs["vc"].data_ptr(), bufs["h"].data_ptr(),
-                                     self_mask.data_ptr(), R, LkS, slot0, bufs["sync"].data_ptr(), dtype_code(x_in.dtype), _stream()),
+                                     self_mask.data_ptr(), R, LkS, slot0, bufs["sync"].data_ptr(), _ptr(bufs.get("p")), dtype_code(x_in.dtype), _stream()),
           "bist_decoder_stack_fwd")
     return bufs["x0" if (5 * n_layers - 1) % 2 == 0 else "x1"][:R]       # the residual stream ping-pongs: write k lands in buffer (k - 1) % 2
 

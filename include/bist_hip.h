@@ -325,9 +325,14 @@ typedef struct BistDecLayer {
 } BistDecLayer;
 int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk_max, int32_t dtype);
 int64_t bist_decoder_layer_desc_bytes(void);
+/* pbuf (nullable): f32 [2][8][16][512] scratch (256 KiB).  With it and R <= 16 rows (one decode step at a time) the launch takes the
+ * HEAD-LOCAL form: workgroup hh < 8 owns head hh through a whole attention sublayer (LayerNorm, its 64 query columns -- and the new
+ * rows' key / value columns of the self-attention --, the core, and a PARTIAL output projection over its 64 context columns, K = 64,
+ * f32 into pbuf); the sum over the heads, the bias and the residual are taken at the head of the next phase by every workgroup.  One
+ * grid barrier per attention sublayer instead of three: 6 per layer instead of 14.                                                */
 int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, const void* x_in, void* xbuf0, void* xbuf1, void* qbuf,
                            void* kcache, void* vcache, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, int32_t slot0,
-                           void* sync, int32_t dtype, void* stream);
+                           void* sync, float* pbuf, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 2 of both directions (encoder.py:125-134 / 152-165): query position (b,i) attends,

@@ -508,3 +508,42 @@ def test_device_side_beam_update_equals_the_host_beam_loop(hip):
             assert float(a[1]) == float(b[1])
     store = model.__dict__.get("_bist_step_graphs", {})
     assert any(isinstance(k, tuple) and k[0] == "beam_state" for k in store), "the device-side beam path was not taken"
+
+
+def test_head_local_decoder_kernel_equals_the_column_split_kernel(hip):
+    """The persistent decoder kernel's head-local form (R <= 16 rows: workgroup hh owns head hh through an attention sublayer and writes a
+    partial output projection; 6 grid barriers per layer) against its column-split form (14 barriers per layer; taken when the caller
+    passes no partial buffer) on the same decode steps: row counts 1, 5, 14, 16, with and without earlier rows in the self-attention
+    pools.  Same arithmetic up to the order of the f32 sums over the heads: outputs within 3e-2 (bf16 residual stream), finite."""
+    from bist_amd.data.batch import subsequent_mask
+    from bist_amd.model.decode import _turn_for_rows
+    M, Batch = hip
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=3, nb_venc_blocks=3, nb_cenc_blocks=3)
+    V, C = 300, 256
+    ob = O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=61)
+    model, _ = build_model(M, cfg, V, C, torch.bfloat16)
+    b = to_batch(Batch, ob, torch.bfloat16)
+    dec = model.mutlimodal_decoder
+    with torch.no_grad():
+        ft = model.encode(b)
+        b.trg, b.trg_mask = torch.full((1, 1), O.SOS_ID, device="cuda"), subsequent_mask(1, "cuda")
+        ft = model.decode(b, ft)
+        st = dec.__dict__["_bist_dec_state"]
+        for n, Lt in ((1, 1), (5, 1), (2, 7), (4, 4)):
+            g = torch.Generator().manual_seed(10 * n + Lt)
+            trg = torch.randint(4, V, (n, Lt), generator=g).cuda()
+            outs = {}
+            for head_local in (True, False):
+                saved = st.get("p")
+                if not head_local:
+                    st["p"] = None
+                try:
+                    bn, fn = _turn_for_rows(b, ft, n, {})
+                    bn.trg, bn.trg_mask = trg, subsequent_mask(Lt, "cuda")
+                    outs[head_local] = model.decode(bn, dict(fn))["decoded_text"].float().cpu()
+                finally:
+                    st["p"] = saved
+            assert torch.isfinite(outs[True]).all()
+            err = (outs[True] - outs[False]).abs().max().item()
+            assert err <= 3e-2, (n, Lt, err)
+        dec.check_decode_errors()

@@ -630,7 +630,7 @@ def test_new_entry_points_refuse_calls_outside_their_envelope():
     def stack(R, LkS, slot0):
         return lib.bist_decoder_stack_fwd(desc.data_ptr(), 1, bufs["x0"].data_ptr(), bufs["x0"].data_ptr(), bufs["x1"].data_ptr(), bufs["q"].data_ptr(),
                                           bufs["kc"].data_ptr(), bufs["vc"].data_ptr(), bufs["h"].data_ptr(), z(64, 64, dt=torch.uint8).data_ptr(),
-                                          R, LkS, slot0, bufs["sync"].data_ptr(), 1, st)
+                                          R, LkS, slot0, bufs["sync"].data_ptr(), None, 1, st)
     assert stack(5, 64, 60) != 0 and b"slot" in lib.bist_last_error()          # slots 60..64 leave the pool
     assert stack(5, 48, 0) != 0                                                  # LkS must be 32 or 64
     assert stack(40, 32, 0) != 0                                                 # more rows than key slots
