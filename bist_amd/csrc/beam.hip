@@ -5,7 +5,7 @@
 //   beam_topk_kernel    one workgroup per hypothesis row: lp_vec = logp[row] + lp[row] (decode.py:72, the same f32 addition), its
 //                       KC = beam + 2 largest entries in descending order (value, token id) and lp_vec[<eos>] -- the loop of
 //                       decode.py:79-97 takes at most `beam` candidates per row and skips at most two symbols;
-//   beam_select_kernel  one thread: decode.py:74-97 literally -- the completed-hypothesis score of every row (from min_len on), then
+//   beam_select_kernel  one wave (lane 0 walks the candidates out of LDS, the masks are rewritten one slot per lane): decode.py:74-97 literally -- the completed-hypothesis score of every row (from min_len on), then
 //                       the rows in order, their candidates in descending order, into a list of at most `beam` entries with
 //                       replace-the-minimum (first minimal index, strict comparisons) and the early break; it writes the next step's
 //                       inputs in place (token per surviving hypothesis, its running score, its ancestry mask over the decoder
@@ -82,57 +82,71 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const BeamArgs a) {
   if (nan) atomicOr(a.flag, 2);
 }
 
-__global__ void beam_select_kernel(const BeamArgs a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int n = a.n, beam = a.beam, KC = a.KC, l = a.step;
-  a.rec_n[l] = n;
-  int cnt = 0, argmin = 0;
-  int parent[KC_MAX], token[KC_MAX];
-  float score[KC_MAX];
-  for (int idx = 0; idx < n; ++idx) {
-    // completed hypothesis of this row (decode.py:74-78): len(out) = l tokens so far
-    a.rec_comp[l * beam + idx] = l >= a.min_len ? a.eos_val[idx] + a.penalty * (float)(l + 1) : -INFINITY;
-    for (int c = 0; c < KC; ++c) {
-      const int o = a.cand_idx[idx * KC + c];
-      if (o < 0) break;
-      if (o == a.unk || (!a.dec_eos && o == a.eos)) continue;
-      const float new_lp = a.cand_val[idx * KC + c];
-      if (cnt == beam) {
-        if (score[argmin] < new_lp) {
-          parent[argmin] = idx; token[argmin] = o; score[argmin] = new_lp;
-          argmin = 0;
-          for (int j = 1; j < beam; ++j) if (score[j] < score[argmin]) argmin = j;       // first minimal index
-        } else {
-          break;
-        }
-      } else {
-        parent[cnt] = idx; token[cnt] = o; score[cnt] = new_lp; ++cnt;
+__global__ __launch_bounds__(64) void beam_select_kernel(const BeamArgs a) {
+  // one wave: the candidates are staged in LDS by all lanes, lane 0 walks them (decode.py:74-97 is sequential by construction: at most
+  // beam * KC short iterations on LDS operands), and the ancestry masks are rewritten one slot per lane
+  __shared__ float s_val[KC_MAX * KC_MAX], s_eos[KC_MAX], s_score[KC_MAX];
+  __shared__ int s_idx[KC_MAX * KC_MAX], s_parent[KC_MAX], s_token[KC_MAX], s_cnt;
+  const int n = a.n, beam = a.beam, KC = a.KC, l = a.step, lane = threadIdx.x;
+  for (int i = lane; i < n * KC; i += 64) { s_val[i] = a.cand_val[i]; s_idx[i] = a.cand_idx[i]; }
+  if (lane < n) s_eos[lane] = a.eos_val[lane];
+  __syncthreads();
+  if (lane == 0) {
+    int cnt = 0, argmin = 0;
+    int parent[KC_MAX], token[KC_MAX];
+    float score[KC_MAX];
+    for (int idx = 0; idx < n; ++idx) {
+      for (int c = 0; c < KC; ++c) {
+        const int o = s_idx[idx * KC + c];
+        if (o < 0) break;
+        if (o == a.unk || (!a.dec_eos && o == a.eos)) continue;
+        const float new_lp = s_val[idx * KC + c];
         if (cnt == beam) {
-          argmin = 0;
-          for (int j = 1; j < beam; ++j) if (score[j] < score[argmin]) argmin = j;
+          if (score[argmin] < new_lp) {
+            parent[argmin] = idx; token[argmin] = o; score[argmin] = new_lp;
+            argmin = 0;
+            for (int j = 1; j < beam; ++j) if (score[j] < score[argmin]) argmin = j;       // first minimal index
+          } else {
+            break;
+          }
+        } else {
+          parent[cnt] = idx; token[cnt] = o; score[cnt] = new_lp; ++cnt;
+          if (cnt == beam) {
+            argmin = 0;
+            for (int j = 1; j < beam; ++j) if (score[j] < score[argmin]) argmin = j;
+          }
         }
       }
     }
+    if (cnt < beam) atomicOr(a.flag, 4);
+    for (int j = 0; j < cnt; ++j) { s_parent[j] = parent[j]; s_token[j] = token[j]; s_score[j] = score[j]; }
+    s_cnt = cnt;
+    a.rec_n[l] = n;
   }
-  if (cnt < beam) atomicOr(a.flag, 4);
-  // next step's inputs: token, running score, ancestry mask (the parent's slots and the hypothesis's own new slot)
-  unsigned char nm[KC_MAX][64];
-  for (int j = 0; j < cnt; ++j) {
-    for (int s = 0; s < 64; ++s) nm[j][s] = a.mask64[parent[j] * 64 + s];
-    const int own = a.slot0_next + j;
-    if (own < 64) nm[j][own] = 1;
+  __syncthreads();
+  const int cnt = s_cnt;
+  // completed hypothesis of each row (decode.py:74-78): len(out) = l tokens so far
+  if (lane < n) a.rec_comp[l * beam + lane] = l >= a.min_len ? s_eos[lane] + a.penalty * (float)(l + 1) : -INFINITY;
+  // next step's inputs: token, running score (lane j), ancestry mask (lane = slot: the parent's slots and the hypothesis's own new one)
+  if (lane < beam) {
+    const bool live = lane < cnt;
+    a.rec_parent[l * beam + lane] = live ? s_parent[lane] : -1;
+    a.rec_token[l * beam + lane] = live ? s_token[lane] : -1;
+    a.rec_score[l * beam + lane] = live ? s_score[lane] : -INFINITY;
+    a.tok[lane] = live ? (long)s_token[lane] : 0L;
+    a.lp[lane] = live ? s_score[lane] : 0.f;
   }
-  for (int j = 0; j < beam; ++j) {
-    const bool live = j < cnt;
-    a.rec_parent[l * beam + j] = live ? parent[j] : -1;
-    a.rec_token[l * beam + j] = live ? token[j] : -1;
-    a.rec_score[l * beam + j] = live ? score[j] : -INFINITY;
-    a.tok[j] = live ? (long)token[j] : 0L;
-    a.lp[j] = live ? score[j] : 0.f;
-    for (int s = 0; s < 64; ++s) a.mask64[j * 64 + s] = live ? nm[j][s] : (unsigned char)(s == 0);
-    if (a.mask_out)
-      for (int s = 0; s < a.LkS_next; ++s) a.mask_out[j * a.LkS_next + s] = live ? nm[j][s] : (unsigned char)(s == 0);
-  }
+  unsigned char nm[KC_MAX];
+#pragma unroll
+  for (int j = 0; j < KC_MAX; ++j)
+    if (j < beam) nm[j] = j < cnt ? (unsigned char)(a.mask64[s_parent[j] * 64 + lane] | (lane == a.slot0_next + j)) : (unsigned char)(lane == 0);
+  __syncthreads();                                       // every lane has read the old masks of its slot before any is rewritten
+#pragma unroll
+  for (int j = 0; j < KC_MAX; ++j)
+    if (j < beam) {
+      a.mask64[j * 64 + lane] = nm[j];
+      if (a.mask_out && lane < a.LkS_next) a.mask_out[j * a.LkS_next + lane] = nm[j];
+    }
 }
 
 }  // namespace

@@ -499,8 +499,9 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
 // context rows) go through L2 as in the column-split form: store, drain, workgroup barrier, sc1 load.
 // =====================================================================================================================
 __device__ __forceinline__ void st16f(float* p, const f32x4& v, bool wt) {
-  st8(p, make_uint2(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1])), wt);
-  st8(p + 2, make_uint2(__builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])), wt);
+  const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];       // (a bit_cast of a vector ELEMENT lvalue reads element 0: copy out first)
+  st8(p, make_uint2(__float_as_uint(v0), __float_as_uint(v1)), wt);
+  st8(p + 2, make_uint2(__float_as_uint(v2), __float_as_uint(v3)), wt);
 }
 
 // LN of the R <= 16 rows held in LDS (xs: [16][512] bf16, linear) into the swizzled image rows 0..15 (rows >= R zero): four rows per wave
@@ -758,9 +759,10 @@ extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, 
             (bf16_t*)vcache, slot0, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, nullptr, pbuf};
   a.dbg = bist_dev_dbg(1);
   a.stamps = bist_dev_stamps(1);
-  // one 16-row tile (a decode step at a time: R = hypotheses) and a partial buffer: the head-local form, 6 grid barriers per layer instead of 14
-  static const int colsplit = [] { const char* e = getenv("BIST_DECSTACK_COLSPLIT"); return e ? atoi(e) : 0; }();      // tuning aid
-  if (R <= 16 && pbuf && !colsplit) {
+  // a partial buffer and one 16-row tile select the head-local form (6 grid barriers per layer instead of 14).  Measured on the beam-5
+  // turn of BASELINE configs[4] it is the SLOWER one (431 vs ~380 us per six-layer step; profiles/README.md, round 3): a head's chain of
+  // L2 round trips (q rows, context rows, partials) is longer than the barriers it removes, so callers pass pbuf = null by default.
+  if (R <= 16 && pbuf) {
     BIST_REQUIRE((reinterpret_cast<uintptr_t>(pbuf) & 15) == 0, "bist_decoder_stack_fwd: pbuf must be 16-byte aligned");
     BIST_LDS_OPTIN(&decstack_head_kernel, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
     hipLaunchKernelGGL(decstack_head_kernel, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 from typing import Dict
 
+import os
 import torch
 import torch.nn as nn
 
@@ -139,6 +140,7 @@ class MultimodalDecoder8(nn.Module):
 
     # ---- one persistent launch for all decoder layers of a decode step (bist_decoder_stack_fwd) ------------------------------
     FUSED_DECODE = True
+    HEAD_LOCAL = os.environ.get("BIST_DECSTACK_HEADLOCAL", "0") == "1"      # the kernel's head-local form for <= 16 rows: measured slower, opt-in
 
     def _fused_decode_ok(self, b, ft, x) -> bool:
         a = self.args
@@ -293,11 +295,13 @@ class MultimodalDecoder8(nn.Module):
             # [n, LkS] over the pool slots: a hypothesis attends its ancestors' slots and its own)
             slot0, mask = incr
             assert Lt == 1 and mask.shape[0] == n
-            out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(n, d).contiguous(), st, mask, n, mask.shape[1], slot0)
+            out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(n, d).contiguous(), st, mask, n, mask.shape[1], slot0,
+                                    head_local=self.HEAD_LOCAL)
         else:
             R = n * Lt
             LkS = 32 if R <= 32 else 64
-            out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(R, d).contiguous(), st, self._self_mask(st, b, n, Lt, LkS), R, LkS)
+            out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(R, d).contiguous(), st, self._self_mask(st, b, n, Lt, LkS), R, LkS,
+                                    head_local=self.HEAD_LOCAL)
         ft.update(ft["_bist_reasoning"][-1])
         return out.view(n, Lt, d)
 

@@ -512,9 +512,9 @@ def test_device_side_beam_update_equals_the_host_beam_loop(hip):
 
 def test_head_local_decoder_kernel_equals_the_column_split_kernel(hip):
     """The persistent decoder kernel's head-local form (R <= 16 rows: workgroup hh owns head hh through an attention sublayer and writes a
-    partial output projection; 6 grid barriers per layer) against its column-split form (14 barriers per layer; taken when the caller
-    passes no partial buffer) on the same decode steps: row counts 1, 5, 14, 16, with and without earlier rows in the self-attention
-    pools.  Same arithmetic up to the order of the f32 sums over the heads: outputs within 3e-2 (bf16 residual stream), finite."""
+    partial output projection; 6 grid barriers per layer; opt-in, BIST_DECSTACK_HEADLOCAL=1) against its column-split form (14 barriers
+    per layer; the default: the caller passes no partial buffer) on the same decode steps: row counts 1, 5, 14, 16, with and without earlier rows in the self-attention
+    pools.  Same arithmetic up to the order of the f32 sums over the heads: outputs within two bf16 ulps of the largest magnitude (the residual stream is bf16), mean difference <= 2e-3, finite."""
     from bist_amd.data.batch import subsequent_mask
     from bist_amd.model.decode import _turn_for_rows
     M, Batch = hip
@@ -534,16 +534,15 @@ def test_head_local_decoder_kernel_equals_the_column_split_kernel(hip):
             trg = torch.randint(4, V, (n, Lt), generator=g).cuda()
             outs = {}
             for head_local in (True, False):
-                saved = st.get("p")
-                if not head_local:
-                    st["p"] = None
+                dec.HEAD_LOCAL = head_local
                 try:
                     bn, fn = _turn_for_rows(b, ft, n, {})
                     bn.trg, bn.trg_mask = trg, subsequent_mask(Lt, "cuda")
                     outs[head_local] = model.decode(bn, dict(fn))["decoded_text"].float().cpu()
                 finally:
-                    st["p"] = saved
+                    dec.__dict__.pop("HEAD_LOCAL", None)
             assert torch.isfinite(outs[True]).all()
-            err = (outs[True] - outs[False]).abs().max().item()
-            assert err <= 3e-2, (n, Lt, err)
+            diff = (outs[True] - outs[False]).abs()
+            ulp2 = 2.0 ** -6 * outs[False].abs().max().item()            # two bf16 ulps at the largest magnitude of the rows
+            assert diff.max().item() <= ulp2 and diff.mean().item() <= 2e-3, (n, Lt, diff.max().item(), diff.mean().item())
         dec.check_decode_errors()
