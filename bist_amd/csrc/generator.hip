@@ -97,6 +97,103 @@ __global__ __launch_bounds__(256) void text_vector_kernel(const float* __restric
   *reinterpret_cast<uint4*>(out + row * d + c0) = *reinterpret_cast<const uint4*>(o);
 }
 
+// Decode-step form of MultiPointerGenerator.forward (generator.py:84-127) for hypothesis rows that share ONE dialogue (beam search,
+// decode.py:59-66).  The pointer attentions' keys do not change during a turn, so the caller folds each source's query projection into
+// them once per turn:  scores_j[t] = (W_q x + b_q) . k_j[t] = x . M_j[t] + c_j[t]  with  M_j = K_j W_q  [L, d],  c_j = K_j b_q  [L];  and
+// the switch logits' text-vector blocks into  E_j = enc_j W_sw,j^T  [L, n + 1]  (W_sw [x | tgt | tv_0 | ..], generator.py:92,119-121):
+//   sw_logits = W_sw,x x + W_sw,tgt tgt + b + sum_j p_j E_j.
+// One workgroup per row does the n masked softmaxes (generator.py:106-110, single head, fill -1e9), the switch and the mixture of
+// pointer_mix_kernel -- a step's pointer heads are ONE launch after the vocabulary product instead of eighteen (2 x {2 mask ops, 2
+// projections, attention core, text vector}, 4 switch products, mixture).  d <= 1024, L_j <= 128.
+struct PtrDecSrcK { const float* M; const float* c; const unsigned char* mask; const float* E; const long* text; float* p_out; int L; };
+struct PtrDecArgs { PtrDecSrcK s[3]; int n; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void pointer_decode_mix_kernel(const T* __restrict__ x, const T* __restrict__ tgt, const float* __restrict__ logits,
+                                                                 PtrDecArgs a, const T* __restrict__ Wsw, long ldw, const T* __restrict__ bsw,
+                                                                 float scale, float* __restrict__ out, int d, int V) {
+  __shared__ float xs[1024], ts[1024], pr[3][128], swl[4], red[4];
+  const long row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int k = tid; k < d; k += 256) { xs[k] = to_f(x[row * d + k]); ts[k] = to_f(tgt[row * d + k]); }
+  __syncthreads();
+  // scores: wave w takes the keys w, w + 4, ..; its lanes split the d channels (float4 loads, a key's row is contiguous)
+  for (int j = 0; j < a.n; ++j) {
+    const PtrDecSrcK& sj = a.s[j];
+    for (int t = w; t < sj.L; t += 4) {
+      const float* m = sj.M + (long)t * d;
+      float acc = 0.f;
+      for (int k = lane * 4; k < d; k += 256) {
+        const float4 q = *reinterpret_cast<const float4*>(m + k);
+        acc += q.x * xs[k] + q.y * xs[k + 1] + q.z * xs[k + 2] + q.w * xs[k + 3];
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) pr[j][t] = sj.mask[t] ? (acc + sj.c[t]) * scale : -1e9f;
+    }
+  }
+  __syncthreads();
+  if (w < a.n) {                              // softmax of source w on wave w
+    const int L = a.s[w].L;
+    float mx = -INFINITY;
+    for (int t = lane; t < L; t += 64) mx = fmaxf(mx, pr[w][t]);
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int t = lane; t < L; t += 64) den += expf(pr[w][t] - mx);
+    den = wave_sum(den);
+    for (int t = lane; t < L; t += 64) {
+      const float pv = expf(pr[w][t] - mx) / den;
+      pr[w][t] = pv;
+      if (a.s[w].p_out) a.s[w].p_out[row * L + t] = pv;
+    }
+  }
+  __syncthreads();
+  const int ns = a.n + 1;
+  if (w < ns) {                               // switch logit w on wave w
+    const T* wr = Wsw + (long)w * ldw;
+    float acc = 0.f;
+    for (int k = lane; k < d; k += 64) acc += to_f(wr[k]) * xs[k] + to_f(wr[d + k]) * ts[k];
+    for (int j = 0; j < a.n; ++j)
+      for (int t = lane; t < a.s[j].L; t += 64) acc += pr[j][t] * a.s[j].E[t * ns + w];
+    acc = wave_sum(acc);
+    if (lane == 0) swl[w] = acc + to_f(bsw[w]);
+  }
+  // the mixture (pointer_mix_kernel with the rows' shared texts)
+  const float* lg = logits + row * V;
+  float* o = out + row * V;
+  float mx = -INFINITY;
+  for (int v = tid; v < V; v += 256) mx = fmaxf(mx, lg[v]);
+  mx = block_reduce(mx, red, true);           // (its barriers also publish swl)
+  float den = 0.f;
+  for (int v = tid; v < V; v += 256) den += expf(lg[v] - mx);
+  den = block_reduce(den, red, false);
+  float sw[4];
+  {
+    float m2 = -INFINITY, d2 = 0.f;
+    for (int j = 0; j < ns; ++j) m2 = fmaxf(m2, swl[j]);
+    for (int j = 0; j < ns; ++j) { sw[j] = expf(swl[j] - m2); d2 += sw[j]; }
+    for (int j = 0; j < ns; ++j) sw[j] /= d2;
+  }
+  const float vs = sw[a.n] / den;
+  for (int v = tid; v < V; v += 256) o[v] = vs * expf(lg[v] - mx);
+  __syncthreads();
+  for (int j = 0; j < a.n; ++j) {             // deterministic scatter_add, as in pointer_mix_kernel
+    const long* text = a.s[j].text;
+    const int L = a.s[j].L;
+    for (int t = tid; t < L; t += 256) {
+      const long id = text[t];
+      bool first = true;
+      for (int u = 0; u < t; ++u) first = first && text[u] != id;
+      if (first) {
+        float acc = 0.f;
+        for (int u = t; u < L; ++u) if (text[u] == id) acc += sw[j] * pr[j][u];
+        o[id] += acc;
+      }
+    }
+    __syncthreads();
+  }
+  for (int v = tid; v < V; v += 256) o[v] = logf(o[v]);
+}
+
 // Generator.forward (generator.py:21-27): log_softmax over the vocabulary.
 __global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int V) {
   __shared__ float red[4];
@@ -163,6 +260,33 @@ extern "C" int bist_pointer_mix_fwd(const float* logits, const float* switch_log
   hipLaunchKernelGGL(pointer_mix_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, switch_logits, a, out, V, Lt,
                      sigmoid_switch);
   BIST_LAUNCH_CHECK("bist_pointer_mix_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_pointer_decode_mix_fwd(const void* x, const void* tgt, const float* logits, const BistPtrDecSrc* src, int32_t n_ptr,
+                                           const void* Wsw, int64_t ldw, const void* bsw, float scale, float* out, int64_t rows, int32_t d,
+                                           int32_t V, int32_t dtype, void* stream) {
+  BIST_REQUIRE(x && tgt && logits && src && Wsw && bsw && out && rows > 0 && V > 2, "bist_pointer_decode_mix_fwd: bad argument");
+  BIST_REQUIRE(n_ptr >= 1 && n_ptr <= 3 && d >= 4 && d <= 1024 && d % 4 == 0 && ldw >= (int64_t)(n_ptr + 2) * d,
+               "bist_pointer_decode_mix_fwd: 1..3 pointer sources, d a multiple of 4 and at most 1024, W_sw rows of (n + 2) d");
+  BIST_REQUIRE(dtype == BIST_BF16 || dtype == BIST_F32, "bist_pointer_decode_mix_fwd: bf16 or f32");
+  PtrDecArgs a;
+  a.n = n_ptr;
+  for (int j = 0; j < 3; ++j) a.s[j] = PtrDecSrcK{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  for (int j = 0; j < n_ptr; ++j) {
+    const BistPtrDecSrc& sj = src[j];
+    BIST_REQUIRE(sj.M && sj.c && sj.mask && sj.E && sj.text && sj.L >= 1 && sj.L <= 128 && ((uintptr_t)sj.M & 15) == 0,
+                 "bist_pointer_decode_mix_fwd: bad pointer source %d (1..128 positions, M 16-byte aligned)", j);
+    a.s[j] = PtrDecSrcK{sj.M, sj.c, sj.mask, sj.E, (const long*)sj.text, sj.p_out, sj.L};
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == BIST_BF16)
+    hipLaunchKernelGGL(pointer_decode_mix_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)tgt, logits, a,
+                       (const bf16_t*)Wsw, (long)ldw, (const bf16_t*)bsw, scale, out, d, V);
+  else
+    hipLaunchKernelGGL(pointer_decode_mix_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)x, (const float*)tgt, logits, a,
+                       (const float*)Wsw, (long)ldw, (const float*)bsw, scale, out, d, V);
+  BIST_LAUNCH_CHECK("bist_pointer_decode_mix_fwd");
   return BIST_OK;
 }
 

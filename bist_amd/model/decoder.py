@@ -203,6 +203,9 @@ class MultimodalDecoder8(nn.Module):
                 kv["K"][l][c][:Lks[c]].copy_(kvp[:, :512])
                 kv["VT"][l][c][:, :Lks[c]].copy_(kvp[:, 512:].t())
         kv["owner"], kv["src"], kv["turn"] = cache, src, turn  # the reasoning results these keys / values were projected from (one list per turn)
+        kv["stamp"] = object()                                 # this projection's identity: per-turn constants of other modules hang on it
+        for hook in self.__dict__.get("_bist_turn_hooks", {}).values():       # (the pointer generator's folded keys: generator._turn_consts)
+            hook(b, ft, kv)
 
     def select_decode_cache(self, ft, turn) -> bool:
         """A captured graph has just projected this turn's memories (it wrote the cache buffers of ``ft``'s dialogue geometry): make
@@ -303,6 +306,7 @@ class MultimodalDecoder8(nn.Module):
             out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(R, d).contiguous(), st, self._self_mask(st, b, n, Lt, LkS), R, LkS,
                                     head_local=self.HEAD_LOCAL)
         ft.update(ft["_bist_reasoning"][-1])
+        ft["_bist_turn_consts"] = (self, st["kv"])       # the rows share one dialogue whose per-turn constants live with these caches
         return out.view(n, Lt, d)
 
     # Keys the reasoning layers write per decoder layer (decoder.py:126-181); everything else in ``ft`` is static.

@@ -6,6 +6,7 @@ both compute dtypes), the softmax / copy-distribution scatter / mixture / log ar
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
@@ -119,9 +120,78 @@ class MultiPointerGenerator(nn.Module):
         for a in pointer_attn:
             a.keep_attn = True
 
+    DECODE_FAST = os.environ.get("BIST_POINTER_DECODE", "1") != "0"      # tuning aid: 0 = the pointer heads of a decode step as separate launches
+
+    def _turn_consts(self, b, ft, kv, names, mask_unk):
+        """The per-TURN constants of the decode-step launch (bist_pointer_decode_mix_fwd) for the dialogue whose memories the decoder has
+        just projected into ``kv`` (decoder.prepare_decode_cache calls this; row 0 of every tensor: all rows hold the same dialogue).
+        Buffers are allocated once per dialogue geometry and rewritten in place: captured step graphs hold their addresses."""
+        d = self.pointer_gen_W.weight.shape[1] // (len(names) + 2)
+        ns = len(names) + 1
+        key = (tuple(names), tuple(ft["encoded_" + n].shape[1] for n in names))
+        g = kv.setdefault("gen_by_len", {}).get(key)
+        if g is None:
+            g = kv["gen_by_len"][key] = {"key": key, "src": []}
+            for name in names:
+                enc = ft["encoded_" + name]
+                L, dev = enc.shape[1], enc.device
+                f32 = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
+                g["src"].append({"M": f32(L, d), "c": f32(L), "E": f32(L, ns), "mask": torch.zeros(L, device=dev, dtype=torch.uint8),
+                                 "text": torch.zeros(L, device=dev, dtype=torch.long)})
+        kv["gen"] = g
+        for idx, name in enumerate(names):
+            text, (enc, _), mask = _pointer_source(name, {"encoded_" + name: ft["encoded_" + name]}, b)
+            sj, at, enc0 = g["src"][idx], self.pointer_attn[idx], enc[0]
+            L = enc0.shape[0]
+            m = mask[0].reshape(-1)
+            if mask_unk:
+                m = m & (text[0] != UNK)                                                   # generator.py:106-107
+            sj["mask"].copy_(m)
+            sj["text"].copy_(text[0])
+            kp = Fn.linear(enc0, at.linears[1].weight, at.linears[1].bias)                 # the keys of generator.py:109, [L, d]
+            wq = at.linears[0].weight
+            ops.gemm(kp, wq, sj["M"], M=L, N=d, K=d, a_rs=d, a_ks=1, b_rs=1, b_ks=wq.stride(0), ldc=d)     # M = K W_q
+            Fn.linear(kp, at.linears[0].bias.view(1, d), None, out=sj["c"].view(L, 1), out_dtype=torch.float32)    # c = K b_q
+            Fn.linear(enc0, Fn.column_block(self.pointer_gen_W.weight, 2 + idx, d), None, out=sj["E"], out_dtype=torch.float32)
+        g["stamp"] = kv["stamp"]
+        return g
+
+    def _forward_decode(self, ft, batch, args):
+        """One decode step's heads for rows that share one dialogue, or None when the case is outside the launch's envelope."""
+        tc = ft.get("_bist_turn_consts")
+        x = ft["decoded_text"]
+        tgt = ft.get("encoded_tgt")
+        names = args.ptr_ft.split(",")
+        if tc is None or not self.DECODE_FAST or torch.is_grad_enabled() or not x.is_cuda or tgt is None or tgt.shape != x.shape or x.shape[-1] > 1024 \
+                or x.shape[-1] % 8 or len(names) > 3 or any(ft.get("encoded_" + n) is None or ft["encoded_" + n].shape[1] > 128 for n in names):
+            return None
+        dec, kv = tc
+        B, Lt, d = x.shape
+        hooks = dec.__dict__.setdefault("_bist_turn_hooks", {})
+        key = (id(self), tuple(names), bool(args.mask_unk))
+        if key not in hooks:                 # from now on the decoder refreshes the constants whenever it projects a turn's memories
+            hooks[key] = lambda b_, ft_, kv_, names=names, mu=bool(args.mask_unk): self._turn_consts(b_, ft_, kv_, names, mu)
+        g = kv.get("gen")
+        if g is None or g.get("stamp") is not kv.get("stamp") or g["key"] != (tuple(names), tuple(ft["encoded_" + n].shape[1] for n in names)):
+            g = self._turn_consts(batch, ft, kv, names, bool(args.mask_unk))
+        logits = Fn.linear(x, self.vocab_gen, None, out_dtype=torch.float32)
+        srcs = []
+        for idx, sj in enumerate(g["src"]):
+            s2 = dict(sj)
+            if getattr(self.pointer_attn[idx], "keep_attn", False):
+                s2["p"] = torch.empty((B * Lt, sj["text"].shape[0]), device=x.device, dtype=torch.float32)
+                self.pointer_attn[idx].attn = s2["p"].view(B, 1, Lt, -1)
+            srcs.append(s2)
+        out = ops.pointer_decode_mix(x.reshape(B * Lt, d).contiguous(), tgt.reshape(B * Lt, d).contiguous(), logits.view(B * Lt, -1), srcs,
+                                     self.pointer_gen_W.weight, self.pointer_gen_W.bias, 1.0 / (d ** 0.5))
+        return out.view(B, Lt, -1)
+
     def forward(self, ft, batch, args):
         x = ft["decoded_text"]
         B, Lt, d = x.shape
+        fast = self._forward_decode(ft, batch, args) if "_bist_turn_consts" in ft else None
+        if fast is not None:
+            return fast
         logits = Fn.linear(Fn.fan_take(ft, "decoded_text"), self.vocab_gen, None, out_dtype=torch.float32)
         ps, texts, vec = [], [], [Fn.fan_take(ft, "decoded_text"), ft["encoded_tgt"]]     # generator.py:92
         for idx, name in enumerate(args.ptr_ft.split(",")):

@@ -711,6 +711,34 @@ def pointer_mix(logits: Tensor, switch_logits: Tensor, ptr_p: Sequence[Tensor], 
     return out
 
 
+def pointer_decode_mix(x: Tensor, tgt: Tensor, logits: Tensor, srcs: Sequence[dict], wsw: Tensor, bsw: Tensor, scale: float) -> Tensor:
+    """The pointer heads of one decode step for rows that share one dialogue, one launch (bist_pointer_decode_mix_fwd): x / tgt
+    [rows,d], logits f32 [rows,V], srcs: per source the turn's constants {"M" f32 [L,d], "c" f32 [L], "mask" u8 [L], "E" f32 [L,n+1],
+    "text" int64 [L], optional "p" f32 [rows,L] to receive the pointer probabilities}; wsw = pointer_gen_W.weight, bsw its bias."""
+    rows, d = x.shape
+    V = logits.shape[-1]
+    n = len(srcs)
+    _dev(x, tgt, logits, wsw, bsw)
+    if logits.dtype != torch.float32 or not (x.is_contiguous() and tgt.is_contiguous() and logits.is_contiguous()) or tgt.shape != x.shape \
+            or tgt.dtype != x.dtype or wsw.dtype != x.dtype or bsw.dtype != x.dtype or wsw.shape != (n + 1, (n + 2) * d) or wsw.stride(1) != 1:
+        raise ValueError("bist_amd.pointer_decode_mix: bad operands")
+    arr = (_lib.BistPtrDecSrc * n)()
+    for j, sj in enumerate(srcs):
+        L = sj["text"].shape[0]
+        M, c, mask, E, text, pout = sj["M"], sj["c"], sj["mask"], sj["E"], sj["text"], sj.get("p")
+        _dev(M, c, mask, E, text)
+        if M.dtype != torch.float32 or tuple(M.shape) != (L, d) or c.dtype != torch.float32 or c.numel() != L or mask.dtype != torch.uint8 \
+                or mask.numel() != L or E.dtype != torch.float32 or tuple(E.shape) != (L, n + 1) or text.dtype != torch.int64 \
+                or not all(t.is_contiguous() for t in (M, c, mask, E, text)) or (pout is not None and (pout.dtype != torch.float32 or tuple(pout.shape) != (rows, L) or not pout.is_contiguous())):
+            raise ValueError("bist_amd.pointer_decode_mix: bad constants of source %d" % j)
+        arr[j].M, arr[j].c, arr[j].mask, arr[j].E, arr[j].text = M.data_ptr(), c.data_ptr(), mask.data_ptr(), E.data_ptr(), text.data_ptr()
+        arr[j].p_out, arr[j].L = (pout.data_ptr() if pout is not None else None), L
+    out = torch.empty((rows, V), device=x.device, dtype=torch.float32)
+    check(lib.bist_pointer_decode_mix_fwd(x.data_ptr(), tgt.data_ptr(), logits.data_ptr(), arr, n, wsw.data_ptr(), wsw.stride(0), bsw.data_ptr(),
+                                          float(scale), out.data_ptr(), rows, d, V, dtype_code(x.dtype), _stream()), "bist_pointer_decode_mix_fwd")
+    return out
+
+
 def log_softmax(x: Tensor) -> Tensor:
     _dev(x)
     if x.dtype != torch.float32:

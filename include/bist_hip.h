@@ -514,6 +514,19 @@ int bist_pointer_mix_bwd(const float* logits, const float* switch_logits, int32_
                          const int64_t* const* ptr_text, const int32_t* ptr_len, const float* out, const float* dout,
                          float* dlogits, float* dswitch_logits, float* const* dptr_p, int64_t rows, int32_t Lt, int32_t V,
                          int32_t sigmoid_switch, void* stream);
+/* Decode-step form of MultiPointerGenerator.forward (model/generator.py:84-127) for rows that share one dialogue (the hypotheses of
+ * a beam-search turn, model/decode.py:59-66): per source j the caller holds, per TURN, M_j = K_j W_q [L_j][d] and c_j = K_j b_q [L_j]
+ * (K_j the projected keys of generator.py:109, so that scores = x.M_j^T + c_j), mask_j [L_j] (generator.py:106-107), E_j = enc_j W_sw,j^T
+ * [L_j][n_ptr+1] (the text vector's block of the switch product, generator.py:117-121) and the source's token ids text_j [L_j];
+ * x = the decoded rows [rows][d], tgt = their target embeddings, logits f32 [rows][V] the vocabulary product (generator.py:90),
+ * Wsw [n_ptr+1][ldw] = pointer_gen_W.weight with blocks [x | tgt | tv_0 | ..], bsw its bias, scale = 1/sqrt(d).  out f32 [rows][V] =
+ * the log mixture of bist_pointer_mix_fwd; p_out (optional) receives the pointer probabilities [rows][L_j].  src is a HOST array.   */
+typedef struct BistPtrDecSrc {
+  const float* M; const float* c; const uint8_t* mask; const float* E; const int64_t* text; float* p_out; int32_t L; int32_t pad_;
+} BistPtrDecSrc;
+int bist_pointer_decode_mix_fwd(const void* x, const void* tgt, const float* logits, const BistPtrDecSrc* src, int32_t n_ptr,
+                                const void* Wsw, int64_t ldw, const void* bsw, float scale, float* out, int64_t rows, int32_t d,
+                                int32_t V, int32_t dtype, void* stream);
 /* The pointer generator's text vector (generator.py:117-118), inference: out[row, :] = sum_t p[row, t] * enc[row / Lt, t, :]
  * (p f32 [rows][L], enc [rows / Lt][L][d], out [rows][d] in dtype); training uses the batched bist_gemm (it needs the backward products). */
 int bist_text_vector_fwd(const float* p, const void* enc, void* out, int64_t rows, int32_t Lt, int32_t L, int32_t d, int32_t dtype,

@@ -8,6 +8,7 @@ argmax (it is the throughput path, not the parity gate).
 """
 import argparse
 import json
+import math
 import os
 
 import numpy as np
@@ -546,3 +547,88 @@ def test_head_local_decoder_kernel_equals_the_column_split_kernel(hip):
             ulp2 = 2.0 ** -6 * outs[False].abs().max().item()            # two bf16 ulps at the largest magnitude of the rows
             assert diff.max().item() <= ulp2 and diff.mean().item() <= 2e-3, (n, Lt, diff.max().item(), diff.mean().item())
         dec.check_decode_errors()
+
+
+def test_pointer_decode_launch_matches_its_formulas(hip):
+    """bist_pointer_decode_mix_fwd (the pointer heads of a decode step in one launch: folded keys M = K W_q, c = K b_q, switch blocks
+    E = enc W_sw^T) against the same formulas in torch f64 on random f32 operands: scores -> masked softmax -> switch -> log mixture
+    (generator.py:84-127).  f32 arithmetic: log-probs within 2e-5 where the mixture is above 1e-30, pointer probabilities within 1e-6."""
+    from bist_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows, d, V, Ls = 5, 512, 301, (20, 61)
+    n, ns = len(Ls), len(Ls) + 1
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x, tgt, logits = rnd(rows, d), rnd(rows, d), rnd(rows, V) * 3
+    wsw, bsw = rnd(ns, (n + 2) * d) * 0.05, rnd(ns)
+    srcs, ref_p = [], []
+    for L in Ls:
+        mask = (torch.rand(L, generator=g) > 0.2).to(torch.uint8)
+        srcs.append({"M": rnd(L, d) * 0.3, "c": rnd(L), "mask": mask, "E": rnd(L, ns) * 0.2, "text": torch.randint(0, V, (L,), generator=g)})
+    scale = 1.0 / d ** 0.5
+    X, T = x.double(), tgt.double()
+    swl = X @ wsw[:, :d].double().t() + T @ wsw[:, d:2 * d].double().t() + bsw.double()
+    for sj in srcs:
+        sc = (X @ sj["M"].double().t() + sj["c"].double()) * scale
+        sc = sc.masked_fill(sj["mask"][None] == 0, -1e9)
+        p = torch.softmax(sc, -1)
+        ref_p.append(p)
+        swl = swl + p @ sj["E"].double()
+    sw = torch.softmax(swl, -1)
+    mix = sw[:, n:n + 1] * torch.softmax(logits.double(), -1)
+    for j, sj in enumerate(srcs):
+        mix = mix.scatter_add(1, sj["text"][None].expand(rows, -1), sw[:, j:j + 1] * ref_p[j])
+    dsrc = [{k: v.cuda() for k, v in sj.items()} for sj in srcs]
+    for sj, L in zip(dsrc, Ls):
+        sj["p"] = torch.empty(rows, L, device="cuda")
+    out = ops.pointer_decode_mix(x.cuda(), tgt.cuda(), logits.cuda(), dsrc, wsw.cuda(), bsw.cuda(), scale)
+    torch.cuda.synchronize()
+    for j in range(n):
+        assert (dsrc[j]["p"].cpu().double() - ref_p[j]).abs().max().item() <= 1e-6
+    keep = mix > 1e-30
+    assert ((out.cpu().double() - mix.log()).abs()[keep]).max().item() <= 2e-5
+    assert torch.isfinite(out).all()
+
+
+def test_decode_step_pointer_heads_in_one_launch_equal_the_separate_launches(hip):
+    """A decode step's generator with the per-turn folded keys (MultiPointerGenerator._forward_decode) against the separate launches of
+    generator.py:84-127 (two projections, attention core, text vector per source, four switch products, mixture) on the same decoded
+    rows, bf16 model, d=512, L=3: 1 and 5 hypothesis rows, two different dialogues in turn (the constants are rewritten in place).
+    The folded form keeps q.k in f32 where the separate form rounds q, k and the text vector to bf16: log-probs within 6e-2 over the
+    entries above log 1e-6 and the same arg-max token in every row."""
+    from bist_amd.data.batch import subsequent_mask
+    from bist_amd.model.decode import _turn_for_rows
+    from bist_amd.model.generator import MultiPointerGenerator
+    M, Batch = hip
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=3, nb_venc_blocks=3, nb_cenc_blocks=3)
+    V, C = 300, 256
+    model, _ = build_model(M, cfg, V, C, torch.bfloat16)
+    assert isinstance(model.generator, MultiPointerGenerator)
+    args = _args(cfg)
+    taken = 0
+    for seed, (Lq, Lh) in ((61, (20, 30)), (62, (20, 30)), (63, (17, 41))):
+        ob = O.det_batch(1, 8, 9, C, Lq, Lh, 15, 12, V, seed=seed)
+        b = to_batch(Batch, ob, torch.bfloat16)
+        with torch.no_grad():
+            ft = model.encode(b)
+            b.trg, b.trg_mask = torch.full((1, 1), O.SOS_ID, device="cuda"), subsequent_mask(1, "cuda")
+            ft = model.decode(b, ft)                      # (leaves the per-layer reasoning results in ft)
+            for n, Lt in ((1, 1), (5, 1), (1, 6)):
+                bn, fn = _turn_for_rows(b, ft, n, {})
+                bn.trg = torch.randint(4, V, (n, Lt), generator=torch.Generator().manual_seed(seed + n)).cuda()
+                bn.trg_mask = subsequent_mask(Lt, "cuda")
+                f2 = model.decode(bn, dict(fn))
+                assert "_bist_turn_consts" in f2, "the persistent decoder kernel was not taken"
+                outs = {}
+                for fast in (True, False):
+                    model.generator.DECODE_FAST = fast
+                    try:
+                        outs[fast] = model.generator(dict(f2), bn, args).float().cpu()
+                    finally:
+                        model.generator.__dict__.pop("DECODE_FAST", None)
+                taken += 1
+                a, r = outs[True], outs[False]
+                assert a.shape == r.shape and torch.isfinite(a).all()
+                keep = r > math.log(1e-6)
+                assert (a - r).abs()[keep].max().item() <= 6e-2, (seed, n, Lt, (a - r).abs()[keep].max().item())
+                assert torch.equal(a.argmax(-1), r.argmax(-1)), (seed, n, Lt)
+    assert taken == 9
