@@ -33,11 +33,16 @@ struct BeamArgs {
   float penalty;
 };
 
+// order-preserving map of a float onto an unsigned (larger float <-> larger unsigned; -inf smallest of the finite order)
+__device__ __forceinline__ unsigned ord_of(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float float_of(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
 __global__ __launch_bounds__(256) void beam_topk_kernel(const BeamArgs a) {
-  __shared__ float sval[256];
-  __shared__ int sidx[256];
-  __shared__ int scnt[256];
-  const int row = blockIdx.x, tid = threadIdx.x;
+  // KC + 1 rounds of "largest remaining entry": every thread keeps 16 entries in registers; a round is a 64-bit (value, ~index) maximum
+  // per thread, a shuffle reduction per wave and ONE barrier (the four wave results alternate between two LDS slots).  Equal values
+  // come out in successive rounds, so "this round's value == the last one's" finds every tie among the KC + 1 largest.
+  __shared__ unsigned long long skey[2][4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* lr = a.logp + (long)row * a.V;
   const float base = a.lp[row];
   constexpr int PER = 16;                              // V <= 4096
@@ -52,32 +57,31 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const BeamArgs a) {
   if (tid == 0) a.eos_val[row] = lr[a.eos] + base;
   float last = INFINITY;
   for (int k = 0; k <= a.KC; ++k) {                    // KC + 1 rounds: the extra one only checks distinctness
-    float best = -INFINITY; int bi = 0x7fffffff, cnt = 0;
+    unsigned long long best = 0ull;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int i = tid + 256 * u;
-      if (v[u] > best) { best = v[u]; bi = i; cnt = 1; }
-      else if (v[u] == best && v[u] > -INFINITY) { ++cnt; }
+      const unsigned long long key = ((unsigned long long)ord_of(v[u]) << 32) | (unsigned)(0xffffffffu - (unsigned)(tid + 256 * u));   // smaller index wins a tie
+      best = key > best ? key : best;
     }
-    sval[tid] = best; sidx[tid] = bi; scnt[tid] = cnt;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const unsigned long long o = __shfl_xor(best, s);
+      best = o > best ? o : best;
+    }
+    if (lane == 0) skey[k & 1][w] = best;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s) {
-        const float o = sval[tid + s];
-        if (o > sval[tid]) { sval[tid] = o; sidx[tid] = sidx[tid + s]; scnt[tid] = scnt[tid + s]; }
-        else if (o == sval[tid] && o > -INFINITY) { scnt[tid] += scnt[tid + s]; sidx[tid] = min(sidx[tid], sidx[tid + s]); }
-      }
-      __syncthreads();
-    }
-    const float bv = sval[0]; const int bidx = sidx[0], bc = scnt[0];
+    unsigned long long b4 = skey[k & 1][0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) b4 = skey[k & 1][i] > b4 ? skey[k & 1][i] : b4;
+    const float bv = float_of((unsigned)(b4 >> 32));
+    const int bidx = (int)(0xffffffffu - (unsigned)(b4 & 0xffffffffu));
     if (tid == 0) {
-      if (bc > 1 || bv == last) atomicOr(a.flag, 1);
+      if (bv == last) atomicOr(a.flag, 1);
       if (k < a.KC) { a.cand_val[row * a.KC + k] = bv; a.cand_idx[row * a.KC + k] = bv > -INFINITY ? bidx : -1; }
     }
     last = bv;
 #pragma unroll
     for (int u = 0; u < PER; ++u) if (tid + 256 * u == bidx) v[u] = -INFINITY;
-    __syncthreads();
   }
   if (nan) atomicOr(a.flag, 2);
 }

@@ -108,27 +108,40 @@ __global__ __launch_bounds__(256) void text_vector_kernel(const float* __restric
 struct PtrDecSrcK { const float* M; const float* c; const unsigned char* mask; const float* E; const long* text; float* p_out; int L; };
 struct PtrDecArgs { PtrDecSrcK s[3]; int n; };
 
-template <typename T>
+template <typename T, bool LDSROW>
 __global__ __launch_bounds__(256) void pointer_decode_mix_kernel(const T* __restrict__ x, const T* __restrict__ tgt, const float* __restrict__ logits,
                                                                  PtrDecArgs a, const T* __restrict__ Wsw, long ldw, const T* __restrict__ bsw,
                                                                  float scale, float* __restrict__ out, int d, int V) {
   __shared__ float xs[1024], ts[1024], pr[3][128], swl[4], red[4];
+  __shared__ float orow[LDSROW ? 4096 : 1];
+  __shared__ int tx[3][128];                  // the sources' token ids (the scatter walks them L^2 / 2 times: out of LDS, not global memory)
   const long row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int k = tid; k < d; k += 256) { xs[k] = to_f(x[row * d + k]); ts[k] = to_f(tgt[row * d + k]); }
+  for (int j = 0; j < a.n; ++j)
+    for (int t = tid; t < a.s[j].L; t += 256) tx[j][t] = (int)a.s[j].text[t];
   __syncthreads();
-  // scores: wave w takes the keys w, w + 4, ..; its lanes split the d channels (float4 loads, a key's row is contiguous)
-  for (int j = 0; j < a.n; ++j) {
-    const PtrDecSrcK& sj = a.s[j];
-    for (int t = w; t < sj.L; t += 4) {
-      const float* m = sj.M + (long)t * d;
-      float acc = 0.f;
-      for (int k = lane * 4; k < d; k += 256) {
-        const float4 q = *reinterpret_cast<const float4*>(m + k);
-        acc += q.x * xs[k] + q.y * xs[k + 1] + q.z * xs[k + 2] + q.w * xs[k + 3];
+  // scores: a quarter wave (16 lanes) per key, sixteen keys in flight per workgroup; the 16 lanes split the d channels (float4 loads,
+  // 256 contiguous bytes per quarter wave and step), so a key costs independent loads and four shuffle steps instead of a serial
+  // load -> sum chain (a wave per key measured 38 us per launch at 80 keys: ~20 dependent round trips per wave)
+  {
+    const int sub = lane >> 4, l16 = lane & 15;
+    for (int j = 0; j < a.n; ++j) {
+      const PtrDecSrcK& sj = a.s[j];
+      for (int t0 = 0; t0 < sj.L; t0 += 16) {
+        const int t = t0 + 4 * w + sub;
+        float acc = 0.f;
+        if (t < sj.L) {
+          const float* m = sj.M + (long)t * d;
+#pragma unroll 8
+          for (int k = l16 * 4; k < d; k += 64) {
+            const float4 q = *reinterpret_cast<const float4*>(m + k);
+            acc += q.x * xs[k] + q.y * xs[k + 1] + q.z * xs[k + 2] + q.w * xs[k + 3];
+          }
+        }
+        acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
+        if (l16 == 0 && t < sj.L) pr[j][t] = sj.mask[t] ? (acc + sj.c[t]) * scale : -1e9f;
       }
-      acc = wave_sum(acc);
-      if (lane == 0) pr[j][t] = sj.mask[t] ? (acc + sj.c[t]) * scale : -1e9f;
     }
   }
   __syncthreads();
@@ -157,14 +170,17 @@ __global__ __launch_bounds__(256) void pointer_decode_mix_kernel(const T* __rest
     acc = wave_sum(acc);
     if (lane == 0) swl[w] = acc + to_f(bsw[w]);
   }
-  // the mixture (pointer_mix_kernel with the rows' shared texts)
+  // the mixture (pointer_mix_kernel with the rows' shared texts).  LDSROW: the vocabulary row lives in LDS between its one read and its one
+  // write (V <= 4096) -- three passes, the scatter and the log otherwise cost six dependent global round trips of a 5-workgroup launch
   const float* lg = logits + row * V;
-  float* o = out + row * V;
+  float* og = out + row * V;
+  float* o = LDSROW ? orow : og;
   float mx = -INFINITY;
-  for (int v = tid; v < V; v += 256) mx = fmaxf(mx, lg[v]);
-  mx = block_reduce(mx, red, true);           // (its barriers also publish swl)
+  for (int v = tid; v < V; v += 256) { const float l = lg[v]; if (LDSROW) orow[v] = l; mx = fmaxf(mx, l); }
+  mx = block_reduce(mx, red, true);           // (its barriers also publish swl and orow)
+  const float* lsrc = LDSROW ? orow : lg;
   float den = 0.f;
-  for (int v = tid; v < V; v += 256) den += expf(lg[v] - mx);
+  for (int v = tid; v < V; v += 256) den += expf(lsrc[v] - mx);
   den = block_reduce(den, red, false);
   float sw[4];
   {
@@ -174,13 +190,13 @@ __global__ __launch_bounds__(256) void pointer_decode_mix_kernel(const T* __rest
     for (int j = 0; j < ns; ++j) sw[j] /= d2;
   }
   const float vs = sw[a.n] / den;
-  for (int v = tid; v < V; v += 256) o[v] = vs * expf(lg[v] - mx);
+  for (int v = tid; v < V; v += 256) o[v] = vs * expf(lsrc[v] - mx);
   __syncthreads();
   for (int j = 0; j < a.n; ++j) {             // deterministic scatter_add, as in pointer_mix_kernel
-    const long* text = a.s[j].text;
+    const int* text = tx[j];
     const int L = a.s[j].L;
     for (int t = tid; t < L; t += 256) {
-      const long id = text[t];
+      const int id = text[t];
       bool first = true;
       for (int u = 0; u < t; ++u) first = first && text[u] != id;
       if (first) {
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256) void pointer_decode_mix_kernel(const T* __rest
     }
     __syncthreads();
   }
-  for (int v = tid; v < V; v += 256) o[v] = logf(o[v]);
+  for (int v = tid; v < V; v += 256) og[v] = logf(o[v]);
 }
 
 // Generator.forward (generator.py:21-27): log_softmax over the vocabulary.
@@ -280,12 +296,11 @@ extern "C" int bist_pointer_decode_mix_fwd(const void* x, const void* tgt, const
     a.s[j] = PtrDecSrcK{sj.M, sj.c, sj.mask, sj.E, (const long*)sj.text, sj.p_out, sj.L};
   }
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == BIST_BF16)
-    hipLaunchKernelGGL(pointer_decode_mix_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)tgt, logits, a,
-                       (const bf16_t*)Wsw, (long)ldw, (const bf16_t*)bsw, scale, out, d, V);
-  else
-    hipLaunchKernelGGL(pointer_decode_mix_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)x, (const float*)tgt, logits, a,
-                       (const float*)Wsw, (long)ldw, (const float*)bsw, scale, out, d, V);
+#define BIST_PDM(T, LR) hipLaunchKernelGGL((pointer_decode_mix_kernel<T, LR>), dim3((unsigned)rows), dim3(256), 0, st, (const T*)x, (const T*)tgt, \
+                                          logits, a, (const T*)Wsw, (long)ldw, (const T*)bsw, scale, out, d, V)
+  if (dtype == BIST_BF16) { if (V <= 4096) BIST_PDM(bf16_t, true); else BIST_PDM(bf16_t, false); }
+  else { if (V <= 4096) BIST_PDM(float, true); else BIST_PDM(float, false); }
+#undef BIST_PDM
   BIST_LAUNCH_CHECK("bist_pointer_decode_mix_fwd");
   return BIST_OK;
 }

@@ -23,23 +23,25 @@ from ..data.batch import subsequent_mask
 BATCH_HYPOTHESES = True      # False: one model.decode call per hypothesis, like the reference
 
 
-def _rows(t, n):
-    """[1, ...] -> contiguous [n, ...] copies (the kernels want dense batches)."""
-    return t.expand(n, *t.shape[1:]).contiguous()
+def _rows(t, n, lazy=False):
+    """[1, ...] -> contiguous [n, ...] copies (the kernels want dense batches); lazy: the stride-0 view, no launch."""
+    v = t.expand(n, *t.shape[1:])
+    return v if lazy else v.contiguous()
 
 
-def _turn_for_rows(batch, ft, n, cache):
+def _turn_for_rows(batch, ft, n, cache, lazy=False):
     """The turn's static inputs replicated for n hypotheses: ids / masks of the dialogue and the encoded text plus the
-    per-layer reasoning results (never the video tensor).  Built once per row count."""
+    per-layer reasoning results (never the video tensor).  Built once per row count.  lazy: stride-0 views instead of copies (~40
+    launches per turn) -- for a caller that only hands them to _TurnBuffers.load, which copies them when a step graph needs rows."""
     hit = cache.get(n)
     if hit is None:
         b = types.SimpleNamespace(**{k: v for k, v in vars(batch).items()})
         for name in ("query", "his", "cap", "query_mask", "his_mask", "cap_mask"):
             v = getattr(batch, name, None)
-            setattr(b, name, _rows(v, n) if v is not None else None)
+            setattr(b, name, _rows(v, n, lazy) if v is not None else None)
         b.fts = None
-        f = {k: _rows(ft[k], n) for k in ("encoded_query", "encoded_his", "encoded_cap") if ft.get(k) is not None}
-        f["_bist_reasoning"] = [{k: _rows(v, n) for k, v in layer.items()} for layer in ft["_bist_reasoning"]]
+        f = {k: _rows(ft[k], n, lazy) for k in ("encoded_query", "encoded_his", "encoded_cap") if ft.get(k) is not None}
+        f["_bist_reasoning"] = [{k: _rows(v, n, lazy) for k, v in layer.items()} for layer in ft["_bist_reasoning"]]
         if "_bist_turn" in ft:
             f["_bist_turn"] = ft["_bist_turn"]
         f["_bist_shared_rows"] = True          # every row is the same dialogue (the decoder's persistent kernel relies on it)
@@ -56,18 +58,35 @@ class _TurnBuffers:
 
     def __init__(self, bn, fn, decoder=None):
         self.decoder = decoder
+        dense = lambda v: torch.empty(v.shape, device=v.device, dtype=v.dtype).copy_(v)       # (v may be a stride-0 view)
         self.b = types.SimpleNamespace(**vars(bn))
         for name in ("query", "his", "cap", "query_mask", "his_mask", "cap_mask"):
             v = getattr(bn, name, None)
-            setattr(self.b, name, v.clone() if v is not None else None)
-        self.f = {k: v.clone() for k, v in fn.items() if torch.is_tensor(v)}
+            setattr(self.b, name, dense(v) if v is not None else None)
+        self.f = {k: dense(v) for k, v in fn.items() if torch.is_tensor(v)}
         self.f["_bist_shared_rows"] = True
-        self.f["_bist_reasoning"] = [{k: v.clone() for k, v in layer.items()} for layer in fn["_bist_reasoning"]]
-        self.loaded = None               # the (bn, fn) pair currently held
+        self.f["_bist_reasoning"] = [{k: dense(v) for k, v in layer.items()} for layer in fn["_bist_reasoning"]]
+        self.loaded = None               # the (bn, fn) pair whose memories the decoder's caches hold
+        self.rows_of = None              # the (bn, fn) pair whose rows the static buffers hold
 
-    def load(self, bn, fn):
+    def load(self, bn, fn, need_rows=True):
+        """need_rows=False: the step graph about to be replayed reads nothing of these buffers (persistent decoder kernel on its
+        key / value caches + the pointer heads on their per-turn constants: both were projected by the turn's first-step graph), so
+        the ~40 row copies are skipped when the decoder's caches already hold this turn."""
+        dec = self.decoder
+        fresh = dec is not None and hasattr(dec, "decode_cache_is") and dec.decode_cache_is(fn.get("_bist_turn"))
+        if (need_rows or not fresh) and self.rows_of is not fn:
+            self._copy_rows(bn, fn)
+            self.rows_of = fn
         if self.loaded is fn:
             return
+        self.loaded = fn
+        if dec is not None:          # a new turn: re-project the memories' keys / values (from the static buffers) unless the first step did
+            if dec._fused_decode_ok(self.b, self.f, self.f["encoded_query"][:, :1]):
+                # (the turn's first step -- the replayed encode + first-step graph -- has usually projected them already: same turn token)
+                dec.prepare_decode_cache(self.b, self.f, src=fn["_bist_reasoning"], turn=fn.get("_bist_turn"))
+
+    def _copy_rows(self, bn, fn):
         dsts, srcs = [], []
         for name in ("query", "his", "cap", "query_mask", "his_mask", "cap_mask"):
             v = getattr(bn, name, None)
@@ -90,12 +109,6 @@ class _TurnBuffers:
             else:
                 for d_, s_ in zip(ds, ss):
                     d_.copy_(s_)
-        self.loaded = fn
-        if self.decoder is not None:          # the static buffers now hold a new turn: re-project the memories' keys / values
-            dec = self.decoder
-            if dec._fused_decode_ok(self.b, self.f, self.f["encoded_query"][:, :1]):
-                # (the turn's first step -- the replayed encode + first-step graph -- has usually projected them already: same turn token)
-                dec.prepare_decode_cache(self.b, self.f, src=fn["_bist_reasoning"], turn=fn.get("_bist_turn"))
 
 
 def _descending(lp_vec, k):
@@ -183,20 +196,25 @@ def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args,
     tb = store.get(("turn",) + geom)
     if tb is None:
         tb = store[("turn",) + geom] = _TurnBuffers(bn, fn, getattr(model, "mutlimodal_decoder", None))
-    tb.load(bn, fn)
     key = ("incr", pos, slot0, LkS, None if shared is None else (shared[0].data_ptr(), shared[1].data_ptr())) + geom
     g = store.get(key)
+    tb.load(bn, fn, need_rows=g is None or not g[4])
     if g is None:
         strg = shared[0] if shared is not None else torch.zeros((n, 1), dtype=torch.long, device=dev)
         smask = shared[1] if shared is not None else torch.zeros((n, LkS), dtype=torch.uint8, device=dev)
         sb = types.SimpleNamespace(**vars(tb.b))
         sb.trg, sb.trg_mask = strg, None
 
+        flags = {}
+
         def run():
             f = dict(tb.f)
             f["_bist_incr"] = (slot0, smask)
             f2 = model.decode(sb, f, pos)
-            return model.generator(f2, sb, train_args).float()
+            out = model.generator(f2, sb, train_args).float()
+            # neither the decoder layers nor the heads read the rows of tb: the replays of this graph do not need them refreshed
+            flags["self_contained"] = "_bist_turn_consts" in f2 and bool(f2.get("_bist_ptr_fast"))
+            return out
         if shared is None:
             strg.copy_(new_tokens)
             smask.copy_(torch.from_numpy(mask_np))
@@ -208,8 +226,8 @@ def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args,
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = run()
-        g = store[key] = (graph, strg, smask, out)
-    graph, strg, smask, out = g
+        g = store[key] = (graph, strg, smask, out, bool(flags.get("self_contained")))
+    graph, strg, smask, out, _ = g
     if shared is None:
         strg.copy_(new_tokens)
         smask.copy_(torch.from_numpy(mask_np))
@@ -330,7 +348,7 @@ def _device_beam_turn(model, batch, ft, out0, max_len, unk_symbol, end_symbol, b
     lks = lambda slot0: 32 if slot0 + beam <= 32 else 64
     bs.step(out0, 1, 0, min_len, unk_symbol, end_symbol, dec_eos, penalty, beam, lks(beam) if max_len > 1 else 0)
     if max_len > 1:
-        bn, fn = _turn_for_rows(batch, ft, beam, {})
+        bn, fn = _turn_for_rows(batch, ft, beam, {}, lazy=True)
     for l in range(1, max_len):
         slot0 = l * beam
         out = _graph_step_incr(model, bn, fn, None, l, slot0, None, train_args, shared=(bs.tok, bs.mask[lks(slot0)]))

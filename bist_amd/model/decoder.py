@@ -207,6 +207,11 @@ class MultimodalDecoder8(nn.Module):
         for hook in self.__dict__.get("_bist_turn_hooks", {}).values():       # (the pointer generator's folded keys: generator._turn_consts)
             hook(b, ft, kv)
 
+    def decode_cache_is(self, turn) -> bool:
+        """The current key / value caches (and the constants that hang on them) hold the memories of turn ``turn``."""
+        st = self.__dict__.get("_bist_dec_state")
+        return turn is not None and st is not None and st.get("kv") is not None and st["kv"].get("turn") is turn
+
     def select_decode_cache(self, ft, turn) -> bool:
         """A captured graph has just projected this turn's memories (it wrote the cache buffers of ``ft``'s dialogue geometry): make
         those buffers the current ones and mark them as holding turn ``turn``.  False if that geometry has no buffers yet."""

@@ -184,6 +184,7 @@ class MultiPointerGenerator(nn.Module):
             srcs.append(s2)
         out = ops.pointer_decode_mix(x.reshape(B * Lt, d).contiguous(), tgt.reshape(B * Lt, d).contiguous(), logits.view(B * Lt, -1), srcs,
                                      self.pointer_gen_W.weight, self.pointer_gen_W.bias, 1.0 / (d ** 0.5))
+        ft["_bist_ptr_fast"] = True
         return out.view(B, Lt, -1)
 
     def forward(self, ft, batch, args):
