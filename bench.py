@@ -40,19 +40,37 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICRO
 CFG = dict(L=6, d=512, h=8, B=16, T=32, S=49, C=2048, Lq=20, Lh=60, Lc=25, Lt=20, V=3000)
 
 
+REGION_SOURCES = ("common.hpp", "gemm.hip", "rowops.hip", "attention.hip", "attention_mfma.hip", "st1_fused.hip")
+REGION_PMC = "r03_attn_fwd_B64_pmc.json"
+
+
+def region_sources_sha():
+    """sha256 over the sources of the kernels of the roofline region (P0 GEMM, LayerNorm, the fused stage-1 launches, stage 2, the
+    small products): the key of the committed counter passes -- traffic measured on other kernels is not this build's traffic."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in REGION_SOURCES:
+        with open(os.path.join(ROOT, "bist_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def region_traffic(B, T):
-    """HBM bytes of one pass over the roofline region from the committed PMC passes (profiles/r02_attn_fwd_B64_pmc.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of scripts/prof_attn.py, FETCH_SIZE doubled per the gfx950 note of
-    MI355X_MICROARCH.md); None when the geometry differs from the profiled one.  Counters cannot be read from inside a timed
-    run, so this is the offline figure of the same kernels and shapes."""
+    """HBM bytes of one pass over the roofline region from the committed PMC passes (profiles/r03_attn_fwd_B64_pmc.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of scripts/prof_attn.py, FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md).  Counters cannot be read from inside a timed run, so this is the offline figure of the same kernels and
+    shapes: (None, reason) when the geometry differs from the profiled one or the region's kernel sources changed since the passes
+    (the file carries their sha256, scripts/pmc_region.py)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_attn_fwd_B64_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", REGION_PMC)) as f:
             t = json.load(f)
     except OSError:
-        return None
+        return None, "profiles/%s is missing" % REGION_PMC
     if t.get("B") != B or t.get("T") != T:
-        return None
-    return t
+        return None, "the committed counter passes are of B=%s T=%s" % (t.get("B"), t.get("T"))
+    if t.get("region_sources_sha256") != region_sources_sha():
+        return None, "the region's kernel sources changed since the committed counter passes (re-run scripts/prof_round_r03.sh)"
+    return t, None
 
 
 def model_args(L, d, h, dropout):
@@ -167,6 +185,7 @@ def main():
     ap.add_argument("--cpu-rows", default="all", choices=["all", "step"], help="cpu_baseline: every BASELINE.md row, or the training step only")
     ap.add_argument("--no-decode", action="store_true", help="skip the beam-search turn timing (BASELINE configs[4])")
     ap.add_argument("--no-t128", action="store_true", help="skip the T=128 (BASELINE configs[3]) step / forward timing")
+    ap.add_argument("--no-f32", action="store_true", help="skip the float32 side line (the same step in the parity dtype)")
     ap.add_argument("--no-graph", action="store_true", help="launch the kernels of a step eagerly instead of replaying a hipGraph")
     a = ap.parse_args()
 
@@ -336,7 +355,7 @@ def main():
         attn64 = region_report(64, c["T"], b64)
         del b64
     roof = attn64 if attn64 is not None else attn
-    traffic = region_traffic(roof["B"], roof["T"]) if rank == 0 else None
+    traffic, traffic_note = region_traffic(roof["B"], roof["T"]) if rank == 0 else (None, None)
     dom = max(roof["kernels"], key=lambda k: k["avg_launch_ms"])
 
     # BASELINE configs[3]: T=128 on the same model (its own trainer; rank 0 of a one-GPU run only)
@@ -353,6 +372,19 @@ def main():
                 "ms_per_step": dt128 / 5 * 1e3, "tokens_per_s": float(b128.ntokens.item()) * 5 / dt128, "attn_fwd": region_report(c["B"], 128, b128)}
         del tr128, b128
 
+    # the same step in float32 -- the dtype the parity tests hold to 1e-3 against the oracle; bf16 above is the throughput dtype
+    f32 = None
+    if rank == 0 and world == 1 and not a.no_f32 and a.dtype == "bf16":
+        model.train()
+        b32 = synthetic_batch(c["B"], T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"], seed=1234,
+                              dtype=torch.float32)
+        tr32 = Trainer(model, args, c["V"], compute_dtype=torch.float32, use_graph=not a.no_graph)
+        dt32 = timed_steps(tr32, b32, 2, 4)
+        model.eval()
+        f32 = {"what": "the same training step with float32 operands and float32 kernels (the dtype of the 1e-3 parity tests); not the headline",
+               "ms_per_step": dt32 / 4 * 1e3, "tokens_per_s": float(b32.ntokens.item()) * 4 / dt32}
+        del tr32, b32
+
     out = {
         "metric": "training-step tokens/sec (BiST hot path: fwd + pointer-generator losses + bwd + Adam)",
         "value": ntok_all * a.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -364,13 +396,14 @@ def main():
                    "clips_per_s": c["B"] * world * a.steps / dt},
         "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": roof["frac_of_mfma_peak"], "traffic": (traffic or {}).get("traffic_bytes"),
-                     "traffic_detail": traffic,
+                     "traffic_detail": traffic if traffic is not None else {"note": traffic_note},
                      "region": f"fused BiST attention forward F_P0+F_VL (SURVEY 8d): P0 + LayerNorm + one VidEncoderLayer4, inference, "
                                f"B={roof['B']}, T={roof['T']}, 7x7, C=2048, one hipGraph replay",
                      "gflop_alg": roof["gflop_alg"], "avg_launch_ms": roof["ms"], "kernel": dom["kernel"], "kernels": roof["kernels"]},
         "attn_fwd": {"what": "the same region on the bench batch", **attn, "at_B64": attn64},
         "decode": decode,
         "t128": t128,
+        "f32": f32,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_rows, a.cpu_threads)

@@ -41,8 +41,11 @@ rows_v = B * T * S
 # pass (lower bound) or once per direction (this build: two stage-1 launches), weights, stage-1 outputs written and read once
 alg_lo = 2 * (rows_v * C + rows_v * d + rows_v * d + (C * d + 40 * d * d) + 2 * B * (S + T) * Lq * d)
 alg_hi = alg_lo + 2 * rows_v * d
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                   # (region_sources_sha: the key bench.py checks before quoting these bytes)
 print(json.dumps({
-    "B": B, "T": T, "passes_averaged": iters,
+    "B": B, "T": T, "passes_averaged": iters, "region_sources_sha256": bench.region_sources_sha(),
     "fetch_bytes_corrected": fb, "write_bytes": wb, "traffic_bytes": fb + wb,
     "algorithmic_bytes_range": [alg_lo, alg_hi], "ratio_to_algorithmic": [(fb + wb) / alg_hi, (fb + wb) / alg_lo],
     "per_kernel_bytes": {k: {"fetch": round(v[0]), "write": round(v[1]), "launches_per_pass": v[2] / iters} for k, v in

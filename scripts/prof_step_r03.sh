@@ -5,7 +5,7 @@ TAG=$1; shift
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 8 --warmup 3 --no-t128 --no-cpu-baseline --no-decode > gpurun_out/prof_$TAG.json 2> gpurun_out/prof_$TAG.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 8 --warmup 3 --no-t128 --no-f32 --no-cpu-baseline --no-decode > gpurun_out/prof_$TAG.json 2> gpurun_out/prof_$TAG.err
 T=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
 python scripts/step_launch_counts.py $T > gpurun_out/r03_step_${TAG}_one_step.txt 2>&1
 python scripts/step_timeline.py $T 48 > gpurun_out/r03_step_${TAG}_timeline.txt 2>&1
