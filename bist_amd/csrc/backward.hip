@@ -515,6 +515,41 @@ __global__ void adam_kernel(float* __restrict__ p, const TG* __restrict__ g, flo
   if (work) work[i] = from_f<TW>(pi);
 }
 
+// adam_kernel on 4 elements per thread (16-byte accesses of p / m / v, 8 or 16 of the gradient and the working copy): n4 = n / 4
+template <typename TG, typename TW>
+__global__ __launch_bounds__(256) void adam4_kernel(float* __restrict__ p, const TG* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    TW* __restrict__ work, long n4, float b1, float b2, float eps, const float* __restrict__ hyper) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gscale = hyper[3];
+  float gi[4];
+  if constexpr (sizeof(TG) == 2) {
+    const uint2 q = reinterpret_cast<const uint2*>(g)[i];
+    gi[0] = __builtin_bit_cast(float, q.x << 16); gi[1] = __builtin_bit_cast(float, q.x & 0xffff0000u);
+    gi[2] = __builtin_bit_cast(float, q.y << 16); gi[3] = __builtin_bit_cast(float, q.y & 0xffff0000u);
+  } else {
+    const float4 q = reinterpret_cast<const float4*>(g)[i];
+    gi[0] = q.x; gi[1] = q.y; gi[2] = q.z; gi[3] = q.w;
+  }
+  const float4 pm = reinterpret_cast<const float4*>(p)[i], mm = reinterpret_cast<const float4*>(m)[i], vm = reinterpret_cast<const float4*>(v)[i];
+  float pv[4] = {pm.x, pm.y, pm.z, pm.w}, mv[4] = {mm.x, mm.y, mm.z, mm.w}, vv[4] = {vm.x, vm.y, vm.z, vm.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) adam_elem(pv[e], mv[e], vv[e], gi[e] * gscale, lr, b1, b2, eps, bc1, bc2);
+  reinterpret_cast<float4*>(m)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+  reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  reinterpret_cast<float4*>(p)[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+  if (work) {
+    if constexpr (sizeof(TW) == 2) {
+      typedef __attribute__((ext_vector_type(2))) float f32x2_;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+      const bf16x2_ lo = __builtin_convertvector(f32x2_{pv[0], pv[1]}, bf16x2_), hi = __builtin_convertvector(f32x2_{pv[2], pv[3]}, bf16x2_);
+      reinterpret_cast<uint2*>(work)[i] = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+    } else {
+      reinterpret_cast<float4*>(work)[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    }
+  }
+}
+
 // Adam on 4 elements per thread with the step's scalars in hyper = {lr, 1 - beta1^t, 1 - beta2^t, grad_scale, apply}; the gradient is
 // CLEARED after it is read, so the next backward pass accumulates into zeros without a memset of its own.  apply == 0 (nothing
 // pending): only the clear.
@@ -948,8 +983,15 @@ extern "C" int bist_adam_step_dev(float* p, const void* g, float* m, float* v, v
                                   float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream) {
   BIST_REQUIRE(p && g && m && v && hyper && n > 0, "bist_adam_step_dev: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = blocks_for(n, 256);
-#define ADAM(TG, TW) hipLaunchKernelGGL((adam_kernel<TG, TW>), dim3(grid), dim3(256), 0, st, p, (const TG*)g, m, v, (TW*)work, (long)n, 0.f, beta1, beta2, eps, 1.f, 1.f, 1.f, hyper)
+  // whole 16-byte groups: four elements per thread
+  const bool vec = n % 4 == 0 && ((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) % 16 == 0 && (uintptr_t)g % (grad_dtype == BIST_BF16 ? 8 : 16) == 0 &&
+                   (!work || (uintptr_t)work % (work_dtype == BIST_BF16 ? 8 : 16) == 0);
+  const unsigned grid = vec ? blocks_for(n / 4, 256) : blocks_for(n, 256);
+#define ADAM(TG, TW)                                                                                                                                  \
+  do {                                                                                                                                                \
+    if (vec) hipLaunchKernelGGL((adam4_kernel<TG, TW>), dim3(grid), dim3(256), 0, st, p, (const TG*)g, m, v, (TW*)work, (long)(n / 4), beta1, beta2, eps, hyper); \
+    else hipLaunchKernelGGL((adam_kernel<TG, TW>), dim3(grid), dim3(256), 0, st, p, (const TG*)g, m, v, (TW*)work, (long)n, 0.f, beta1, beta2, eps, 1.f, 1.f, 1.f, hyper); \
+  } while (0)
   if (grad_dtype == BIST_F32 && (work == nullptr || work_dtype == BIST_F32)) ADAM(float, float);
   else if (grad_dtype == BIST_F32 && work_dtype == BIST_BF16) ADAM(float, bf16_t);
   else if (grad_dtype == BIST_BF16 && (work == nullptr || work_dtype == BIST_BF16)) ADAM(bf16_t, bf16_t);
