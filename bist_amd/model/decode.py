@@ -137,6 +137,20 @@ def _graph_store(model):
     return model.__dict__["_bist_step_graphs"]
 
 
+# Every dialogue geometry (token lengths of query / history / caption, frame count) holds one first-step graph, up to max_len step graphs,
+# their static buffers and the decoder's key / value caches (~13 graphs; first sight costs 45-150 ms of captures against ~8 ms per replayed
+# turn: scripts/decode_geometries.py).  When more than this many are held, all of them are dropped.
+MAX_GEOMETRIES = int(os.environ.get("BIST_DECODE_MAX_GEOMETRIES", "48"))
+
+
+def _drop_graphs(model):
+    """Forget every captured decode graph of the model together with the buffers whose addresses they hold."""
+    model.__dict__["_bist_step_graphs"] = {}
+    dec = getattr(model, "mutlimodal_decoder", None)
+    if dec is not None:
+        dec.__dict__.pop("_bist_dec_state", None)
+
+
 def _graph_step(model, bn, fn, trg, train_args):
     """decode + generator for the n hypothesis rows of one step, replayed from a hipGraph (captured once per geometry:
     row count, prefix length, dialogue lengths, dtype); returns the log-probs [n, 1, V] as a numpy array."""
@@ -247,6 +261,9 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True):
     store = _graph_store(model)
     g = store.get(("first",) + geom)
     if g is None:
+        if sum(1 for k in store if isinstance(k, tuple) and k and k[0] == "first") >= MAX_GEOMETRIES:
+            _drop_graphs(model)              # bounded memory over a test set of many dialogue lengths: start over (re-captured on demand)
+            store = _graph_store(model)
         sb = types.SimpleNamespace(**vars(batch))
         for f in _TURN_FIELDS:
             v = getattr(batch, f, None)

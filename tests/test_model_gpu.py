@@ -632,3 +632,39 @@ def test_decode_step_pointer_heads_in_one_launch_equal_the_separate_launches(hip
                 assert (a - r).abs()[keep].max().item() <= 6e-2, (seed, n, Lt, (a - r).abs()[keep].max().item())
                 assert torch.equal(a.argmax(-1), r.argmax(-1)), (seed, n, Lt)
     assert taken == 9
+
+
+def test_beam_search_over_more_dialogue_geometries_than_the_graph_store_holds(hip):
+    """decode.MAX_GEOMETRIES bounds the captured decode graphs (a test set has thousands of (query, history, caption) lengths): with room
+    for two geometries, turns over three geometries in rotation (A B C A B C A) drop and re-capture the store on the way; every turn
+    gives the n-best list and scores of the same turn decoded with an unbounded store, and the store never holds more than two
+    first-step graphs."""
+    import bist_amd.model.decode as D
+    from bist_amd.model.decode import beam_search_decode
+    M, Batch = hip
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    V, C = 300, 256
+    model, _ = build_model(M, cfg, V, C, torch.bfloat16)
+    shapes = [(20, 30, 15), (12, 45, 10), (17, 22, 13)]
+    dialogues = [O.det_batch(1, 8, 9, C, *shapes[i % 3], 12, V, seed=70 + i) for i in range(7)]
+
+    def turns(limit):
+        model.__dict__.pop("_bist_step_graphs", None); model.__dict__.pop("_bist_step_graphs_key", None)
+        old, D.MAX_GEOMETRIES = D.MAX_GEOMETRIES, limit
+        out, held = [], 0
+        try:
+            with torch.no_grad():
+                for ob in dialogues:
+                    out.append(beam_search_decode(model, to_batch(Batch, ob, torch.bfloat16), 12, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID, beam=5,
+                                                  penalty=1.0, nbest=5, train_args=_args(cfg))[0])
+                    held = max(held, sum(1 for k in model.__dict__["_bist_step_graphs"] if isinstance(k, tuple) and k and k[0] == "first"))
+        finally:
+            D.MAX_GEOMETRIES = old
+        return out, held
+    small, held_small = turns(2)
+    big, held_big = turns(48)
+    assert held_small <= 2 and held_big == 3
+    for i, (a, b) in enumerate(zip(small, big)):
+        assert [list(map(int, x[0])) for x in a] == [list(map(int, x[0])) for x in b], i
+        assert all(float(x[1]) == float(y[1]) for x, y in zip(a, b)), i
+    model.__dict__.pop("_bist_step_graphs", None); model.__dict__.pop("_bist_step_graphs_key", None)
