@@ -62,6 +62,10 @@ class BistPtrDecSrc(C.Structure):
                 ("L", C.c_int32), ("pad_", C.c_int32)]
 
 
+class BistKvFill(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("K", C.c_void_p), ("VT", C.c_void_p), ("Lk", C.c_int32), ("LkP", C.c_int32), ("ld", C.c_int64)]
+
+
 class BistLnBwdSet(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("a", C.c_void_p), ("dx", C.c_void_p), ("da", C.c_void_p), ("db", C.c_void_p),
                 ("dx_add", C.c_void_p), ("dz", C.c_void_p), ("drop_row0", C.c_uint64)]
@@ -142,6 +146,7 @@ SIGNATURES = {
     "bist_noam_hyper": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "bist_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _P]),
     "bist_text_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
+    "bist_decoder_cache_fill": (C.c_int, [_P, _I32, _I32, _P]),
     "bist_pointer_decode_mix_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _P, _I64, _P, _F, _P, _I64, _I32, _I32, _I32, _P]),
     "bist_noam_hyper_pending": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "bist_adam_apply_dev": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _P]),

@@ -741,6 +741,54 @@ static int bist_decoder_stack_device_ok(void) {
   return good;
 }
 
+// The per-turn key / value caches of the decoder kernel's three memories out of the packed [k | v] projections (decoder.py:42-55: the
+// memories' keys and values do not depend on the prefix): job j copies K rows [Lk][512] and writes V transposed [512][LkP] (the PV
+// product's B operand reads 8 consecutive keys per lane), rows >= Lk of VT's columns zero.  One launch for every (layer, memory) of
+// a turn instead of two strided copies each.  blockIdx.x = job, blockIdx.y = tile of 16 keys.
+struct KvFillK { const bf16_t* src; bf16_t* K; bf16_t* VT; int Lk, LkP; long ld; };
+struct KvFillArgs { KvFillK j[32]; };
+
+__global__ __launch_bounds__(256) void kv_cache_fill_kernel(const KvFillArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t vt[16][512 + 8];
+  const KvFillK& jb = a.j[blockIdx.x];
+  const int t0 = blockIdx.y * 16, tid = threadIdx.x;
+  if (t0 >= jb.LkP) return;
+  // 16 rows x 1024 columns = 1024 16-byte pieces: four per thread; the k half goes straight out, the v half into LDS
+  for (int i = tid; i < 16 * 128; i += 256) {
+    const int r = i >> 7, c8 = (i & 127) * 8, t = t0 + r;
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    if (t < jb.Lk) q = *reinterpret_cast<const uint4*>(jb.src + (long)t * jb.ld + c8);
+    if (c8 < 512) { if (t < jb.Lk) *reinterpret_cast<uint4*>(jb.K + (long)t * 512 + c8) = q; }
+    else *reinterpret_cast<uint4*>(&vt[r][c8 - 512]) = q;
+  }
+  __syncthreads();
+  for (int c = tid; c < 512; c += 256) {          // column c of V: 16 keys = 32 contiguous bytes of VT's row c
+    __attribute__((aligned(16))) bf16_t o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = vt[r][c];
+    uint4* dst = reinterpret_cast<uint4*>(jb.VT + (long)c * jb.LkP + t0);
+    dst[0] = *reinterpret_cast<const uint4*>(&o[0]);
+    dst[1] = *reinterpret_cast<const uint4*>(&o[8]);
+  }
+}
+
+extern "C" int bist_decoder_cache_fill(const BistKvFill* jobs, int32_t n_jobs, int32_t dtype, void* stream) {
+  BIST_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 32 && dtype == BIST_BF16, "bist_decoder_cache_fill: 1..32 jobs, bf16");
+  KvFillArgs a;
+  int maxp = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const BistKvFill& b = jobs[j];
+    BIST_REQUIRE(b.src && b.K && b.VT && b.Lk >= 1 && b.Lk <= b.LkP && (b.LkP == 32 || b.LkP == 64) && b.ld >= 1024 && b.ld % 8 == 0 &&
+                 (((uintptr_t)b.src | (uintptr_t)b.K | (uintptr_t)b.VT) & 15) == 0,
+                 "bist_decoder_cache_fill: job %d: 1 <= Lk <= LkP in {32, 64}, rows of [k | v] 16-byte aligned", j);
+    a.j[j] = KvFillK{(const bf16_t*)b.src, (bf16_t*)b.K, (bf16_t*)b.VT, b.Lk, b.LkP, (long)b.ld};
+    maxp = b.LkP > maxp ? b.LkP : maxp;
+  }
+  hipLaunchKernelGGL(kv_cache_fill_kernel, dim3((unsigned)n_jobs, (unsigned)(maxp / 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  BIST_LAUNCH_CHECK("bist_decoder_cache_fill");
+  return BIST_OK;
+}
+
 extern "C" int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk_max, int32_t dtype) {
   return dtype == BIST_BF16 && d == D && h == H && R >= 1 && R <= 64 && Lk_max >= 1 && Lk_max <= 64 && bist_decoder_stack_device_ok();
 }

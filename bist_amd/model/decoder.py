@@ -13,7 +13,7 @@ import ctypes as C
 from .. import functional as Fn
 from .. import ops
 from .. import zbatch as Z
-from .._lib import BistDecLayer, lib
+from .._lib import BistDecLayer, BistKvFill, check, lib
 from .encoder import _cross_attention, _feed_forward, _self_attention
 from .modules import LayerNorm, SublayerConnection, clones
 
@@ -196,16 +196,58 @@ class MultimodalDecoder8(nn.Module):
         st["kv"] = kv
         for c in range(3):
             kv["mask"][c][:Lks[c]].copy_(masks[c].to(torch.uint8))
+        # projections: the history's and the query's keys / values of ALL layers are one product each (they read the encoded text only:
+        # on a side stream, beside the per-layer products of the fused modalities, together with the other modules' per-turn constants);
+        # then ONE launch scatters the 3 nl packed results into the caches (keys copied, values transposed: bist_decoder_cache_fill)
+        wb = self._packed_memory_weights(nl)
+        main = torch.cuda.current_stream()
+        side = Fn.side_stream(0) if (Fn.CONCURRENT and mems(0)[0].is_cuda) else None
+        jobs = (BistKvFill * (3 * nl))()
+        keep = []
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side if side is not None else main):
+            for c in (0, 1):
+                kvp = Fn.linear(mems(0)[c], wb[c][0], wb[c][1])                               # [Lk, nl * 1024]
+                if side is not None:
+                    kvp.record_stream(main)                                                   # (read by the fill launch on the main stream)
+                keep.append(kvp)
+                for l in range(nl):
+                    jb = jobs[l * 3 + c]
+                    jb.src, jb.K, jb.VT = kvp.data_ptr() + l * 1024 * kvp.element_size(), kv["K"][l][c].data_ptr(), kv["VT"][l][c].data_ptr()
+                    jb.Lk, jb.LkP, jb.ld = Lks[c], LkPs[c], kvp.stride(0)
+            kv["stamp"] = object()                               # this projection's identity: per-turn constants of other modules hang on it
+            for hook in self.__dict__.get("_bist_turn_hooks", {}).values():       # (the pointer generator's folded keys: generator._turn_consts)
+                hook(b, ft, kv)
         for l, layer in enumerate(self.layers):
-            for c, mem in enumerate(mems(l)):
-                w, bias = layer.attn[1 + c]._packed((1, 2))                                   # [W_k; W_v], one product per memory
-                kvp = Fn.linear(mem, w, bias)                                                 # [Lk, 1024]
-                kv["K"][l][c][:Lks[c]].copy_(kvp[:, :512])
-                kv["VT"][l][c][:, :Lks[c]].copy_(kvp[:, 512:].t())
+            w, bias = layer.attn[3]._packed((1, 2))                                           # [W_k; W_v] of the fused-modalities memory
+            kvp = Fn.linear(mems(l)[2], w, bias)                                              # [Lk, 1024]
+            keep.append(kvp)
+            jb = jobs[l * 3 + 2]
+            jb.src, jb.K, jb.VT, jb.Lk, jb.LkP, jb.ld = kvp.data_ptr(), kv["K"][l][2].data_ptr(), kv["VT"][l][2].data_ptr(), Lks[2], LkPs[2], kvp.stride(0)
+        if side is not None:
+            main.wait_stream(side)
+        check(lib.bist_decoder_cache_fill(jobs, 3 * nl, ops.dtype_code(dtype), ops._stream()), "bist_decoder_cache_fill")
         kv["owner"], kv["src"], kv["turn"] = cache, src, turn  # the reasoning results these keys / values were projected from (one list per turn)
-        kv["stamp"] = object()                                 # this projection's identity: per-turn constants of other modules hang on it
-        for hook in self.__dict__.get("_bist_turn_hooks", {}).values():       # (the pointer generator's folded keys: generator._turn_consts)
-            hook(b, ft, kv)
+
+    def _packed_memory_weights(self, nl):
+        """[W_k; W_v] of every layer's history (c = 0) and query (c = 1) attention stacked row-wise, [nl * 1024, 512] + bias: one product per
+        memory and turn.  Cached by the parameters' values; rewritten in place (captured graphs hold the addresses)."""
+        out = []
+        cache = self.__dict__.setdefault("_bist_mem_pack", {})
+        for c in (0, 1):
+            parts = [self.layers[l].attn[1 + c]._packed((1, 2)) for l in range(nl)]
+            key = ops.weights_key(*[p for l in range(nl) for p in (self.layers[l].attn[1 + c].linears[1].weight, self.layers[l].attn[1 + c].linears[1].bias,
+                                                                   self.layers[l].attn[1 + c].linears[2].weight, self.layers[l].attn[1 + c].linears[2].bias)])
+            hit = cache.get(c)
+            if hit is None or hit[0] != key:
+                w, bias = torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
+                if hit is not None and hit[1].shape == w.shape and hit[1].dtype == w.dtype and hit[1].device == w.device:
+                    hit[1].copy_(w); hit[2].copy_(bias)
+                    w, bias = hit[1], hit[2]
+                hit = cache[c] = (key, w, bias)
+            out.append((hit[1], hit[2]))
+        return out
 
     def decode_cache_is(self, turn) -> bool:
         """The current key / value caches (and the constants that hang on them) hold the memories of turn ``turn``."""

@@ -325,6 +325,12 @@ typedef struct BistDecLayer {
 } BistDecLayer;
 int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk_max, int32_t dtype);
 int64_t bist_decoder_layer_desc_bytes(void);
+/* The per-turn key / value caches the persistent decoder kernel reads (BistDecLayer.Kc / VTc): job j takes the packed projection of one
+ * memory for one layer, rows t < Lk of [k(512) | v(512)] at src + t*ld (MultiHeadedAttention.linears[1], [2] of decoder.py:42-55 on the
+ * encoded history / query / fused modalities), copies the keys to K [Lk][512] and writes the values transposed to VT [512][LkP] with
+ * columns Lk..LkP-1 zero.  bf16; jobs is a HOST array of 1..32 entries.                                                        */
+typedef struct BistKvFill { const void* src; void* K; void* VT; int32_t Lk; int32_t LkP; int64_t ld; } BistKvFill;
+int bist_decoder_cache_fill(const BistKvFill* jobs, int32_t n_jobs, int32_t dtype, void* stream);
 /* pbuf (nullable): f32 [2][8][16][512] scratch (256 KiB).  With it and R <= 16 rows (one decode step at a time) the launch takes the
  * HEAD-LOCAL form: workgroup hh < 8 owns head hh through a whole attention sublayer (LayerNorm, its 64 query columns -- and the new
  * rows' key / value columns of the self-attention --, the core, and a PARTIAL output projection over its 64 context columns, K = 64,
