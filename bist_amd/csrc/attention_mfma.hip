@@ -342,6 +342,168 @@ __global__ __launch_bounds__(256) void st1_mfma_kernel(const St1Args a) {
   }
 }
 
+// Backward of the stage-1 core on SAVED probabilities (the fused training forward's side output, St1Args.p_kp > 0): one WAVE per
+// (clip, head, group), four independent waves per workgroup, no workgroup barrier and no f32 slab -- 16 / 9 / 6.5 KiB of LDS per wave
+// (128 / 64 / 32 keys), so 8-16 waves share a CU where st1_mfma_kernel<.., true> keeps 4 (its 150 KiB of slab + images per workgroup made
+// the T = 128 launch run at 0.8 TB/s: 476 us for 366 MB).
+//   dP  = dO . V^T        A = dO rows from the wave's LDS tile, B = V rows STRAIGHT from global memory (16 bytes per lane)
+//   P, mask               read from global in the accumulator layout (16 lanes = 64 contiguous bytes per query row)
+//   dS  = P (dP' - sum_k P dP'), dP' = mask/(1-p) dP, 0 at masked keys  -> dscores, same addresses as st1_mfma_kernel
+//   dV  = P'^T . dO       A = P'^T image [k][32 query rows] (pitch 80 B: written 8 bytes at a time from the accumulator layout, read as
+//                         one 16-byte row piece per lane), B = dO^T by transposing reads; rows staged through the wave's LDS
+template <int KSTEPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void st1_pbwd_kernel(const St1Args a) {
+  constexpr int KPAD = 32 * KSTEPS, DK = 64, NKF = KPAD / 16, PP = 40;       // PP: pitch of the P'^T image in elements
+  constexpr int WAVE_LDS = KPAD * DK * 2 > KPAD * PP * 2 + 32 * DK * 2 ? KPAD * DK * 2 : KPAD * PP * 2 + 32 * DK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T_ = a.T, S_ = a.S, Lq = a.Lq, h = a.h, dir = a.dir;
+  const int G = dir == 0 ? S_ : T_, Kn = dir == 0 ? T_ : S_;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, x = lane & 15, lg = lane >> 4;
+  const int g = blockIdx.x * 4 + w, hh = blockIdx.y, b = blockIdx.z;
+  if (g >= G) return;                                            // (no workgroup barrier below)
+  const long TS_ = (long)T_ * S_;
+  const int d = h * DK;
+  bf16_t* ptr = reinterpret_cast<bf16_t*>(smem + w * WAVE_LDS);  // [KPAD][PP]
+  bf16_t* dt = ptr + KPAD * PP;                                  // [32][DK]
+  bf16_t* stage = ptr;                                           // [KPAD][DK], after both are consumed
+  // ---- loads: the dO tile into LDS, V fragments and probabilities into registers ----------------------------------------
+  const bf16_t* dOb = a.dO + (((long)b * G + g) * Lq) * d + hh * DK;
+  for (int i = lane >> 3; i < 32; i += 8) {
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    if (i < Lq) q = *reinterpret_cast<const uint4*>(dOb + (long)i * d + (lane & 7) * 8);
+    *reinterpret_cast<uint4*>(dt + i * DK + (lane & 7) * 8) = q;
+  }
+  const bf16_t* Vb = a.V + (long)b * TS_ * a.ldv + hh * DK;
+  uint4 vf[2][NKF];
+#pragma unroll
+  for (int ni = 0; ni < NKF; ++ni) {
+    const int k = ni * 16 + x;
+    const long row = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      vf[ks][ni] = k < Kn ? *reinterpret_cast<const uint4*>(Vb + row * a.ldv + ks * 32 + lg * 8) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  const float* Pg = reinterpret_cast<const float*>(a.scores) + (((long)b * G + g) * h + hh) * Lq * a.p_kp;
+  float pv[2][4][NKF];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = mi * 16 + lg * 4 + r;
+#pragma unroll
+      for (int ni = 0; ni < NKF; ++ni) {
+        const int k = ni * 16 + x;
+        pv[mi][r][ni] = (i < Lq && k < Kn) ? Pg[(long)i * a.p_kp + k] : 0.f;
+      }
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- dP = dO . V^T ------------------------------------------------------------------------------------------------------
+  f32x4 dp[2][NKF];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NKF; ++ni) dp[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 af[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) af[mi] = frag_rows(dt, DK, mi * 16, ks * 32, lane);
+#pragma unroll
+    for (int ni = 0; ni < NKF; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) dp[mi][ni] = mfma_bf16(af[mi], vf[ks][ni], dp[mi][ni]);
+  }
+  // ---- dS, and the P'^T image ---------------------------------------------------------------------------------------------
+  const unsigned long long dkey = a.drop.p > 0.f ? a.drop.key() : 0ULL;
+  const float dks = a.drop.p > 0.f ? a.drop.keep_scale() : 1.f;
+  const unsigned char* mk = a.tmask ? a.tmask + (long)b * Kn : nullptr;
+  float* dsc = reinterpret_cast<float*>(a.dscores) + (long)b * Lq * h * TS_;
+  bf16_t* dsc16 = reinterpret_cast<bf16_t*>(a.dscores) + (long)b * Lq * h * TS_;
+  unsigned keym = 0u;                                            // bit ni: key ni * 16 + x is live (inside the range and not masked)
+#pragma unroll
+  for (int ni = 0; ni < NKF; ++ni) {
+    const int k = ni * 16 + x;
+    if (k < Kn && !(mk && mk[k] == 0)) keym |= 1u << ni;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    uint32_t pk[NKF][2];                                         // P' of (r = 0..3) as two bf16 pairs per key fragment
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = mi * 16 + lg * 4 + r;
+      const unsigned long long dbase = ((((unsigned long long)b * G + g) * h + hh) * Lq + i) * Kn;
+      float part = 0.f, pd[NKF];
+#pragma unroll
+      for (int ni = 0; ni < NKF; ++ni) {
+        const int k = ni * 16 + x;
+        const float mul = a.drop.p > 0.f ? drop_mul(dkey, dbase + k, a.drop.p, dks) : 1.f;
+        dp[mi][ni][r] *= mul;                                    // dP = mask/(1-p) * dP'
+        pd[ni] = pv[mi][r][ni] * mul;                            // P' = mask/(1-p) * P
+        part += pv[mi][r][ni] * dp[mi][ni][r];
+      }
+      part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 8, 64);
+#pragma unroll
+      for (int ni = 0; ni < NKF; ++ni) {
+        const int k = ni * 16 + x;
+        if (i < Lq && k < Kn) {
+          const float gq = ((keym >> ni) & 1u) ? pv[mi][r][ni] * (dp[mi][ni][r] - part) : 0.f;
+          const long col = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+          if (a.dsc_bf16) dsc16[((long)i * h + hh) * TS_ + col] = (bf16_t)gq;
+          else dsc[((long)i * h + hh) * TS_ + col] = gq;
+        }
+        const uint32_t hb = (uint32_t)__builtin_bit_cast(unsigned short, (bf16_t)pd[ni]);
+        if (r & 1) pk[ni][r >> 1] |= hb << 16; else pk[ni][r >> 1] = hb;
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NKF; ++ni)                             // row k = ni * 16 + x, query rows mi * 16 + lg * 4 .. + 3: 8 bytes
+      *reinterpret_cast<uint2*>(ptr + (ni * 16 + x) * PP + mi * 16 + lg * 4) = make_uint2(pk[ni][0], pk[ni][1]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- dV = P'^T . dO   (M = k, N = c, K = i) ---------------------------------------------------------------------------------
+  f32x4 dv[NKF][4];
+  {
+    uint4 bfr[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bfr[ni] = frag_cols(dt, DK, ni * 16, 0, lane);
+#pragma unroll
+    for (int mi = 0; mi < NKF; ++mi) {
+      const uint4 af = *reinterpret_cast<const uint4*>(ptr + (mi * 16 + x) * PP + lg * 8);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) dv[mi][ni] = mfma_bf16(af, bfr[ni], f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();                               // every lane has read its fragments: the images may be overwritten
+#pragma unroll
+  for (int mi = 0; mi < NKF; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) stage[(mi * 16 + lg * 4 + r) * DK + ni * 16 + x] = (bf16_t)dv[mi][ni][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  bf16_t* dVb = a.dV + (long)b * TS_ * a.lddv + hh * DK;
+  for (int k = lane >> 3; k < Kn; k += 8) {
+    const long row = dir == 0 ? (long)k * S_ + g : (long)g * S_ + k;
+    *reinterpret_cast<uint4*>(dVb + row * a.lddv + (lane & 7) * 8) = *reinterpret_cast<const uint4*>(stage + k * DK + (lane & 7) * 8);
+  }
+}
+
+template <int KSTEPS>
+int launch_pbwd(const St1Args& a, int B, hipStream_t st) {
+  constexpr int KPAD = 32 * KSTEPS;
+  constexpr int WAVE_LDS = KPAD * 64 * 2 > KPAD * 40 * 2 + 32 * 64 * 2 ? KPAD * 64 * 2 : KPAD * 40 * 2 + 32 * 64 * 2;
+  const int G = a.dir == 0 ? a.S : a.T;
+  dim3 grid((unsigned)((G + 3) / 4), (unsigned)a.h, (unsigned)B);
+  hipLaunchKernelGGL((st1_pbwd_kernel<KSTEPS>), grid, dim3(256), (size_t)4 * WAVE_LDS, st, a);
+  bist_count_launch(BIST_K_ST1_PBWD);
+  return launched("st1_pbwd_kernel");
+}
+
 template <typename TS, int KSTEPS, bool BWD>
 int launch_one(const St1Args& a, int B, size_t lds, hipStream_t st) {
   BIST_LDS_OPTIN((&st1_mfma_kernel<TS, KSTEPS, BWD>), 160 * 1024, "bist_st_stage1_pv (matrix-core kernel)", -1);      // > 64 KiB of dynamic LDS
@@ -822,6 +984,11 @@ int bist_st1_mfma(const void* scores, int sc_is_f32, const void* V, const unsign
                      (bwd ? (size_t)Gc * 32 * 64 * 2 : 0) + 16;
   static const int dbg = [] { const char* e = getenv("BIST_ST1_DBG"); return e ? atoi(e) : 0; }();
   if (p_kp > 0 && (!bwd || !sc_is_f32 || p_kp < Kn)) return 0;
+  static const int old_pbwd = [] { const char* e = getenv("BIST_ST1_PBWD_SLAB"); return e ? atoi(e) : 0; }();      // tuning aid: 1 = the slab kernel on saved probabilities
+  if (p_kp > 0 && !old_pbwd) {
+    St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, 4, dsc_bf16, p_kp, dbg, drop};
+    return ksteps == 1 ? launch_pbwd<1>(a, B, st) : (ksteps == 2 ? launch_pbwd<2>(a, B, st) : launch_pbwd<4>(a, B, st));
+  }
   St1Args a{scores, (const bf16_t*)V, tmask, (bf16_t*)O, (const bf16_t*)dO, dscores, (bf16_t*)dV, T, S, Lq, h, ldv, lddv, dir, Gc, dsc_bf16, p_kp, dbg, drop};
 #define GO(TS_, KS_)                                                                   \
   return bwd ? launch_one<TS_, KS_, true>(a, B, lds, st) : launch_one<TS_, KS_, false>(a, B, lds, st)
