@@ -672,3 +672,32 @@ def test_layernorm_epilogue_of_the_256_tile_product(M, K, monkeypatch):
     assert bool((d <= 2 ** -5 * torch.clamp(want.float().abs(), min=1.0)).all()) and d.mean().item() <= 4e-3, (d.max().item(), d.mean().item())
     ws = ops._workspace(x.device)
     assert int(ws.view(torch.int32)[:1024].abs().max().item()) == 0, "exchange flags / error word must be zero after the launch"
+
+
+@pytest.mark.parametrize("B,G,Lq,d,with_add", [(16, 49, 20, 512, True), (3, 32, 20, 512, False), (2, 5, 7, 64, True), (1, 128, 20, 512, True)])
+def test_group_sum_mask_equals_the_two_separate_passes(B, G, Lq, d, with_add):
+    """bist_group_sum_mask (the head of the fused stage-1 launch's backward: sum of dy over the groups + the other gradient of the
+    un-expanded query, and the dropout-masked dy, in ONE pass; four group slices per workgroup) against the two passes it replaces:
+    bist_group_sum_add and bist_epilogue_bwd with the same (p, seed) -- the masked copy bit-identical (same counter-based mask, same
+    element index), the sum within bf16 rounding of the f32 sum of the bf16 addends."""
+    from bist_amd import _lib, ops as O_
+    from bist_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B * 1000 + G)
+    dy = torch.randn(B, G, Lq, d, generator=g).to(torch.bfloat16).cuda()
+    add = torch.randn(B * Lq, d, generator=g).to(torch.bfloat16).cuda() if with_add else None
+    drop = (0.1, 12345)
+    M = B * G * Lq
+    out1, dz1 = torch.empty(B * Lq, d, device="cuda", dtype=torch.bfloat16), torch.empty_like(dy)
+    check(lib.bist_group_sum_mask(dy.data_ptr(), add.data_ptr() if add is not None else None, out1.data_ptr(), dz1.data_ptr(), B, G, Lq * d,
+                                  O_.drop_ref(drop), O_.dtype_code(dy.dtype), O_._stream()), "bist_group_sum_mask")
+    dz2 = torch.empty_like(dy)
+    check(lib.bist_epilogue_bwd(dy.data_ptr(), dy.data_ptr(), dz2.data_ptr(), M, d, d, d, d, O_.ACT_NONE, drop[0], drop[1], O_._ptr(O_.DROP_CTR),      # (the same step counter, if a trainer of an earlier test left one)
+                               
+                                O_.dtype_code(dy.dtype), O_._stream()), "bist_epilogue_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(dz1, dz2)
+    kept = (dz1 != 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.01
+    ref = dy.float().sum(1).reshape(B * Lq, d) + (add.float() if add is not None else 0)
+    err = (out1.float() - ref).abs().max().item()
+    assert err <= 2.0 ** -7 * ref.abs().max().item(), err
