@@ -105,15 +105,22 @@ class DeviceFeeder:
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
         self._copied[slot] = ready
+        self._last_slot = slot
         return out, ready
 
     def host_buffers_reusable(self, batches_ago: int = 2) -> None:
-        """Block the host until the copies of the batch staged `batches_ago` (1 or 2) calls ago have read their host buffers.
-        Producers that hand over their OWN pinned tensors and reuse them must call this before overwriting them; pageable
-        producers need nothing (their staging copy is guarded inside the feeder)."""
-        for ev in self._copied if batches_ago <= 1 else self._copied[:]:
-            if ev is not None:
-                ev.synchronize()
+        """Block the host until the copies of the batch staged `batches_ago` (1 = the latest, 2 = the one before) calls ago have read their
+        host buffers.  Producers that hand over their OWN pinned tensors and reuse them must call this before overwriting them; pageable
+        producers need nothing (their staging copy is guarded inside the feeder).  Two slots alternate, so the batch staged k calls ago
+        sits in the latest slot for odd k and in the other one for even k; only that slot's copy event is waited for."""
+        if batches_ago < 1:
+            raise ValueError("batches_ago counts back from the latest staged batch: 1, 2, ...")
+        last = getattr(self, "_last_slot", None)
+        if last is None:
+            return                                   # nothing staged yet
+        ev = self._copied[last if batches_ago % 2 == 1 else last ^ 1]
+        if ev is not None:
+            ev.synchronize()
 
     def _batch(self, tensors, ready) -> Batch:
         torch.cuda.current_stream(self.device).wait_event(ready)

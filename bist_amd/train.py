@@ -44,6 +44,7 @@ ALIGN = 64      # elements; keeps every parameter view 16-byte aligned for the L
 
 ADAM_CLEARS = os.environ.get("BIST_ADAM_CLEARS", "0") != "0"      # tuning aid: 1 = Adam on 4 elements per thread that also clears the gradients it consumed, no memset of the gradient
                                                                   # buffer at the head of a replayed step (measured 11.83-11.91 vs 11.72-11.79 ms per step: not adopted)
+ALWAYS_COPY_INPUTS = os.environ.get("BIST_ALWAYS_COPY_INPUTS", "0") != "0"      # 1 = every step copies the batch into the graph's static buffers (see Trainer.invalidate_inputs)
 EXCHANGE_CHUNKS = int(os.environ.get("BIST_EXCHANGE_CHUNKS", "4"))        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
 
 
@@ -412,7 +413,17 @@ class Trainer:
                 setattr(own, f, v.clone())
         return own
 
+    def invalidate_inputs(self) -> None:
+        """Forget which source tensors are resident in the replayed step's static batch: the next step copies every field again.
+        The residency test of `_graph_open` sees torch's in-place writes (`_version`) and DeviceFeeder refills (`_bist_generation`); a
+        producer that refills a REUSED batch tensor behind both -- a kernel of this library writing through a raw pointer, another
+        process through IPC memory -- must call this (or hand over a new tensor object) before the step, or set
+        BIST_ALWAYS_COPY_INPUTS=1."""
+        self._static_src.clear()
+
     def _graph_open(self, batch):
+        if ALWAYS_COPY_INPUTS:
+            self._static_src.clear()
         key = self._shape_key(batch)
         if self._graph is None or key != self._graph_key:
             self._capture(batch, key)

@@ -880,3 +880,42 @@ def test_gate_handoff_that_cannot_arrive_fails_loudly(env):
     ref = x.detach().clone().requires_grad_(True)
     (torch.relu(ref @ w1.detach().t()) @ w2.detach().t()).sum().backward()
     assert (x2.grad - ref.grad).abs().max().item() <= 2e-4 * ref.grad.abs().max().item()
+
+
+def test_inputs_rewritten_behind_torchs_back_need_invalidate_inputs(env):
+    """The replayed step skips the copy of a source tensor it has already made resident (same object, storage, in-place version,
+    feeder generation).  A refill that bypasses all of those -- here a kernel of this library writing the features through a raw
+    pointer (ops.copy_into: no `_version` bump) -- is NOT seen: the contract is Trainer.invalidate_inputs() (or a new tensor object).
+    With it the step sees the new features (its loss equals the loss of a fresh trainer on them), without it the old ones."""
+    import copy
+    import bist_amd.model as M
+    from bist_amd import ops
+    from bist_amd.data.synthetic import synthetic_batch
+    from bist_amd.train import Trainer
+    cfg = O.Cfg(d_model=64, att_h=4, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    args = _args(cfg)
+    torch.manual_seed(0)
+    base = M.make_model(80, 80, args, ft_sizes=[64]).cuda().eval()
+    b = synthetic_batch(4, T=6, S=9, C=64, Lq=7, Lh=9, Lc=6, Lt=6, vocab=80, dtype=torch.float32)
+    other = synthetic_batch(4, T=6, S=9, C=64, Lq=7, Lh=9, Lc=6, Lt=6, vocab=80, dtype=torch.float32, seed=5)
+    new_fts = (other.fts * 3.0 + 1.0).contiguous()
+
+    def first_loss_after_refill(invalidate):
+        tr = Trainer(copy.deepcopy(base), args, 80, compute_dtype=torch.float32, warmup=20, factor=1e-9, use_graph=True)   # (rate ~ 0: the weights stay put)
+        bb = copy.copy(b)
+        bb.fts = b.fts.clone()
+        before = tr.step(bb)["out"].item()
+        version = bb.fts._version
+        ops.copy_into(bb.fts, new_fts)                     # raw-pointer write: torch's version counter does not move
+        assert bb.fts._version == version and torch.equal(bb.fts, new_fts)
+        if invalidate:
+            tr.invalidate_inputs()
+        return before, tr.step(bb)["out"].item()
+    stale0, stale1 = first_loss_after_refill(False)
+    fresh0, fresh1 = first_loss_after_refill(True)
+    assert abs(stale0 - fresh0) <= 1e-6 * abs(stale0)
+    assert abs(stale1 - stale0) <= 1e-4 * abs(stale0)      # the refill was not seen: the same batch again
+    assert abs(fresh1 - fresh0) > 1e-3 * abs(fresh0)       # seen
+    tr = Trainer(copy.deepcopy(base), args, 80, compute_dtype=torch.float32, warmup=20, factor=1e-9, use_graph=True)
+    bb = copy.copy(b); bb.fts = new_fts
+    assert abs(tr.step(bb)["out"].item() - fresh1) <= 1e-4 * abs(fresh1)
