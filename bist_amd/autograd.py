@@ -963,6 +963,45 @@ class PointerMixFn(Function):
         return (dlogits, dsw, None, None, None, *[g.view(p.shape) for g, p in zip(dps, ps)], *([None] * n))
 
 
+class PointerAttnFn(Function):
+    """(p, tv) of a pointer attention (generator.py:106-118): p = softmax(q.k^T / sqrt(d), masked -1e9) f32 [B,Lt,L] over one head of d
+    channels, tv = p . enc (the text vector).  mask [B or 1, L] uint8; text int64 [B,L] or None (then position t also needs
+    text[b,t] != unk, generator.py:106-107).  One launch forward, one backward (bist_pointer_attn_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, q, k, enc, m8, text, unk):
+        B, Lt, d = q.shape
+        L = k.shape[1]
+        q, k, enc = q.contiguous(), k.contiguous(), enc.contiguous()
+        p = torch.empty((B, Lt, L), device=q.device, dtype=torch.float32)
+        tv = torch.empty((B, Lt, d), device=q.device, dtype=enc.dtype)
+        scale = 1.0 / math.sqrt(d)
+        check(lib.bist_pointer_attn_fwd(q.data_ptr(), k.data_ptr(), enc.data_ptr(), _ptr(m8), (L if (m8 is not None and m8.shape[0] > 1) else 0),
+                                        _ptr(text), int(unk), p.data_ptr(), tv.data_ptr(), B, Lt, L, d, scale, dtype_code(q.dtype), _stream()),
+              "bist_pointer_attn_fwd")
+        ctx.save_for_backward(q, k, enc, p)
+        ctx.scale = scale
+        return p, tv
+
+    @staticmethod
+    def backward(ctx, dp, dtv):
+        q, k, enc, p = ctx.saved_tensors
+        B, Lt, d = q.shape
+        L = k.shape[1]
+        dq, dk, denc = torch.empty_like(q), torch.empty_like(k), torch.empty_like(enc)
+        if dp is None and dtv is None:
+            return dq.zero_(), dk.zero_(), denc.zero_(), None, None, None
+        if dp is not None:
+            dp = dp.contiguous() if dp.dtype == torch.float32 else dp.float().contiguous()
+        if dtv is not None:
+            dtv = dtv.contiguous() if dtv.dtype == enc.dtype else dtv.to(enc.dtype).contiguous()
+        else:
+            denc.zero_()
+        check(lib.bist_pointer_attn_bwd(q.data_ptr(), k.data_ptr(), enc.data_ptr(), p.data_ptr(), _ptr(dp), _ptr(dtv), dq.data_ptr(), dk.data_ptr(),
+                                        denc.data_ptr(), B, Lt, L, d, ctx.scale, dtype_code(q.dtype), _stream()), "bist_pointer_attn_bwd")
+        return dq, dk, denc, None, None, None
+
+
 class LogSoftmaxFn(Function):
     @staticmethod
     def forward(ctx, x):

@@ -97,6 +97,146 @@ __global__ __launch_bounds__(256) void text_vector_kernel(const float* __restric
   *reinterpret_cast<uint4*>(out + row * d + c0) = *reinterpret_cast<const uint4*>(o);
 }
 
+// The pointer attention of (Multi)PointerGenerator in TRAINING (generator.py:106-118): single head over d channels.
+//   forward : p[b,i,:] = softmax_t(live(b,t) ? scale q[b,i].k[b,t] : -1e9),  live = mask[b,t] && (!mask_unk || text[b,t] != unk);
+//             tv[b,i,:] = sum_t p[b,i,t] enc[b,t,:]  (the text vector), one wave per (b, i): two launches' worth of the generic attention
+//             core (which also multiplied P by a value operand nobody reads), two mask operations and the cast + fallback product.
+//   backward: dpt = dp + dtv . enc^T;  dS = p (dpt - sum_t p dpt) scale;  dq = dS k;  dk = dS^T q;  denc = p^T dtv -- one workgroup per b.
+template <typename T>
+__global__ __launch_bounds__(256) void pointer_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ enc,
+                                                               const unsigned char* __restrict__ mask, long mask_bs, const long* __restrict__ text,
+                                                               long unk, float* __restrict__ p, T* __restrict__ tv, int rows, int Lt, int L, int d,
+                                                               float scale) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const int b = (int)(row / Lt);
+  const T* qr = q + row * d;
+  const T* kb = k + (long)b * L * d;
+  float s0 = -INFINITY, s1 = -INFINITY;                 // scores of keys lane and lane + 64
+  for (int t = 0; t < L; ++t) {
+    float acc = 0.f;
+    for (int c = lane * E; c < d; c += 64 * E) {
+      T a[E], x[E];
+      *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(qr + c);
+      *reinterpret_cast<uint4*>(x) = *reinterpret_cast<const uint4*>(kb + (long)t * d + c);
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc += to_f(a[e]) * to_f(x[e]);
+    }
+    acc = wave_sum(acc);
+    bool live = mask == nullptr || mask[(long)b * mask_bs + t] != 0;
+    if (text != nullptr && text[(long)b * L + t] == unk) live = false;
+    const float v = live ? acc * scale : -1e9f;
+    if ((t & 63) == lane) { if (t < 64) s0 = v; else s1 = v; }
+  }
+  const float mx = wave_max(fmaxf(s0, s1));
+  const float e0 = lane < L ? expf(s0 - mx) : 0.f, e1 = lane + 64 < L ? expf(s1 - mx) : 0.f;
+  const float inv = 1.f / wave_sum(e0 + e1);
+  const float p0 = e0 * inv, p1 = e1 * inv;
+  if (lane < L) p[row * L + lane] = p0;
+  if (lane + 64 < L) p[row * L + lane + 64] = p1;
+  if (tv) {
+    const T* eb = enc + (long)b * L * d;
+    for (int c0 = 0; c0 < d; c0 += 64 * E) {              // (every lane walks the loop: the shuffles below need the whole wave)
+      const int c = c0 + lane * E;
+      const bool act = c < d;
+      float acc[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = 0.f;
+      for (int t = 0; t < L; ++t) {
+        const float pt = __shfl(t < 64 ? p0 : p1, t & 63, 64);
+        if (act) {
+          T x[E];
+          *reinterpret_cast<uint4*>(x) = *reinterpret_cast<const uint4*>(eb + (long)t * d + c);
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[e] += pt * to_f(x[e]);
+        }
+      }
+      if (act) {
+        T o[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = from_f<T>(acc[e]);
+        *reinterpret_cast<uint4*>(tv + row * d + c) = *reinterpret_cast<const uint4*>(o);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pointer_attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ enc,
+                                                               const float* __restrict__ p, const float* __restrict__ dp, const T* __restrict__ dtv,
+                                                               T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ denc, int Lt, int L, int d,
+                                                               float scale) {
+  constexpr int E = 16 / (int)sizeof(T);
+  __shared__ float ps[32][129], ds[32][129];            // Lt <= 32, L <= 128
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
+  const T* qb = q + (long)b * Lt * d;
+  const T* kb = k + (long)b * L * d;
+  const T* eb = enc ? enc + (long)b * L * d : nullptr;
+  const T* db = dtv ? dtv + (long)b * Lt * d : nullptr;
+  const float* pb = p + (long)b * Lt * L;
+  for (int e = tid; e < Lt * L; e += 256) {
+    const int i = e / L, t = e - i * L;
+    ps[i][t] = pb[e];
+    ds[i][t] = dp ? dp[(long)b * Lt * L + e] : 0.f;
+  }
+  __syncthreads();
+  if (db) {                                             // dpt += dtv[i] . enc[t]: a wave per (i, t) pair
+    for (int e = w; e < Lt * L; e += 4) {
+      const int i = e / L, t = e - i * L;
+      float acc = 0.f;
+      for (int c = lane * E; c < d; c += 64 * E) {
+        T a[E], x[E];
+        *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(db + (long)i * d + c);
+        *reinterpret_cast<uint4*>(x) = *reinterpret_cast<const uint4*>(eb + (long)t * d + c);
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc += to_f(a[j]) * to_f(x[j]);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) ds[i][t] += acc;
+    }
+    __syncthreads();
+  }
+  for (int i = w; i < Lt; i += 4) {                     // softmax backward, a wave per query row
+    const float a0 = lane < L ? ps[i][lane] * ds[i][lane] : 0.f, a1 = lane + 64 < L ? ps[i][lane + 64] * ds[i][lane + 64] : 0.f;
+    const float part = wave_sum(a0 + a1);
+    if (lane < L) ds[i][lane] = ps[i][lane] * (ds[i][lane] - part) * scale;
+    if (lane + 64 < L) ds[i][lane + 64] = ps[i][lane + 64] * (ds[i][lane + 64] - part) * scale;
+  }
+  __syncthreads();
+  // column pairs: dq[i][c] = sum_t dS[i][t] k[t][c];  dk[t][c] = sum_i dS[i][t] q[i][c];  denc[t][c] = sum_i p[i][t] dtv[i][c]
+  for (int c = tid * 2; c < d; c += 512) {
+    float qa[32][2], da[32][2], acc[32][2];               // (fully unrolled below: registers, not scratch)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      qa[i][0] = qa[i][1] = da[i][0] = da[i][1] = acc[i][0] = acc[i][1] = 0.f;
+      if (i < Lt) {
+        qa[i][0] = to_f(qb[(long)i * d + c]); qa[i][1] = to_f(qb[(long)i * d + c + 1]);
+        if (db) { da[i][0] = to_f(db[(long)i * d + c]); da[i][1] = to_f(db[(long)i * d + c + 1]); }
+      }
+    }
+    for (int t = 0; t < L; ++t) {
+      const float k0 = to_f(kb[(long)t * d + c]), k1 = to_f(kb[(long)t * d + c + 1]);
+      float g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        if (i < Lt) {
+          const float s_ = ds[i][t], pt = ps[i][t];
+          acc[i][0] += s_ * k0; acc[i][1] += s_ * k1;
+          g0 += s_ * qa[i][0]; g1 += s_ * qa[i][1];
+          h0 += pt * da[i][0]; h1 += pt * da[i][1];
+        }
+      }
+      dk[((long)b * L + t) * d + c] = from_f<T>(g0); dk[((long)b * L + t) * d + c + 1] = from_f<T>(g1);
+      if (db) { denc[((long)b * L + t) * d + c] = from_f<T>(h0); denc[((long)b * L + t) * d + c + 1] = from_f<T>(h1); }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      if (i < Lt) { dq[((long)b * Lt + i) * d + c] = from_f<T>(acc[i][0]); dq[((long)b * Lt + i) * d + c + 1] = from_f<T>(acc[i][1]); }
+  }
+}
+
 // Decode-step form of MultiPointerGenerator.forward (generator.py:84-127) for hypothesis rows that share ONE dialogue (beam search,
 // decode.py:59-66).  The pointer attentions' keys do not change during a turn, so the caller folds each source's query projection into
 // them once per turn:  scores_j[t] = (W_q x + b_q) . k_j[t] = x . M_j[t] + c_j[t]  with  M_j = K_j W_q  [L, d],  c_j = K_j b_q  [L];  and
@@ -276,6 +416,39 @@ extern "C" int bist_pointer_mix_fwd(const float* logits, const float* switch_log
   hipLaunchKernelGGL(pointer_mix_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, switch_logits, a, out, V, Lt,
                      sigmoid_switch);
   BIST_LAUNCH_CHECK("bist_pointer_mix_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_pointer_attn_fwd(const void* q, const void* k, const void* enc, const uint8_t* mask, int64_t mask_bs, const int64_t* text,
+                                     int64_t unk, float* p, void* tv, int64_t B, int32_t Lt, int32_t L, int32_t d, float scale, int32_t dtype,
+                                     void* stream) {
+  BIST_REQUIRE(q && k && p && B > 0 && Lt > 0 && L >= 1 && L <= 128 && d > 0 && (!tv || enc), "bist_pointer_attn_fwd: bad argument (1..128 positions)");
+  const int e = dtype == BIST_BF16 ? 8 : 4;
+  BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && d % e == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)enc | (uintptr_t)tv) & 15) == 0,
+               "bist_pointer_attn_fwd: bf16 / f32, 16-byte aligned rows");
+  const long rows = B * Lt;
+  hipStream_t st = (hipStream_t)stream;
+#define PA(TT) hipLaunchKernelGGL(pointer_attn_fwd_kernel<TT>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)enc, mask, \
+                                  (long)mask_bs, (const long*)text, (long)unk, p, (TT*)tv, (int)rows, Lt, L, d, scale)
+  if (dtype == BIST_BF16) PA(bf16_t); else PA(float);
+#undef PA
+  BIST_LAUNCH_CHECK("bist_pointer_attn_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_pointer_attn_bwd(const void* q, const void* k, const void* enc, const float* p, const float* dp, const void* dtv, void* dq,
+                                     void* dk, void* denc, int64_t B, int32_t Lt, int32_t L, int32_t d, float scale, int32_t dtype, void* stream) {
+  BIST_REQUIRE(q && k && p && dq && dk && (dp || dtv) && B > 0 && Lt >= 1 && Lt <= 32 && L >= 1 && L <= 128 && d > 0 && d % 8 == 0,
+               "bist_pointer_attn_bwd: bad argument (<= 32 query rows, <= 128 positions, d a multiple of 8)");
+  BIST_REQUIRE(!dtv || (enc && denc), "bist_pointer_attn_bwd: the text vector's gradient needs enc and denc");
+  BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)enc | (uintptr_t)dtv) & 15) == 0,
+               "bist_pointer_attn_bwd: bf16 / f32, 16-byte aligned rows");
+  hipStream_t st = (hipStream_t)stream;
+#define PB(TT) hipLaunchKernelGGL(pointer_attn_bwd_kernel<TT>, dim3((unsigned)B), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)enc, p, dp, \
+                                  (const TT*)dtv, (TT*)dq, (TT*)dk, (TT*)denc, Lt, L, d, scale)
+  if (dtype == BIST_BF16) PB(bf16_t); else PB(float);
+#undef PB
+  BIST_LAUNCH_CHECK("bist_pointer_attn_bwd");
   return BIST_OK;
 }
 

@@ -225,6 +225,28 @@ def pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch=False):
     return ops.pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch)
 
 
+POINTER_ATTN = os.environ.get("BIST_POINTER_ATTN", "1") != "0"      # tuning aid: 0 = the pointer attentions on the generic attention core + a text-vector product
+
+
+def pointer_attn_ok(q: Tensor, k: Tensor, enc: Tensor) -> bool:
+    """Inside the envelope of bist_pointer_attn_fwd / _bwd: <= 32 query rows per sequence, <= 128 positions, channels a multiple of 8."""
+    return (POINTER_ATTN and q.is_cuda and q.dim() == 3 and q.dtype == k.dtype == enc.dtype and q.dtype in (torch.bfloat16, torch.float32)
+            and q.shape[1] <= 32 and k.shape[1] <= 128 and q.shape[2] % 8 == 0 and k.shape == enc.shape)
+
+
+def pointer_attn(q: Tensor, k: Tensor, enc: Tensor, mask: Optional[Tensor], text: Optional[Tensor], unk: int = 0):
+    """(p f32 [B,Lt,L], text vector [B,Lt,d]) of one pointer attention (autograd.PointerAttnFn); mask [B,1,L] / [B,L] / [1,L] boolean."""
+    m8 = None
+    if mask is not None:
+        m8 = ag._mask_u8(mask.reshape(-1, mask.shape[-1]))
+        m8 = m8 if m8.is_contiguous() else m8.contiguous()
+    if text is not None:
+        text = text.contiguous()
+    if _grad():
+        return ag.PointerAttnFn.apply(q, k, enc, m8, text, unk)
+    return ag.PointerAttnFn.forward(_NoCtx(), q, k, enc, m8, text, unk)
+
+
 def log_softmax(x):
     return ag.LogSoftmaxFn.apply(x) if _grad() else ops.log_softmax(x)
 

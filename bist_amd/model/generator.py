@@ -75,6 +75,22 @@ def _text_vector(p: Tensor, enc: Tensor) -> Tensor:
     return Fn.bmm_nn(Fn.cast(p, enc.dtype), enc)
 
 
+def _pointer_head(attn, x: Tensor, enc_k: Tensor, enc_v: Tensor, mask: Tensor, text: Tensor, mask_unk: bool):
+    """(p [B,Lt,L] f32, text vector [B,Lt,d]) of one pointer source (generator.py:104-118).  Inside its envelope: the two projections as one
+    launch and the attention + text vector as one (Fn.pointer_attn: no value product, no separate mask operations); else the generic
+    attention core and a product."""
+    B, Lt, d = x.shape
+    if Fn.pointer_attn_ok(x, enc_k, enc_v) and attn.h == 1:
+        q, k = Fn.linear_pair(x, attn.linears[0].weight, attn.linears[0].bias, enc_k, attn.linears[1].weight, attn.linears[1].bias)
+        p, tv = Fn.pointer_attn(q.view(B, Lt, d), k.view(B, -1, d), enc_v, mask, text if mask_unk else None, UNK)
+        attn.attn = p.view(B, 1, Lt, -1)
+        return p, tv
+    if mask_unk:
+        mask = mask & (text != UNK).unsqueeze(-2)                                             # generator.py:106-107
+    p = _pointer_probs(attn, x, enc_k, mask)
+    return p, _text_vector(p, enc_v)
+
+
 def _switch_logits(lin: nn.Linear, parts) -> Tensor:
     """lin(cat(parts)) without the concat: each part multiplies its own column block."""
     d = parts[0].shape[-1]
@@ -101,11 +117,9 @@ class PointerGenerator(nn.Module):
         if args.ptr_ft == "query+cap":
             raise NotImplementedError("ptr_ft='query+cap' is outside the hot path")
         text, (enc_k, enc_v), mask = _pointer_source(args.ptr_ft, ft, batch)
-        if args.mask_unk:
-            mask = mask & (text != UNK).unsqueeze(-2)
         logits = Fn.linear(Fn.fan_take(ft, "decoded_text"), self.vocab_gen, None, out_dtype=torch.float32)
-        p = _pointer_probs(self.pointer_attn, Fn.fan_take(ft, "decoded_text"), enc_k, mask)
-        sw = _switch_logits(self.pointer_gen_W, [Fn.fan_take(ft, "decoded_text"), _text_vector(p, enc_v), ft["encoded_tgt"]])    # generator.py:71
+        p, tv = _pointer_head(self.pointer_attn, Fn.fan_take(ft, "decoded_text"), enc_k, enc_v, mask, text, bool(args.mask_unk))
+        sw = _switch_logits(self.pointer_gen_W, [Fn.fan_take(ft, "decoded_text"), tv, ft["encoded_tgt"]])    # generator.py:71
         return Fn.pointer_mix(logits, sw, [p], [text], Lt, sigmoid_switch=True).view(B, Lt, -1)
 
 
@@ -197,10 +211,8 @@ class MultiPointerGenerator(nn.Module):
         ps, texts, vec = [], [], [Fn.fan_take(ft, "decoded_text"), ft["encoded_tgt"]]     # generator.py:92
         for idx, name in enumerate(args.ptr_ft.split(",")):
             text, (enc_k, enc_v), mask = _pointer_source(name, ft, batch)
-            if args.mask_unk:
-                mask = mask & (text != UNK).unsqueeze(-2)                                 # generator.py:106-107
-            p = _pointer_probs(self.pointer_attn[idx], Fn.fan_take(ft, "decoded_text"), enc_k, mask)
+            p, tv = _pointer_head(self.pointer_attn[idx], Fn.fan_take(ft, "decoded_text"), enc_k, enc_v, mask, text, bool(args.mask_unk))
             ps.append(p); texts.append(text)
-            vec.append(_text_vector(p, enc_v))
+            vec.append(tv)
         sw = _switch_logits(self.pointer_gen_W, vec)
         return Fn.pointer_mix(logits, sw, ps, texts, Lt).view(B, Lt, -1)

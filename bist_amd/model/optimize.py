@@ -1,14 +1,9 @@
 """Noam learning-rate wrapper and the loss/step driver (reference: model/optimize.py)."""
 from __future__ import annotations
 
-import os
-
 import torch
 
-from .. import functional as Fn
 from .. import ops
-
-AE_SIDE_STREAM = os.environ.get("BIST_AE_SIDE_STREAM", "1") != "0"      # tuning aid: 0 = the auto-encoder heads in line after the response head
 
 
 class NoamOpt:
@@ -59,34 +54,18 @@ class SimpleLossCompute:
                     keys.append(("temporal_ae", "temporal_ft"))
                 if a.t2s:
                     keys.append(("spatial_ae", "spatial_ft"))
-        # Training on the device: the auto-encoder heads (independent of the response head: vocabulary product, log-softmax, loss on the last
-        # layer's caption / temporal / spatial outputs) go to the s2t stream, which has nothing left to do -- forward under the pointer
-        # generator, and autograd runs their backward there too, under the generator's.  Otherwise this stretch between the forward
-        # and the backward pass is ~90 launches on ONE stream with every other stream idle.
+        # (The auto-encoder heads stay on this stream, behind the response head.  They were tried on the idle s2t stream -- 9.84 -> 9.78 ms per
+        # step -- but they share the embedding matrix with the response head's vocabulary product: the two weight-gradient products
+        # then accumulate into ONE gradient region from two streams, a read-modify-write race that showed up as a rare mismatch of the
+        # embedding after a few steps.)
         ae = {}
-        side = None
-        x0 = ft.get("decoded_text")
-        if keys and AE_SIDE_STREAM and Fn.CONCURRENT and torch.is_grad_enabled() and x0 is not None and x0.is_cuda:
-            main, side = torch.cuda.current_stream(), Fn.side_stream(0)
-            side.wait_stream(main)
         q = batch.query.reshape(-1) if keys else None
-
-        def ae_terms():
-            for name, key in keys:
-                lp = self.ae_generator(ft, batch, a, key)
-                ae[name] = self.criterion.loss(lp.reshape(-1, lp.size(-1)), q, batch.qntokens.reshape(1))
-        if side is not None:
-            with torch.cuda.stream(side):
-                ae_terms()
-                for v in ae.values():
-                    v.record_stream(main)
         out = self.generator(ft, batch, a)
         V = out.size(-1)
         t = {"out": self.criterion.loss(out.reshape(-1, V), batch.trg_y.reshape(-1), batch.ntokens.reshape(1))}
-        if side is not None:
-            main.wait_stream(side)
-        else:
-            ae_terms()
+        for name, key in keys:
+            lp = self.ae_generator(ft, batch, a, key)
+            ae[name] = self.criterion.loss(lp.reshape(-1, lp.size(-1)), q, batch.qntokens.reshape(1))
         t.update(ae)
         return t, out
 

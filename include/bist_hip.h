@@ -520,6 +520,17 @@ int bist_pointer_mix_bwd(const float* logits, const float* switch_logits, int32_
                          const int64_t* const* ptr_text, const int32_t* ptr_len, const float* out, const float* dout,
                          float* dlogits, float* dswitch_logits, float* const* dptr_p, int64_t rows, int32_t Lt, int32_t V,
                          int32_t sigmoid_switch, void* stream);
+/* The pointer attention of (Multi)PointerGenerator with its text vector, training and evaluation (model/generator.py:106-118: a
+ * single-head MultiHeadedAttention whose value product and output projection the reference computes and throws away, then
+ * `(p.unsqueeze(-1) * enc.unsqueeze(1)).sum(2)`): q [B][Lt][d] and k [B][L][d] the projected queries / keys, mask [B][L] (row stride
+ * mask_bs, 0 = one row for all) and, when text != NULL, also text[b][t] != unk (generator.py:106-107);
+ * p f32 [B][Lt][L] = softmax_t(scale q.k, masked -1e9); tv [B][Lt][d] = sum_t p enc[b][t] (NULL: not wanted).
+ * Backward: dp f32 (the mixture's gradient, nullable), dtv (nullable) -> dq, dk, denc (written, not accumulated).             */
+int bist_pointer_attn_fwd(const void* q, const void* k, const void* enc, const uint8_t* mask, int64_t mask_bs, const int64_t* text,
+                          int64_t unk, float* p, void* tv, int64_t B, int32_t Lt, int32_t L, int32_t d, float scale, int32_t dtype,
+                          void* stream);
+int bist_pointer_attn_bwd(const void* q, const void* k, const void* enc, const float* p, const float* dp, const void* dtv, void* dq,
+                          void* dk, void* denc, int64_t B, int32_t Lt, int32_t L, int32_t d, float scale, int32_t dtype, void* stream);
 /* Decode-step form of MultiPointerGenerator.forward (model/generator.py:84-127) for rows that share one dialogue (the hypotheses of
  * a beam-search turn, model/decode.py:59-66): per source j the caller holds, per TURN, M_j = K_j W_q [L_j][d] and c_j = K_j b_q [L_j]
  * (K_j the projected keys of generator.py:109, so that scores = x.M_j^T + c_j), mask_j [L_j] (generator.py:106-107), E_j = enc_j W_sw,j^T

@@ -566,9 +566,9 @@ def test_deferred_optimiser_is_the_same_training_run(env):
     # (key-projection biases have an exactly-zero gradient -- softmax is shift invariant -- so theirs is rounding noise that Adam
     # normalises into full-size steps of random sign in BOTH runs: left out)
     keys = [k for k in p1 if not k.endswith("linears.1.bias")]
-    worst = max((p1[k].detach() - p2[k].detach()).abs().max().item() for k in keys)
+    worst, worst_key = max(((p1[k].detach() - p2[k].detach()).abs().max().item(), k) for k in keys)
     scale = max(p1[k].detach().abs().max().item() for k in keys)
-    assert worst <= 2e-2 * scale, (worst, scale)      # six Adam steps apart by the fp32-atomics order only (see the test above)
+    assert worst <= 2e-2 * scale, (worst, worst_key, scale)      # six Adam steps apart by the fp32-atomics order only (see the test above)
     step = (w2 - t2.master).abs().max().item()
     assert step > 1e-5                                # and flush() did move the weights
     t2.flush()                                        # idempotent
@@ -919,3 +919,75 @@ def test_inputs_rewritten_behind_torchs_back_need_invalidate_inputs(env):
     tr = Trainer(copy.deepcopy(base), args, 80, compute_dtype=torch.float32, warmup=20, factor=1e-9, use_graph=True)
     bb = copy.copy(b); bb.fts = new_fts
     assert abs(tr.step(bb)["out"].item() - fresh1) <= 1e-4 * abs(fresh1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,Lt,L,d,use_text", [(3, 7, 11, 64, True), (16, 20, 25, 512, True), (2, 32, 128, 128, False), (1, 1, 1, 64, True)])
+def test_pointer_attention_launch_forward_and_backward(env, dtype, tol, B, Lt, L, d, use_text):
+    """bist_pointer_attn_fwd / _bwd (pointer attention + text vector of generator.py:104-118 as one launch each way) against torch
+    autograd in float64 on the same (dtype-rounded) operands: probabilities, text vector, and the gradients of q, k and the encoded
+    text for random upstream gradients of BOTH outputs; mask with padded positions and <unk> tokens (generator.py:106-107)."""
+    from bist_amd import functional as Fn
+    g = torch.Generator().manual_seed(B * 100 + L)
+    q = (torch.randn(B, Lt, d, generator=g) * 2).to(dtype).cuda().requires_grad_(True)
+    k = (torch.randn(B, L, d, generator=g) * 2).to(dtype).cuda().requires_grad_(True)
+    enc = torch.randn(B, L, d, generator=g).to(dtype).cuda().requires_grad_(True)
+    mask = (torch.rand(B, 1, L, generator=g) > 0.2)
+    mask[:, :, 0] = True
+    text = torch.randint(0, 5, (B, L), generator=g)              # id 0 = <unk>
+    text[:, 0] = 3
+    gp, gtv = torch.randn(B, Lt, L, generator=g).cuda(), torch.randn(B, Lt, d, generator=g).to(dtype).cuda()
+    assert Fn.pointer_attn_ok(q, k, enc)
+    p, tv = Fn.pointer_attn(q, k, enc, mask.cuda(), text.cuda() if use_text else None, 0)
+    (p * gp).sum().backward(retain_graph=True)
+    dq1, dk1 = q.grad.clone(), k.grad.clone()
+    q.grad = k.grad = None
+    ((p * gp).sum() + (tv.float() * gtv.float()).sum()).backward()
+    q6, k6, e6 = (t.detach().double().requires_grad_(True) for t in (q, k, enc))
+    live = mask.cuda() & ((text.cuda() != 0).unsqueeze(1) if use_text else True)
+    sc = (q6 @ k6.transpose(1, 2)) / math.sqrt(d)
+    p6 = torch.softmax(sc.masked_fill(~live, -1e9), -1)
+    tv6 = p6 @ e6
+    ((p6 * gp.double()).sum() + (tv6 * gtv.double()).sum()).backward()
+    scale = lambda t: max(1.0, t.abs().max().item())
+    assert (p.double() - p6).abs().max().item() <= tol
+    assert (tv.double() - tv6).abs().max().item() <= tol * scale(tv6)
+    for name, got, ref in (("dq", q.grad, q6.grad), ("dk", k.grad, k6.grad), ("denc", enc.grad, e6.grad)):
+        assert (got.double() - ref).abs().max().item() <= 2 * tol * scale(ref), name
+    # only the probabilities' gradient (no text-vector gradient): the same kernel with dtv = NULL
+    (p6.detach().requires_grad_(False))
+    q7, k7 = (t.detach().double().requires_grad_(True) for t in (q, k))
+    p7 = torch.softmax(((q7 @ k7.transpose(1, 2)) / math.sqrt(d)).masked_fill(~live, -1e9), -1)
+    (p7 * gp.double()).sum().backward()
+    assert (dq1.double() - q7.grad).abs().max().item() <= 2 * tol * scale(q7.grad) and (dk1.double() - k7.grad).abs().max().item() <= 2 * tol * scale(k7.grad)
+
+
+def test_pointer_heads_in_one_launch_train_like_the_generic_attention_path(env):
+    """A training step's losses and parameter gradients with the pointer heads on bist_pointer_attn_* (one launch per source each way,
+    projections paired) against the generic attention core + text-vector product (BIST_POINTER_ATTN=0): float32, same model and batch,
+    dropout off -- losses within 1e-5 relative, every parameter gradient within 2e-4 of the largest entry."""
+    import copy
+    import bist_amd.model as M
+    from bist_amd import functional as Fn
+    from bist_amd.data.synthetic import synthetic_batch
+    from bist_amd.train import Trainer
+    cfg = O.Cfg(d_model=64, att_h=4, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    args = _args(cfg)
+    torch.manual_seed(0)
+    base = M.make_model(80, 80, args, ft_sizes=[64]).cuda().eval()
+    b = synthetic_batch(4, T=6, S=9, C=64, Lq=7, Lh=9, Lc=6, Lt=6, vocab=80, dtype=torch.float32)
+    res = {}
+    for on in (True, False):
+        Fn.POINTER_ATTN = on
+        try:
+            tr = Trainer(copy.deepcopy(base), args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=False)
+            terms = tr.backward(b)
+            torch.cuda.synchronize()
+            res[on] = ({k_: v.item() for k_, v in terms.items()}, tr.flat_grad.float().clone())
+        finally:
+            Fn.POINTER_ATTN = True
+    for k_ in res[True][0]:
+        assert abs(res[True][0][k_] - res[False][0][k_]) <= 1e-5 * abs(res[False][0][k_]), k_
+    ga, gb = res[True][1], res[False][1]
+    assert (ga - gb).abs().max().item() <= 2e-4 * gb.abs().max().item()
+    assert ga.abs().max().item() > 0
