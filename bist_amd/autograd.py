@@ -963,6 +963,57 @@ class PointerMixFn(Function):
         return (dlogits, dsw, None, None, None, *[g.view(p.shape) for g, p in zip(dps, ps)], *([None] * n))
 
 
+class SwitchLogitsFn(Function):
+    """lin(cat(parts, -1)) of the pointer generators' switch (generator.py:69-71, 119-121) without the concatenation: one launch forward,
+    two backward (bist_switch_logits_fwd / _bwd); parts: n <= 4 tensors [rows, d]; returns f32 [rows, ns].  Under the trainer the weight
+    gradient accumulates into the flat gradient view and the bias gradient into its fp32 accumulator, like LinearFn."""
+
+    @staticmethod
+    def forward(ctx, w, bias, *parts):
+        ctx.shapes = [tuple(p.shape) for p in parts]
+        parts = [p.reshape(-1, p.shape[-1]) for p in parts]
+        parts = [p if p.is_contiguous() else p.contiguous() for p in parts]
+        rows, d = parts[0].shape
+        ns, n = w.shape[0], len(parts)
+        out = torch.empty((rows, ns), device=w.device, dtype=torch.float32)
+        arr = (C.c_void_p * n)(*[p.data_ptr() for p in parts])
+        check(lib.bist_switch_logits_fwd(arr, n, w.data_ptr(), w.stride(0), _ptr(bias), out.data_ptr(), rows, d, ns, dtype_code(w.dtype), _stream()),
+              "bist_switch_logits_fwd")
+        ctx.save_for_backward(w, *parts)
+        ctx.w_dst = getattr(w, "_grad_view", None)
+        ctx.b_dst = getattr(bias, "_acc32", None) if bias is not None else None
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dsw):
+        w, *parts = ctx.saved_tensors
+        rows, d = parts[0].shape
+        ns, n = w.shape[0], len(parts)
+        dsw = dsw.contiguous() if dsw.dtype == torch.float32 else dsw.float().contiguous()
+        need = ctx.needs_input_grad
+        dparts = [torch.empty_like(p) if need[2 + j] else None for j, p in enumerate(parts)]
+        arr = (C.c_void_p * n)(*[p.data_ptr() for p in parts])
+        darr = (C.c_void_p * n)(*[_ptr(g) for g in dparts])
+        dw = db = None
+        has_bias = ctx.bias_dtype is not None
+        if ctx.w_dst is not None:
+            wd, acc_w = ctx.w_dst, 1
+        else:
+            wd, acc_w = (torch.empty_like(w) if need[0] else None), 0
+            dw = wd
+        if has_bias and need[1] and wd is not None:
+            bd, acc_b = (ctx.b_dst, 1) if ctx.b_dst is not None else (torch.empty((ns,), device=w.device, dtype=torch.float32), 0)
+        else:
+            bd, acc_b = None, 0
+        check(lib.bist_switch_logits_bwd(arr, n, w.data_ptr(), w.stride(0), dsw.data_ptr(), darr if any(g is not None for g in dparts) else None,
+                                        _ptr(wd), wd.stride(0) if wd is not None else 0, dtype_code(wd.dtype) if wd is not None else 0, acc_w,
+                                        _ptr(bd), acc_b, rows, d, ns, dtype_code(w.dtype), _stream()), "bist_switch_logits_bwd")
+        if has_bias and need[1] and ctx.b_dst is None and bd is not None:
+            db = bd.to(ctx.bias_dtype)
+        return (dw, db, *[g.view(sh) if g is not None else None for g, sh in zip(dparts, ctx.shapes)])
+
+
 class PointerAttnFn(Function):
     """(p, tv) of a pointer attention (generator.py:106-118): p = softmax(q.k^T / sqrt(d), masked -1e9) f32 [B,Lt,L] over one head of d
     channels, tv = p . enc (the text vector).  mask [B or 1, L] uint8; text int64 [B,L] or None (then position t also needs

@@ -97,6 +97,151 @@ __global__ __launch_bounds__(256) void text_vector_kernel(const float* __restric
   *reinterpret_cast<uint4*>(out + row * d + c0) = *reinterpret_cast<const uint4*>(o);
 }
 
+// The switch logits of (Multi)PointerGenerator (generator.py:71, 119-121): pointer_gen_W applied to the concatenation of n_parts <= 4
+// [rows, d] tensors WITHOUT the concatenation -- part j multiplies column block j of W [ns <= 4][n_parts d].  One launch forward (a wave
+// per row) and two backward (the parts' gradients: a wave per row; the weight / bias gradient: a workgroup per part, four row slices
+// per workgroup) where a product per part took 4 launches forward and 12 backward (cast + dX + dW each).
+struct SwParts { const void* x[4]; void* dx[4]; int n; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void switch_logits_fwd_kernel(SwParts a, const T* __restrict__ W, long ldw, const T* __restrict__ bias,
+                                                                float* __restrict__ out, long rows, int d, int ns) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < a.n; ++j) {
+    const T* xr = reinterpret_cast<const T*>(a.x[j]) + row * d;
+    for (int c = lane * E; c < d; c += 64 * E) {
+      T xv[E];
+      *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(xr + c);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        if (s_ < ns) {
+          T wv[E];
+          *reinterpret_cast<uint4*>(wv) = *reinterpret_cast<const uint4*>(W + (long)s_ * ldw + (long)j * d + c);
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[s_] += to_f(xv[e]) * to_f(wv[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    if (s_ < ns) {
+      const float v = wave_sum(acc[s_]);
+      if (lane == 0) out[row * ns + s_] = v + (bias ? to_f(bias[s_]) : 0.f);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void switch_logits_bwd_x_kernel(SwParts a, const T* __restrict__ W, long ldw, const float* __restrict__ dsw,
+                                                                  long rows, int d, int ns) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float g[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) g[s_] = s_ < ns ? dsw[row * ns + s_] : 0.f;
+  for (int j = 0; j < a.n; ++j) {
+    T* dr = reinterpret_cast<T*>(a.dx[j]) + row * d;
+    if (a.dx[j] == nullptr) continue;
+    for (int c = lane * E; c < d; c += 64 * E) {
+      float acc[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        if (s_ < ns) {
+          T wv[E];
+          *reinterpret_cast<uint4*>(wv) = *reinterpret_cast<const uint4*>(W + (long)s_ * ldw + (long)j * d + c);
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[e] += g[s_] * to_f(wv[e]);
+        }
+      }
+      T o[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = from_f<T>(acc[e]);
+      *reinterpret_cast<uint4*>(dr + c) = *reinterpret_cast<const uint4*>(o);
+    }
+  }
+}
+
+// dW[s][j d + c] (+)= sum_rows dsw[row][s] part_j[row][c];  db[s] (+)= sum_rows dsw[row][s].  blockIdx.x = part, blockIdx.y = chunk of 64 E
+// columns; thread = (column piece lane, row slice sl): the four slices meet in LDS.
+template <typename T, typename TW>
+__global__ __launch_bounds__(256) void switch_logits_bwd_w_kernel(SwParts a, const float* __restrict__ dsw, TW* __restrict__ dW, long lddw, int dw_acc,
+                                                                  float* __restrict__ db, int db_acc, long rows, int d, int ns) {
+  constexpr int E = 16 / (int)sizeof(T);
+  __shared__ float part[3][64][4][E];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6, j = blockIdx.x;
+  const int c = (blockIdx.y * 64 + lane) * E;
+  const bool act = c < d;
+  const T* xb = reinterpret_cast<const T*>(a.x[j]);
+  float acc[4][E];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[s_][e] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const long per = (rows + 3) / 4, r0 = sl * per, r1 = min(rows, r0 + per);
+  // eight rows per step: their loads are in flight together (one row per step made this a chain of ~80 dependent round trips)
+  for (long rb = r0; rb < r1; rb += 8) {
+    uint4 xq[8];
+    float g[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long r = rb + u;
+      const bool ok = r < r1;
+      xq[u] = (ok && act) ? *reinterpret_cast<const uint4*>(xb + r * d + c) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) g[u][s_] = (ok && s_ < ns) ? dsw[r * ns + s_] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const T* xv = reinterpret_cast<const T*>(&xq[u]);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[s_][e] += g[u][s_] * to_f(xv[e]);
+        bsum[s_] += g[u][s_];
+      }
+    }
+  }
+  if (sl > 0) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int e = 0; e < E; ++e) part[sl - 1][lane][s_][e] = acc[s_][e];
+  }
+  __shared__ float bpart[4][4];
+  if (lane == 0)
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) bpart[sl][s_] = bsum[s_];
+  __syncthreads();
+  if (sl == 0 && act) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      if (s_ < ns) {
+        TW* dst = dW + (long)s_ * lddw + (long)j * d + c;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float v = acc[s_][e] + part[0][lane][s_][e] + part[1][lane][s_][e] + part[2][lane][s_][e];
+          dst[e] = from_f<TW>(dw_acc ? to_f(dst[e]) + v : v);
+        }
+      }
+    }
+  }
+  if (db && j == 0 && blockIdx.y == 0 && threadIdx.x < ns) {
+    const int s_ = threadIdx.x;
+    const float v = bpart[0][s_] + bpart[1][s_] + bpart[2][s_] + bpart[3][s_];
+    db[s_] = db_acc ? db[s_] + v : v;
+  }
+}
+
 // The pointer attention of (Multi)PointerGenerator in TRAINING (generator.py:106-118): single head over d channels.
 //   forward : p[b,i,:] = softmax_t(live(b,t) ? scale q[b,i].k[b,t] : -1e9),  live = mask[b,t] && (!mask_unk || text[b,t] != unk);
 //             tv[b,i,:] = sum_t p[b,i,t] enc[b,t,:]  (the text vector), one wave per (b, i): two launches' worth of the generic attention
@@ -416,6 +561,60 @@ extern "C" int bist_pointer_mix_fwd(const float* logits, const float* switch_log
   hipLaunchKernelGGL(pointer_mix_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, switch_logits, a, out, V, Lt,
                      sigmoid_switch);
   BIST_LAUNCH_CHECK("bist_pointer_mix_fwd");
+  return BIST_OK;
+}
+
+static int sw_parts(SwParts& a, const void* const* parts, void* const* dparts, int32_t n_parts, const char* who) {
+  BIST_REQUIRE(parts && n_parts >= 1 && n_parts <= 4, "%s: 1..4 parts", who);
+  a.n = n_parts;
+  for (int j = 0; j < 4; ++j) { a.x[j] = nullptr; a.dx[j] = nullptr; }
+  for (int j = 0; j < n_parts; ++j) {
+    BIST_REQUIRE(parts[j] && ((uintptr_t)parts[j] & 15) == 0 && (!dparts || ((uintptr_t)dparts[j] & 15) == 0), "%s: part %d null or not 16-byte aligned", who, j);
+    a.x[j] = parts[j];
+    a.dx[j] = dparts ? dparts[j] : nullptr;
+  }
+  return BIST_OK;
+}
+
+extern "C" int bist_switch_logits_fwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const void* bias, float* out,
+                                      int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream) {
+  BIST_REQUIRE(W && out && rows > 0 && ns >= 1 && ns <= 4 && d > 0, "bist_switch_logits_fwd: bad argument (<= 4 switch logits)");
+  const int e = dtype == BIST_BF16 ? 8 : 4;
+  BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && d % e == 0 && ldw % e == 0 && ((uintptr_t)W & 15) == 0, "bist_switch_logits_fwd: bf16 / f32, 16-byte rows");
+  SwParts a;
+  if (sw_parts(a, parts, nullptr, n_parts, "bist_switch_logits_fwd") != BIST_OK) return BIST_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (dtype == BIST_BF16) hipLaunchKernelGGL(switch_logits_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, (const bf16_t*)W, (long)ldw, (const bf16_t*)bias, out, (long)rows, d, ns);
+  else hipLaunchKernelGGL(switch_logits_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, a, (const float*)W, (long)ldw, (const float*)bias, out, (long)rows, d, ns);
+  BIST_LAUNCH_CHECK("bist_switch_logits_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_switch_logits_bwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const float* dsw, void* const* dparts,
+                                      void* dW, int64_t lddw, int32_t dw_dtype, int32_t dw_accumulate, float* db, int32_t db_accumulate,
+                                      int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream) {
+  BIST_REQUIRE(W && dsw && rows > 0 && ns >= 1 && ns <= 4 && d > 0, "bist_switch_logits_bwd: bad argument (<= 4 switch logits)");
+  const int e = dtype == BIST_BF16 ? 8 : 4;
+  BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && d % e == 0 && ldw % e == 0 && ((uintptr_t)W & 15) == 0, "bist_switch_logits_bwd: bf16 / f32, 16-byte rows");
+  BIST_REQUIRE(!dW || dw_dtype == BIST_BF16 || dw_dtype == BIST_F32, "bist_switch_logits_bwd: bad weight-gradient dtype");
+  SwParts a;
+  if (sw_parts(a, parts, dparts, n_parts, "bist_switch_logits_bwd") != BIST_OK) return BIST_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dparts) {
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (dtype == BIST_BF16) hipLaunchKernelGGL(switch_logits_bwd_x_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, (const bf16_t*)W, (long)ldw, dsw, (long)rows, d, ns);
+    else hipLaunchKernelGGL(switch_logits_bwd_x_kernel<float>, dim3(grid), dim3(256), 0, st, a, (const float*)W, (long)ldw, dsw, (long)rows, d, ns);
+    BIST_LAUNCH_CHECK("bist_switch_logits_bwd (parts)");
+  }
+  if (dW) {
+    dim3 grid((unsigned)n_parts, (unsigned)((d / e + 63) / 64));
+#define SWW(TT, TWW) hipLaunchKernelGGL((switch_logits_bwd_w_kernel<TT, TWW>), grid, dim3(256), 0, st, a, dsw, (TWW*)dW, (long)lddw, dw_accumulate, db, db_accumulate, (long)rows, d, ns)
+    if (dtype == BIST_BF16) { if (dw_dtype == BIST_BF16) SWW(bf16_t, bf16_t); else SWW(bf16_t, float); }
+    else { if (dw_dtype == BIST_BF16) SWW(float, bf16_t); else SWW(float, float); }
+#undef SWW
+    BIST_LAUNCH_CHECK("bist_switch_logits_bwd (weights)");
+  }
   return BIST_OK;
 }
 

@@ -225,6 +225,20 @@ def pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch=False):
     return ops.pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch)
 
 
+def switch_logits_ok(w: Tensor, bias: Optional[Tensor], parts) -> bool:
+    d = parts[0].shape[-1]
+    return (POINTER_ATTN and w.is_cuda and w.dtype in (torch.bfloat16, torch.float32) and 1 <= len(parts) <= 4 and w.shape[0] <= 4
+            and w.shape[1] == len(parts) * d and d % 8 == 0 and w.stride(1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0
+            and all(p.dtype == w.dtype and p.shape[-1] == d and p.numel() == parts[0].numel() for p in parts) and (bias is None or bias.dtype == w.dtype))
+
+
+def switch_logits(w: Tensor, bias: Optional[Tensor], parts) -> Tensor:
+    """lin(cat(parts, -1)) as f32 [rows, ns] (autograd.SwitchLogitsFn)."""
+    if _grad():
+        return ag.SwitchLogitsFn.apply(w, bias, *parts)
+    return ag.SwitchLogitsFn.forward(_NoCtx(), w, bias, *parts)
+
+
 POINTER_ATTN = os.environ.get("BIST_POINTER_ATTN", "1") != "0"      # tuning aid: 0 = the pointer attentions on the generic attention core + a text-vector product
 
 

@@ -94,6 +94,8 @@ def _pointer_head(attn, x: Tensor, enc_k: Tensor, enc_v: Tensor, mask: Tensor, t
 def _switch_logits(lin: nn.Linear, parts) -> Tensor:
     """lin(cat(parts)) without the concat: each part multiplies its own column block."""
     d = parts[0].shape[-1]
+    if Fn.switch_logits_ok(lin.weight, lin.bias, parts):
+        return Fn.switch_logits(lin.weight, lin.bias, parts)          # one launch (three with its backward) instead of one product per part
     out = None
     for j, p in enumerate(parts):
         out = Fn.linear(p, Fn.column_block(lin.weight, j, d), lin.bias if j == 0 else None, out=out, accumulate=j > 0,

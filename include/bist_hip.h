@@ -520,6 +520,15 @@ int bist_pointer_mix_bwd(const float* logits, const float* switch_logits, int32_
                          const int64_t* const* ptr_text, const int32_t* ptr_len, const float* out, const float* dout,
                          float* dlogits, float* dswitch_logits, float* const* dptr_p, int64_t rows, int32_t Lt, int32_t V,
                          int32_t sigmoid_switch, void* stream);
+/* The switch logits of (Multi)PointerGenerator (model/generator.py:69-71, 119-121: pointer_gen_W(torch.cat(parts, -1))) without the
+ * concatenation: part j [rows][d] multiplies column block j of W [ns][ldw >= n_parts d]; out f32 [rows][ns] = sum_j part_j . W_j^T + bias.
+ * Backward: dparts[j] = dsw . W_j (written; entries may be NULL = not wanted, or the whole array NULL), dW [ns][lddw] and db [ns]
+ * written or accumulated (dW NULL = not wanted; db only together with dW).  parts / dparts are HOST arrays of n_parts <= 4 pointers.   */
+int bist_switch_logits_fwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const void* bias, float* out,
+                           int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream);
+int bist_switch_logits_bwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const float* dsw, void* const* dparts,
+                           void* dW, int64_t lddw, int32_t dw_dtype, int32_t dw_accumulate, float* db, int32_t db_accumulate,
+                           int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream);
 /* The pointer attention of (Multi)PointerGenerator with its text vector, training and evaluation (model/generator.py:106-118: a
  * single-head MultiHeadedAttention whose value product and output projection the reference computes and throws away, then
  * `(p.unsqueeze(-1) * enc.unsqueeze(1)).sum(2)`): q [B][Lt][d] and k [B][L][d] the projected queries / keys, mask [B][L] (row stride

@@ -991,3 +991,29 @@ def test_pointer_heads_in_one_launch_train_like_the_generic_attention_path(env):
     ga, gb = res[True][1], res[False][1]
     assert (ga - gb).abs().max().item() <= 2e-4 * gb.abs().max().item()
     assert ga.abs().max().item() > 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("rows,d,n,ns", [(320, 512, 4, 3), (37, 64, 3, 1), (5, 128, 1, 4)])
+def test_switch_logits_launch_forward_and_backward(env, dtype, tol, rows, d, n, ns):
+    """bist_switch_logits_fwd / _bwd (pointer_gen_W over the un-concatenated parts, generator.py:69-71, 119-121) against
+    torch.nn.functional.linear on the concatenation in float64: logits, the gradient of every part, of the weight and of the bias."""
+    from bist_amd import functional as Fn
+    g = torch.Generator().manual_seed(rows + d)
+    parts = [torch.randn(rows, d, generator=g).to(dtype).cuda().requires_grad_(True) for _ in range(n)]
+    w = (torch.randn(ns, n * d, generator=g) * 0.1).to(dtype).cuda().requires_grad_(True)
+    b = torch.randn(ns, generator=g).to(dtype).cuda().requires_grad_(True)
+    gout = torch.randn(rows, ns, generator=g).cuda()
+    assert Fn.switch_logits_ok(w, b, parts)
+    out = Fn.switch_logits(w, b, parts)
+    (out * gout).sum().backward()
+    p6 = [p.detach().double().requires_grad_(True) for p in parts]
+    w6, b6 = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.linear(torch.cat(p6, -1), w6, b6)
+    (ref * gout.double()).sum().backward()
+    sc = lambda t: max(1.0, t.abs().max().item())
+    assert (out.double() - ref).abs().max().item() <= tol * sc(ref)
+    for j in range(n):
+        assert (parts[j].grad.double() - p6[j].grad).abs().max().item() <= tol * sc(p6[j].grad), j
+    assert (w.grad.double() - w6.grad).abs().max().item() <= 2 * tol * sc(w6.grad)
+    assert (b.grad.double() - b6.grad).abs().max().item() <= 2 * tol * sc(b6.grad)
