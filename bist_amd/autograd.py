@@ -129,19 +129,21 @@ class LinearFn(Function):
                 dres = dres.view(res_shape) if dres.numel() == math.prod(res_shape) else dres
             else:
                 dres = dy.view(res_shape)
-        dz = dy if dy.dtype == x2.dtype else ops.cast(dy, x2.dtype)
         tag = getattr(ctx, "gate_tag", None)
         handed = (pre is not None and len(pre) == 4 and act == ACT_RELU and pre[1:3] == (float(drop_p), int(drop_seed))
                   and pre[0].numel() == M * N and pre[0].dtype == x2.dtype)
+        masked = (pre is not None and len(pre) == 3 and act == ACT_NONE and pre[1:] == (float(drop_p), int(drop_seed)) and pre[0].numel() == M * N
+                  and pre[0].dtype == x2.dtype)
+        # (a handed-over gradient replaces dy altogether: dy may then be an uninitialised placeholder of another dtype -- no cast of it)
+        dz = dy if (dy.dtype == x2.dtype or handed or masked) else ops.cast(dy, x2.dtype)
         if tag is not None and tag.gated and not handed:
             raise RuntimeError("bist_amd: a consuming linear layer gated its input gradient with this layer's drop(relu(.)) output, but "
                                "the gated tensor did not reach this backward (second consumer, hook or view on the hidden activation): "
                                "masking it again would be wrong -- set BIST_GATE_HANDOFF=0 for such graphs")
         if handed:
             dz = pre[0].view(M, N)                     # already gated (y > 0, 1/(1-p)) by the consumer's dX product
-        elif pre is not None and len(pre) == 3 and act == ACT_NONE and pre[1:] == (float(drop_p), int(drop_seed)) and pre[0].numel() == M * N \
-                and pre[0].dtype == x2.dtype:
-            dz = pre[0].view(M, N)                     # already masked by the LayerNorm backward that produced dy
+        elif masked:
+            dz = pre[0].view(M, N)                     # already masked by the LayerNorm backward that produced dy (or handed over in the operand dtype)
         elif act == ACT_RELU or drop_p > 0:
             dz2 = torch.empty_like(dz)
             yy = y if y is not None else dz
@@ -961,6 +963,69 @@ class PointerMixFn(Function):
                                        dlogits.data_ptr(), dsw.data_ptr(), dd, rows, Lt, V, 1 if sig else 0, _stream()),
               "bist_pointer_mix_bwd")
         return (dlogits, dsw, None, None, None, *[g.view(p.shape) for g, p in zip(dps, ps)], *([None] * n))
+
+
+class StackRowsFn(Function):
+    """n <= 4 same-shaped tensors [..., d] behind one another as [n * rows, d] (one launch, bist_stack_rows); the gradient's slices go
+    back as views."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        xs = [x.reshape(-1, x.shape[-1]) for x in xs]
+        xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
+        rows, d = xs[0].shape
+        out = torch.empty((len(xs) * rows, d), device=xs[0].device, dtype=xs[0].dtype)
+        arr = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        check(lib.bist_stack_rows(arr, len(xs), out.data_ptr(), rows * d * out.element_size(), _stream()), "bist_stack_rows")
+        ctx.n, ctx.rows = len(xs), rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return tuple(g[j * ctx.rows:(j + 1) * ctx.rows].view(ctx.shapes[j]) for j in range(ctx.n))
+
+
+class XentSmoothLossFn(Function):
+    """G losses (one [1] tensor each) of G groups of M rows that share their targets: sum_rows KL(smoothed target || softmax(logits)) /
+    denom straight from the f32 logits [G * M, V] (bist_xent_smooth_fwd / _bwd: no log-probabilities, no f32 gradient of them).  The
+    logits' gradient leaves in the operand dtype of the producing projection and travels as `_bist_dz` of an uninitialised f32
+    placeholder (LinearFn.backward takes it from there: autograd would cast a bf16 gradient of an f32 tensor back to f32)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, denom, smoothing, pad, G, grad_dtype):
+        R, V = logits.shape
+        M = R // G
+        logits, target = logits.contiguous(), target.contiguous()
+        rows = torch.empty((R,), device=logits.device, dtype=torch.float32)
+        lse = torch.empty((R,), device=logits.device, dtype=torch.float32)
+        check(lib.bist_xent_smooth_fwd(logits.data_ptr(), target.data_ptr(), M, R, V, smoothing, pad, rows.data_ptr(), lse.data_ptr(), _stream()),
+              "bist_xent_smooth_fwd")
+        out = torch.empty((G,), device=logits.device, dtype=torch.float32)
+        check(lib.bist_sum_div_groups(rows.data_ptr(), M, G, _ptr(denom), out.data_ptr(), _stream()), "bist_sum_div_groups")
+        ctx.save_for_backward(logits, lse, target, denom)
+        ctx.cfg = (M, G, smoothing, pad, grad_dtype)
+        return tuple(out[g:g + 1] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        logits, lse, target, denom = ctx.saved_tensors
+        M, G, smoothing, pad, grad_dtype = ctx.cfg
+        R, V = logits.shape
+        gs = [g if g is not None else torch.zeros(1, device=logits.device) for g in gouts]
+        if all(g.data_ptr() == gs[0].data_ptr() for g in gs) and gs[0].numel() == 1:
+            gout = gs[0].float().expand(G).contiguous() if G > 1 else gs[0].float().contiguous()
+        else:
+            gout = torch.cat([g.reshape(1).float() for g in gs])
+        dl = torch.empty((R, V), device=logits.device, dtype=grad_dtype)
+        check(lib.bist_xent_smooth_bwd(logits.data_ptr(), lse.data_ptr(), target.data_ptr(), M, R, gout.data_ptr(), _ptr(denom), dl.data_ptr(),
+                                       dtype_code(grad_dtype), V, smoothing, pad, _stream()), "bist_xent_smooth_bwd")
+        if grad_dtype == torch.float32:
+            return dl, None, None, None, None, None, None
+        holder = torch.empty((R, V), device=logits.device, dtype=torch.float32)       # never read: the consumer takes _bist_dz
+        holder._bist_dz = (dl, 0.0, 0)
+        return holder, None, None, None, None, None, None
 
 
 class SwitchLogitsFn(Function):

@@ -530,6 +530,72 @@ __global__ __launch_bounds__(256) void label_smoothing_kernel(const float* __res
   if (threadIdx.x == 0) row_loss[row] = acc + (conf > 0.f ? conf * (logf(conf) - lp[t]) : 0.f);
 }
 
+// Generator.forward + LabelSmoothing on the same rows (generator.py:21-27, label_smoothing.py: KL(smoothed one-hot || softmax(logits))) as ONE
+// pass over the logits, for G groups of M rows that share the targets (the auto-encoder heads of optimize.py:66-82: the caption / temporal /
+// spatial outputs against the same query tokens): row r has target[r % M].
+//   row_loss = conf (log conf - logp_t) + sum_{v != t, pad} s (log s - logp_v),  logp = logits - lse,  s = smoothing / (V - 2);  0 at pad targets
+//   d row_loss / d logits[v] = softmax[v] - td[v]   (the smoothed target sums to 1)
+// so neither the log-probabilities nor their f32 gradient are ever stored; the backward writes the logits' gradient in the dtype of the
+// two products that consume it.
+__global__ __launch_bounds__(256) void xent_smooth_fwd_kernel(const float* __restrict__ logits, const long* __restrict__ target, long M,
+                                                              float* __restrict__ row_loss, float* __restrict__ lse, int V, float smoothing, int pad) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const long t = target[row % M];
+  const float* lg = logits + row * V;
+  float mx = -INFINITY, sum = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) { const float l = lg[v]; mx = fmaxf(mx, l); if (v != t && v != pad) sum += l; }
+  mx = block_reduce(mx, red, true);
+  sum = block_reduce(sum, red, false);
+  float den = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) den += expf(lg[v] - mx);
+  den = block_reduce(den, red, false);
+  if (threadIdx.x == 0) {
+    const float l = mx + logf(den);
+    lse[row] = l;
+    const float s = smoothing / (float)(V - 2), conf = 1.f - smoothing;
+    float loss = 0.f;
+    if (t != pad) {
+      if (conf > 0.f) loss += conf * (logf(conf) - (lg[t] - l));
+      if (s > 0.f) loss += s * ((float)(V - 2) * (logf(s) + l) - sum);
+    }
+    row_loss[row] = loss;
+  }
+}
+
+template <typename TD>
+__global__ __launch_bounds__(256) void xent_smooth_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse, const long* __restrict__ target,
+                                                              long M, const float* __restrict__ gout, const long* __restrict__ denom,
+                                                              TD* __restrict__ dlogits, int V, float smoothing, int pad) {
+  const long row = blockIdx.x;
+  const long t = target[row % M];
+  const float sc = gout[row / M] / (denom ? (float)denom[0] : 1.f);
+  const float s = smoothing / (float)(V - 2), conf = 1.f - smoothing, l = lse[row];
+  const float* lg = logits + row * V;
+  TD* g = dlogits + row * V;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    float d_ = 0.f;
+    if (t != pad) d_ = sc * (expf(lg[v] - l) - ((v == t) ? conf : (v == pad ? 0.f : s)));
+    g[v] = from_f<TD>(d_);
+  }
+}
+
+// out[g] = sum(x[g M .. (g + 1) M)) / denom[0]: one workgroup per group, fixed order
+__global__ __launch_bounds__(256) void sum_div_groups_kernel(const float* __restrict__ x, long M, const long* __restrict__ denom, float* __restrict__ out) {
+  __shared__ float red[4];
+  const float* xg = x + (long)blockIdx.x * M;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < M; i += 256) acc += xg[i];
+  acc = block_reduce(acc, red, false);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc / (denom ? (float)denom[0] : 1.f);
+}
+
+struct StackSrc { const uint4* s[4]; };
+__global__ __launch_bounds__(256) void stack_rows_kernel(StackSrc a, uint4* __restrict__ out, long n16) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) out[(long)blockIdx.y * n16 + i] = a.s[blockIdx.y][i];
+}
+
 // out[0] (+)= sum(x[0..n)) / denom[0]   -- single workgroup, fixed order: bitwise reproducible
 __global__ __launch_bounds__(256) void sum_div_kernel(const float* __restrict__ x, long n, const long* __restrict__ denom,
                                                       float* __restrict__ out, int accumulate) {
@@ -704,6 +770,52 @@ extern "C" int bist_label_smoothing_fwd(const float* logp, const int64_t* target
   hipLaunchKernelGGL(label_smoothing_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logp, (const long*)target,
                      row_loss, V, smoothing, pad);
   BIST_LAUNCH_CHECK("bist_label_smoothing_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_xent_smooth_fwd(const float* logits, const int64_t* target, int64_t M, int64_t rows, int32_t V, float smoothing, int32_t pad,
+                                    float* row_loss, float* lse, void* stream) {
+  BIST_REQUIRE(logits && target && row_loss && lse && M > 0 && rows > 0 && rows % M == 0 && V > 2, "bist_xent_smooth_fwd: bad argument (rows a multiple of M)");
+  BIST_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "bist_xent_smooth_fwd: smoothing out of range");
+  hipLaunchKernelGGL(xent_smooth_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, (const long*)target, (long)M, row_loss,
+                     lse, V, smoothing, pad);
+  BIST_LAUNCH_CHECK("bist_xent_smooth_fwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_xent_smooth_bwd(const float* logits, const float* lse, const int64_t* target, int64_t M, int64_t rows, const float* gout,
+                                    const int64_t* denom, void* dlogits, int32_t dlogits_dtype, int32_t V, float smoothing, int32_t pad, void* stream) {
+  BIST_REQUIRE(logits && lse && target && gout && dlogits && M > 0 && rows > 0 && rows % M == 0 && V > 2, "bist_xent_smooth_bwd: bad argument");
+  BIST_REQUIRE(dlogits_dtype == BIST_BF16 || dlogits_dtype == BIST_F32, "bist_xent_smooth_bwd: bad gradient dtype");
+  hipStream_t st = (hipStream_t)stream;
+  if (dlogits_dtype == BIST_BF16)
+    hipLaunchKernelGGL(xent_smooth_bwd_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, logits, lse, (const long*)target, (long)M, gout,
+                       (const long*)denom, (bf16_t*)dlogits, V, smoothing, pad);
+  else
+    hipLaunchKernelGGL(xent_smooth_bwd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, logits, lse, (const long*)target, (long)M, gout,
+                       (const long*)denom, (float*)dlogits, V, smoothing, pad);
+  BIST_LAUNCH_CHECK("bist_xent_smooth_bwd");
+  return BIST_OK;
+}
+
+extern "C" int bist_sum_div_groups(const float* x, int64_t M, int32_t G, const int64_t* denom, float* out, void* stream) {
+  BIST_REQUIRE(x && out && M > 0 && G > 0, "bist_sum_div_groups: bad argument");
+  hipLaunchKernelGGL(sum_div_groups_kernel, dim3((unsigned)G), dim3(256), 0, (hipStream_t)stream, x, (long)M, (const long*)denom, out);
+  BIST_LAUNCH_CHECK("bist_sum_div_groups");
+  return BIST_OK;
+}
+
+extern "C" int bist_stack_rows(const void* const* srcs, int32_t n, void* out, int64_t bytes_each, void* stream) {
+  BIST_REQUIRE(srcs && out && n >= 1 && n <= 4 && bytes_each > 0 && bytes_each % 16 == 0 && ((uintptr_t)out & 15) == 0, "bist_stack_rows: 1..4 sources of a multiple of 16 bytes");
+  StackSrc a;
+  for (int j = 0; j < 4; ++j) a.s[j] = nullptr;
+  for (int j = 0; j < n; ++j) {
+    BIST_REQUIRE(srcs[j] && ((uintptr_t)srcs[j] & 15) == 0, "bist_stack_rows: source %d null or not 16-byte aligned", j);
+    a.s[j] = (const uint4*)srcs[j];
+  }
+  const long n16 = bytes_each / 16;
+  hipLaunchKernelGGL(stack_rows_kernel, dim3((unsigned)((n16 + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a, (uint4*)out, n16);
+  BIST_LAUNCH_CHECK("bist_stack_rows");
   return BIST_OK;
 }
 

@@ -225,6 +225,19 @@ def pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch=False):
     return ops.pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch)
 
 
+def stack_rows(xs) -> Tensor:
+    if _grad():
+        return ag.StackRowsFn.apply(*xs)
+    return ag.StackRowsFn.forward(_NoCtx(), *xs)
+
+
+def xent_smooth_losses(logits: Tensor, target: Tensor, denom, smoothing: float, pad: int, G: int, grad_dtype):
+    """G device scalars [1]: label-smoothed KL of softmax(logits) per group of rows / denom (autograd.XentSmoothLossFn)."""
+    if _grad():
+        return ag.XentSmoothLossFn.apply(logits, target, denom, smoothing, pad, G, grad_dtype)
+    return ag.XentSmoothLossFn.forward(_NoCtx(), logits, target, denom, smoothing, pad, G, grad_dtype)
+
+
 def switch_logits_ok(w: Tensor, bias: Optional[Tensor], parts) -> bool:
     d = parts[0].shape[-1]
     return (POINTER_ATTN and w.is_cuda and w.dtype in (torch.bfloat16, torch.float32) and 1 <= len(parts) <= 4 and w.shape[0] <= 4

@@ -1,9 +1,14 @@
 """Noam learning-rate wrapper and the loss/step driver (reference: model/optimize.py)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
+from .. import functional as Fn
 from .. import ops
+
+AE_GROUPED = os.environ.get("BIST_AE_GROUPED", "1") != "0"      # tuning aid: 0 = one vocabulary product / log-softmax / loss chain per auto-encoder head
 
 
 class NoamOpt:
@@ -63,11 +68,39 @@ class SimpleLossCompute:
         out = self.generator(ft, batch, a)
         V = out.size(-1)
         t = {"out": self.criterion.loss(out.reshape(-1, V), batch.trg_y.reshape(-1), batch.ntokens.reshape(1))}
-        for name, key in keys:
-            lp = self.ae_generator(ft, batch, a, key)
-            ae[name] = self.criterion.loss(lp.reshape(-1, lp.size(-1)), q, batch.qntokens.reshape(1))
+        grouped = self._ae_grouped(ft, batch, keys, q) if (keys and AE_GROUPED) else None
+        if grouped is not None:
+            ae = grouped
+        else:
+            for name, key in keys:
+                lp = self.ae_generator(ft, batch, a, key)
+                ae[name] = self.criterion.loss(lp.reshape(-1, lp.size(-1)), q, batch.qntokens.reshape(1))
         t.update(ae)
         return t, out
+
+    def _ae_grouped(self, ft, batch, keys, q):
+        """The auto-encoder heads as ONE chain (optimize.py:66-82 runs one per output): their inputs stacked (one launch), one vocabulary
+        product against the shared embedding, one pass from the logits to the row losses and one to the logits' gradient
+        (bist_xent_smooth_*: log-softmax and label smoothing fused, the gradient written in the product's operand dtype) -- 4 launches
+        forward and 3 backward where three separate heads take 12 and 15.  None when the heads do not share one projection / shape."""
+        gen, crit = self.ae_generator, self.criterion
+        if not (getattr(gen, "shared_W", False) and hasattr(crit, "smoothing")):
+            return None
+        xs = []
+        for _, key in keys:
+            spare = (ft.get("_bist_alias") or {}).get(key)
+            xs.append(spare.pop(0) if spare else ft[key])
+        x0 = xs[0]
+        if not (x0.is_cuda and all(x.shape == x0.shape and x.dtype == x0.dtype for x in xs) and 1 <= len(xs) <= 4
+                and x0.dtype in (torch.bfloat16, torch.float32) and (x0.numel() * x0.element_size()) % 16 == 0
+                and q.numel() * x0.shape[-1] == x0.numel()):
+            return None
+        G = len(xs)
+        logits = Fn.linear(Fn.stack_rows(xs), gen.proj, None, out_dtype=torch.float32)                 # [G * M, V]
+        if crit.size != logits.shape[-1]:
+            return None
+        losses = Fn.xent_smooth_losses(logits, q, batch.qntokens.reshape(1), crit.smoothing, crit.padding_idx, G, x0.dtype)
+        return {name: losses[g] for g, (name, _) in enumerate(keys)}
 
     def __call__(self, ft, batch):
         t, _ = self.terms(ft, batch)

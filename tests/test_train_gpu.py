@@ -1017,3 +1017,80 @@ def test_switch_logits_launch_forward_and_backward(env, dtype, tol, rows, d, n, 
         assert (parts[j].grad.double() - p6[j].grad).abs().max().item() <= tol * sc(p6[j].grad), j
     assert (w.grad.double() - w6.grad).abs().max().item() <= 2 * tol * sc(w6.grad)
     assert (b.grad.double() - b6.grad).abs().max().item() <= 2 * tol * sc(b6.grad)
+
+
+@pytest.mark.parametrize("G,M,V,smoothing", [(3, 320, 3000, 0.1), (1, 7, 80, 0.0), (2, 33, 301, 0.3)])
+def test_fused_log_softmax_label_smoothing_loss(env, G, M, V, smoothing):
+    """bist_xent_smooth_fwd / _bwd + bist_sum_div_groups (log-softmax and the label-smoothed KL of label_smoothing.py in one pass from the
+    logits, G groups of M rows sharing their targets) against torch: KLDivLoss(sum) of log_softmax against the smoothed one-hot rows
+    (confidence on the target, smoothing / (V - 2) elsewhere, nothing on the pad column or on pad rows), per group / denom, and the
+    logits' gradient for different upstream gradients per group -- float32 and handed over in bf16."""
+    from bist_amd import functional as Fn
+    g = torch.Generator().manual_seed(G * 1000 + M)
+    pad = 1
+    logits = (torch.randn(G * M, V, generator=g) * 3).cuda().requires_grad_(True)
+    target = torch.randint(0, V, (M,), generator=g)
+    target[::5] = pad
+    denom = torch.tensor([int((target != pad).sum())], dtype=torch.long).cuda()
+    ups = torch.rand(G, generator=g).cuda() + 0.5
+    losses = Fn.xent_smooth_losses(logits, target.cuda(), denom, smoothing, pad, G, torch.float32)
+    sum(l * u for l, u in zip(losses, ups)).backward()
+    l6 = logits.detach().double().requires_grad_(True)
+    lp = torch.log_softmax(l6, -1).view(G, M, V)
+    td = torch.full((M, V), smoothing / (V - 2), dtype=torch.float64)
+    td.scatter_(1, target[:, None], 1.0 - smoothing)
+    td[:, pad] = 0
+    td[target == pad] = 0
+    td = td.cuda()
+    ref = [(torch.where(td > 0, td * (td.clamp_min(1e-300).log() - lp[gi]), torch.zeros_like(td))).sum() / denom.double() for gi in range(G)]
+    sum(r * u.double() for r, u in zip(ref, ups)).backward()
+    for gi in range(G):
+        assert abs(losses[gi].item() - ref[gi].item()) <= 2e-5 * max(1.0, abs(ref[gi].item())), gi
+    assert (logits.grad.double() - l6.grad).abs().max().item() <= 1e-6 * max(1.0, l6.grad.abs().max().item()) + 1e-7
+    # the bf16 hand-over: the gradient arrives as `_bist_dz` of a placeholder
+    lg2 = logits.detach().clone().requires_grad_(True)
+    got = {}
+    def hook(gr):
+        got["dz"] = getattr(gr, "_bist_dz", None)
+    lg2.register_hook(hook)
+    losses2 = Fn.xent_smooth_losses(lg2, target.cuda(), denom, smoothing, pad, G, torch.bfloat16)
+    sum(l * u for l, u in zip(losses2, ups)).backward()
+    assert got["dz"] is not None and got["dz"][0].dtype == torch.bfloat16 and got["dz"][1:] == (0.0, 0)
+    assert (got["dz"][0].double() - l6.grad).abs().max().item() <= 2.0 ** -8 * l6.grad.abs().max().item()
+
+
+def test_grouped_auto_encoder_heads_train_like_the_separate_heads(env):
+    """The three auto-encoder heads as one chain (stacked inputs, one vocabulary product, fused log-softmax + label smoothing;
+    optimize.SimpleLossCompute._ae_grouped) against one chain per head (BIST_AE_GROUPED=0): float32 trainer, dropout off -- every loss
+    term within 1e-5 relative, every parameter gradient within 2e-4 of the largest entry; bf16: terms within 2 %, gradient cosine >= 0.999."""
+    import copy
+    import bist_amd.model as M
+    import bist_amd.model.optimize as OP
+    from bist_amd.data.synthetic import synthetic_batch
+    from bist_amd.train import Trainer
+    cfg = O.Cfg(d_model=64, att_h=4, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    args = _args(cfg)
+    torch.manual_seed(0)
+    base = M.make_model(80, 80, args, ft_sizes=[64]).cuda().eval()
+    for dtype in (torch.float32, torch.bfloat16):
+        b = synthetic_batch(4, T=6, S=9, C=64, Lq=8, Lh=9, Lc=6, Lt=6, vocab=80, dtype=dtype)
+        res = {}
+        for on in (True, False):
+            OP.AE_GROUPED = on
+            try:
+                tr = Trainer(copy.deepcopy(base), args, 80, compute_dtype=dtype, warmup=20, factor=2.0, use_graph=False)
+                terms = tr.backward(b)
+                torch.cuda.synchronize()
+                res[on] = ({k_: v.item() for k_, v in terms.items()}, tr.flat_grad.float().clone())
+            finally:
+                OP.AE_GROUPED = True
+        assert set(res[True][0]) == set(res[False][0]) and len(res[True][0]) == 4
+        ga, gb = res[True][1], res[False][1]
+        if dtype == torch.float32:
+            for k_ in res[True][0]:
+                assert abs(res[True][0][k_] - res[False][0][k_]) <= 1e-5 * abs(res[False][0][k_]), k_
+            assert (ga - gb).abs().max().item() <= 2e-4 * gb.abs().max().item()
+        else:
+            for k_ in res[True][0]:
+                assert abs(res[True][0][k_] - res[False][0][k_]) <= 2e-2 * abs(res[False][0][k_]), k_
+            assert torch.nn.functional.cosine_similarity(ga.double(), gb.double(), dim=0).item() >= 0.999
