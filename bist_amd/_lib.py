@@ -148,8 +148,8 @@ SIGNATURES = {
     "bist_text_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     "bist_decoder_cache_fill": (C.c_int, [_P, _I32, _I32, _P]),
     "bist_xent_smooth_fwd": (C.c_int, [_P, _P, _I64, _I64, _I32, _F, _I32, _P, _P, _P]),
-    "bist_xent_smooth_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I32, _I32, _F, _I32, _P]),
-    "bist_sum_div_groups": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
+    "bist_xent_smooth_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _P, _I32, _I32, _F, _I32, _P]),
+    "bist_sum_div_groups": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _P]),
     "bist_stack_rows": (C.c_int, [_P, _I32, _P, _I64, _P]),
     "bist_switch_logits_fwd": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "bist_switch_logits_bwd": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P, _I32, _I64, _I32, _I32, _I32, _P]),

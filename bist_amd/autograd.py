@@ -965,6 +965,19 @@ class PointerMixFn(Function):
         return (dlogits, dsw, None, None, None, *[g.view(p.shape) for g, p in zip(dps, ps)], *([None] * n))
 
 
+class SumTermsFn(Function):
+    """Sum of same-shaped f32 terms in one launch (bist_add_n); every term receives the upstream gradient itself."""
+
+    @staticmethod
+    def forward(ctx, *terms):
+        ctx.n = len(terms)
+        return ops.add_n([t.contiguous() for t in terms])
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) * ctx.n
+
+
 class StackRowsFn(Function):
     """n <= 4 same-shaped tensors [..., d] behind one another as [n * rows, d] (one launch, bist_stack_rows); the gradient's slices go
     back as views."""
@@ -1002,11 +1015,11 @@ class XentSmoothLossFn(Function):
         lse = torch.empty((R,), device=logits.device, dtype=torch.float32)
         check(lib.bist_xent_smooth_fwd(logits.data_ptr(), target.data_ptr(), M, R, V, smoothing, pad, rows.data_ptr(), lse.data_ptr(), _stream()),
               "bist_xent_smooth_fwd")
-        out = torch.empty((G,), device=logits.device, dtype=torch.float32)
-        check(lib.bist_sum_div_groups(rows.data_ptr(), M, G, _ptr(denom), out.data_ptr(), _stream()), "bist_sum_div_groups")
+        out = torch.empty((G, 4), device=logits.device, dtype=torch.float32)           # (one 16-byte slot per term: the terms feed bist_add_n)
+        check(lib.bist_sum_div_groups(rows.data_ptr(), M, G, _ptr(denom), out.data_ptr(), 4, _stream()), "bist_sum_div_groups")
         ctx.save_for_backward(logits, lse, target, denom)
         ctx.cfg = (M, G, smoothing, pad, grad_dtype)
-        return tuple(out[g:g + 1] for g in range(G))
+        return tuple(out[g, :1] for g in range(G))
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -1014,12 +1027,12 @@ class XentSmoothLossFn(Function):
         M, G, smoothing, pad, grad_dtype = ctx.cfg
         R, V = logits.shape
         gs = [g if g is not None else torch.zeros(1, device=logits.device) for g in gouts]
-        if all(g.data_ptr() == gs[0].data_ptr() for g in gs) and gs[0].numel() == 1:
-            gout = gs[0].float().expand(G).contiguous() if G > 1 else gs[0].float().contiguous()
+        if all(g.data_ptr() == gs[0].data_ptr() for g in gs) and gs[0].numel() == 1 and gs[0].dtype == torch.float32:
+            gout, gstride = gs[0], 0                       # the terms were summed: ONE upstream gradient, read in place
         else:
-            gout = torch.cat([g.reshape(1).float() for g in gs])
+            gout, gstride = torch.cat([g.reshape(1).float() for g in gs]), 1
         dl = torch.empty((R, V), device=logits.device, dtype=grad_dtype)
-        check(lib.bist_xent_smooth_bwd(logits.data_ptr(), lse.data_ptr(), target.data_ptr(), M, R, gout.data_ptr(), _ptr(denom), dl.data_ptr(),
+        check(lib.bist_xent_smooth_bwd(logits.data_ptr(), lse.data_ptr(), target.data_ptr(), M, R, gout.data_ptr(), gstride, _ptr(denom), dl.data_ptr(),
                                        dtype_code(grad_dtype), V, smoothing, pad, _stream()), "bist_xent_smooth_bwd")
         if grad_dtype == torch.float32:
             return dl, None, None, None, None, None, None

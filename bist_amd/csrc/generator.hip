@@ -565,11 +565,11 @@ __global__ __launch_bounds__(256) void xent_smooth_fwd_kernel(const float* __res
 
 template <typename TD>
 __global__ __launch_bounds__(256) void xent_smooth_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse, const long* __restrict__ target,
-                                                              long M, const float* __restrict__ gout, const long* __restrict__ denom,
+                                                              long M, const float* __restrict__ gout, int gout_stride, const long* __restrict__ denom,
                                                               TD* __restrict__ dlogits, int V, float smoothing, int pad) {
   const long row = blockIdx.x;
   const long t = target[row % M];
-  const float sc = gout[row / M] / (denom ? (float)denom[0] : 1.f);
+  const float sc = gout[(row / M) * gout_stride] / (denom ? (float)denom[0] : 1.f);
   const float s = smoothing / (float)(V - 2), conf = 1.f - smoothing, l = lse[row];
   const float* lg = logits + row * V;
   TD* g = dlogits + row * V;
@@ -581,13 +581,14 @@ __global__ __launch_bounds__(256) void xent_smooth_bwd_kernel(const float* __res
 }
 
 // out[g] = sum(x[g M .. (g + 1) M)) / denom[0]: one workgroup per group, fixed order
-__global__ __launch_bounds__(256) void sum_div_groups_kernel(const float* __restrict__ x, long M, const long* __restrict__ denom, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sum_div_groups_kernel(const float* __restrict__ x, long M, const long* __restrict__ denom, float* __restrict__ out,
+                                                             int out_stride) {
   __shared__ float red[4];
   const float* xg = x + (long)blockIdx.x * M;
   float acc = 0.f;
   for (long i = threadIdx.x; i < M; i += 256) acc += xg[i];
   acc = block_reduce(acc, red, false);
-  if (threadIdx.x == 0) out[blockIdx.x] = acc / (denom ? (float)denom[0] : 1.f);
+  if (threadIdx.x == 0) out[(long)blockIdx.x * out_stride] = acc / (denom ? (float)denom[0] : 1.f);
 }
 
 struct StackSrc { const uint4* s[4]; };
@@ -784,23 +785,25 @@ extern "C" int bist_xent_smooth_fwd(const float* logits, const int64_t* target, 
 }
 
 extern "C" int bist_xent_smooth_bwd(const float* logits, const float* lse, const int64_t* target, int64_t M, int64_t rows, const float* gout,
-                                    const int64_t* denom, void* dlogits, int32_t dlogits_dtype, int32_t V, float smoothing, int32_t pad, void* stream) {
-  BIST_REQUIRE(logits && lse && target && gout && dlogits && M > 0 && rows > 0 && rows % M == 0 && V > 2, "bist_xent_smooth_bwd: bad argument");
+                                    int32_t gout_stride, const int64_t* denom, void* dlogits, int32_t dlogits_dtype, int32_t V, float smoothing,
+                                    int32_t pad, void* stream) {
+  BIST_REQUIRE(logits && lse && target && gout && dlogits && M > 0 && rows > 0 && rows % M == 0 && V > 2 && (gout_stride == 0 || gout_stride == 1),
+               "bist_xent_smooth_bwd: bad argument (gout_stride 1 = one upstream gradient per group, 0 = one for all)");
   BIST_REQUIRE(dlogits_dtype == BIST_BF16 || dlogits_dtype == BIST_F32, "bist_xent_smooth_bwd: bad gradient dtype");
   hipStream_t st = (hipStream_t)stream;
   if (dlogits_dtype == BIST_BF16)
     hipLaunchKernelGGL(xent_smooth_bwd_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, logits, lse, (const long*)target, (long)M, gout,
-                       (const long*)denom, (bf16_t*)dlogits, V, smoothing, pad);
+                       gout_stride, (const long*)denom, (bf16_t*)dlogits, V, smoothing, pad);
   else
     hipLaunchKernelGGL(xent_smooth_bwd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, logits, lse, (const long*)target, (long)M, gout,
-                       (const long*)denom, (float*)dlogits, V, smoothing, pad);
+                       gout_stride, (const long*)denom, (float*)dlogits, V, smoothing, pad);
   BIST_LAUNCH_CHECK("bist_xent_smooth_bwd");
   return BIST_OK;
 }
 
-extern "C" int bist_sum_div_groups(const float* x, int64_t M, int32_t G, const int64_t* denom, float* out, void* stream) {
-  BIST_REQUIRE(x && out && M > 0 && G > 0, "bist_sum_div_groups: bad argument");
-  hipLaunchKernelGGL(sum_div_groups_kernel, dim3((unsigned)G), dim3(256), 0, (hipStream_t)stream, x, (long)M, (const long*)denom, out);
+extern "C" int bist_sum_div_groups(const float* x, int64_t M, int32_t G, const int64_t* denom, float* out, int32_t out_stride, void* stream) {
+  BIST_REQUIRE(x && out && M > 0 && G > 0 && out_stride >= 1, "bist_sum_div_groups: bad argument");
+  hipLaunchKernelGGL(sum_div_groups_kernel, dim3((unsigned)G), dim3(256), 0, (hipStream_t)stream, x, (long)M, (const long*)denom, out, out_stride);
   BIST_LAUNCH_CHECK("bist_sum_div_groups");
   return BIST_OK;
 }

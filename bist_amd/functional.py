@@ -225,6 +225,19 @@ def pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch=False):
     return ops.pointer_mix(logits, sw, ps, texts, Lt, sigmoid_switch)
 
 
+def sum_terms(terms) -> Tensor:
+    """The sum of the loss terms (device scalars [1], f32) as one launch instead of a chain of additions."""
+    terms = list(terms)
+    if len(terms) == 1:
+        return terms[0]
+    if all(t.is_cuda and t.dtype == torch.float32 and t.shape == terms[0].shape and t.data_ptr() % 16 == 0 for t in terms) and len(terms) <= 8:
+        return ag.SumTermsFn.apply(*terms) if _grad() else ops.add_n([t.contiguous() for t in terms])
+    out = terms[0]
+    for t in terms[1:]:
+        out = out + t
+    return out
+
+
 def stack_rows(xs) -> Tensor:
     if _grad():
         return ag.StackRowsFn.apply(*xs)

@@ -104,9 +104,7 @@ class SimpleLossCompute:
 
     def __call__(self, ft, batch):
         t, _ = self.terms(ft, batch)
-        loss = None
-        for v in t.values():
-            loss = v if loss is None else loss + v
+        loss = Fn.sum_terms(t.values())
         if self.opt is not None:
             loss.backward()
             self.opt.step()

@@ -210,10 +210,7 @@ class Trainer:
     def forward_loss(self, batch):
         ft = self.model.forward(batch)
         terms, logp = self.loss_compute.terms(ft, batch)
-        loss = None
-        for t in terms.values():
-            loss = t if loss is None else loss + t
-        return loss, terms
+        return Fn.sum_terms(terms.values()), terms
 
     def _adam_dev(self, lo: int, hi: int) -> None:
         """Adam on flat elements [lo, hi) with this step's scalars read from ``self.hyper`` (device): capturable."""

@@ -523,14 +523,15 @@ int bist_pointer_mix_bwd(const float* logits, const float* switch_logits, int32_
 /* Generator.forward (model/generator.py:21-27: log_softmax of the vocabulary product) and LabelSmoothing (model/label_smoothing.py)
  * on the same rows as one pass each way, for G = rows / M groups of M rows sharing the targets (the query auto-encoder heads of
  * model/optimize.py:66-82): row r has target[r % M].  Forward: row_loss f32 [rows] (KL of the smoothed one-hot target against
- * softmax(logits); 0 at pad targets) and the rows' log-sum-exp.  Backward: dlogits[r][v] = gout[r / M] / denom * (softmax - smoothed
- * target), written in dlogits_dtype.  bist_sum_div_groups: out[g] = sum of the group's M row losses / denom.
+ * softmax(logits); 0 at pad targets) and the rows' log-sum-exp.  Backward: dlogits[r][v] = gout[(r / M) * gout_stride] / denom * (softmax - smoothed
+ * target), written in dlogits_dtype (gout_stride 0: one upstream gradient for all groups).  bist_sum_div_groups: out[g * out_stride] = sum of the group's M row losses / denom.
  * bist_stack_rows: n <= 4 equally sized buffers behind one another (one launch; srcs is a HOST array).                              */
 int bist_xent_smooth_fwd(const float* logits, const int64_t* target, int64_t M, int64_t rows, int32_t V, float smoothing, int32_t pad,
                          float* row_loss, float* lse, void* stream);
 int bist_xent_smooth_bwd(const float* logits, const float* lse, const int64_t* target, int64_t M, int64_t rows, const float* gout,
-                         const int64_t* denom, void* dlogits, int32_t dlogits_dtype, int32_t V, float smoothing, int32_t pad, void* stream);
-int bist_sum_div_groups(const float* x, int64_t M, int32_t G, const int64_t* denom, float* out, void* stream);
+                         int32_t gout_stride, const int64_t* denom, void* dlogits, int32_t dlogits_dtype, int32_t V, float smoothing,
+                         int32_t pad, void* stream);
+int bist_sum_div_groups(const float* x, int64_t M, int32_t G, const int64_t* denom, float* out, int32_t out_stride, void* stream);
 int bist_stack_rows(const void* const* srcs, int32_t n, void* out, int64_t bytes_each, void* stream);
 /* The switch logits of (Multi)PointerGenerator (model/generator.py:69-71, 119-121: pointer_gen_W(torch.cat(parts, -1))) without the
  * concatenation: part j [rows][d] multiplies column block j of W [ns][ldw >= n_parts d]; out f32 [rows][ns] = sum_j part_j . W_j^T + bias.
