@@ -247,64 +247,105 @@ __global__ __launch_bounds__(256) void switch_logits_bwd_w_kernel(SwParts a, con
 //             tv[b,i,:] = sum_t p[b,i,t] enc[b,t,:]  (the text vector), one wave per (b, i): two launches' worth of the generic attention
 //             core (which also multiplied P by a value operand nobody reads), two mask operations and the cast + fallback product.
 //   backward: dpt = dp + dtv . enc^T;  dS = p (dpt - sum_t p dpt) scale;  dq = dS k;  dk = dS^T q;  denc = p^T dtv -- one workgroup per b.
+// sc[i][t] (+)= a[i] . b[t] over d channels for i < M <= 32, t < N <= 128: bf16 on the matrix cores (16x16x32 tiles, wave-strided over the
+// <= 16 output tiles, fragments straight from global memory: lane (x, kg) reads 16 bytes of row x at k0 + 8 kg), f32 with a wave per pair.
+template <typename T>
+__device__ __forceinline__ void small_nt_product(const T* __restrict__ a, const T* __restrict__ b, int M, int N, int d, float (*sc)[129], bool add,
+                                                 int w, int lane) {
+  if constexpr (sizeof(T) == 2) {
+    const int x = lane & 15, kg = lane >> 4;
+    const int NT = (N + 15) / 16, tiles = ((M + 15) / 16) * NT;
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    for (int tile = w; tile < tiles; tile += 4) {
+      const int mi = tile / NT, ni = tile - mi * NT;
+      const int ia = mi * 16 + x, tb = ni * 16 + x;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kb0 = 0; kb0 < d; kb0 += 256) {             // eight k-steps per round: their sixteen loads are in flight together
+        uint4 af[8], bf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k0 = kb0 + 32 * u;
+          af[u] = (ia < M && k0 < d) ? *reinterpret_cast<const uint4*>(a + (long)ia * d + k0 + kg * 8) : zero;
+          bf[u] = (tb < N && k0 < d) ? *reinterpret_cast<const uint4*>(b + (long)tb * d + k0 + kg * 8) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[u]), __builtin_bit_cast(bf16x8, bf[u]), acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                      // D[m = 4 kg + r][n = x]
+        const int i = mi * 16 + 4 * kg + r, t = ni * 16 + x;
+        if (i < M && t < N) sc[i][t] = add ? sc[i][t] + acc[r] : acc[r];
+      }
+    }
+  } else {
+    constexpr int E = 4;
+    for (int e = w; e < M * N; e += 4) {
+      const int i = e / N, t = e - i * N;
+      float acc = 0.f;
+      for (int c = lane * E; c < d; c += 64 * E) {
+        const float4 u = *reinterpret_cast<const float4*>(a + (long)i * d + c), v = *reinterpret_cast<const float4*>(b + (long)t * d + c);
+        acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) sc[i][t] = add ? sc[i][t] + acc : acc;
+    }
+  }
+}
+
+// forward: one workgroup per sequence b (Lt <= 32 target positions, L <= 128 source positions)
 template <typename T>
 __global__ __launch_bounds__(256) void pointer_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ enc,
                                                                const unsigned char* __restrict__ mask, long mask_bs, const long* __restrict__ text,
-                                                               long unk, float* __restrict__ p, T* __restrict__ tv, int rows, int Lt, int L, int d,
-                                                               float scale) {
-  constexpr int E = 16 / (int)sizeof(T);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long row = (long)blockIdx.x * 4 + w;
-  if (row >= rows) return;
-  const int b = (int)(row / Lt);
-  const T* qr = q + row * d;
-  const T* kb = k + (long)b * L * d;
-  float s0 = -INFINITY, s1 = -INFINITY;                 // scores of keys lane and lane + 64
-  for (int t = 0; t < L; ++t) {
-    float acc = 0.f;
-    for (int c = lane * E; c < d; c += 64 * E) {
-      T a[E], x[E];
-      *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(qr + c);
-      *reinterpret_cast<uint4*>(x) = *reinterpret_cast<const uint4*>(kb + (long)t * d + c);
+                                                               long unk, float* __restrict__ p, T* __restrict__ tv, int Lt, int L, int d, float scale) {
+  __shared__ float sc[32][129];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
+  small_nt_product<T>(q + (long)b * Lt * d, k + (long)b * L * d, Lt, L, d, sc, false, w, lane);
+  __syncthreads();
+  for (int i = w; i < Lt; i += 4) {                     // masked softmax, a wave per target position
+    float s0 = -INFINITY, s1 = -INFINITY;
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc += to_f(a[e]) * to_f(x[e]);
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int t = lane + 64 * h2;
+      if (t < L) {
+        bool live = mask == nullptr || mask[(long)b * mask_bs + t] != 0;
+        if (text != nullptr && text[(long)b * L + t] == unk) live = false;
+        const float v = live ? sc[i][t] * scale : -1e9f;
+        if (h2 == 0) s0 = v; else s1 = v;
+      }
     }
-    acc = wave_sum(acc);
-    bool live = mask == nullptr || mask[(long)b * mask_bs + t] != 0;
-    if (text != nullptr && text[(long)b * L + t] == unk) live = false;
-    const float v = live ? acc * scale : -1e9f;
-    if ((t & 63) == lane) { if (t < 64) s0 = v; else s1 = v; }
+    const float mx = wave_max(fmaxf(s0, s1));
+    const float e0 = lane < L ? expf(s0 - mx) : 0.f, e1 = lane + 64 < L ? expf(s1 - mx) : 0.f;
+    const float inv = 1.f / wave_sum(e0 + e1);
+    if (lane < L) { sc[i][lane] = e0 * inv; p[((long)b * Lt + i) * L + lane] = e0 * inv; }
+    if (lane + 64 < L) { sc[i][lane + 64] = e1 * inv; p[((long)b * Lt + i) * L + lane + 64] = e1 * inv; }
   }
-  const float mx = wave_max(fmaxf(s0, s1));
-  const float e0 = lane < L ? expf(s0 - mx) : 0.f, e1 = lane + 64 < L ? expf(s1 - mx) : 0.f;
-  const float inv = 1.f / wave_sum(e0 + e1);
-  const float p0 = e0 * inv, p1 = e1 * inv;
-  if (lane < L) p[row * L + lane] = p0;
-  if (lane + 64 < L) p[row * L + lane + 64] = p1;
-  if (tv) {
-    const T* eb = enc + (long)b * L * d;
-    for (int c0 = 0; c0 < d; c0 += 64 * E) {              // (every lane walks the loop: the shuffles below need the whole wave)
-      const int c = c0 + lane * E;
-      const bool act = c < d;
-      float acc[E];
+  if (tv == nullptr) return;
+  __syncthreads();
+  const T* eb = enc + (long)b * L * d;
+  for (int c = tid * 2; c < d; c += 512) {              // text vector by column pairs
+    float acc[32][2];
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc[e] = 0.f;
-      for (int t = 0; t < L; ++t) {
-        const float pt = __shfl(t < 64 ? p0 : p1, t & 63, 64);
-        if (act) {
-          T x[E];
-          *reinterpret_cast<uint4*>(x) = *reinterpret_cast<const uint4*>(eb + (long)t * d + c);
+    for (int i = 0; i < 32; ++i) acc[i][0] = acc[i][1] = 0.f;
+    for (int tb0 = 0; tb0 < L; tb0 += 8) {                // eight positions per round: their loads are in flight together
+      float e0[8], e1[8];
 #pragma unroll
-          for (int e = 0; e < E; ++e) acc[e] += pt * to_f(x[e]);
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int t = tb0 + u;
+        e0[u] = t < L ? to_f(eb[(long)t * d + c]) : 0.f;
+        e1[u] = t < L ? to_f(eb[(long)t * d + c + 1]) : 0.f;
       }
-      if (act) {
-        T o[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) o[e] = from_f<T>(acc[e]);
-        *reinterpret_cast<uint4*>(tv + row * d + c) = *reinterpret_cast<const uint4*>(o);
+      for (int u = 0; u < 8; ++u) {
+        const int t = min(tb0 + u, L - 1);                   // (beyond L the operands are zero)
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+          if (i < Lt) { const float pt = sc[i][t]; acc[i][0] += pt * e0[u]; acc[i][1] += pt * e1[u]; }
       }
     }
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      if (i < Lt) { tv[((long)b * Lt + i) * d + c] = from_f<T>(acc[i][0]); tv[((long)b * Lt + i) * d + c + 1] = from_f<T>(acc[i][1]); }
   }
 }
 
@@ -313,7 +354,6 @@ __global__ __launch_bounds__(256) void pointer_attn_bwd_kernel(const T* __restri
                                                                const float* __restrict__ p, const float* __restrict__ dp, const T* __restrict__ dtv,
                                                                T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ denc, int Lt, int L, int d,
                                                                float scale) {
-  constexpr int E = 16 / (int)sizeof(T);
   __shared__ float ps[32][129], ds[32][129];            // Lt <= 32, L <= 128
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
   const T* qb = q + (long)b * Lt * d;
@@ -327,20 +367,8 @@ __global__ __launch_bounds__(256) void pointer_attn_bwd_kernel(const T* __restri
     ds[i][t] = dp ? dp[(long)b * Lt * L + e] : 0.f;
   }
   __syncthreads();
-  if (db) {                                             // dpt += dtv[i] . enc[t]: a wave per (i, t) pair
-    for (int e = w; e < Lt * L; e += 4) {
-      const int i = e / L, t = e - i * L;
-      float acc = 0.f;
-      for (int c = lane * E; c < d; c += 64 * E) {
-        T a[E], x[E];
-        *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(db + (long)i * d + c);
-        *reinterpret_cast<uint4*>(x) = *reinterpret_cast<const uint4*>(eb + (long)t * d + c);
-#pragma unroll
-        for (int j = 0; j < E; ++j) acc += to_f(a[j]) * to_f(x[j]);
-      }
-      acc = wave_sum(acc);
-      if (lane == 0) ds[i][t] += acc;
-    }
+  if (db) {                                             // dpt += dtv . enc^T
+    small_nt_product<T>(db, eb, Lt, L, d, ds, true, w, lane);
     __syncthreads();
   }
   for (int i = w; i < Lt; i += 4) {                     // softmax backward, a wave per query row
@@ -361,8 +389,10 @@ __global__ __launch_bounds__(256) void pointer_attn_bwd_kernel(const T* __restri
         if (db) { da[i][0] = to_f(db[(long)i * d + c]); da[i][1] = to_f(db[(long)i * d + c + 1]); }
       }
     }
+    float kn0 = to_f(kb[c]), kn1 = to_f(kb[c + 1]);        // (next position's keys: loaded one position ahead)
     for (int t = 0; t < L; ++t) {
-      const float k0 = to_f(kb[(long)t * d + c]), k1 = to_f(kb[(long)t * d + c + 1]);
+      const float k0 = kn0, k1 = kn1;
+      if (t + 1 < L) { kn0 = to_f(kb[(long)(t + 1) * d + c]); kn1 = to_f(kb[(long)(t + 1) * d + c + 1]); }
       float g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
@@ -688,14 +718,14 @@ extern "C" int bist_switch_logits_bwd(const void* const* parts, int32_t n_parts,
 extern "C" int bist_pointer_attn_fwd(const void* q, const void* k, const void* enc, const uint8_t* mask, int64_t mask_bs, const int64_t* text,
                                      int64_t unk, float* p, void* tv, int64_t B, int32_t Lt, int32_t L, int32_t d, float scale, int32_t dtype,
                                      void* stream) {
-  BIST_REQUIRE(q && k && p && B > 0 && Lt > 0 && L >= 1 && L <= 128 && d > 0 && (!tv || enc), "bist_pointer_attn_fwd: bad argument (1..128 positions)");
-  const int e = dtype == BIST_BF16 ? 8 : 4;
+  BIST_REQUIRE(q && k && p && B > 0 && Lt >= 1 && Lt <= 32 && L >= 1 && L <= 128 && d > 0 && (!tv || enc),
+               "bist_pointer_attn_fwd: bad argument (<= 32 target positions, 1..128 source positions)");
+  const int e = dtype == BIST_BF16 ? 32 : 4;
   BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && d % e == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)enc | (uintptr_t)tv) & 15) == 0,
-               "bist_pointer_attn_fwd: bf16 / f32, 16-byte aligned rows");
-  const long rows = B * Lt;
+               "bist_pointer_attn_fwd: bf16 (d a multiple of 32) / f32 (of 4), 16-byte aligned rows");
   hipStream_t st = (hipStream_t)stream;
-#define PA(TT) hipLaunchKernelGGL(pointer_attn_fwd_kernel<TT>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)enc, mask, \
-                                  (long)mask_bs, (const long*)text, (long)unk, p, (TT*)tv, (int)rows, Lt, L, d, scale)
+#define PA(TT) hipLaunchKernelGGL(pointer_attn_fwd_kernel<TT>, dim3((unsigned)B), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)enc, mask, \
+                                  (long)mask_bs, (const long*)text, (long)unk, p, (TT*)tv, Lt, L, d, scale)
   if (dtype == BIST_BF16) PA(bf16_t); else PA(float);
 #undef PA
   BIST_LAUNCH_CHECK("bist_pointer_attn_fwd");
@@ -704,8 +734,8 @@ extern "C" int bist_pointer_attn_fwd(const void* q, const void* k, const void* e
 
 extern "C" int bist_pointer_attn_bwd(const void* q, const void* k, const void* enc, const float* p, const float* dp, const void* dtv, void* dq,
                                      void* dk, void* denc, int64_t B, int32_t Lt, int32_t L, int32_t d, float scale, int32_t dtype, void* stream) {
-  BIST_REQUIRE(q && k && p && dq && dk && (dp || dtv) && B > 0 && Lt >= 1 && Lt <= 32 && L >= 1 && L <= 128 && d > 0 && d % 8 == 0,
-               "bist_pointer_attn_bwd: bad argument (<= 32 query rows, <= 128 positions, d a multiple of 8)");
+  BIST_REQUIRE(q && k && p && dq && dk && (dp || dtv) && B > 0 && Lt >= 1 && Lt <= 32 && L >= 1 && L <= 128 && d > 0 && d % (dtype == BIST_BF16 ? 32 : 4) == 0,
+               "bist_pointer_attn_bwd: bad argument (<= 32 query rows, <= 128 positions, d a multiple of 32 (bf16) / 4 (f32))");
   BIST_REQUIRE(!dtv || (enc && denc), "bist_pointer_attn_bwd: the text vector's gradient needs enc and denc");
   BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)enc | (uintptr_t)dtv) & 15) == 0,
                "bist_pointer_attn_bwd: bf16 / f32, 16-byte aligned rows");
