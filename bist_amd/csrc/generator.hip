@@ -21,16 +21,22 @@ struct PtrArgs { PtrSrc s[3]; int n; };
 // MultiPointerGenerator / PointerGenerator (model/generator.py:36-75, 84-127):
 //   out[row, v] = log( sw[n] * softmax(logits[row])[v] + sum_j sw[j] * sum_{t: text_j[b,t]==v} p_j[row, t] )
 // with sw = softmax(switch[row, :n+1]) (n > 1) or sw = (1-sigmoid, sigmoid) (single pointer).
+template <bool LDSROW>
 __global__ __launch_bounds__(256) void pointer_mix_kernel(const float* __restrict__ logits, const float* __restrict__ sw_logits,
                                                           PtrArgs a, float* __restrict__ out, int V, int Lt, int sigmoid_switch) {
+  // LDSROW (V <= 4096): the vocabulary row lives in LDS between its one read and its one write -- otherwise the three passes, the
+  // scatter and the log are six dependent global round trips per workgroup
   __shared__ float red[4];
+  __shared__ float orow[LDSROW ? 4096 : 1];
   const long row = blockIdx.x;
   const int b = (int)(row / Lt);
   const float* lg = logits + row * V;
-  float* o = out + row * V;
+  float* og = out + row * V;
+  float* o = LDSROW ? orow : og;
   float mx = -INFINITY;
-  for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, lg[v]);
+  for (int v = threadIdx.x; v < V; v += 256) { const float l = lg[v]; if (LDSROW) orow[v] = l; mx = fmaxf(mx, l); }
   mx = block_reduce(mx, red, true);
+  if (LDSROW) lg = orow;
   float den = 0.f;
   for (int v = threadIdx.x; v < V; v += 256) den += expf(lg[v] - mx);
   den = block_reduce(den, red, false);
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) void pointer_mix_kernel(const float* __restric
     }
     __syncthreads();                       // the next source may hold the same ids
   }
-  for (int v = threadIdx.x; v < V; v += 256) o[v] = logf(o[v]);
+  for (int v = threadIdx.x; v < V; v += 256) og[v] = logf(o[v]);
 }
 
 // The pointer generator's text vector, inference (generator.py:117-118): out[row, c] = sum_t p[row, t] * enc[b, t, c], p f32 [rows, L],
@@ -655,8 +661,12 @@ extern "C" int bist_pointer_mix_fwd(const float* logits, const float* switch_log
     BIST_REQUIRE(ptr_p[j] && ptr_text[j] && ptr_len[j] > 0, "bist_pointer_mix_fwd: bad pointer source %d", j);
     a.s[j] = PtrSrc{ptr_p[j], (const long*)ptr_text[j], ptr_len[j]};
   }
-  hipLaunchKernelGGL(pointer_mix_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, switch_logits, a, out, V, Lt,
-                     sigmoid_switch);
+  if (V <= 4096)
+    hipLaunchKernelGGL(pointer_mix_kernel<true>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, switch_logits, a, out, V, Lt,
+                       sigmoid_switch);
+  else
+    hipLaunchKernelGGL(pointer_mix_kernel<false>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, switch_logits, a, out, V, Lt,
+                       sigmoid_switch);
   BIST_LAUNCH_CHECK("bist_pointer_mix_fwd");
   return BIST_OK;
 }
