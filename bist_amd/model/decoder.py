@@ -105,10 +105,10 @@ class MultimodalDecoder8(nn.Module):
 
         def other(k):            # a second alias of ft[k] where the producer handed several out (one consumer each: no gradient accumulation pass)
             lst = spare.get(k)
-            return lst.pop(0) if lst else ft[k]
+            return lst.pop(0) if lst else Fn.fan_take(ft, k)
         parts = [Fn.fan_take(ft, "encoded_query")]
         if self.c_N > 0:
-            parts.append(ft["cap_ft"])
+            parts.append(Fn.fan_take(ft, "cap_ft"))
         if args.t2s:
             parts.append(other("spatial_ft"))
         if args.s2t:
@@ -484,6 +484,10 @@ class MultimodalDecoder8(nn.Module):
             elif self.c_N > 0:
                 in_ft = self.c_layers[l](in_ft, ft, b)
                 ft["cap_ft"], in_ft["cap"] = Fn.layernorm_res(in_ft["cap"], self.cap_out_norm.a_2, self.cap_out_norm.b_2, self.cap_out_norm.eps)                               # :132
+            if torch.is_grad_enabled() and l + 1 == len(self.layers) and getattr(self.args, "auto_encoder", 0) and "_z" not in in_ft:
+                # the last layer's outputs also feed the auto-encoder heads (optimize.py:66-82): an alias per consumer, one-pass gradient sum
+                for k_ in ("cap_ft", "spatial_ft", "temporal_ft"):
+                    Fn.fan_set(ft, k_, 2)
             self._fuse(ft)
             if cache is not None:
                 cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})

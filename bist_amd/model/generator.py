@@ -33,7 +33,7 @@ class Generator(nn.Module):
 
     def forward(self, ft, batch, args, ft_key="decoded_text"):
         spare = (ft.get("_bist_alias") or {}).get(ft_key)        # an alias of ft[ft_key] set aside for this consumer (one-pass gradient sum)
-        x = spare.pop(0) if spare else ft[ft_key]
+        x = spare.pop(0) if spare else Fn.fan_take(ft, ft_key)
         if self.shared_W:
             logits = Fn.linear(x, self.proj, None, out_dtype=torch.float32)
         else:
@@ -121,7 +121,7 @@ class PointerGenerator(nn.Module):
         text, (enc_k, enc_v), mask = _pointer_source(args.ptr_ft, ft, batch)
         logits = Fn.linear(Fn.fan_take(ft, "decoded_text"), self.vocab_gen, None, out_dtype=torch.float32)
         p, tv = _pointer_head(self.pointer_attn, Fn.fan_take(ft, "decoded_text"), enc_k, enc_v, mask, text, bool(args.mask_unk))
-        sw = _switch_logits(self.pointer_gen_W, [Fn.fan_take(ft, "decoded_text"), tv, ft["encoded_tgt"]])    # generator.py:71
+        sw = _switch_logits(self.pointer_gen_W, [Fn.fan_take(ft, "decoded_text"), tv, Fn.fan_take(ft, "encoded_tgt")])    # generator.py:71
         return Fn.pointer_mix(logits, sw, [p], [text], Lt, sigmoid_switch=True).view(B, Lt, -1)
 
 
@@ -210,7 +210,7 @@ class MultiPointerGenerator(nn.Module):
         if fast is not None:
             return fast
         logits = Fn.linear(Fn.fan_take(ft, "decoded_text"), self.vocab_gen, None, out_dtype=torch.float32)
-        ps, texts, vec = [], [], [Fn.fan_take(ft, "decoded_text"), ft["encoded_tgt"]]     # generator.py:92
+        ps, texts, vec = [], [], [Fn.fan_take(ft, "decoded_text"), Fn.fan_take(ft, "encoded_tgt")]     # generator.py:92
         for idx, name in enumerate(args.ptr_ft.split(",")):
             text, (enc_k, enc_v), mask = _pointer_source(name, ft, batch)
             p, tv = _pointer_head(self.pointer_attn[idx], Fn.fan_take(ft, "decoded_text"), enc_k, enc_v, mask, text, bool(args.mask_unk))
