@@ -642,25 +642,37 @@ class FanOutFn(Function):
     [B*T*S, d] gradient; the encoded texts feed every decoder layer."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, join=False):
         ctx.n = n
+        ctx.join = bool(join)
         ctx.set_materialize_grads(False)        # aliases nobody read carry no gradient: None, not a zero tensor autograd would fill and we would sum
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
         gs = [g for g in grads if g is not None]
+        if ctx.join and len(gs) > 1 and gs[0].is_cuda:
+            # join=True (a fan made on the MAIN stream whose consumers run on the side streams too): the sum waits for the present position of
+            # every side stream.  The engine orders a gradient behind its producing NODE's stream; measured with a fan for encoded_tgt, that
+            # did not cover a gradient arriving from the caption stream in the replayed step (it ran 0.4 ms faster and updated unrelated
+            # weights differently from the eager step; with this wait both agree bit for bit)
+            from . import functional as Fn_
+            if Fn_.CONCURRENT:
+                cur = torch.cuda.current_stream()
+                for st in Fn_.live_side_streams():
+                    if st != cur:
+                        cur.wait_stream(st)
         for g in gs:                          # a gradient finished on another stream than its node's carries the event to wait on
             ev = getattr(g, "_bist_ready", None)
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
         if not gs:
-            return None, None
+            return None, None, None
         if len(gs) == 1:
-            return gs[0], None
+            return gs[0], None, None
         if len({g.dtype for g in gs}) > 1:
             gs = [g.to(gs[0].dtype) for g in gs]
-        return ops.add_n(gs), None
+        return ops.add_n(gs), None, None
 
 
 class CastFn(Function):

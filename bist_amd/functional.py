@@ -191,9 +191,9 @@ def permute_ts(x):
 class Fan:
     """Hands out the aliases of FanOutFn one by one; once they are used up (or without autograd) the tensor itself."""
 
-    def __init__(self, x, n: int):
+    def __init__(self, x, n: int, join: bool = False):
         self.x = x
-        self._it = iter(ag.FanOutFn.apply(x, n)) if (n > 1 and _grad() and x.requires_grad and x.is_cuda) else iter(())
+        self._it = iter(ag.FanOutFn.apply(x, n, join)) if (n > 1 and _grad() and x.requires_grad and x.is_cuda) else iter(())
 
     def take(self):
         return next(self._it, self.x)
@@ -207,10 +207,11 @@ def fan_take(ft, key):
     return f.take() if f is not None else ft[key]
 
 
-def fan_set(ft, key, n: int):
-    """ft[key] will be read by up to n consumers (unused aliases cost nothing)."""
+def fan_set(ft, key, n: int, join: bool = False):
+    """ft[key] will be read by up to n consumers (unused aliases cost nothing).  join: made on the main stream with consumers on the side
+    streams too -- the gradient sum then waits for every side stream (autograd.FanOutFn)."""
     if _grad() and ft.get(key) is not None and ft[key].requires_grad and ft[key].is_cuda:
-        ft.setdefault("_bist_fans", {})[key] = Fan(ft[key], n)
+        ft.setdefault("_bist_fans", {})[key] = Fan(ft[key], n, join)
 
 
 def cast(x, dtype):
@@ -366,6 +367,22 @@ FUSED_DECODE = os.environ.get("BIST_FUSED_DECODE", "1") != "0"      # tuning aid
 
 
 EVAL_SCHED = int(os.environ.get("BIST_EVAL_SCHED", "1"))      # tuning aid: stream schedule of the fused inference layer (0: one fork after the input projection, 1: two chains forked ahead of it, 2: stage-1 launches on the main stream)
+
+
+def live_side_streams():
+    """The side streams of this device whose present position a stream may wait for: all of them, or -- while the current stream is
+    being captured into a hipGraph -- those that have joined the capture (a wait on a stream outside it would leave the graph)."""
+    cap = torch.cuda.is_current_stream_capturing()
+    out = []
+    for (dev, _), st in _SIDE.items():
+        if dev != torch.cuda.current_device():
+            continue
+        if cap:
+            with torch.cuda.stream(st):
+                if not torch.cuda.is_current_stream_capturing():
+                    continue
+        out.append(st)
+    return out
 
 
 def join_side_streams() -> None:

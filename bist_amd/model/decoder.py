@@ -18,6 +18,7 @@ from .encoder import _cross_attention, _feed_forward, _self_attention
 from .modules import LayerNorm, SublayerConnection, clones
 
 Tensor = torch.Tensor
+FAN_JOIN = os.environ.get("BIST_FAN_JOIN", "1") != "0"      # 0 = the gradient sums of the multi-stream fans rely on the engine's ordering alone
 
 
 class MultimodalDecoderLayer12(nn.Module):
@@ -383,9 +384,9 @@ class MultimodalDecoder8(nn.Module):
             # accumulation is a pairwise elementwise launch per extra reader): the query feeds the three reasoning chains, every layer's
             # fusion logits and decoder layer, and two readers per pointer attention; the caption every caption layer and its pointer
             L_ = len(self.layers)
-            Fn.fan_set(ft, "encoded_query", 3 + 2 * L_ + 2)
-            Fn.fan_set(ft, "encoded_his", L_ + 2)
-            Fn.fan_set(ft, "encoded_cap", L_ + 2)
+            Fn.fan_set(ft, "encoded_query", 3 + 2 * L_ + 2, join=FAN_JOIN)
+            Fn.fan_set(ft, "encoded_his", L_ + 2, join=FAN_JOIN)
+            Fn.fan_set(ft, "encoded_cap", L_ + 2, join=FAN_JOIN)
         q = ft["encoded_query"]
         in_ft = {"t2s": Fn.fan_take(ft, "encoded_query"), "s2t": Fn.fan_take(ft, "encoded_query"), "audio": q, "cap": Fn.fan_take(ft, "encoded_query")}
         fused_train = False
@@ -404,7 +405,7 @@ class MultimodalDecoder8(nn.Module):
                 # rows and the value projection's weight-gradient / dX products of its backward).  The value / output projection weights
                 # of all layers go to fragment order in ONE launch, into buffers that keep their addresses (hipGraph replays re-run it).
                 ft["_bist_fused_train"] = True
-                ft["_bist_vft_fan"] = Fn.Fan(vft_, 4 * L)
+                ft["_bist_vft_fan"] = Fn.Fan(vft_, 4 * L, FAN_JOIN)
                 ws, outs = [], []
                 for vl in self.v_layers[:L]:
                     for ai in (1, 4):
@@ -415,10 +416,10 @@ class MultimodalDecoder8(nn.Module):
                     and ft["spatiotemporal_ft"].shape[1] >= 64):      # from 64 frames: 21.9 vs 22.3 ms at T = 128; 11.8 vs 11.7 ms at T = 32
                 # t2s works on a region-major copy of the video tensor (made once, shared by all layers): contiguous score
                 # runs and value tiles in its stage-1 core instead of 16-byte pieces (Fn.permute_ts)
-                ft["_bist_vft_fan"] = Fn.Fan(ft["spatiotemporal_ft"], 2 * L + 1)
-                ft["_bist_vftp_fan"] = Fn.Fan(Fn.permute_ts(ft["_bist_vft_fan"].take()), 2 * L)
+                ft["_bist_vft_fan"] = Fn.Fan(ft["spatiotemporal_ft"], 2 * L + 1, FAN_JOIN)
+                ft["_bist_vftp_fan"] = Fn.Fan(Fn.permute_ts(ft["_bist_vft_fan"].take()), 2 * L, FAN_JOIN)
             else:
-                ft["_bist_vft_fan"] = Fn.Fan(ft["spatiotemporal_ft"], 4 * L)
+                ft["_bist_vft_fan"] = Fn.Fan(ft["spatiotemporal_ft"], 4 * L, FAN_JOIN)
         dec_pending = None
         # inference with the reasoning cache: the decoder layers run AFTER the reasoning layers, as the persistent launch of later decode
         # steps (bist_decoder_stack_fwd) -- which also leaves this call's self-attention keys / values in the per-layer pools
