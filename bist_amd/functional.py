@@ -188,6 +188,32 @@ def permute_ts(x):
     return ag.PermuteTSFn.apply(x) if (_grad() and x.requires_grad) else ops.permute_ts(x)
 
 
+# Tensors that cross from one stream's chain to another's in a training step (the decoder / caption layers on the caption stream read the
+# encoded texts, the fused memories and the decoder input of the main stream and save them for their backward; the value projections
+# issued ahead on the caption stream are consumed on the main one; every layer boundary hands tensors between the chains).  The caching
+# allocator gives a block back to its HOME stream's pool as soon as the last host-side reference is dropped -- possibly long before the
+# foreign stream's kernels have run: in a replayed graph the streams really run side by side.  Found when the main stream stopped
+# waiting for the caption stream's last backward launches: a weight-gradient product there read a recycled `encoded_his`, and the
+# value projections' outputs were recycled under the main stream's stage-1 nodes (each a full Adam step of difference in a few weight
+# matrices between the replayed and the eager step).  Such tensors are kept alive here until the streams have been joined (Trainer:
+# after the backward pass; release_taken() for other training loops).  (record_stream at the same places does as well.)
+_TAKEN = []
+KEEP_TAKEN = os.environ.get("BIST_KEEP_TAKEN", "1") != "0"
+
+
+def _keep_taken(t):
+    if KEEP_TAKEN and torch.is_tensor(t) and t.is_cuda and _grad():
+        if len(_TAKEN) > 16384:              # a training loop that never joins: bounded
+            del _TAKEN[:8192]
+        _TAKEN.append(t)
+    return t
+
+
+def release_taken() -> None:
+    """Drop the references to the cross-stream tensors of a step whose streams have been joined."""
+    _TAKEN.clear()
+
+
 class Fan:
     """Hands out the aliases of FanOutFn one by one; once they are used up (or without autograd) the tensor itself."""
 
@@ -196,7 +222,7 @@ class Fan:
         self._it = iter(ag.FanOutFn.apply(x, n, join)) if (n > 1 and _grad() and x.requires_grad and x.is_cuda) else iter(())
 
     def take(self):
-        return next(self._it, self.x)
+        return _keep_taken(next(self._it, self.x))
 
 
 def fan_take(ft, key):
@@ -204,7 +230,7 @@ def fan_take(ft, key):
     gradients are summed in ONE bist_add_n launch by FanOutFn instead of pairwise by autograd), else ft[key] itself."""
     fans = ft.get("_bist_fans")
     f = fans.get(key) if fans else None
-    return f.take() if f is not None else ft[key]
+    return f.take() if f is not None else _keep_taken(ft[key])
 
 
 def fan_set(ft, key, n: int, join: bool = False):

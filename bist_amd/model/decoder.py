@@ -442,10 +442,12 @@ class MultimodalDecoder8(nn.Module):
                 v4 = self.v_layers[l].train_value(vb, 4) if both_v else None      # stream; an edge between two side streams crashes hipGraph capture
                 ev = torch.cuda.Event()
                 ev.record(side_)
+            Fn._keep_taken(v1); Fn._keep_taken(v4)               # allocated on this stream, consumed (and saved) on the main one
             ft["_bist_v_pre"] = (v1, v4, ev)
         Fn.param_gate(1)                     # deferred optimiser: layer 0's parameters (and everything outside the layer stacks) are final
         if values_ahead:
             issue_values(0)
+        conc_keep = Fn.CONCURRENT and x.is_cuda
         for l, layer in enumerate(self.layers):
             Fn.param_gate(1 + min(l + 1, len(self.layers) - 1))      # layer l + 1: its value projection is issued during layer l
             fork_cap = self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda
@@ -485,6 +487,10 @@ class MultimodalDecoder8(nn.Module):
             elif self.c_N > 0:
                 in_ft = self.c_layers[l](in_ft, ft, b)
                 ft["cap_ft"], in_ft["cap"] = Fn.layernorm_res(in_ft["cap"], self.cap_out_norm.a_2, self.cap_out_norm.b_2, self.cap_out_norm.eps)                               # :132
+            if torch.is_grad_enabled() and conc_keep:
+                # every tensor handed from one stream's chain to another's at this layer boundary (see Fn._keep_taken)
+                for t_ in (*[v for v in in_ft.values() if torch.is_tensor(v)], ft.get("cap_ft"), ft.get("spatial_ft"), ft.get("temporal_ft")):
+                    Fn._keep_taken(t_)
             if torch.is_grad_enabled() and l + 1 == len(self.layers) and getattr(self.args, "auto_encoder", 0) and "_z" not in in_ft:
                 # the last layer's outputs also feed the auto-encoder heads (optimize.py:66-82): an alias per consumer, one-pass gradient sum
                 for k_ in ("cap_ft", "spatial_ft", "temporal_ft"):
@@ -501,6 +507,7 @@ class MultimodalDecoder8(nn.Module):
                 # layer: it goes to the caption stream (ahead of the next caption layer) and runs under the next
                 # layer's visual reasoning; the join at the end of that layer (or below) waits for it.
                 side.wait_stream(main)
+                Fn._keep_taken(x); Fn._keep_taken(ft.get("encoded_ft"))
                 with torch.cuda.stream(side):
                     x = layer(b, ft, x)                                                      # :182
                 dec_pending = side

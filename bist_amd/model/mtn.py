@@ -21,6 +21,8 @@ from .modules import (Embeddings, MultiHeadedAttention, PositionalEncoding, Posi
 
 from .. import functional as Fn
 
+TGT_EMBED_ON_DECODER_STREAM = __import__("os").environ.get("BIST_TGT_EMBED_SIDE", "1") != "0"      # tuning aid, see MTN.multimodal_decode_text
+
 Tensor = torch.Tensor
 
 
@@ -88,10 +90,17 @@ class MTN(nn.Module):
         return self.multimodal_decode_text(b, ft, pos0)
 
     def multimodal_decode_text(self, b, ft, pos0: int = 0):
-        ft["encoded_tgt"] = embed_with_position(self.tgt_embed, b.trg, pos0)     # not layer-normed (mtn.py:58-59)
-        # (encoded_tgt has two consumers -- the decoder layers on the caption stream and the generator's switch on the main stream -- and keeps
-        # autograd's own accumulation: with a FanOutFn here the replayed step ran 0.4 ms FASTER and computed a different update than the
-        # eager step, i.e. a dependency was lost in the capture; not understood, so not used)
+        if TGT_EMBED_ON_DECODER_STREAM and Fn.KEEP_TAKEN and torch.is_grad_enabled() and Fn.CONCURRENT and Fn.PIPELINE_DECODER and b.trg.is_cuda:
+            # Training: the target embedding on the stream of the decoder layers.  Its gradient's last addend comes from decoder layer 0 at the
+            # very end of that stream's backward chain; as a main-stream node, autograd's accumulation made the MAIN stream wait there -- with
+            # everything the engine issued on it afterwards (the text encoders' and the input projection's backward) -- for ~0.4 ms.
+            main, side = torch.cuda.current_stream(), Fn.side_stream(1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ft["encoded_tgt"] = embed_with_position(self.tgt_embed, b.trg, pos0)
+            Fn._keep_taken(ft["encoded_tgt"])             # (allocated on that stream; the generator reads it on the main one)
+        else:
+            ft["encoded_tgt"] = embed_with_position(self.tgt_embed, b.trg, pos0)     # not layer-normed (mtn.py:58-59)
         return self.mutlimodal_decoder(b, ft, ft["encoded_tgt"])
 
 

@@ -311,6 +311,7 @@ class Trainer:
         finally:
             ops.WGRAD_STREAM = None
             ops.WGRAD_KEEP.clear()
+            Fn.release_taken()
         return terms
 
     def _backward_close(self) -> None:
