@@ -8,6 +8,7 @@ naming (reference: model/mtn.py) so that train.py / generate.py call it unchange
 from __future__ import annotations
 
 import copy
+import os
 from typing import Dict
 
 import torch
@@ -21,7 +22,7 @@ from .modules import (Embeddings, MultiHeadedAttention, PositionalEncoding, Posi
 
 from .. import functional as Fn
 
-TGT_EMBED_ON_DECODER_STREAM = __import__("os").environ.get("BIST_TGT_EMBED_SIDE", "1") != "0"      # tuning aid, see MTN.multimodal_decode_text
+TGT_EMBED_ON_DECODER_STREAM = os.environ.get("BIST_TGT_EMBED_SIDE", "1") != "0"      # tuning aid, see MTN.multimodal_decode_text
 
 Tensor = torch.Tensor
 
