@@ -72,6 +72,8 @@ class MTN(nn.Module):
         return self.decode(b, self.encode(b))
 
     def encode(self, b) -> Dict[str, Tensor]:
+        if torch.is_grad_enabled():
+            Fn.release_taken()        # a training loop without bist_amd.train.Trainer: the previous step's cross-stream tensors may go now
         return self.encode_vid(b, self.encode_text(b, {}))
 
     def encode_text(self, b, ft):
