@@ -299,6 +299,50 @@ __device__ __forceinline__ void small_nt_product(const T* __restrict__ a, const 
   }
 }
 
+// out[r][:] = sum_j coef(r, j) mat[j][:] for r < R, j < J, d channels (a multiple of 64): a thread per (row, 64-column group); the
+// coefficients sit in LDS (coef(r, j) = cf[r][j], or cf[j][r] when TR), the matrix rows come from global memory 16 bytes at a time (the
+// eight lanes of a row read one contiguous run; other rows re-read it out of L1).  Plain loops: the unrolled per-row accumulators of the
+// first version were 35 KiB of once-run code (42 us per launch, most of it instruction fetch).
+template <typename T, bool TR>
+__device__ __forceinline__ void lds_coef_times_rows(const float (*cf)[129], int R, int J, const T* __restrict__ mat, int d, T* __restrict__ out, int tid) {
+  constexpr int E = 16 / (int)sizeof(T), NV = 64 / E;
+  const int ngroups = d / 64;
+  for (int task = tid; task < R * ngroups; task += 256) {
+    const int r = task / ngroups, c0 = (task - r * ngroups) * 64;
+    float acc[64];
+#pragma unroll
+    for (int e = 0; e < 64; ++e) acc[e] = 0.f;
+    for (int j0 = 0; j0 < J; j0 += 4) {                    // four matrix rows per round: their loads are in flight together
+      uint4 raw[4][NV];
+      float cj[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = min(j0 + jj, J - 1);
+        cj[jj] = (j0 + jj < J) ? (TR ? cf[j][r] : cf[r][j]) : 0.f;
+        const T* mr = mat + (long)j * d + c0;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) raw[jj][u] = *reinterpret_cast<const uint4*>(mr + u * E);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+          const T* v = reinterpret_cast<const T*>(&raw[jj][u]);
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[u * E + e] += cj[jj] * to_f(v[e]);
+        }
+    }
+    T* orow = out + (long)r * d + c0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      T v[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = from_f<T>(acc[u * E + e]);
+      *reinterpret_cast<uint4*>(orow + u * E) = *reinterpret_cast<const uint4*>(v);
+    }
+  }
+}
+
 // forward: one workgroup per sequence b (Lt <= 32 target positions, L <= 128 source positions)
 template <typename T>
 __global__ __launch_bounds__(256) void pointer_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ enc,
@@ -328,31 +372,7 @@ __global__ __launch_bounds__(256) void pointer_attn_fwd_kernel(const T* __restri
   }
   if (tv == nullptr) return;
   __syncthreads();
-  const T* eb = enc + (long)b * L * d;
-  for (int c = tid * 2; c < d; c += 512) {              // text vector by column pairs
-    float acc[32][2];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i][0] = acc[i][1] = 0.f;
-    for (int tb0 = 0; tb0 < L; tb0 += 8) {                // eight positions per round: their loads are in flight together
-      float e0[8], e1[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int t = tb0 + u;
-        e0[u] = t < L ? to_f(eb[(long)t * d + c]) : 0.f;
-        e1[u] = t < L ? to_f(eb[(long)t * d + c + 1]) : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int t = min(tb0 + u, L - 1);                   // (beyond L the operands are zero)
-#pragma unroll
-        for (int i = 0; i < 32; ++i)
-          if (i < Lt) { const float pt = sc[i][t]; acc[i][0] += pt * e0[u]; acc[i][1] += pt * e1[u]; }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i)
-      if (i < Lt) { tv[((long)b * Lt + i) * d + c] = from_f<T>(acc[i][0]); tv[((long)b * Lt + i) * d + c + 1] = from_f<T>(acc[i][1]); }
-  }
+  lds_coef_times_rows<T, false>(sc, Lt, L, enc + (long)b * L * d, d, tv + (long)b * Lt * d, tid);      // text vector = p . enc
 }
 
 template <typename T>
@@ -384,38 +404,10 @@ __global__ __launch_bounds__(256) void pointer_attn_bwd_kernel(const T* __restri
     if (lane + 64 < L) ds[i][lane + 64] = ps[i][lane + 64] * (ds[i][lane + 64] - part) * scale;
   }
   __syncthreads();
-  // column pairs: dq[i][c] = sum_t dS[i][t] k[t][c];  dk[t][c] = sum_i dS[i][t] q[i][c];  denc[t][c] = sum_i p[i][t] dtv[i][c]
-  for (int c = tid * 2; c < d; c += 512) {
-    float qa[32][2], da[32][2], acc[32][2];               // (fully unrolled below: registers, not scratch)
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      qa[i][0] = qa[i][1] = da[i][0] = da[i][1] = acc[i][0] = acc[i][1] = 0.f;
-      if (i < Lt) {
-        qa[i][0] = to_f(qb[(long)i * d + c]); qa[i][1] = to_f(qb[(long)i * d + c + 1]);
-        if (db) { da[i][0] = to_f(db[(long)i * d + c]); da[i][1] = to_f(db[(long)i * d + c + 1]); }
-      }
-    }
-    float kn0 = to_f(kb[c]), kn1 = to_f(kb[c + 1]);        // (next position's keys: loaded one position ahead)
-    for (int t = 0; t < L; ++t) {
-      const float k0 = kn0, k1 = kn1;
-      if (t + 1 < L) { kn0 = to_f(kb[(long)(t + 1) * d + c]); kn1 = to_f(kb[(long)(t + 1) * d + c + 1]); }
-      float g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        if (i < Lt) {
-          const float s_ = ds[i][t], pt = ps[i][t];
-          acc[i][0] += s_ * k0; acc[i][1] += s_ * k1;
-          g0 += s_ * qa[i][0]; g1 += s_ * qa[i][1];
-          h0 += pt * da[i][0]; h1 += pt * da[i][1];
-        }
-      }
-      dk[((long)b * L + t) * d + c] = from_f<T>(g0); dk[((long)b * L + t) * d + c + 1] = from_f<T>(g1);
-      if (db) { denc[((long)b * L + t) * d + c] = from_f<T>(h0); denc[((long)b * L + t) * d + c + 1] = from_f<T>(h1); }
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i)
-      if (i < Lt) { dq[((long)b * Lt + i) * d + c] = from_f<T>(acc[i][0]); dq[((long)b * Lt + i) * d + c + 1] = from_f<T>(acc[i][1]); }
-  }
+  // the three products on three workgroups per sequence (blockIdx.y; each repeats the small steps above: they are latency, not work)
+  if (blockIdx.y == 0) lds_coef_times_rows<T, false>(ds, Lt, L, kb, d, dq + (long)b * Lt * d, tid);                  // dq = dS k
+  else if (blockIdx.y == 1) lds_coef_times_rows<T, true>(ds, L, Lt, qb, d, dk + (long)b * L * d, tid);               // dk = dS^T q
+  else if (db) lds_coef_times_rows<T, true>(ps, L, Lt, db, d, denc + (long)b * L * d, tid);                          // d enc = p^T dtv
 }
 
 // Decode-step form of MultiPointerGenerator.forward (generator.py:84-127) for hypothesis rows that share ONE dialogue (beam search,
@@ -730,9 +722,8 @@ extern "C" int bist_pointer_attn_fwd(const void* q, const void* k, const void* e
                                      void* stream) {
   BIST_REQUIRE(q && k && p && B > 0 && Lt >= 1 && Lt <= 32 && L >= 1 && L <= 128 && d > 0 && (!tv || enc),
                "bist_pointer_attn_fwd: bad argument (<= 32 target positions, 1..128 source positions)");
-  const int e = dtype == BIST_BF16 ? 32 : 4;
-  BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && d % e == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)enc | (uintptr_t)tv) & 15) == 0,
-               "bist_pointer_attn_fwd: bf16 (d a multiple of 32) / f32 (of 4), 16-byte aligned rows");
+  BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && d % 64 == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)enc | (uintptr_t)tv) & 15) == 0,
+               "bist_pointer_attn_fwd: bf16 / f32, d a multiple of 64, 16-byte aligned rows");
   hipStream_t st = (hipStream_t)stream;
 #define PA(TT) hipLaunchKernelGGL(pointer_attn_fwd_kernel<TT>, dim3((unsigned)B), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)enc, mask, \
                                   (long)mask_bs, (const long*)text, (long)unk, p, (TT*)tv, Lt, L, d, scale)
@@ -744,13 +735,13 @@ extern "C" int bist_pointer_attn_fwd(const void* q, const void* k, const void* e
 
 extern "C" int bist_pointer_attn_bwd(const void* q, const void* k, const void* enc, const float* p, const float* dp, const void* dtv, void* dq,
                                      void* dk, void* denc, int64_t B, int32_t Lt, int32_t L, int32_t d, float scale, int32_t dtype, void* stream) {
-  BIST_REQUIRE(q && k && p && dq && dk && (dp || dtv) && B > 0 && Lt >= 1 && Lt <= 32 && L >= 1 && L <= 128 && d > 0 && d % (dtype == BIST_BF16 ? 32 : 4) == 0,
-               "bist_pointer_attn_bwd: bad argument (<= 32 query rows, <= 128 positions, d a multiple of 32 (bf16) / 4 (f32))");
+  BIST_REQUIRE(q && k && p && dq && dk && (dp || dtv) && B > 0 && Lt >= 1 && Lt <= 32 && L >= 1 && L <= 128 && d > 0 && d % 64 == 0,
+               "bist_pointer_attn_bwd: bad argument (<= 32 query rows, <= 128 positions, d a multiple of 64)");
   BIST_REQUIRE(!dtv || (enc && denc), "bist_pointer_attn_bwd: the text vector's gradient needs enc and denc");
   BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)enc | (uintptr_t)dtv) & 15) == 0,
                "bist_pointer_attn_bwd: bf16 / f32, 16-byte aligned rows");
   hipStream_t st = (hipStream_t)stream;
-#define PB(TT) hipLaunchKernelGGL(pointer_attn_bwd_kernel<TT>, dim3((unsigned)B), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)enc, p, dp, \
+#define PB(TT) hipLaunchKernelGGL(pointer_attn_bwd_kernel<TT>, dim3((unsigned)B, dtv ? 3u : 2u), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)enc, p, dp, \
                                   (const TT*)dtv, (TT*)dq, (TT*)dk, (TT*)denc, Lt, L, d, scale)
   if (dtype == BIST_BF16) PB(bf16_t); else PB(float);
 #undef PB

@@ -296,9 +296,9 @@ POINTER_ATTN = os.environ.get("BIST_POINTER_ATTN", "1") != "0"      # tuning aid
 
 
 def pointer_attn_ok(q: Tensor, k: Tensor, enc: Tensor) -> bool:
-    """Inside the envelope of bist_pointer_attn_fwd / _bwd: <= 32 query rows per sequence, <= 128 positions, channels a multiple of 32."""
+    """Inside the envelope of bist_pointer_attn_fwd / _bwd: <= 32 query rows per sequence, <= 128 positions, channels a multiple of 64."""
     return (POINTER_ATTN and q.is_cuda and q.dim() == 3 and q.dtype == k.dtype == enc.dtype and q.dtype in (torch.bfloat16, torch.float32)
-            and q.shape[1] <= 32 and k.shape[1] <= 128 and q.shape[2] % 32 == 0 and k.shape == enc.shape)
+            and q.shape[1] <= 32 and k.shape[1] <= 128 and q.shape[2] % 64 == 0 and k.shape == enc.shape)
 
 
 def pointer_attn(q: Tensor, k: Tensor, enc: Tensor, mask: Optional[Tensor], text: Optional[Tensor], unk: int = 0):
