@@ -308,7 +308,7 @@ __device__ __forceinline__ void lds_coef_times_rows(const float (*cf)[129], int 
   constexpr int E = 16 / (int)sizeof(T), NV = 64 / E;
   const int ngroups = d / 64;
   for (int task = tid; task < R * ngroups; task += 256) {
-    const int r = task / ngroups, c0 = (task - r * ngroups) * 64;
+    const int r = task / ngroups, gi = task - r * ngroups;      // piece u of this thread: columns (u ngroups + gi) E .. (the ngroups lanes of a row read one contiguous run)
     float acc[64];
 #pragma unroll
     for (int e = 0; e < 64; ++e) acc[e] = 0.f;
@@ -319,9 +319,9 @@ __device__ __forceinline__ void lds_coef_times_rows(const float (*cf)[129], int 
       for (int jj = 0; jj < 4; ++jj) {
         const int j = min(j0 + jj, J - 1);
         cj[jj] = (j0 + jj < J) ? (TR ? cf[j][r] : cf[r][j]) : 0.f;
-        const T* mr = mat + (long)j * d + c0;
+        const T* mr = mat + (long)j * d + gi * E;
 #pragma unroll
-        for (int u = 0; u < NV; ++u) raw[jj][u] = *reinterpret_cast<const uint4*>(mr + u * E);
+        for (int u = 0; u < NV; ++u) raw[jj][u] = *reinterpret_cast<const uint4*>(mr + u * ngroups * E);
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
@@ -332,13 +332,13 @@ __device__ __forceinline__ void lds_coef_times_rows(const float (*cf)[129], int 
           for (int e = 0; e < E; ++e) acc[u * E + e] += cj[jj] * to_f(v[e]);
         }
     }
-    T* orow = out + (long)r * d + c0;
+    T* orow = out + (long)r * d + gi * E;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       T v[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) v[e] = from_f<T>(acc[u * E + e]);
-      *reinterpret_cast<uint4*>(orow + u * E) = *reinterpret_cast<const uint4*>(v);
+      *reinterpret_cast<uint4*>(orow + u * ngroups * E) = *reinterpret_cast<const uint4*>(v);
     }
   }
 }

@@ -32,3 +32,14 @@ for name, fn in (("forward", fwd), ("backward", bwd)):
     gr.replay(); torch.cuda.synchronize()
     e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
     print(name, "50 launches replayed:", round(e0.elapsed_time(e1) / 50 * 1e3, 2), "us per launch")
+def fwd_no_tv():
+    check(lib.bist_pointer_attn_fwd(q.data_ptr(), k.data_ptr(), None, None, 0, None, 0, p.data_ptr(), None, B, Lt, L, d, d ** -0.5, ops.dtype_code(q.dtype), ops._stream()), "fwd")
+s = torch.cuda.Stream(); gr = torch.cuda.CUDAGraph()
+with torch.cuda.stream(s):
+    fwd_no_tv()
+    with torch.cuda.graph(gr):
+        for _ in range(50): fwd_no_tv()
+torch.cuda.synchronize(); gr.replay(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
+print("forward without the text vector (scores + softmax only):", round(e0.elapsed_time(e1) / 50 * 1e3, 2), "us per launch")
