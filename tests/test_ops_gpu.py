@@ -701,3 +701,31 @@ def test_group_sum_mask_equals_the_two_separate_passes(B, G, Lq, d, with_add):
     ref = dy.float().sum(1).reshape(B * Lq, d) + (add.float() if add is not None else 0)
     err = (out1.float() - ref).abs().max().item()
     assert err <= 2.0 ** -7 * ref.abs().max().item(), err
+
+
+def test_decoder_cache_fill_copies_keys_and_transposes_values():
+    """bist_decoder_cache_fill (the persistent decoder kernel's per-turn caches out of the packed [k | v] projections, decoder.py:42-55):
+    for jobs of different lengths and paddings, K rows = the k halves, VT = the v halves transposed with columns Lk..LkP-1 zero -- bit for
+    bit; rows of K beyond Lk are left alone."""
+    import ctypes as C
+    from bist_amd import ops as O_
+    from bist_amd._lib import BistKvFill, check, lib
+    g = torch.Generator().manual_seed(3)
+    specs = [(20, 32, 1024), (60, 64, 6144), (33, 64, 1024), (1, 32, 2048)]
+    jobs = (BistKvFill * len(specs))()
+    keep = []
+    for j, (Lk, LkP, ld) in enumerate(specs):
+        src = torch.randn(Lk, ld, generator=g).to(torch.bfloat16).cuda()
+        off = 1024 * (j % 2) if ld > 1024 else 0                       # a [k | v] pair somewhere inside a wider packed row
+        K = torch.full((LkP, 512), 7.0, dtype=torch.bfloat16).cuda()
+        VT = torch.full((512, LkP), 7.0, dtype=torch.bfloat16).cuda()
+        keep.append((src, off, K, VT, Lk, LkP))
+        jobs[j].src, jobs[j].K, jobs[j].VT = src.data_ptr() + off * 2, K.data_ptr(), VT.data_ptr()
+        jobs[j].Lk, jobs[j].LkP, jobs[j].ld = Lk, LkP, ld
+    check(lib.bist_decoder_cache_fill(jobs, len(specs), O_.dtype_code(torch.bfloat16), O_._stream()), "bist_decoder_cache_fill")
+    torch.cuda.synchronize()
+    for src, off, K, VT, Lk, LkP in keep:
+        assert torch.equal(K[:Lk], src[:, off:off + 512])
+        assert bool((K[Lk:] == 7.0).all())
+        assert torch.equal(VT[:, :Lk], src[:, off + 512:off + 1024].t())
+        assert bool((VT[:, Lk:] == 0).all())
