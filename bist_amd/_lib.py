@@ -151,8 +151,8 @@ SIGNATURES = {
     "bist_xent_smooth_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _P, _I32, _I32, _F, _I32, _P]),
     "bist_sum_div_groups": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _P]),
     "bist_stack_rows": (C.c_int, [_P, _I32, _P, _I64, _P]),
-    "bist_switch_logits_fwd": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _P]),
-    "bist_switch_logits_bwd": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P, _I32, _I64, _I32, _I32, _I32, _P]),
+    "bist_switch_logits_fwd": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _I32, _I64, _I32, _I32, _I32, _P]),
+    "bist_switch_logits_bwd": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P, _P, _P, _I64, _I32, _I32, _P, _I32, _I64, _I32, _I32, _I32, _P]),
     "bist_pointer_attn_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _F, _I32, _P]),
     "bist_pointer_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F, _I32, _P]),
     "bist_pointer_decode_mix_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _P, _I64, _P, _F, _P, _I64, _I32, _I32, _I32, _P]),

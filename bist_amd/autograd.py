@@ -532,6 +532,9 @@ class FuseFn(Function):
         return (dscore, *dxs)
 
 
+FUSE_ONE_LAUNCH = os.environ.get("BIST_FUSE_ONE_LAUNCH", "1") != "0"      # tuning aid: 0 = the fusion logits and their backward as one product per part
+
+
 class FuseDynFn(Function):
     """The dynamic modality fusion of decoder.py:142-159 as ONE autograd node: score = cat(parts) W^T + b through per-part column blocks
     (never the concat), out = sum_j softmax(score)[..., j] xs[j] with xs = parts[xs_idx[j]].  Every modality tensor feeds both the score
@@ -543,9 +546,20 @@ class FuseDynFn(Function):
         d = parts[0].shape[-1]
         p2 = [p.reshape(-1, d) for p in parts]
         p2 = [p if p.is_contiguous() else p.contiguous() for p in p2]
-        score = None
-        for j, pj in enumerate(p2):                      # concat order of the reference: query, cap, spatial, temporal
-            score = ops.linear(pj, W[:, j * d:(j + 1) * d], bias if j == 0 else None, out=score, accumulate=j > 0)
+        n_, ns_ = len(p2), W.shape[0]
+        one = (FUSE_ONE_LAUNCH and 1 <= n_ <= 4 and ns_ <= 4 and d % 8 == 0 and W.stride(1) == 1 and W.stride(0) % 8 == 0 and W.data_ptr() % 16 == 0
+               and W.dtype in (torch.bfloat16, torch.float32) and all(p.dtype == W.dtype and p.data_ptr() % 16 == 0 for p in p2)
+               and (bias is None or bias.dtype == W.dtype))
+        if one:                                          # the fusion logits as ONE launch over the un-concatenated parts (bist_switch_logits_fwd)
+            score = torch.empty((p2[0].shape[0], ns_), device=W.device, dtype=W.dtype)
+            arr = (C.c_void_p * n_)(*[p.data_ptr() for p in p2])
+            check(lib.bist_switch_logits_fwd(arr, n_, W.data_ptr(), W.stride(0), _ptr(bias), score.data_ptr(), dtype_code(score.dtype), p2[0].shape[0], d, ns_,
+                                             dtype_code(W.dtype), _stream()), "bist_switch_logits_fwd")
+        else:
+            score = None
+            for j, pj in enumerate(p2):                  # concat order of the reference: query, cap, spatial, temporal
+                score = ops.linear(pj, W[:, j * d:(j + 1) * d], bias if j == 0 else None, out=score, accumulate=j > 0)
+        ctx.one = one
         xs = [p2[k] for k in xs_idx]
         out = ops.fuse_modalities(score, xs)
         ctx.save_for_backward(W, score, *p2)
@@ -571,6 +585,25 @@ class FuseDynFn(Function):
               "bist_fuse_modalities_bwd")
         from_sum = {k: dxs[j] for j, k in enumerate(xs_idx)}
         gw = ctx.w_dst
+        if getattr(ctx, "one", False):
+            # every part's gradient (dscore . W_j + the weighted sum's addend) in one launch, the weight and bias gradients in another
+            # (bist_switch_logits_bwd) where a product per part took eight
+            n_ = len(p2)
+            dps = [torch.empty((M, d), device=pj.device, dtype=pj.dtype) for pj in p2]
+            arr = (C.c_void_p * n_)(*[p.data_ptr() for p in p2])
+            darr = (C.c_void_p * n_)(*[g.data_ptr() for g in dps])
+            rarr = (C.c_void_p * n_)(*[_ptr(from_sum.get(j)) for j in range(n_)])
+            wd = gw if gw is not None else torch.empty(W.shape, device=W.device, dtype=W.dtype)
+            want_b = bdt is not None
+            bd = (ctx.b_dst if ctx.b_dst is not None else torch.empty((n,), device=W.device, dtype=torch.float32)) if want_b else None
+            check(lib.bist_switch_logits_bwd(arr, n_, W.data_ptr(), W.stride(0), dscore.data_ptr(), dtype_code(dscore.dtype), darr, rarr,
+                                            wd.data_ptr(), wd.stride(0), dtype_code(wd.dtype), 1 if gw is not None else 0,
+                                            _ptr(bd), 1 if (want_b and ctx.b_dst is not None) else 0, M, d, n, dtype_code(W.dtype), _stream()),
+                  "bist_switch_logits_bwd")
+            db = None
+            if want_b and ctx.b_dst is None:
+                db = _to_dtype_from_f32(bd, bdt)
+            return (None if gw is not None else wd, db, None, *[g.view(shapes[j]) for j, g in enumerate(dps)])
         dW = None if gw is not None else torch.empty(W.shape, device=W.device, dtype=W.dtype)
         grads = []
         for j, pj in enumerate(p2):
@@ -1059,16 +1092,16 @@ class SwitchLogitsFn(Function):
     gradient accumulates into the flat gradient view and the bias gradient into its fp32 accumulator, like LinearFn."""
 
     @staticmethod
-    def forward(ctx, w, bias, *parts):
+    def forward(ctx, w, bias, out_dtype, *parts):
         ctx.shapes = [tuple(p.shape) for p in parts]
         parts = [p.reshape(-1, p.shape[-1]) for p in parts]
         parts = [p if p.is_contiguous() else p.contiguous() for p in parts]
         rows, d = parts[0].shape
         ns, n = w.shape[0], len(parts)
-        out = torch.empty((rows, ns), device=w.device, dtype=torch.float32)
+        out = torch.empty((rows, ns), device=w.device, dtype=out_dtype or torch.float32)
         arr = (C.c_void_p * n)(*[p.data_ptr() for p in parts])
-        check(lib.bist_switch_logits_fwd(arr, n, w.data_ptr(), w.stride(0), _ptr(bias), out.data_ptr(), rows, d, ns, dtype_code(w.dtype), _stream()),
-              "bist_switch_logits_fwd")
+        check(lib.bist_switch_logits_fwd(arr, n, w.data_ptr(), w.stride(0), _ptr(bias), out.data_ptr(), dtype_code(out.dtype), rows, d, ns,
+                                         dtype_code(w.dtype), _stream()), "bist_switch_logits_fwd")
         ctx.save_for_backward(w, *parts)
         ctx.w_dst = getattr(w, "_grad_view", None)
         ctx.b_dst = getattr(bias, "_acc32", None) if bias is not None else None
@@ -1080,9 +1113,9 @@ class SwitchLogitsFn(Function):
         w, *parts = ctx.saved_tensors
         rows, d = parts[0].shape
         ns, n = w.shape[0], len(parts)
-        dsw = dsw.contiguous() if dsw.dtype == torch.float32 else dsw.float().contiguous()
+        dsw = dsw.contiguous() if dsw.dtype in (torch.float32, w.dtype) else dsw.float().contiguous()
         need = ctx.needs_input_grad
-        dparts = [torch.empty_like(p) if need[2 + j] else None for j, p in enumerate(parts)]
+        dparts = [torch.empty_like(p) if need[3 + j] else None for j, p in enumerate(parts)]
         arr = (C.c_void_p * n)(*[p.data_ptr() for p in parts])
         darr = (C.c_void_p * n)(*[_ptr(g) for g in dparts])
         dw = db = None
@@ -1096,12 +1129,13 @@ class SwitchLogitsFn(Function):
             bd, acc_b = (ctx.b_dst, 1) if ctx.b_dst is not None else (torch.empty((ns,), device=w.device, dtype=torch.float32), 0)
         else:
             bd, acc_b = None, 0
-        check(lib.bist_switch_logits_bwd(arr, n, w.data_ptr(), w.stride(0), dsw.data_ptr(), darr if any(g is not None for g in dparts) else None,
+        check(lib.bist_switch_logits_bwd(arr, n, w.data_ptr(), w.stride(0), dsw.data_ptr(), dtype_code(dsw.dtype),
+                                        darr if any(g is not None for g in dparts) else None, None,
                                         _ptr(wd), wd.stride(0) if wd is not None else 0, dtype_code(wd.dtype) if wd is not None else 0, acc_w,
                                         _ptr(bd), acc_b, rows, d, ns, dtype_code(w.dtype), _stream()), "bist_switch_logits_bwd")
         if has_bias and need[1] and ctx.b_dst is None and bd is not None:
             db = bd.to(ctx.bias_dtype)
-        return (dw, db, *[g.view(sh) if g is not None else None for g, sh in zip(dparts, ctx.shapes)])
+        return (dw, db, None, *[g.view(sh) if g is not None else None for g, sh in zip(dparts, ctx.shapes)])
 
 
 class PointerAttnFn(Function):

@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256) void text_vector_kernel(const float* __restric
 // [rows, d] tensors WITHOUT the concatenation -- part j multiplies column block j of W [ns <= 4][n_parts d].  One launch forward (a wave
 // per row) and two backward (the parts' gradients: a wave per row; the weight / bias gradient: a workgroup per part, four row slices
 // per workgroup) where a product per part took 4 launches forward and 12 backward (cast + dX + dW each).
-struct SwParts { const void* x[4]; void* dx[4]; int n; };
+struct SwParts { const void* x[4]; void* dx[4]; const void* res[4]; int n; };
 
-template <typename T>
+template <typename T, typename TO>
 __global__ __launch_bounds__(256) void switch_logits_fwd_kernel(SwParts a, const T* __restrict__ W, long ldw, const T* __restrict__ bias,
-                                                                float* __restrict__ out, long rows, int d, int ns) {
+                                                                TO* __restrict__ out, long rows, int d, int ns) {
   constexpr int E = 16 / (int)sizeof(T);
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -137,13 +137,13 @@ __global__ __launch_bounds__(256) void switch_logits_fwd_kernel(SwParts a, const
   for (int s_ = 0; s_ < 4; ++s_) {
     if (s_ < ns) {
       const float v = wave_sum(acc[s_]);
-      if (lane == 0) out[row * ns + s_] = v + (bias ? to_f(bias[s_]) : 0.f);
+      if (lane == 0) out[row * ns + s_] = from_f<TO>(v + (bias ? to_f(bias[s_]) : 0.f));
     }
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void switch_logits_bwd_x_kernel(SwParts a, const T* __restrict__ W, long ldw, const float* __restrict__ dsw,
+template <typename T, typename TS>
+__global__ __launch_bounds__(256) void switch_logits_bwd_x_kernel(SwParts a, const T* __restrict__ W, long ldw, const TS* __restrict__ dsw,
                                                                   long rows, int d, int ns) {
   constexpr int E = 16 / (int)sizeof(T);
   const int lane = threadIdx.x & 63;
@@ -151,14 +151,21 @@ __global__ __launch_bounds__(256) void switch_logits_bwd_x_kernel(SwParts a, con
   if (row >= rows) return;
   float g[4];
 #pragma unroll
-  for (int s_ = 0; s_ < 4; ++s_) g[s_] = s_ < ns ? dsw[row * ns + s_] : 0.f;
+  for (int s_ = 0; s_ < 4; ++s_) g[s_] = s_ < ns ? to_f(dsw[row * ns + s_]) : 0.f;
   for (int j = 0; j < a.n; ++j) {
     T* dr = reinterpret_cast<T*>(a.dx[j]) + row * d;
     if (a.dx[j] == nullptr) continue;
+    const T* rr = a.res[j] ? reinterpret_cast<const T*>(a.res[j]) + row * d : nullptr;      // an addend of the part's gradient from elsewhere
     for (int c = lane * E; c < d; c += 64 * E) {
       float acc[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) acc[e] = 0.f;
+      if (rr) {
+        T rv[E];
+        *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(rr + c);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = to_f(rv[e]);
+      }
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_) {
         if (s_ < ns) {
@@ -178,8 +185,8 @@ __global__ __launch_bounds__(256) void switch_logits_bwd_x_kernel(SwParts a, con
 
 // dW[s][j d + c] (+)= sum_rows dsw[row][s] part_j[row][c];  db[s] (+)= sum_rows dsw[row][s].  blockIdx.x = part, blockIdx.y = chunk of 64 E
 // columns; thread = (column piece lane, row slice sl): the four slices meet in LDS.
-template <typename T, typename TW>
-__global__ __launch_bounds__(256) void switch_logits_bwd_w_kernel(SwParts a, const float* __restrict__ dsw, TW* __restrict__ dW, long lddw, int dw_acc,
+template <typename T, typename TW, typename TS>
+__global__ __launch_bounds__(256) void switch_logits_bwd_w_kernel(SwParts a, const TS* __restrict__ dsw, TW* __restrict__ dW, long lddw, int dw_acc,
                                                                   float* __restrict__ db, int db_acc, long rows, int d, int ns) {
   constexpr int E = 16 / (int)sizeof(T);
   __shared__ float part[3][64][4][E];
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256) void switch_logits_bwd_w_kernel(SwParts a, con
       const bool ok = r < r1;
       xq[u] = (ok && act) ? *reinterpret_cast<const uint4*>(xb + r * d + c) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) g[u][s_] = (ok && s_ < ns) ? dsw[r * ns + s_] : 0.f;
+      for (int s_ = 0; s_ < 4; ++s_) g[u][s_] = (ok && s_ < ns) ? to_f(dsw[r * ns + s_]) : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -663,54 +670,69 @@ extern "C" int bist_pointer_mix_fwd(const float* logits, const float* switch_log
   return BIST_OK;
 }
 
-static int sw_parts(SwParts& a, const void* const* parts, void* const* dparts, int32_t n_parts, const char* who) {
+static int sw_parts(SwParts& a, const void* const* parts, void* const* dparts, const void* const* residuals, int32_t n_parts, const char* who) {
   BIST_REQUIRE(parts && n_parts >= 1 && n_parts <= 4, "%s: 1..4 parts", who);
   a.n = n_parts;
-  for (int j = 0; j < 4; ++j) { a.x[j] = nullptr; a.dx[j] = nullptr; }
+  for (int j = 0; j < 4; ++j) { a.x[j] = nullptr; a.dx[j] = nullptr; a.res[j] = nullptr; }
   for (int j = 0; j < n_parts; ++j) {
-    BIST_REQUIRE(parts[j] && ((uintptr_t)parts[j] & 15) == 0 && (!dparts || ((uintptr_t)dparts[j] & 15) == 0), "%s: part %d null or not 16-byte aligned", who, j);
+    BIST_REQUIRE(parts[j] && ((uintptr_t)parts[j] & 15) == 0 && (!dparts || ((uintptr_t)dparts[j] & 15) == 0) && (!residuals || ((uintptr_t)residuals[j] & 15) == 0),
+                 "%s: part %d null or not 16-byte aligned", who, j);
     a.x[j] = parts[j];
     a.dx[j] = dparts ? dparts[j] : nullptr;
+    a.res[j] = residuals ? residuals[j] : nullptr;
   }
   return BIST_OK;
 }
 
-extern "C" int bist_switch_logits_fwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const void* bias, float* out,
-                                      int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream) {
+extern "C" int bist_switch_logits_fwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const void* bias, void* out,
+                                      int32_t out_dtype, int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream) {
   BIST_REQUIRE(W && out && rows > 0 && ns >= 1 && ns <= 4 && d > 0, "bist_switch_logits_fwd: bad argument (<= 4 switch logits)");
   const int e = dtype == BIST_BF16 ? 8 : 4;
   BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && d % e == 0 && ldw % e == 0 && ((uintptr_t)W & 15) == 0, "bist_switch_logits_fwd: bf16 / f32, 16-byte rows");
+  BIST_REQUIRE(out_dtype == BIST_F32 || out_dtype == dtype, "bist_switch_logits_fwd: the logits are f32 or of the operand dtype");
   SwParts a;
-  if (sw_parts(a, parts, nullptr, n_parts, "bist_switch_logits_fwd") != BIST_OK) return BIST_EINVAL;
+  if (sw_parts(a, parts, nullptr, nullptr, n_parts, "bist_switch_logits_fwd") != BIST_OK) return BIST_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((rows + 3) / 4);
-  if (dtype == BIST_BF16) hipLaunchKernelGGL(switch_logits_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, (const bf16_t*)W, (long)ldw, (const bf16_t*)bias, out, (long)rows, d, ns);
-  else hipLaunchKernelGGL(switch_logits_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, a, (const float*)W, (long)ldw, (const float*)bias, out, (long)rows, d, ns);
+#define SWF(TT, TOO) hipLaunchKernelGGL((switch_logits_fwd_kernel<TT, TOO>), dim3(grid), dim3(256), 0, st, a, (const TT*)W, (long)ldw, (const TT*)bias, (TOO*)out, (long)rows, d, ns)
+  if (dtype == BIST_BF16) { if (out_dtype == BIST_F32) SWF(bf16_t, float); else SWF(bf16_t, bf16_t); }
+  else SWF(float, float);
+#undef SWF
   BIST_LAUNCH_CHECK("bist_switch_logits_fwd");
   return BIST_OK;
 }
 
-extern "C" int bist_switch_logits_bwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const float* dsw, void* const* dparts,
-                                      void* dW, int64_t lddw, int32_t dw_dtype, int32_t dw_accumulate, float* db, int32_t db_accumulate,
-                                      int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream) {
+extern "C" int bist_switch_logits_bwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const void* dsw, int32_t dsw_dtype,
+                                      void* const* dparts, const void* const* residuals, void* dW, int64_t lddw, int32_t dw_dtype,
+                                      int32_t dw_accumulate, float* db, int32_t db_accumulate, int64_t rows, int32_t d, int32_t ns, int32_t dtype,
+                                      void* stream) {
   BIST_REQUIRE(W && dsw && rows > 0 && ns >= 1 && ns <= 4 && d > 0, "bist_switch_logits_bwd: bad argument (<= 4 switch logits)");
   const int e = dtype == BIST_BF16 ? 8 : 4;
   BIST_REQUIRE((dtype == BIST_BF16 || dtype == BIST_F32) && d % e == 0 && ldw % e == 0 && ((uintptr_t)W & 15) == 0, "bist_switch_logits_bwd: bf16 / f32, 16-byte rows");
+  BIST_REQUIRE(dsw_dtype == BIST_F32 || dsw_dtype == dtype, "bist_switch_logits_bwd: the logits' gradient is f32 or of the operand dtype");
   BIST_REQUIRE(!dW || dw_dtype == BIST_BF16 || dw_dtype == BIST_F32, "bist_switch_logits_bwd: bad weight-gradient dtype");
+  BIST_REQUIRE(!residuals || dparts, "bist_switch_logits_bwd: residuals go with dparts");
   SwParts a;
-  if (sw_parts(a, parts, dparts, n_parts, "bist_switch_logits_bwd") != BIST_OK) return BIST_EINVAL;
+  if (sw_parts(a, parts, dparts, residuals, n_parts, "bist_switch_logits_bwd") != BIST_OK) return BIST_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const bool s32 = dsw_dtype == BIST_F32;
   if (dparts) {
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (dtype == BIST_BF16) hipLaunchKernelGGL(switch_logits_bwd_x_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, (const bf16_t*)W, (long)ldw, dsw, (long)rows, d, ns);
-    else hipLaunchKernelGGL(switch_logits_bwd_x_kernel<float>, dim3(grid), dim3(256), 0, st, a, (const float*)W, (long)ldw, dsw, (long)rows, d, ns);
+#define SWX(TT, TSS) hipLaunchKernelGGL((switch_logits_bwd_x_kernel<TT, TSS>), dim3(grid), dim3(256), 0, st, a, (const TT*)W, (long)ldw, (const TSS*)dsw, (long)rows, d, ns)
+    if (dtype == BIST_BF16) { if (s32) SWX(bf16_t, float); else SWX(bf16_t, bf16_t); }
+    else SWX(float, float);
+#undef SWX
     BIST_LAUNCH_CHECK("bist_switch_logits_bwd (parts)");
   }
   if (dW) {
     dim3 grid((unsigned)n_parts, (unsigned)((d / e + 63) / 64));
-#define SWW(TT, TWW) hipLaunchKernelGGL((switch_logits_bwd_w_kernel<TT, TWW>), grid, dim3(256), 0, st, a, dsw, (TWW*)dW, (long)lddw, dw_accumulate, db, db_accumulate, (long)rows, d, ns)
-    if (dtype == BIST_BF16) { if (dw_dtype == BIST_BF16) SWW(bf16_t, bf16_t); else SWW(bf16_t, float); }
-    else { if (dw_dtype == BIST_BF16) SWW(float, bf16_t); else SWW(float, float); }
+#define SWW(TT, TWW, TSS) hipLaunchKernelGGL((switch_logits_bwd_w_kernel<TT, TWW, TSS>), grid, dim3(256), 0, st, a, (const TSS*)dsw, (TWW*)dW, (long)lddw, dw_accumulate, db, db_accumulate, (long)rows, d, ns)
+    if (dtype == BIST_BF16) {
+      if (dw_dtype == BIST_BF16) { if (s32) SWW(bf16_t, bf16_t, float); else SWW(bf16_t, bf16_t, bf16_t); }
+      else { if (s32) SWW(bf16_t, float, float); else SWW(bf16_t, float, bf16_t); }
+    } else {
+      if (dw_dtype == BIST_BF16) SWW(float, bf16_t, float); else SWW(float, float, float);
+    }
 #undef SWW
     BIST_LAUNCH_CHECK("bist_switch_logits_bwd (weights)");
   }

@@ -285,11 +285,11 @@ def switch_logits_ok(w: Tensor, bias: Optional[Tensor], parts) -> bool:
             and all(p.dtype == w.dtype and p.shape[-1] == d and p.numel() == parts[0].numel() for p in parts) and (bias is None or bias.dtype == w.dtype))
 
 
-def switch_logits(w: Tensor, bias: Optional[Tensor], parts) -> Tensor:
-    """lin(cat(parts, -1)) as f32 [rows, ns] (autograd.SwitchLogitsFn)."""
+def switch_logits(w: Tensor, bias: Optional[Tensor], parts, out_dtype=None) -> Tensor:
+    """lin(cat(parts, -1)) as [rows, ns] in f32 (default) or the operand dtype (autograd.SwitchLogitsFn)."""
     if _grad():
-        return ag.SwitchLogitsFn.apply(w, bias, *parts)
-    return ag.SwitchLogitsFn.forward(_NoCtx(), w, bias, *parts)
+        return ag.SwitchLogitsFn.apply(w, bias, out_dtype, *parts)
+    return ag.SwitchLogitsFn.forward(_NoCtx(), w, bias, out_dtype, *parts)
 
 
 POINTER_ATTN = os.environ.get("BIST_POINTER_ATTN", "1") != "0"      # tuning aid: 0 = the pointer attentions on the generic attention core + a text-vector product

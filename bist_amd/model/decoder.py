@@ -18,6 +18,11 @@ from .encoder import _cross_attention, _feed_forward, _self_attention
 from .modules import LayerNorm, SublayerConnection, clones
 
 Tensor = torch.Tensor
+def ag_fuse_one() -> bool:
+    from .. import autograd as ag
+    return ag.FUSE_ONE_LAUNCH
+
+
 FAN_JOIN = os.environ.get("BIST_FAN_JOIN", "1") != "0"      # 0 = the gradient sums of the multi-stream fans rely on the engine's ordering alone
 
 
@@ -124,9 +129,13 @@ class MultimodalDecoder8(nn.Module):
             # two (autograd.FuseDynFn); parts = [query, cap, spatial, temporal], score column j -> temporal, spatial, cap (decoder.py:156-159)
             ft["encoded_ft"] = Fn.fuse_dyn(W, bias, parts, (3, 2, 1))
             return
-        score = None
-        for j, p in enumerate(parts):                      # concat order: query, cap, spatial, temporal
-            score = Fn.linear(p, Fn.column_block(W, j, d), bias if j == 0 else None, out=score, accumulate=j > 0)
+        if torch.is_grad_enabled() and ag_fuse_one() and Fn.switch_logits_ok(W, bias, parts):
+            # training without the one-node form (the lock-step layer hands out aliases): the same one-launch logits as autograd.FuseDynFn
+            score = Fn.switch_logits(W, bias, parts, out_dtype=parts[0].dtype)
+        else:
+            score = None
+            for j, p in enumerate(parts):                  # concat order: query, cap, spatial, temporal
+                score = Fn.linear(p, Fn.column_block(W, j, d), bias if j == 0 else None, out=score, accumulate=j > 0)
         # score column -> modality (decoder.py:156-165): 0 temporal, 1 spatial, 2 cap (both directions);
         # one direction: 0 that direction, 1 cap.  Without a caption layer: 0 temporal, 1 spatial.
         if args.t2s and args.s2t:

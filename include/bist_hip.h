@@ -533,15 +533,19 @@ int bist_xent_smooth_bwd(const float* logits, const float* lse, const int64_t* t
                          int32_t pad, void* stream);
 int bist_sum_div_groups(const float* x, int64_t M, int32_t G, const int64_t* denom, float* out, int32_t out_stride, void* stream);
 int bist_stack_rows(const void* const* srcs, int32_t n, void* out, int64_t bytes_each, void* stream);
-/* The switch logits of (Multi)PointerGenerator (model/generator.py:69-71, 119-121: pointer_gen_W(torch.cat(parts, -1))) without the
- * concatenation: part j [rows][d] multiplies column block j of W [ns][ldw >= n_parts d]; out f32 [rows][ns] = sum_j part_j . W_j^T + bias.
- * Backward: dparts[j] = dsw . W_j (written; entries may be NULL = not wanted, or the whole array NULL), dW [ns][lddw] and db [ns]
- * written or accumulated (dW NULL = not wanted; db only together with dW).  parts / dparts are HOST arrays of n_parts <= 4 pointers.   */
-int bist_switch_logits_fwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const void* bias, float* out,
-                           int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream);
-int bist_switch_logits_bwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const float* dsw, void* const* dparts,
-                           void* dW, int64_t lddw, int32_t dw_dtype, int32_t dw_accumulate, float* db, int32_t db_accumulate,
-                           int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream);
+/* A small linear layer over the CONCATENATION of n_parts <= 4 tensors [rows][d] without the concatenation: part j multiplies column block
+ * j of W [ns <= 4][ldw >= n_parts d]; out [rows][ns] = sum_j part_j . W_j^T + bias, f32 or (out_dtype) the operand dtype.  The switch logits
+ * of (Multi)PointerGenerator (model/generator.py:69-71, 119-121: pointer_gen_W(torch.cat(parts, -1))) and the fusion logits of
+ * MultimodalDecoder8 (model/decoder.py:142-159: vc_combine_W(torch.cat(...))).
+ * Backward: dsw [rows][ns] f32 or (dsw_dtype) the operand dtype; dparts[j] = dsw . W_j (+ residuals[j]: an addend of that part's gradient
+ * from elsewhere, e.g. the fusion's weighted sum) written (entries / the arrays may be NULL), dW [ns][lddw] and db [ns] written or
+ * accumulated (dW NULL = not wanted; db only together with dW).  parts / dparts / residuals are HOST arrays of n_parts pointers.        */
+int bist_switch_logits_fwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const void* bias, void* out,
+                           int32_t out_dtype, int64_t rows, int32_t d, int32_t ns, int32_t dtype, void* stream);
+int bist_switch_logits_bwd(const void* const* parts, int32_t n_parts, const void* W, int64_t ldw, const void* dsw, int32_t dsw_dtype,
+                           void* const* dparts, const void* const* residuals, void* dW, int64_t lddw, int32_t dw_dtype,
+                           int32_t dw_accumulate, float* db, int32_t db_accumulate, int64_t rows, int32_t d, int32_t ns, int32_t dtype,
+                           void* stream);
 /* The pointer attention of (Multi)PointerGenerator with its text vector, training and evaluation (model/generator.py:106-118: a
  * single-head MultiHeadedAttention whose value product and output projection the reference computes and throws away, then
  * `(p.unsqueeze(-1) * enc.unsqueeze(1)).sum(2)`): q [B][Lt][d] and k [B][L][d] the projected queries / keys, mask [B][L] (row stride
