@@ -22,3 +22,11 @@ t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
 print(f"20 steps: host time to issue {t_issue * 1e3 / 20:.2f} ms per step (median call {sorted(host)[10] * 1e3:.2f} ms), wall {t_all * 1e3 / 20:.2f} ms per step")
+
+# the same with the device idle at every call: the launch's own host time, and the time until the step has finished on the device
+call, done = [], []
+for _ in range(12):
+    torch.cuda.synchronize()
+    h0 = time.perf_counter(); tr.step(b); h1 = time.perf_counter(); torch.cuda.synchronize(); h2 = time.perf_counter()
+    call.append(h1 - h0); done.append(h2 - h0)
+print(f"idle device: call {sorted(call)[6] * 1e3:.2f} ms, finished {sorted(done)[6] * 1e3:.2f} ms after the call began")
