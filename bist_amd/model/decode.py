@@ -139,8 +139,9 @@ def _graph_store(model):
 
 # Every dialogue geometry (token lengths of query / history / caption, frame count) holds one first-step graph, up to max_len step graphs,
 # their static buffers and the decoder's key / value caches (~13 graphs; first sight costs 45-150 ms of captures against ~8 ms per replayed
-# turn: scripts/decode_geometries.py).  When more than this many are held, all of them are dropped.
-MAX_GEOMETRIES = int(os.environ.get("BIST_DECODE_MAX_GEOMETRIES", "48"))
+# turn: scripts/decode_geometries.py).  When more than this many are held, all of them are dropped.  (Measured over a test-set-like sweep,
+# scripts/decode_eval_sweep.py: ~25 MiB of buffers and ~0.2 GiB of reserved graph pools per geometry.)
+MAX_GEOMETRIES = int(os.environ.get("BIST_DECODE_MAX_GEOMETRIES", "192"))
 
 
 def _drop_graphs(model):
@@ -392,7 +393,11 @@ def _device_beam_turn(model, batch, ft, out0, max_len, unk_symbol, end_symbol, b
     return [([], 0)], None
 
 
-BUCKET = int(os.environ.get("BIST_DECODE_BUCKET", "0"))      # 0 / 1 = off (default: at the bench geometry (20, 60, 25) -> (24, 64, 32) costs 0.8 ms per turn)
+# Token tensors of a dialogue padded to multiples of this many positions (0 / 1 = off).  Default 8: a test set has a different (query,
+# history, caption) length triple in nearly every turn and every new triple costs ~110 ms of captures; at the bench geometry (20, 60, 25)
+# -> (24, 64, 32) the padding costs 0-0.1 ms of a 7.6 ms turn (scripts/bench_decode.py), over 300 turns of growing histories it saves a
+# third of the captures, 16 two thirds (scripts/decode_eval_sweep.py: 107 / 77 / 43 ms per turn for 0 / 8 / 16).
+BUCKET = int(os.environ.get("BIST_DECODE_BUCKET", "8"))
 
 
 def _bucketed(batch, pad_symbol):

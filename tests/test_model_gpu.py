@@ -368,7 +368,8 @@ def test_beam_search_turns_of_different_dialogue_lengths_do_not_share_state(hip,
     assert [list(map(int, x[0])) for x in fast[0]] == [list(map(int, x[0])) for x in fast[4]]
 
 
-def test_beam_search_on_length_buckets_gives_the_same_n_best(hip, golden_dir):
+@pytest.mark.parametrize("bucket", [0, 8, 16])
+def test_beam_search_on_length_buckets_gives_the_same_n_best(hip, golden_dir, bucket):
     """decode.BUCKET pads the dialogue's token tensors to multiples of 8 so that dialogues of many lengths share their graphs: the
     padded positions are masked everywhere, the n-best lists and scores are those of the unpadded dialogue (fp32, reference golden)."""
     import bist_amd.model.decode as D
@@ -380,13 +381,13 @@ def test_beam_search_on_length_buckets_gives_the_same_n_best(hip, golden_dir):
     ob = O.det_batch(1, dm["T"], dm["S"], dm["C"], dm["Lq"], dm["Lh"], dm["Lc"], dm["Lt"], dm["V"], seed=dm["seed"])
     model, _ = build_model(M, cfg, dm["V"], dm["C"])
     assert any(getattr(ob, f).shape[1] % 8 for f in ("query", "his", "cap")), "the golden dialogue would not be padded"
-    D.BUCKET = 8
+    old, D.BUCKET = D.BUCKET, bucket           # (0: the exact geometry; 8 is the default)
     try:
         with torch.no_grad():
             hyps, best = beam_search_decode(model, to_batch(Batch, ob), dm["maxlen"], O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID, beam=meta["beam"],
                                             penalty=1.0, nbest=5, train_args=_args(cfg))
     finally:
-        D.BUCKET = 0
+        D.BUCKET = old
     assert len(hyps) == int(g["beam5_n"])
     for i, (toks, score) in enumerate(hyps):
         assert [int(t) for t in toks] == g[f"beam5_hyp{i}"].tolist(), f"hyp {i}"
