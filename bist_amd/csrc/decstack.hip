@@ -345,6 +345,82 @@ __device__ __forceinline__ void core_unit(const bf16_t* Q, const bf16_t* K, cons
   if (row < R) st8(ctx + (long)row * D + head * 64 + 16 * w + 4 * kg, make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3])), wt);
 }
 
+// The same unit over a LONG memory (a dialogue history of 65 .. 256 tokens: LkP = 128 or 256) in NC = LkP / 64 chunks of four key tiles
+// with a running maximum / denominator (the chunk's probabilities go into the P.V product unnormalised, the context is rescaled when the
+// maximum moves and divided once at the end): the register footprint of the short form, a few more dependent round trips -- the short
+// form stays as it is for LkP <= 64.  MASK_FILL is finite, so the running maximum is finite after the first chunk and a chunk that lies
+// wholly behind Lk contributes exp(-inf) = 0.
+template <int NC>
+__device__ __forceinline__ void core_unit_long(const bf16_t* Q, const bf16_t* K, const bf16_t* VT, const unsigned char* mask, int Lk, int LkP,
+                                               bf16_t* ctx, int R, int head, int mt, int w, int x, int kg, bool wt) {
+  const int row = 16 * mt + x, rowc = min(row, R - 1);
+  uint4 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = ld16(Q, ((long)rowc * D + head * 64 + 32 * ks + 8 * kg) * 2);
+  const bf16_t* vrow = VT + (long)(head * 64 + 16 * w + x) * LkP + 4 * kg;
+  float m = -INFINITY, den = 0.f;
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int c = 0; c < NC; ++c) {
+    uint4 kf[2][4];
+    uint32_t mk[4];
+    uint2 vv[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int g = 4 * c + kt;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) kf[ks][kt] = ld16(K, ((long)(16 * g + x) * D + head * 64 + 32 * ks + 8 * kg) * 2);
+      mk[kt] = *reinterpret_cast<const uint32_t*>(mask + 16 * g + 4 * kg);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { vv[j][0] = ld8(vrow + 64 * c + 32 * j); vv[j][1] = ld8(vrow + 64 * c + 32 * j + 16); }
+    f32x4 s[4];
+    float cm = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[kt] = mfma16(kf[0][kt], qf[0], s[kt]);              // S^T[key 4lg+r][row x]
+      s[kt] = mfma16(kf[1][kt], qf[1], s[kt]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = s[kt][r] * 0.125f;                        // 1 / sqrt(64)
+        if (((mk[kt] >> (8 * r)) & 0xffu) == 0) v = MASK_FILL;
+        if (64 * c + 16 * kt + 4 * kg + r >= Lk) v = -INFINITY;
+        s[kt][r] = v;
+        cm = fmaxf(cm, v);
+      }
+    }
+    const float mn = fmaxf(m, rows_max(cm));
+    const float resc = __expf(m - mn);                      // (first chunk: exp(-inf) = 0 on den = 0, o = 0)
+    float cd = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - mn); cd += s[kt][r]; }
+    den = den * resc + rows_sum(cd);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] *= resc;
+    m = mn;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint4 vf = make_uint4(vv[j][0].x, vv[j][0].y, vv[j][1].x, vv[j][1].y);
+      const uint4 pf = make_uint4(pack2(s[2 * j][0], s[2 * j][1]), pack2(s[2 * j][2], s[2 * j][3]),
+                                  pack2(s[2 * j + 1][0], s[2 * j + 1][1]), pack2(s[2 * j + 1][2], s[2 * j + 1][3]));
+      o = mfma16(vf, pf, o);                                // O^T[channel 4lg+r][row x]
+    }
+  }
+  const float inv = 1.f / den;
+  if (row < R) st8(ctx + (long)row * D + head * 64 + 16 * w + 4 * kg, make_uint2(pack2(o[0] * inv, o[1] * inv), pack2(o[2] * inv, o[3] * inv)), wt);
+}
+
+// one memory's core unit, by the padded length of the memory
+__device__ __forceinline__ void core_memory(const bf16_t* Q, const bf16_t* K, const bf16_t* VT, const unsigned char* mask, int Lk, int LkP,
+                                            bf16_t* ctx, int R, int head, int mt, int w, int x, int kg, bool wt) {
+  if (LkP <= 64) core_unit<false>(Q, K, VT, mask, 0, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
+  else if (LkP <= 128) core_unit_long<2>(Q, K, VT, mask, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
+  else core_unit_long<4>(Q, K, VT, mask, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
+}
+
 __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* img = smem;                       // [64][1024 B]
@@ -440,7 +516,7 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
         const int head = wg & 7, mt = wg >> 3;
         if (mt < MTR) {
           if (j == 0) core_unit<true>(a.qbuf, a.kcache + (long)l * (64 * D), a.vcache + (long)l * (64 * D), a.smask, a.LkS, a.slot0 + R, a.LkS, ctx, R, head, mt, w, x, kg, wt);
-          else core_unit<false>(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], 0, Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, head, mt, w, x, kg, wt);
+          else core_memory(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, head, mt, w, x, kg, wt);
         }
         grid_barrier(a.sync, ++phase * NWG, a.dbg);
         STAMP();
@@ -656,7 +732,7 @@ __global__ __launch_bounds__(NT, 1) void decstack_head_kernel(const DecArgs a) {
         load_wo(Lp->Wo[j]);                                        // flies under the core
         head_sync();                                               // q (and this step's k / v rows) are in L2
         if (j == 0) core_unit<true>(a.qbuf, a.kcache + (long)l * (64 * D), a.vcache + (long)l * (64 * D), a.smask, a.LkS, a.slot0 + R, a.LkS, ctx, R, hh, 0, w, x, kg, wt);
-        else core_unit<false>(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], 0, Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, hh, 0, w, x, kg, wt);
+        else core_memory(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, hh, 0, w, x, kg, wt);
         head_sync();                                               // the context rows of head hh are in L2
         {
           const int rowc = min(x, R - 1);
@@ -778,9 +854,9 @@ extern "C" int bist_decoder_cache_fill(const BistKvFill* jobs, int32_t n_jobs, i
   int maxp = 0;
   for (int j = 0; j < n_jobs; ++j) {
     const BistKvFill& b = jobs[j];
-    BIST_REQUIRE(b.src && b.K && b.VT && b.Lk >= 1 && b.Lk <= b.LkP && (b.LkP == 32 || b.LkP == 64) && b.ld >= 1024 && b.ld % 8 == 0 &&
+    BIST_REQUIRE(b.src && b.K && b.VT && b.Lk >= 1 && b.Lk <= b.LkP && (b.LkP == 32 || b.LkP == 64 || b.LkP == 128 || b.LkP == 256) && b.ld >= 1024 && b.ld % 8 == 0 &&
                  (((uintptr_t)b.src | (uintptr_t)b.K | (uintptr_t)b.VT) & 15) == 0,
-                 "bist_decoder_cache_fill: job %d: 1 <= Lk <= LkP in {32, 64}, rows of [k | v] 16-byte aligned", j);
+                 "bist_decoder_cache_fill: job %d: 1 <= Lk <= LkP in {32, 64, 128, 256}, rows of [k | v] 16-byte aligned", j);
     a.j[j] = KvFillK{(const bf16_t*)b.src, (bf16_t*)b.K, (bf16_t*)b.VT, b.Lk, b.LkP, (long)b.ld};
     maxp = b.LkP > maxp ? b.LkP : maxp;
   }
@@ -790,7 +866,7 @@ extern "C" int bist_decoder_cache_fill(const BistKvFill* jobs, int32_t n_jobs, i
 }
 
 extern "C" int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk_max, int32_t dtype) {
-  return dtype == BIST_BF16 && d == D && h == H && R >= 1 && R <= 64 && Lk_max >= 1 && Lk_max <= 64 && bist_decoder_stack_device_ok();
+  return dtype == BIST_BF16 && d == D && h == H && R >= 1 && R <= 64 && Lk_max >= 1 && Lk_max <= 256 && bist_decoder_stack_device_ok();
 }
 
 extern "C" int64_t bist_decoder_layer_desc_bytes(void) { return (int64_t)sizeof(DecLayerDev); }

@@ -130,7 +130,7 @@ def _graph_store(model):
     """The model's captured step graphs, dropped when the parameter VALUES changed since they were captured: the graphs bake the
     addresses of derived operands (packed / fragment-ordered weights), whose contents are refreshed only by eager code."""
     from .. import ops
-    key = (ops.WEIGHTS_EPOCH, sum(p._version for p in model.parameters()))
+    key = (ops.WEIGHTS_EPOCH, sum(p._version for p in ops.module_parameters(model)))
     if model.__dict__.get("_bist_step_graphs_key") != key:
         model.__dict__["_bist_step_graphs"] = {}
         model.__dict__["_bist_step_graphs_key"] = key

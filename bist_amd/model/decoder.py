@@ -192,7 +192,7 @@ class MultimodalDecoder8(nn.Module):
         mems = lambda l: (ft["encoded_his"][0], ft["encoded_query"][0], cache[l]["encoded_ft"][0])
         masks = (b.his_mask[0].reshape(-1), b.query_mask[0].reshape(-1), b.query_mask[0].reshape(-1))
         Lks = [m.shape[0] for m in mems(0)]
-        LkPs = [32 if k <= 32 else 64 for k in Lks]
+        LkPs = [32 if k <= 32 else 64 if k <= 64 else 128 if k <= 128 else 256 for k in Lks]     # (histories of 65 .. 256 tokens: the kernel's long core)
         # one set of cache buffers per dialogue geometry, kept for the decoder's lifetime: captured step graphs of that geometry hold
         # their addresses (and the descriptor's), so they are never freed or re-used for another geometry
         kvs = st.setdefault("kv_by_len", {})
@@ -282,7 +282,7 @@ class MultimodalDecoder8(nn.Module):
         """Device array of BistDecLayer descriptors for the current cache buffers (one per dialogue geometry; its CONTENT is rebuilt in
         place when the parameters change, so its address stays valid for captured graphs)."""
         kv = st["kv"]
-        ps = [p for layer in self.layers for p in layer.parameters()]
+        ps = ops.module_parameters(self.layers)
         key = ops.weights_key(*ps)
         hit = kv.get("desc")
         if hit is not None and hit[0] == key:

@@ -388,6 +388,22 @@ def weights_key(*params: Tensor):
     return (WEIGHTS_EPOCH,) + tuple((p.data_ptr(), p._version) for p in params)
 
 
+def _module_list(root):
+    """The modules under `root`, cached on it; rebuilt when any of them gained or lost a child."""
+    hit = root.__dict__.get("_bist_module_list")
+    if hit is not None and sum(len(m._modules) for m in hit[0]) == hit[1]:
+        return hit[0]
+    mods = list(root.modules())
+    root.__dict__["_bist_module_list"] = (mods, sum(len(m._modules) for m in mods))
+    return mods
+
+
+def module_parameters(root) -> list:
+    """The Parameter objects under `root` as they are NOW (a replaced Parameter is seen: the modules' dicts are read at every call), without
+    nn.Module.parameters()' recursive generators -- 0.3 instead of 1.7 ms for the whole model, paid at the head of every decode turn."""
+    return [p for m in _module_list(root) for p in m._parameters.values() if p is not None]
+
+
 def pack_frag_rows(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """[rows, cols] bf16 weight in MFMA-fragment order (bist_pack_frag_rows); `out` keeps a cached copy's address stable."""
     _dev(w)

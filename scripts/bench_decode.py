@@ -1,4 +1,5 @@
-"""Median time of a beam-search turn (BASELINE configs[4]) over N turns; run once per setting of the decoder switches (development aid)."""
+"""Median time of a beam-search turn (BASELINE configs[4]) over N turns; run once per setting of the decoder switches (development aid).
+usage: python scripts/bench_decode.py [turns] [history length]"""
 import os, sys, time, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +12,7 @@ c = bench.CFG
 args = bench.model_args(6, 512, 8, 0.1)
 torch.manual_seed(1)
 model = M.make_model(c["V"], c["V"], args, ft_sizes=[c["C"]]).cuda().to(torch.bfloat16).eval()
-b1 = synthetic_batch(1, T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"], seed=99, dtype=torch.bfloat16)
+b1 = synthetic_batch(1, T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=int(sys.argv[2]) if len(sys.argv) > 2 else c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"], seed=99, dtype=torch.bfloat16)
 ts = []
 with torch.no_grad():
     for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):

@@ -256,19 +256,23 @@ def test_full_size_fp32_matches_reference_digests(hip, golden_dir, tag):
             assert abs(float(score) - float(g[f"{tag}_beam_score{i}"])) <= 1e-3 * max(1.0, abs(float(g[f"{tag}_beam_score{i}"])))
 
 
-@pytest.mark.parametrize("n,Lt", [(1, 1), (3, 5), (5, 12), (2, 7)])
-def test_fused_decoder_stack_matches_the_layer_by_layer_path(hip, n, Lt):
+@pytest.mark.parametrize("n,Lt,Lh", [(1, 1, 30), (3, 5, 30), (5, 12, 30), (2, 7, 30), (5, 1, 65), (3, 5, 100), (5, 12, 128), (2, 7, 129), (5, 3, 200),
+                                     (1, 1, 256)])
+def test_fused_decoder_stack_matches_the_layer_by_layer_path(hip, n, Lt, Lh):
     """bist_decoder_stack_fwd (one persistent launch for all decoder layers of a decode step) against the same layers run one
-    launch per operation, bf16, d_model=512, h=8, on the replicated turn of a beam-search step (n hypotheses x Lt prefix tokens)."""
+    launch per operation, bf16, d_model=512, h=8, on the replicated turn of a beam-search step (n hypotheses x Lt prefix tokens).
+    Lh: tokens of the dialogue history -- up to 64 the attention core holds a memory's scores in registers at once, from 65 to 256 it
+    walks 64-key chunks with a running maximum (decstack.hip core_unit_long)."""
     from bist_amd import _lib, functional as Fn
     from bist_amd.data.batch import subsequent_mask
     from bist_amd.model.decode import _turn_for_rows
     M, Batch = hip
     cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=3, nb_venc_blocks=3, nb_cenc_blocks=3)
     V, C = 300, 256
-    ob = O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=21)
+    ob = O.det_batch(1, 8, 9, C, 20, Lh, 15, 12, V, seed=21)
     model, _ = build_model(M, cfg, V, C, torch.bfloat16)
     b = to_batch(Batch, ob, torch.bfloat16)
+    assert model.mutlimodal_decoder.__dict__.get("_bist_dec_state", {}).get("used") is None
     g = torch.Generator().manual_seed(n * 100 + Lt)
     trg = torch.randint(4, V, (n, Lt), generator=g).cuda()
     outs = {}
@@ -285,9 +289,11 @@ def test_fused_decoder_stack_matches_the_layer_by_layer_path(hip, n, Lt):
             finally:
                 Fn.FUSED_DECODE = True
     assert outs[True].shape == (n, Lt, 512)
+    assert model.mutlimodal_decoder.__dict__["_bist_dec_state"].get("used"), "the persistent kernel did not run"
     err = (outs[True] - outs[False]).abs().max().item()
     assert err <= 6e-2, err                                         # layer-normed outputs, bf16 storage between every operation in both
     assert torch.isfinite(outs[True]).all()
+    model.mutlimodal_decoder.check_decode_errors()
 
 
 def test_incremental_beam_search_equals_full_prefix_recompute(hip):
@@ -302,8 +308,8 @@ def test_incremental_beam_search_equals_full_prefix_recompute(hip):
     V, C = 300, 256
     model, _ = build_model(M, cfg, V, C, torch.bfloat16)
     outs = {}
-    for seed in (31, 32):
-        ob = O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=seed)
+    for seed, Lh in ((31, 30), (32, 30), (33, 150)):       # (150 history tokens: the persistent kernel's long attention core, the 150-key pointer head)
+        ob = O.det_batch(1, 8, 9, C, 20, Lh, 15, 12, V, seed=seed)
         for incr in (False, True):
             D.INCREMENTAL = incr
             try:
@@ -550,13 +556,14 @@ def test_head_local_decoder_kernel_equals_the_column_split_kernel(hip):
         dec.check_decode_errors()
 
 
-def test_pointer_decode_launch_matches_its_formulas(hip):
+@pytest.mark.parametrize("Ls", [(20, 61), (23, 256), (129,)])
+def test_pointer_decode_launch_matches_its_formulas(hip, Ls):
     """bist_pointer_decode_mix_fwd (the pointer heads of a decode step in one launch: folded keys M = K W_q, c = K b_q, switch blocks
     E = enc W_sw^T) against the same formulas in torch f64 on random f32 operands: scores -> masked softmax -> switch -> log mixture
     (generator.py:84-127).  f32 arithmetic: log-probs within 2e-5 where the mixture is above 1e-30, pointer probabilities within 1e-6."""
     from bist_amd import ops
     g = torch.Generator().manual_seed(5)
-    rows, d, V, Ls = 5, 512, 301, (20, 61)
+    rows, d, V = 5, 512, 301
     n, ns = len(Ls), len(Ls) + 1
     rnd = lambda *s: torch.randn(*s, generator=g)
     x, tgt, logits = rnd(rows, d), rnd(rows, d), rnd(rows, V) * 3
