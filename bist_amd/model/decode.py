@@ -396,7 +396,7 @@ def _device_beam_turn(model, batch, ft, out0, max_len, unk_symbol, end_symbol, b
 # Token tensors of a dialogue padded to multiples of this many positions (0 / 1 = off).  Default 8: a test set has a different (query,
 # history, caption) length triple in nearly every turn and every new triple costs ~110 ms of captures; at the bench geometry (20, 60, 25)
 # -> (24, 64, 32) the padding costs 0-0.1 ms of a 7.6 ms turn (scripts/bench_decode.py), over 300 turns of growing histories it saves a
-# third of the captures, 16 two thirds (scripts/decode_eval_sweep.py: 107 / 77 / 43 ms per turn for 0 / 8 / 16).
+# third of the captures, 16 two thirds (scripts/decode_eval_sweep.py: 46 / 31 / 18 ms per turn for 0 / 8 / 16).
 BUCKET = int(os.environ.get("BIST_DECODE_BUCKET", "8"))
 
 
