@@ -107,7 +107,7 @@ SIGNATURES = {
     "bist_beam_step": (C.c_int, [_P] * 14 + [_I32] * 10 + [_F, _P]),
     "bist_decoder_stack_ok": (C.c_int, [_I32] * 5),
     "bist_decoder_layer_desc_bytes": (C.c_int64, []),
-    "bist_decoder_stack_fwd": (C.c_int, [_P, _I32] + [_P] * 8 + [_I32, _I32, _I32, _P, _P, _I32, _P]),
+    "bist_decoder_stack_fwd": (C.c_int, [_P, _I32] + [_P] * 8 + [_I32, _I32, _I32, _I32, _P, _P, _I32, _P]),
     "bist_st_stage2_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, C.POINTER(BistDrop), _I32, _P]),
     "bist_scaled_bias_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "bist_scaled_bias_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),

@@ -414,13 +414,21 @@ __device__ __forceinline__ void core_unit_long(const bf16_t* Q, const bf16_t* K,
 }
 
 // one memory's core unit, by the padded length of the memory
+// (LONG is a property of the LAUNCH: with the long forms compiled into the same kernel, the short-memory turn of BASELINE configs[4] measured
+// 7.33-7.43 ms against 7.12-7.25 ms -- code size and register allocation of the 14-phase loop -- so they live in an instance of their own.)
+template <bool LONG>
 __device__ __forceinline__ void core_memory(const bf16_t* Q, const bf16_t* K, const bf16_t* VT, const unsigned char* mask, int Lk, int LkP,
                                             bf16_t* ctx, int R, int head, int mt, int w, int x, int kg, bool wt) {
-  if (LkP <= 64) core_unit<false>(Q, K, VT, mask, 0, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
-  else if (LkP <= 128) core_unit_long<2>(Q, K, VT, mask, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
-  else core_unit_long<4>(Q, K, VT, mask, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
+  if constexpr (!LONG) {
+    core_unit<false>(Q, K, VT, mask, 0, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
+  } else {
+    if (LkP <= 64) core_unit<false>(Q, K, VT, mask, 0, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
+    else if (LkP <= 128) core_unit_long<2>(Q, K, VT, mask, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
+    else core_unit_long<4>(Q, K, VT, mask, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
+  }
 }
 
+template <bool LONG>
 __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* img = smem;                       // [64][1024 B]
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
         const int head = wg & 7, mt = wg >> 3;
         if (mt < MTR) {
           if (j == 0) core_unit<true>(a.qbuf, a.kcache + (long)l * (64 * D), a.vcache + (long)l * (64 * D), a.smask, a.LkS, a.slot0 + R, a.LkS, ctx, R, head, mt, w, x, kg, wt);
-          else core_memory(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, head, mt, w, x, kg, wt);
+          else core_memory<LONG>(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, head, mt, w, x, kg, wt);
         }
         grid_barrier(a.sync, ++phase * NWG, a.dbg);
         STAMP();
@@ -621,6 +629,7 @@ __device__ __forceinline__ void layernorm_lds_to_image(const char* xs, const bf1
   }
 }
 
+template <bool LONG>
 __global__ __launch_bounds__(NT, 1) void decstack_head_kernel(const DecArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* img = smem;                       // image rows 0..15 [16][1024 B]
@@ -732,7 +741,7 @@ __global__ __launch_bounds__(NT, 1) void decstack_head_kernel(const DecArgs a) {
         load_wo(Lp->Wo[j]);                                        // flies under the core
         head_sync();                                               // q (and this step's k / v rows) are in L2
         if (j == 0) core_unit<true>(a.qbuf, a.kcache + (long)l * (64 * D), a.vcache + (long)l * (64 * D), a.smask, a.LkS, a.slot0 + R, a.LkS, ctx, R, hh, 0, w, x, kg, wt);
-        else core_memory(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, hh, 0, w, x, kg, wt);
+        else core_memory<LONG>(a.qbuf, Lp->Kc[j - 1], Lp->VTc[j - 1], Lp->cmask[j - 1], Lp->Lk[j - 1], Lp->LkP[j - 1], ctx, R, hh, 0, w, x, kg, wt);
         head_sync();                                               // the context rows of head hh are in L2
         {
           const int rowc = min(x, R - 1);
@@ -873,10 +882,13 @@ extern "C" int64_t bist_decoder_layer_desc_bytes(void) { return (int64_t)sizeof(
 
 extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, const void* x_in, void* xbuf0, void* xbuf1, void* qbuf,
                                       void* kcache, void* vcache, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, int32_t slot0,
-                                      void* sync, float* pbuf, int32_t dtype, void* stream) {
+                                      int32_t lk_pad_max, void* sync, float* pbuf, int32_t dtype, void* stream) {
   BIST_REQUIRE(layers_dev && x_in && xbuf0 && xbuf1 && qbuf && kcache && vcache && hbuf && self_mask && sync, "bist_decoder_stack_fwd: null pointer");
   BIST_REQUIRE(dtype == BIST_BF16 && n_layers >= 1 && R >= 1 && R <= 64 && slot0 >= 0 && slot0 + R <= 64 && LkS >= slot0 + R && LkS <= 64 && LkS % 32 == 0,
                "bist_decoder_stack_fwd: bf16, 1..64 rows, slots slot0 .. slot0 + R - 1 inside the LkS (32 or 64) key slots");
+  BIST_REQUIRE(lk_pad_max == 32 || lk_pad_max == 64 || lk_pad_max == 128 || lk_pad_max == 256,
+               "bist_decoder_stack_fwd: lk_pad_max = the largest padded memory length of the layer descriptors (32, 64, 128 or 256)");
+  const bool lng = lk_pad_max > 64;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   BIST_REQUIRE(bist_decoder_stack_device_ok(), "bist_decoder_stack_fwd: this device cannot keep the kernel's %d workgroups resident on one XCD", NWG);
   DecArgs a{(const DecLayerDev*)layers_dev, n_layers, (const bf16_t*)x_in, {(bf16_t*)xbuf0, (bf16_t*)xbuf1}, (bf16_t*)qbuf, (bf16_t*)kcache,
@@ -888,11 +900,19 @@ extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, 
   // L2 round trips (q rows, context rows, partials) is longer than the barriers it removes, so callers pass pbuf = null by default.
   if (R <= 16 && pbuf) {
     BIST_REQUIRE((reinterpret_cast<uintptr_t>(pbuf) & 15) == 0, "bist_decoder_stack_fwd: pbuf must be 16-byte aligned");
-    BIST_LDS_OPTIN(&decstack_head_kernel, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
-    hipLaunchKernelGGL(decstack_head_kernel, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
+    if (lng) {
+      BIST_LDS_OPTIN(&decstack_head_kernel<true>, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
+      hipLaunchKernelGGL(decstack_head_kernel<true>, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
+    } else {
+      BIST_LDS_OPTIN(&decstack_head_kernel<false>, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
+      hipLaunchKernelGGL(decstack_head_kernel<false>, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
+    }
+  } else if (lng) {
+    BIST_LDS_OPTIN(&decstack_kernel<true>, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
+    hipLaunchKernelGGL(decstack_kernel<true>, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
   } else {
-    BIST_LDS_OPTIN(&decstack_kernel, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
-    hipLaunchKernelGGL(decstack_kernel, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
+    BIST_LDS_OPTIN(&decstack_kernel<false>, 128 * 1024, "bist_decoder_stack_fwd", BIST_ELAUNCH);
+    hipLaunchKernelGGL(decstack_kernel<false>, dim3(8 * NWG), dim3(NT), 128 * 1024, st, a);
   }
   BIST_LAUNCH_CHECK("bist_decoder_stack_fwd");
   bist_count_launch(BIST_K_DECSTACK);

@@ -349,6 +349,7 @@ class MultimodalDecoder8(nn.Module):
             self.prepare_decode_cache(b, ft)
         st["used"] = True
         incr = ft.get("_bist_incr")
+        lkp = max(k.shape[0] for k in st["kv"]["K"][0])       # the padded memory lengths of this turn's caches (the long ones pick the kernel's chunked core)
         if incr is not None:
             # one decode step at a time (decode.py's step graphs): x holds only the NEW position's rows [n, 1, d]; the keys / values of
             # the earlier positions are in the per-layer pools from the earlier steps of this turn; incr = (first free slot, mask
@@ -356,12 +357,12 @@ class MultimodalDecoder8(nn.Module):
             slot0, mask = incr
             assert Lt == 1 and mask.shape[0] == n
             out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(n, d).contiguous(), st, mask, n, mask.shape[1], slot0,
-                                    head_local=self.HEAD_LOCAL)
+                                    head_local=self.HEAD_LOCAL, lk_pad_max=lkp)
         else:
             R = n * Lt
             LkS = 32 if R <= 32 else 64
             out = ops.decoder_stack(self._decode_desc(st), len(self.layers), x.reshape(R, d).contiguous(), st, self._self_mask(st, b, n, Lt, LkS), R, LkS,
-                                    head_local=self.HEAD_LOCAL)
+                                    head_local=self.HEAD_LOCAL, lk_pad_max=lkp)
         ft.update(ft["_bist_reasoning"][-1])
         ft["_bist_turn_consts"] = (self, st["kv"])       # the rows share one dialogue whose per-turn constants live with these caches
         return out.view(n, Lt, d)

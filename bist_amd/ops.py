@@ -499,17 +499,18 @@ def decoder_stack_ok(R: int, d: int, h: int, Lk_max: int, dtype: torch.dtype) ->
 
 
 def decoder_stack(desc: Tensor, n_layers: int, x_in: Tensor, bufs: dict, self_mask: Tensor, R: int, LkS: int, slot0: int = 0,
-                  head_local: bool = False) -> Tensor:
+                  head_local: bool = False, lk_pad_max: int = 64) -> Tensor:
     """All decoder layers of one decode step in one persistent launch (bist_decoder_stack_fwd); desc: device bytes of n_layers
     BistDecLayer; bufs: the caller-owned scratch and the per-layer self-attention caches "kc" / "vc" [n_layers, 64, 512] (zero-initialised
     once); the R rows of x_in take the cache slots slot0 ..; returns the [R, 512] rows of the output buffer.  head_local: hand the kernel
-    the partial buffer bufs["p"], which selects its head-local form for R <= 16 (measured slower; see decstack.hip)."""
+    the partial buffer bufs["p"], which selects its head-local form for R <= 16 (measured slower; see decstack.hip).  lk_pad_max: the
+    largest padded memory length in desc (above 64: the kernel instance with the chunked attention core)."""
     _dev(desc, x_in, self_mask)
     if bufs["kc"].shape[0] < n_layers or tuple(self_mask.shape) != (R, LkS) or self_mask.dtype != torch.uint8 or not self_mask.is_contiguous():
         raise ValueError("bist_amd.decoder_stack: caches / mask do not fit the call")
     check(lib.bist_decoder_stack_fwd(desc.data_ptr(), n_layers, x_in.data_ptr(), bufs["x0"].data_ptr(), bufs["x1"].data_ptr(),
                                      bufs["q"].data_ptr(), bufs["kc"].data_ptr(), bufs["vc"].data_ptr(), bufs["h"].data_ptr(),
-                                     self_mask.data_ptr(), R, LkS, slot0, bufs["sync"].data_ptr(), _ptr(bufs.get("p") if head_local else None), dtype_code(x_in.dtype), _stream()),
+                                     self_mask.data_ptr(), R, LkS, slot0, lk_pad_max, bufs["sync"].data_ptr(), _ptr(bufs.get("p") if head_local else None), dtype_code(x_in.dtype), _stream()),
           "bist_decoder_stack_fwd")
     return bufs["x0" if (5 * n_layers - 1) % 2 == 0 else "x1"][:R]       # the residual stream ping-pongs: write k lands in buffer (k - 1) % 2
 

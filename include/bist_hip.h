@@ -311,6 +311,8 @@ int bist_beam_step(const float* logp, float* lp, int64_t* tok, uint8_t* mask64, 
  *   sync: 32 bytes = 8 words the caller zeroes ONCE: words 0, 1
  *   the barrier's arrival / exit counters (the kernel leaves them zero for the next call -- no memset node per call), word 4 a STICKY
  *   error flag to read after a turn: non-zero = a barrier timed out (the 32 workgroups were not co-resident), the results of that call are invalid.
+ *   lk_pad_max: the largest LkP among the descriptors' memories (32, 64, 128 or 256); above 64 the launch is the instance whose attention core
+ *   walks a memory in 64-key chunks (dialogue histories of 65 .. 256 tokens).
  * Result: the rows of xbuf[(5 * n_layers - 1) % 2] (the residual stream ping-pongs between the two buffers, five writes per layer).  Returns BIST_EINVAL outside the envelope (bist_decoder_stack_ok).
  * ------------------------------------------------------------------------------------------ */
 typedef struct BistDecLayer {
@@ -338,7 +340,7 @@ int bist_decoder_cache_fill(const BistKvFill* jobs, int32_t n_jobs, int32_t dtyp
  * grid barrier per attention sublayer instead of three: 6 per layer instead of 14.                                                */
 int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, const void* x_in, void* xbuf0, void* xbuf1, void* qbuf,
                            void* kcache, void* vcache, void* hbuf, const uint8_t* self_mask, int32_t R, int32_t LkS, int32_t slot0,
-                           void* sync, float* pbuf, int32_t dtype, void* stream);
+                           int32_t lk_pad_max, void* sync, float* pbuf, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 2 of both directions (encoder.py:125-134 / 152-165): query position (b,i) attends,
