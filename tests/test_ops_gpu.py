@@ -627,13 +627,15 @@ def test_new_entry_points_refuse_calls_outside_their_envelope():
             "sync": z(8, dt=torch.int32)}
     desc = z(int(lib.bist_decoder_layer_desc_bytes()), dt=torch.uint8)
     st = torch.cuda.current_stream().cuda_stream
-    def stack(R, LkS, slot0):
+    def stack(R, LkS, slot0, lk_pad_max=64):
         return lib.bist_decoder_stack_fwd(desc.data_ptr(), 1, bufs["x0"].data_ptr(), bufs["x0"].data_ptr(), bufs["x1"].data_ptr(), bufs["q"].data_ptr(),
                                           bufs["kc"].data_ptr(), bufs["vc"].data_ptr(), bufs["h"].data_ptr(), z(64, 64, dt=torch.uint8).data_ptr(),
-                                          R, LkS, slot0, bufs["sync"].data_ptr(), None, 1, st)
+                                          R, LkS, slot0, lk_pad_max, bufs["sync"].data_ptr(), None, 1, st)
     assert stack(5, 64, 60) != 0 and b"slot" in lib.bist_last_error()          # slots 60..64 leave the pool
     assert stack(5, 48, 0) != 0                                                  # LkS must be 32 or 64
     assert stack(40, 32, 0) != 0                                                 # more rows than key slots
+    assert stack(5, 32, 0, lk_pad_max=96) != 0 and b"lk_pad_max" in lib.bist_last_error()      # padded memory lengths are 32, 64, 128 or 256
+    assert stack(5, 32, 0, lk_pad_max=512) != 0
     # LayerNorm prologue with K != 512
     x, w, y = z(64, 256), z(512, 256), z(64, 512)
     g = ops.gemm_desc(x, w, y, M=64, N=512, K=256, a_rs=256, b_rs=256, ldc=512)
