@@ -66,6 +66,11 @@ class BistKvFill(C.Structure):
     _fields_ = [("src", C.c_void_p), ("K", C.c_void_p), ("VT", C.c_void_p), ("Lk", C.c_int32), ("LkP", C.c_int32), ("ld", C.c_int64)]
 
 
+class BistStageJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("src_row_bytes", C.c_int64), ("dst_row_bytes", C.c_int64),
+                ("pad", C.c_uint64), ("pad_bytes", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class BistLnBwdSet(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("a", C.c_void_p), ("dx", C.c_void_p), ("da", C.c_void_p), ("db", C.c_void_p),
                 ("dx_add", C.c_void_p), ("dz", C.c_void_p), ("drop_row0", C.c_uint64)]
@@ -147,6 +152,7 @@ SIGNATURES = {
     "bist_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _P]),
     "bist_text_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     "bist_decoder_cache_fill": (C.c_int, [_P, _I32, _I32, _P]),
+    "bist_stage_inputs": (C.c_int, [_P, _I32, _P]),
     "bist_xent_smooth_fwd": (C.c_int, [_P, _P, _I64, _I64, _I32, _F, _I32, _P, _P, _P]),
     "bist_xent_smooth_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _P, _I32, _I32, _F, _I32, _P]),
     "bist_sum_div_groups": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _P]),

@@ -253,12 +253,38 @@ def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args,
 _TURN_FIELDS = ("query", "his", "cap", "fts", "query_mask", "query_mask2", "his_mask", "cap_mask", "temporal_mask")
 
 
-def _graph_first_step(model, batch, start_symbol, train_args, host=True):
+_BUCKETED_FIELDS = {"query": "pad", "his": "pad", "cap": "pad", "query_mask": 0, "query_mask2": 0, "his_mask": 0, "cap_mask": 0}
+
+
+def _staged_shape(f, v, bucket):
+    """Shape of field f in the static buffers of a turn's graphs: the token tensors and their masks reach up to the next multiple of the
+    length bucket (see BUCKET / _bucketed: padded positions carry the pad id and a False mask, so nothing reads them)."""
+    shp = tuple(v.shape)
+    if bucket > 1 and f in _BUCKETED_FIELDS and shp[-1] % bucket:
+        shp = shp[:-1] + (shp[-1] + bucket - shp[-1] % bucket,)
+    return shp
+
+
+def _graph_first_step(model, batch, start_symbol, train_args, host=True, pad_symbol=None):
     """model.encode + the first decode step (prefix = <sos>) of a turn, replayed from one hipGraph per dialogue geometry:
-    ~1000 launches of reasoning at B=1 are launch-bound when issued from Python.  Returns (ft, log-probs [1,1,V] numpy);
-    ft (encoded text, per-layer reasoning) lives in the graph's static outputs until the next turn of this geometry."""
+    ~1000 launches of reasoning at B=1 are launch-bound when issued from Python.  Returns (ft, log-probs [1,1,V] numpy, the turn's
+    batch as the graphs see it); ft (encoded text, per-layer reasoning) lives in the graph's static outputs until the next turn of
+    this geometry.  pad_symbol (not None: length buckets): the dialogue's fields go into the graph's static buffers -- token tensors and
+    masks padded to their bucket on the way -- in ONE launch (bist_stage_inputs)."""
+    from .. import ops
     dev = batch.query.device
-    geom = tuple((f, None if getattr(batch, f, None) is None else (tuple(getattr(batch, f).shape), getattr(batch, f).dtype)) for f in _TURN_FIELDS)
+    bucket = BUCKET if pad_symbol is not None else 0
+    geom = tuple((f, None if getattr(batch, f, None) is None else (_staged_shape(f, getattr(batch, f), bucket), getattr(batch, f).dtype))
+                 for f in _TURN_FIELDS)
+
+    def stage(sb):
+        jobs = []
+        for f in _TURN_FIELDS:
+            v = getattr(batch, f, None)
+            if v is not None:
+                pad = _BUCKETED_FIELDS.get(f, 0)
+                jobs.append((v if v.is_contiguous() else v.contiguous(), getattr(sb, f), pad_symbol if pad == "pad" else pad))
+        ops.stage_inputs(jobs)
     store = _graph_store(model)
     g = store.get(("first",) + geom)
     if g is None:
@@ -268,9 +294,10 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True):
         sb = types.SimpleNamespace(**vars(batch))
         for f in _TURN_FIELDS:
             v = getattr(batch, f, None)
-            setattr(sb, f, v.clone() if v is not None else None)
+            setattr(sb, f, torch.empty(_staged_shape(f, v, bucket), dtype=v.dtype, device=dev) if v is not None else None)
         sb.trg = torch.full((1, 1), start_symbol, dtype=torch.long, device=dev)
         sb.trg_mask = subsequent_mask(1, dev)
+        stage(sb)
 
         def run():
             f2 = model.decode(sb, model.encode(sb))
@@ -288,12 +315,13 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True):
             f2, out = run()
         fused = "_bist_fused_first" in f2
         g = store[("first",) + geom] = (graph, sb, f2, out, fused)
+    else:
+        stage(g[1])
     graph, sb, f2, out, _ = g
-    for f in _TURN_FIELDS:
-        v = getattr(batch, f, None)
-        if v is not None:
-            getattr(sb, f).copy_(v)
     graph.replay()
+    seen = types.SimpleNamespace(**vars(batch))          # the turn's batch as its graphs see it (padded fields): what the later steps replicate
+    for f in _TURN_FIELDS:
+        setattr(seen, f, getattr(sb, f))
     ft = {k: v for k, v in f2.items() if k not in ("_bist_reasoning", "_bist_incr", "_bist_fused_first")}
     ft["_bist_reasoning"] = [dict(layer) for layer in f2["_bist_reasoning"]]
     # the replay projected this turn's memories into the decoder's key / value caches (and left position 0's self-attention
@@ -303,7 +331,7 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True):
     if hasattr(dec, "select_decode_cache"):
         # True: the replayed first step ran the decoder layers through the persistent kernel (position 0 sits in slot 0 of its pools)
         ft["_bist_pool_ready"] = bool(g[4]) and dec.select_decode_cache(ft, ft["_bist_turn"])
-    return ft, (out.cpu().numpy() if host else out)
+    return ft, (out.cpu().numpy() if host else out), seen
 
 
 DEVICE_BEAM = os.environ.get("BIST_DEVICE_BEAM", "1") != "0"      # tuning aid: 0 = the beam update of every step on the host (one D2H + sync per step, like the reference)
@@ -427,14 +455,13 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
     dev = batch.query.device
     use_graphs = (STEP_GRAPHS and BATCH_HYPOTHESES and batch.query.is_cuda and not torch.is_grad_enabled() and not model.training
                   and getattr(type(model.mutlimodal_decoder), "REASONING_CACHE", False))
-    if use_graphs:
-        batch = _bucketed(batch, pad_symbol)
     lp_first = None
     if use_graphs:
         dec0 = getattr(model, "mutlimodal_decoder", None)
         want_dev = (DEVICE_BEAM and INCREMENTAL and max_len * beam <= 64 and beam + 2 <= 16 and dec0 is not None
                     and getattr(dec0, "FUSED_DECODE", False) and Fn.FUSED_DECODE and min_len >= 0)
-        ft, out0 = _graph_first_step(model, batch, start_symbol, train_args, host=not want_dev)
+        # (from here on `batch` is the dialogue as the turn's graphs hold it: token tensors and masks padded to their length bucket)
+        ft, out0, batch = _graph_first_step(model, batch, start_symbol, train_args, host=not want_dev, pad_symbol=pad_symbol)
         if want_dev and ft.get("_bist_pool_ready", False) and out0.shape[-1] <= 4096 and out0.shape[-1] >= beam + 3:
             res = _device_beam_turn(model, batch, ft, out0, max_len, unk_symbol, end_symbol, beam, penalty, nbest, min_len, train_args, dec_eos)
             if res is not None:

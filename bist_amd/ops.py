@@ -396,6 +396,26 @@ def weights_key(*params: Tensor):
     return (WEIGHTS_EPOCH,) + tuple((p.data_ptr(), p._version) for p in params)
 
 
+def stage_inputs(jobs) -> None:
+    """bist_stage_inputs: jobs = [(src, dst, pad)]; src / dst tensors of one dtype whose shapes differ at most in the LAST dimension (dst the
+    longer: its tail takes `pad`), both contiguous; one launch for all of them (at most 16 per launch)."""
+    from ._lib import BistStageJob
+    for k in range(0, len(jobs), 16):
+        part = jobs[k:k + 16]
+        arr = (BistStageJob * len(part))()
+        for jb, (src, dst, pad) in zip(arr, part):
+            _dev(src, dst)
+            es = src.element_size()
+            if (src.dtype != dst.dtype or not src.is_contiguous() or not dst.is_contiguous() or src.shape[:-1] != dst.shape[:-1]
+                    or src.shape[-1] > dst.shape[-1] or src.numel() == 0):
+                raise ValueError("bist_amd.stage_inputs: same dtype, contiguous, equal leading dimensions, destination rows at least as long")
+            jb.src, jb.dst = src.data_ptr(), dst.data_ptr()
+            jb.rows = src.numel() // src.shape[-1]
+            jb.src_row_bytes, jb.dst_row_bytes = src.shape[-1] * es, dst.shape[-1] * es
+            jb.pad, jb.pad_bytes = int(pad or 0) & ((1 << (8 * es)) - 1), es
+        check(lib.bist_stage_inputs(arr, len(part), _stream()), "bist_stage_inputs")
+
+
 def _module_list(root):
     """The modules under `root`, cached on it; rebuilt when any of them gained or lost a child."""
     hit = root.__dict__.get("_bist_module_list")

@@ -613,6 +613,18 @@ int bist_adam_apply_dev(float* p, void* g, float* m, float* v, void* work, int64
 /* dst = cast(src) between f32 and bf16 (n elements). */
 int bist_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The inputs of a dialogue turn staged into the fixed buffers the turn's hipGraphs read -- the place of batch.move_to_cuda() + the
+ * per-field copies in the reference's generate loop (generate.py:30-60 / data/dataset.py:130-150) -- as ONE launch: job j copies `rows`
+ * rows of src_row_bytes to rows of dst_row_bytes >= src_row_bytes and fills each row's tail with the pad_bytes-byte pattern `pad`
+ * (little endian: the pad token id of an int64 tensor, 0 = False of a mask).  The tail is how token tensors reach their length bucket
+ * (model/decode.py: padded positions are masked everywhere).  jobs is a HOST array of 1..16 entries; device pointers, any alignment.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct BistStageJob {
+  const void* src; void* dst; int64_t rows; int64_t src_row_bytes; int64_t dst_row_bytes; uint64_t pad; int32_t pad_bytes; int32_t reserved_;
+} BistStageJob;
+int bist_stage_inputs(const BistStageJob* jobs, int32_t n_jobs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

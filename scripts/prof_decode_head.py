@@ -26,14 +26,12 @@ with torch.no_grad():
     turn = lambda: D.beam_search_decode(model, b1, 12, 2, 0, 3, 1, beam=5, penalty=1.0, nbest=5, train_args=args)
     for _ in range(3):
         turn()
-    bb = D._bucketed(b1, 1)
     store = D._graph_store(model)
     first = [v for k, v in store.items() if isinstance(k, tuple) and k and k[0] == "first"][0]
     print(f"whole turn                          {med(turn):.2f} ms")
-    print(f"_bucketed (pads)                    {med(lambda: D._bucketed(b1, 1)):.2f} ms")
     print(f"_graph_store (parameter versions)   {med(lambda: D._graph_store(model)):.2f} ms")
     print(f"first-step graph replay + sync      {med(first[0].replay):.2f} ms")
-    print(f"_graph_first_step + sync            {med(lambda: D._graph_first_step(model, bb, 2, args, host=False)):.2f} ms")
+    print(f"_graph_first_step + sync            {med(lambda: D._graph_first_step(model, b1, 2, args, host=False, pad_symbol=1)):.2f} ms")
     steps = sorted((k for k in store if isinstance(k, tuple) and k and k[0] == "incr"), key=lambda k: k[1])
     print(f"one later step graph replay + sync  {med(store[steps[3]][0].replay):.2f} ms   ({len(steps)} step graphs)")
 

@@ -437,7 +437,7 @@ def test_persistent_decoder_steps_match_the_reference_golden(hip, golden_dir):
     _lib.lib.bist_launch_count_reset()
     model.__dict__.pop("_bist_step_graphs", None); model.__dict__.pop("_bist_step_graphs_key", None)
     with torch.no_grad():
-        ft, lp0 = D._graph_first_step(model, b, O.SOS_ID, _args(cfg))
+        ft, lp0, _ = D._graph_first_step(model, b, O.SOS_ID, _args(cfg))
         assert ft.get("_bist_pool_ready"), "the turn's first step did not run through the persistent decoder kernel"
         for j in range(n):
             check(lp0.reshape(-1), j, 0)

@@ -731,3 +731,34 @@ def test_decoder_cache_fill_copies_keys_and_transposes_values():
         assert bool((K[Lk:] == 7.0).all())
         assert torch.equal(VT[:, :Lk], src[:, off + 512:off + 1024].t())
         assert bool((VT[:, Lk:] == 0).all())
+
+
+@pytest.mark.gpu
+def test_stage_inputs_copies_and_pads_every_field_in_one_launch():
+    """bist_stage_inputs (the inputs of a dialogue turn into the buffers its hipGraphs read): int64 token rows padded with the pad id, bool
+    mask rows with False, several rows per job, a 16-byte-aligned bulk copy (the feature tensor) and an odd-sized byte copy, 17 jobs (two
+    launches) -- against torch's pad / copy."""
+    from bist_amd import ops
+    g = torch.Generator().manual_seed(3)
+    tok = torch.randint(2, 900, (1, 21), generator=g).cuda()
+    msk = (torch.rand(2, 1, 21, generator=g) > 0.3).cuda()
+    fts = torch.randn(1, 40, 64, generator=g).to(torch.bfloat16).cuda()
+    odd = torch.randint(0, 255, (3, 7), generator=g).to(torch.uint8).cuda()
+    h16 = torch.randn(5, 3, generator=g).to(torch.bfloat16).cuda()
+    jobs, want = [], []
+    for k in range(13):                                   # thirteen token tensors of different bucket sizes
+        dst = torch.full((1, 24 + 8 * (k % 3)), -7, dtype=torch.long, device="cuda")
+        jobs.append((tok, dst, 1)); want.append(torch.nn.functional.pad(tok, (0, dst.shape[1] - 21), value=1))
+    for src, width, pad in ((msk, 24, 0), (fts, 64, 0), (odd, 7, 0), (h16, 8, 0x3F80)):       # 0x3F80 = bf16 1.0
+        dst = torch.empty(src.shape[:-1] + (width,), dtype=src.dtype, device="cuda")
+        if src.dtype != torch.bool:
+            dst.fill_(3)
+        jobs.append((src, dst, pad))
+        val = {0: 0, 0x3F80: 1.0}[pad]
+        want.append(torch.nn.functional.pad(src, (0, width - src.shape[-1]), value=bool(val) if src.dtype == torch.bool else val))
+    ops.stage_inputs(jobs)
+    torch.cuda.synchronize()
+    for (src, dst, _), w in zip(jobs, want):
+        assert torch.equal(dst, w), (tuple(src.shape), tuple(dst.shape), src.dtype)
+    with pytest.raises(ValueError):
+        ops.stage_inputs([(tok, torch.empty(1, 16, dtype=torch.long, device="cuda"), 1)])      # destination rows shorter than the source's
