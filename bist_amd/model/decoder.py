@@ -73,6 +73,11 @@ class MultimodalDecoder8(nn.Module):
     """Layer loop: visual reasoning layer, caption layer, modality fusion, decoder layer
     (reference: decoder.py:62-186).  Only ``enc_st_combine == 'none'`` is in scope."""
 
+    def __getstate__(self):
+        """torch.save / copy.deepcopy: the persistent kernel's scratch, per-turn caches, descriptors and hooks (instance attributes named
+        _bist_*: device buffers whose addresses captured graphs hold, ctypes arrays, closures) stay behind; they are rebuilt on demand."""
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_bist_")}
+
     def __init__(self, v_layer, c_layer, a_layer, layer, venc_N, cenc_N, aenc_N, N, args):
         super().__init__()
         self.layers = clones(layer, N)

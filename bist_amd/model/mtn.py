@@ -53,11 +53,12 @@ class MTN(nn.Module):
         if tr is not None:
             tr.flush()
 
-    def __getstate__(self):           # torch.save(model): flush, and leave the (unpicklable, per-process) trainer reference behind
+    def __getstate__(self):
+        """torch.save(model) / copy.deepcopy(model): flush a pending update, and leave this build's runtime state behind -- the trainer
+        reference, the captured decode graphs and their staleness key, the cached module list (instance attributes named _bist_*: all of
+        them per-process or derived, rebuilt on demand)."""
         self._flush_trainer()
-        state = self.__dict__.copy()
-        state.pop("_bist_trainer", None)
-        return state
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_bist_")}
 
     def train(self, mode: bool = True):
         if not mode:

@@ -676,3 +676,30 @@ def test_beam_search_over_more_dialogue_geometries_than_the_graph_store_holds(hi
         assert [list(map(int, x[0])) for x in a] == [list(map(int, x[0])) for x in b], i
         assert all(float(x[1]) == float(y[1]) for x, y in zip(a, b)), i
     model.__dict__.pop("_bist_step_graphs", None); model.__dict__.pop("_bist_step_graphs_key", None)
+
+
+def test_a_model_that_has_decoded_can_be_saved_and_copied(hip, tmp_path):
+    """After beam search the model holds captured hipGraphs, ctypes descriptors and per-turn device buffers (instance attributes named
+    _bist_*).  torch.save(model) (the reference's checkpoint form, train.py:113) and copy.deepcopy leave them behind; the copy and the
+    reloaded model decode the same n-best lists from their own fresh state."""
+    import copy
+    from bist_amd.model.decode import beam_search_decode
+    M, Batch = hip
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    V, C = 300, 256
+    model, _ = build_model(M, cfg, V, C, torch.bfloat16)
+    ob = O.det_batch(1, 8, 9, C, 20, 70, 15, 12, V, seed=77)
+
+    def turn(m):
+        with torch.no_grad():
+            hyps, _ = beam_search_decode(m, to_batch(Batch, ob, torch.bfloat16), 12, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID, beam=5, penalty=1.0, nbest=5,
+                                         train_args=_args(cfg))
+        return [list(map(int, h[0])) for h in hyps]
+    ref = turn(model)
+    assert "_bist_step_graphs" in model.__dict__ and "_bist_dec_state" in model.mutlimodal_decoder.__dict__
+    twin = copy.deepcopy(model)
+    assert not any(k.startswith("_bist_") for k in twin.__dict__) and not any(k.startswith("_bist_") for k in twin.mutlimodal_decoder.__dict__)
+    path = str(tmp_path / "model.pth.tar")
+    torch.save(model, path)
+    back = torch.load(path, weights_only=False)
+    assert turn(twin) == ref and turn(back) == ref and turn(model) == ref
