@@ -14,7 +14,7 @@ torch.manual_seed(1)
 model = M.make_model(c["V"], c["V"], args, ft_sizes=[c["C"]]).cuda().to(torch.bfloat16).eval()
 turns = int(os.environ.get("TURNS", "300"))
 dialogues = [synthetic_batch(1, T=c["T"], S=c["S"], C=c["C"], Lq=lq, Lh=lh, Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"], seed=s, dtype=torch.bfloat16)
-             for s, (lq, lh) in zip((99, 100, 101, 102), ((20, 60), (20, 60), (12, 45), (20, 60)))]
+             for s, (lq, lh) in zip((99, 100, 101, 102, 103, 104), ((20, 60), (20, 60), (12, 45), (20, 60), (17, 130), (9, 250)))]     # (the last two: the kernel's chunked core)
 first, bad = {}, 0
 t0 = time.time()
 with torch.no_grad():
