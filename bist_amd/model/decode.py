@@ -285,8 +285,21 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True, pad_sym
                 pad = _BUCKETED_FIELDS.get(f, 0)
                 jobs.append((v if v.is_contiguous() else v.contiguous(), getattr(sb, f), pad_symbol if pad == "pad" else pad))
         ops.stage_inputs(jobs)
+    # A geometry seen before: stage and launch first, check the graphs against the parameters' values while the device runs (the walk
+    # over ~900 parameters costs 0.2 ms of host time with the device idle otherwise).  Stale graphs -- the parameters were written
+    # since the capture -- are dropped by _graph_store; what the replay left behind is overwritten by the fresh turn below.
+    held = model.__dict__.get("_bist_step_graphs")
+    g = held.get(("first",) + geom) if held is not None else None
+    launched = False
+    if g is not None:
+        stage(g[1])
+        g[0].replay()
+        launched = True
     store = _graph_store(model)
-    g = store.get(("first",) + geom)
+    if store is not held:
+        if launched:
+            torch.cuda.synchronize(dev)      # (the void replay has finished before its graph objects go)
+        g, launched = None, False
     if g is None:
         if sum(1 for k in store if isinstance(k, tuple) and k and k[0] == "first") >= MAX_GEOMETRIES:
             _drop_graphs(model)              # bounded memory over a test set of many dialogue lengths: start over (re-captured on demand)
@@ -315,10 +328,9 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True, pad_sym
             f2, out = run()
         fused = "_bist_fused_first" in f2
         g = store[("first",) + geom] = (graph, sb, f2, out, fused)
-    else:
-        stage(g[1])
     graph, sb, f2, out, _ = g
-    graph.replay()
+    if not launched:
+        graph.replay()
     seen = types.SimpleNamespace(**vars(batch))          # the turn's batch as its graphs see it (padded fields): what the later steps replicate
     for f in _TURN_FIELDS:
         setattr(seen, f, getattr(sb, f))

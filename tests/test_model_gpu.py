@@ -703,3 +703,29 @@ def test_a_model_that_has_decoded_can_be_saved_and_copied(hip, tmp_path):
     torch.save(model, path)
     back = torch.load(path, weights_only=False)
     assert turn(twin) == ref and turn(back) == ref and turn(model) == ref
+
+
+def test_decode_graphs_follow_the_parameters(hip):
+    """The captured decode graphs bake derived operands (packed / fragment-ordered weights, descriptors).  Writing the parameters in place
+    -- load_state_dict of another checkpoint into the same model -- makes them stale: the next turn (whose first-step graph is launched
+    BEFORE the staleness check, for latency) must come out as the turn of a fresh model with the new weights, and so must the one after."""
+    from bist_amd.model.decode import beam_search_decode
+    M, Batch = hip
+    cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
+    V, C = 300, 256
+    ob = O.det_batch(1, 8, 9, C, 20, 40, 15, 12, V, seed=91)
+
+    def turn(m):
+        with torch.no_grad():
+            hyps, _ = beam_search_decode(m, to_batch(Batch, ob, torch.bfloat16), 12, O.SOS_ID, O.UNK_ID, O.EOS_ID, O.PAD_ID, beam=5, penalty=1.0, nbest=5,
+                                         train_args=_args(cfg))
+        return [(list(map(int, h[0])), round(float(h[1]), 3)) for h in hyps]
+    a, _ = build_model(M, cfg, V, C, torch.bfloat16)
+    torch.manual_seed(1234)
+    b = M.make_model(V, V, _args(cfg), ft_sizes=[C]).cuda().to(torch.bfloat16).eval()
+    want_b = turn(b)
+    first_a = turn(a)
+    assert turn(a) == first_a                              # (replayed)
+    a.load_state_dict(b.state_dict())
+    assert turn(a) == want_b and turn(a) == want_b
+    assert first_a != want_b, "the two checkpoints decode alike: the test would not see stale graphs"
