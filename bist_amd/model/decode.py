@@ -13,7 +13,6 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-import copy
 import os
 import types
 
@@ -258,7 +257,7 @@ _BUCKETED_FIELDS = {"query": "pad", "his": "pad", "cap": "pad", "query_mask": 0,
 
 def _staged_shape(f, v, bucket):
     """Shape of field f in the static buffers of a turn's graphs: the token tensors and their masks reach up to the next multiple of the
-    length bucket (see BUCKET / _bucketed: padded positions carry the pad id and a False mask, so nothing reads them)."""
+    length bucket (see BUCKET: padded positions carry the pad id and a False mask, so nothing reads them; dataset.py:66-67, 92 build the masks from the pad id)."""
     shp = tuple(v.shape)
     if bucket > 1 and f in _BUCKETED_FIELDS and shp[-1] % bucket:
         shp = shp[:-1] + (shp[-1] + bucket - shp[-1] % bucket,)
@@ -433,33 +432,15 @@ def _device_beam_turn(model, batch, ft, out0, max_len, unk_symbol, end_symbol, b
     return [([], 0)], None
 
 
-# Token tensors of a dialogue padded to multiples of this many positions (0 / 1 = off).  Default 8: a test set has a different (query,
-# history, caption) length triple in nearly every turn and every new triple costs ~110 ms of captures; at the bench geometry (20, 60, 25)
-# -> (24, 64, 32) the padding costs 0-0.1 ms of a 7.6 ms turn (scripts/bench_decode.py), over 300 turns of growing histories it saves a
-# third of the captures, 16 two thirds (scripts/decode_eval_sweep.py: 46 / 31 / 18 ms per turn for 0 / 8 / 16).
+# Token tensors of a dialogue (and their masks) padded to multiples of this many positions on their way into the graphs' static buffers
+# (_staged_shape, bist_stage_inputs; 0 / 1 = off).  The graphs and cache buffers are per dialogue GEOMETRY; real dialogues come in every
+# length, buckets bound the number of geometries.  Padded positions carry the pad id, so every mask excludes them (dataset.py:66-67, 92) and
+# the padded rows' own outputs are never read: the result is that of the unpadded dialogue (tested against the reference's golden n-best).
+# Default 8: a test set has a different (query, history, caption) length triple in nearly every turn and every new triple costs ~40 ms of
+# captures; at the bench geometry (20, 60, 25) -> (24, 64, 32) the padding costs 0-0.1 ms of a 7 ms turn (scripts/bench_decode.py), over
+# 300 turns of growing histories it saves a third of the captures, 16 two thirds (scripts/decode_eval_sweep.py: 46 / 31 / 18 ms per turn
+# for 0 / 8 / 16).
 BUCKET = int(os.environ.get("BIST_DECODE_BUCKET", "8"))
-
-
-def _bucketed(batch, pad_symbol):
-    """The dialogue with its token tensors (query, history, caption) padded to multiples of BUCKET.  The graphs and cache buffers of
-    the graph path are per dialogue GEOMETRY; real dialogues come in every length, buckets bound the number of geometries.  Padded
-    positions carry the pad id, so every mask excludes them (dataset.py:66-67, 92) and the padded rows' own outputs are never read:
-    the result is that of the unpadded dialogue."""
-    if BUCKET <= 1:
-        return batch
-    out = None
-    for name in ("query", "his", "cap"):
-        v = getattr(batch, name, None)
-        if v is None or v.shape[1] % BUCKET == 0:
-            continue
-        extra = BUCKET - v.shape[1] % BUCKET
-        if out is None:
-            out = copy.copy(batch)
-        setattr(out, name, torch.nn.functional.pad(v, (0, extra), value=pad_symbol))
-        setattr(out, name + "_mask", torch.nn.functional.pad(getattr(batch, name + "_mask"), (0, extra), value=False))
-        if name == "query" and getattr(batch, "query_mask2", None) is not None:
-            out.query_mask2 = torch.cat([out.query_mask, out.query_mask], dim=0)
-    return out if out is not None else batch
 
 
 def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam=5, penalty=1.0,

@@ -1,8 +1,5 @@
 """Host-side logic of the decode path that needs no GPU: the parameter walk behind the graph store's staleness key and the length
 buckets of a dialogue's token tensors (the reference pads nothing: data/dataset.py builds exact-length batches)."""
-import copy
-import types
-
 import torch
 import torch.nn as nn
 
@@ -31,28 +28,16 @@ def test_module_parameters_are_the_current_parameter_objects():
     assert set(map(id, ops.module_parameters(net))) == set(map(id, net.parameters()))
 
 
-def test_length_buckets_pad_tokens_and_masks_only():
-    """decode._bucketed: query / history / caption token tensors padded with the pad id to multiples of the bucket, their masks with False
-    (so every attention and pointer head excludes the new positions), the stacked query mask rebuilt, nothing else touched; lengths that
-    already are multiples stay the same objects."""
+def test_length_buckets_widen_tokens_and_masks_only():
+    """decode._staged_shape: the static buffers of a turn's graphs hold query / history / caption tokens and their masks at the next multiple
+    of the length bucket (bist_stage_inputs fills the tail with the pad id / False; tests/test_ops_gpu.py), every other field at its own
+    shape; bucket 0 / 1 = exact shapes."""
     import bist_amd.model.decode as D
-    pad = 1
-    b = types.SimpleNamespace(
-        query=torch.randint(2, 9, (1, 5)), his=torch.randint(2, 9, (1, 16)), cap=torch.randint(2, 9, (1, 9)),
-        query_mask=torch.ones(1, 1, 5, dtype=torch.bool), his_mask=torch.ones(1, 1, 16, dtype=torch.bool), cap_mask=torch.ones(1, 1, 9, dtype=torch.bool),
-        fts=torch.zeros(1, 3, 4))
-    b.query_mask2 = torch.cat([b.query_mask, b.query_mask], dim=0)
-    old = D.BUCKET
-    try:
-        D.BUCKET = 8
-        out = D._bucketed(copy.copy(b), pad)
-        assert out.query.shape == (1, 8) and out.cap.shape == (1, 16) and out.his is b.his and out.his_mask is b.his_mask
-        assert torch.equal(out.query[:, :5], b.query) and (out.query[:, 5:] == pad).all()
-        assert out.query_mask.shape == (1, 1, 8) and out.query_mask[..., :5].all() and not out.query_mask[..., 5:].any()
-        assert out.cap_mask.shape == (1, 1, 16) and not out.cap_mask[..., 9:].any()
-        assert out.query_mask2.shape == (2, 1, 8) and torch.equal(out.query_mask2[0], out.query_mask[0])
-        assert out.fts is b.fts
-        D.BUCKET = 0
-        assert D._bucketed(b, pad) is b
-    finally:
-        D.BUCKET = old
+    fields = {"query": (1, 5), "his": (1, 16), "cap": (1, 9), "query_mask": (1, 1, 5), "query_mask2": (2, 1, 5), "his_mask": (1, 1, 16),
+              "cap_mask": (1, 1, 9), "fts": (1, 3, 4), "temporal_mask": (1, 1, 3)}
+    want8 = dict(fields, query=(1, 8), cap=(1, 16), query_mask=(1, 1, 8), query_mask2=(2, 1, 8), cap_mask=(1, 1, 16))
+    for f, shp in fields.items():
+        v = torch.zeros(shp)
+        assert D._staged_shape(f, v, 8) == want8[f], f
+        assert D._staged_shape(f, v, 0) == shp and D._staged_shape(f, v, 1) == shp
+    assert set(D._BUCKETED_FIELDS) <= set(D._TURN_FIELDS)
