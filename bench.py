@@ -288,7 +288,7 @@ def main():
                     run()
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with Fn.capture_graph(g):
                 run()
             for _ in range(3):
                 g.replay()

@@ -380,6 +380,37 @@ def param_gate(k: int) -> None:
         PARAM_GATE(k)
 
 
+class capture_graph:
+    """``with capture_graph(graph):`` = torch.cuda.graph(graph, capture_error_mode="thread_local") with Python's cyclic collector paused.
+    Cyclic garbage may own hipGraphs and device buffers of EARLIER captures (a model that decoded, a trainer: nn.Module trees are cycles, so
+    they die whenever the collector happens to run); destroying those is a runtime call a stream capture does not allow, and the process
+    aborts.  torch.cuda.graph stopped collecting before a capture (2.10: only with torch.compiler.config.force_cudagraph_gc), so the
+    collector is simply not allowed to run between capture begin and end.  (thread_local: other threads -- the RCCL watchdog -- may touch
+    the runtime during a capture.)"""
+
+    def __init__(self, graph, **kw):
+        self.ctx = torch.cuda.graph(graph, capture_error_mode="thread_local", **kw)
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()
+        try:
+            return self.ctx.__enter__()
+        except BaseException:
+            if self.was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was:
+                gc.enable()
+
+
 VALUES_AHEAD = os.environ.get("BIST_VALUES_AHEAD", "1") != "0"      # tuning aid: value projections of layer l+1 on the caption stream
 
 

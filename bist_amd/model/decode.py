@@ -182,7 +182,7 @@ def _graph_step(model, bn, fn, trg, train_args):
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
+        with Fn.capture_graph(graph):   # other threads (RCCL watchdog) may touch the runtime during capture
             out = run()
         g = store[(Lt,) + geom] = (graph, strg, tb.b.trg_mask, out)
     graph, strg, _, out = g
@@ -238,7 +238,7 @@ def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args,
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with Fn.capture_graph(graph):
             out = run()
         g = store[key] = (graph, strg, smask, out, bool(flags.get("self_contained")))
     graph, strg, smask, out, _ = g
@@ -259,9 +259,24 @@ def _staged_shape(f, v, bucket):
     """Shape of field f in the static buffers of a turn's graphs: the token tensors and their masks reach up to the next multiple of the
     length bucket (see BUCKET: padded positions carry the pad id and a False mask, so nothing reads them; dataset.py:66-67, 92 build the masks from the pad id)."""
     shp = tuple(v.shape)
-    if bucket > 1 and f in _BUCKETED_FIELDS and shp[-1] % bucket:
-        shp = shp[:-1] + (shp[-1] + bucket - shp[-1] % bucket,)
-    return shp
+    if f not in _BUCKETED_FIELDS or not bucket:
+        return shp
+    L = shp[-1]
+    if bucket == "class":
+        # the lengths the decoder kernel's caches and the pointer heads come in anyway (their padded lengths): a query goes to 32 (64, 96, ..),
+        # a history to 32 / 64 / 128 / 256 (then multiples of 64), a caption -- it only shapes the first-step graph -- to a multiple of 8
+        if f.startswith("his"):
+            P = 32
+            while P < L and P < 256:
+                P *= 2
+            P = P if L <= P else -(-L // 64) * 64
+        elif f.startswith("query"):
+            P = -(-L // 32) * 32
+        else:
+            P = -(-L // 8) * 8
+    else:
+        P = L if bucket <= 1 else -(-L // bucket) * bucket
+    return shp[:-1] + (P,)
 
 
 def _graph_first_step(model, batch, start_symbol, train_args, host=True, pad_symbol=None):
@@ -323,7 +338,7 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True, pad_sym
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
+        with Fn.capture_graph(graph):   # other threads (RCCL watchdog) may touch the runtime during capture
             f2, out = run()
         fused = "_bist_fused_first" in f2
         g = store[("first",) + geom] = (graph, sb, f2, out, fused)
@@ -436,11 +451,13 @@ def _device_beam_turn(model, batch, ft, out0, max_len, unk_symbol, end_symbol, b
 # (_staged_shape, bist_stage_inputs; 0 / 1 = off).  The graphs and cache buffers are per dialogue GEOMETRY; real dialogues come in every
 # length, buckets bound the number of geometries.  Padded positions carry the pad id, so every mask excludes them (dataset.py:66-67, 92) and
 # the padded rows' own outputs are never read: the result is that of the unpadded dialogue (tested against the reference's golden n-best).
-# Default 8: a test set has a different (query, history, caption) length triple in nearly every turn and every new triple costs ~40 ms of
-# captures; at the bench geometry (20, 60, 25) -> (24, 64, 32) the padding costs 0-0.1 ms of a 7 ms turn (scripts/bench_decode.py), over
-# 300 turns of growing histories it saves a third of the captures, 16 two thirds (scripts/decode_eval_sweep.py: 46 / 31 / 18 ms per turn
-# for 0 / 8 / 16).
-BUCKET = int(os.environ.get("BIST_DECODE_BUCKET", "8"))
+# A test set has a different (query, history, caption) length triple in nearly every turn and every new triple costs ~40 ms of captures.
+# An integer n pads every token tensor to a multiple of n; "class" (the default) pads per field to the lengths the decoder kernel's caches
+# and the pointer heads come in anyway (_staged_shape: query 32 / 64, history 32 / 64 / 128 / 256, caption multiples of 8), so that a test
+# set meets a few dozen geometries in all.  Measured (scripts/decode_eval_sweep.py, 300 turns of growing histories, every turn a new exact
+# triple): 46 / 29 / 18 / 11 ms per turn for 0 / 8 / 16 / "class" (21 of 300 turns capture, 16 first-step graphs held); at the bench
+# geometry (20, 60, 25) -> (32, 64, 32) the padding costs nothing measurable (scripts/bench_decode.py: 6.6-6.9 ms against 7.0-7.3 ms with 8).
+BUCKET = (lambda v: v if v == "class" else int(v))(os.environ.get("BIST_DECODE_BUCKET", "class"))
 
 
 def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam=5, penalty=1.0,

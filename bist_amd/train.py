@@ -375,15 +375,15 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         graph, graph2 = torch.cuda.CUDAGraph(), None
         if self.exchanging:
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch the runtime during capture
+            with Fn.capture_graph(graph):   # other threads (RCCL watchdog) may touch the runtime during capture
                 terms = self._backward_open(batch)
             graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph2, capture_error_mode="thread_local"):
+            with Fn.capture_graph(graph2):
                 self._backward_close()
         else:
             self._skip_head_clear = self.adam_in_step and self.flat_grad.is_cuda and ADAM_CLEARS
             try:
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                with Fn.capture_graph(graph):
                     terms = self.backward(batch, optimizer=self.adam_in_step)
             finally:
                 self._skip_head_clear = False

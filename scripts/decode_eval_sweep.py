@@ -1,7 +1,7 @@
 """A test-set-like sweep of beam_search_decode: dialogues of ten turns each, the history growing turn by turn, query / caption lengths
 drawn per dialogue (generate.py:30-60 iterates such a set) -- total time, average per turn, graph captures and device memory held, for
 the length-bucket and graph-store settings in the environment (development aid).
-usage: [BIST_DECODE_BUCKET=8] [BIST_DECODE_MAX_GEOMETRIES=n] python scripts/decode_eval_sweep.py [dialogues]"""
+usage: [BIST_DECODE_BUCKET=8|16|class] [BIST_DECODE_MAX_GEOMETRIES=n] python scripts/decode_eval_sweep.py [dialogues]"""
 import os, random, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

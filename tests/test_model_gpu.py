@@ -343,7 +343,10 @@ def test_beam_search_turns_of_different_dialogue_lengths_do_not_share_state(hip,
     V, C = 300, 256
     model, _ = build_model(M, cfg, V, C, torch.bfloat16)
     dialogues = [O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=41), O.det_batch(1, 8, 9, C, 12, 45, 10, 12, V, seed=42),
-                 O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=43), O.det_batch(1, 8, 9, C, 12, 45, 10, 12, V, seed=44)]
+                 O.det_batch(1, 8, 9, C, 20, 30, 15, 12, V, seed=43), O.det_batch(1, 8, 9, C, 12, 45, 10, 12, V, seed=44),
+                 # two more exact geometries that fall into the length classes of the first two (decode.BUCKET = "class": (32, 32, 16) and
+                 # (32, 64, 16)): they REPLAY the graphs captured for other lengths, the padded tails masked
+                 O.det_batch(1, 8, 9, C, 9, 17, 11, 12, V, seed=45), O.det_batch(1, 8, 9, C, 31, 64, 16, 12, V, seed=46)]
 
     def turn(ob):
         with torch.no_grad():
@@ -371,10 +374,10 @@ def test_beam_search_turns_of_different_dialogue_lengths_do_not_share_state(hip,
     for i, (a, b) in enumerate(zip(fast, slow)):
         assert [list(map(int, x[0])) for x in a] == [list(map(int, x[0])) for x in b], i
         assert max(abs(float(x[1]) - float(y[1])) for x, y in zip(a, b)) <= 5e-2, i
-    assert [list(map(int, x[0])) for x in fast[0]] == [list(map(int, x[0])) for x in fast[4]]
+    assert [list(map(int, x[0])) for x in fast[0]] == [list(map(int, x[0])) for x in fast[len(dialogues)]]       # (the first dialogue once more, at the end)
 
 
-@pytest.mark.parametrize("bucket", [0, 8, 16])
+@pytest.mark.parametrize("bucket", [0, 8, 16, "class"])
 def test_beam_search_on_length_buckets_gives_the_same_n_best(hip, golden_dir, bucket):
     """decode.BUCKET pads the dialogue's token tensors to multiples of 8 so that dialogues of many lengths share their graphs: the
     padded positions are masked everywhere, the n-best lists and scores are those of the unpadded dialogue (fp32, reference golden)."""
@@ -653,7 +656,7 @@ def test_beam_search_over_more_dialogue_geometries_than_the_graph_store_holds(hi
     cfg = O.Cfg(d_model=512, att_h=8, nb_blocks=2, nb_venc_blocks=2, nb_cenc_blocks=2)
     V, C = 300, 256
     model, _ = build_model(M, cfg, V, C, torch.bfloat16)
-    shapes = [(20, 30, 15), (12, 45, 10), (17, 22, 13)]
+    shapes = [(20, 30, 15), (12, 45, 10), (17, 22, 30)]       # three geometries also under the default length classes: (32, 32, 16), (32, 64, 16), (32, 32, 32)
     dialogues = [O.det_batch(1, 8, 9, C, *shapes[i % 3], 12, V, seed=70 + i) for i in range(7)]
 
     def turns(limit):
