@@ -762,3 +762,36 @@ def test_stage_inputs_copies_and_pads_every_field_in_one_launch():
         assert torch.equal(dst, w), (tuple(src.shape), tuple(dst.shape), src.dtype)
     with pytest.raises(ValueError):
         ops.stage_inputs([(tok, torch.empty(1, 16, dtype=torch.long, device="cuda"), 1)])      # destination rows shorter than the source's
+
+
+@pytest.mark.gpu
+def test_captures_run_with_the_cyclic_collector_paused():
+    """functional.capture_graph: between capture begin and end Python's cyclic collector must not run -- garbage it finds may own hipGraphs
+    or device buffers of earlier captures, and destroying those inside a stream capture aborts the process (seen with torch 2.10, which
+    no longer collects before a capture).  The collector's state is restored afterwards, also when the captured code raises."""
+    import gc
+    from bist_amd import functional as Fn, ops
+    x = torch.ones(64, 512, device="cuda", dtype=torch.bfloat16)
+    a = torch.ones(512, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm(x, a, a)                                  # (warm)
+    assert gc.isenabled()
+    g = torch.cuda.CUDAGraph()
+    with Fn.capture_graph(g):
+        assert not gc.isenabled()
+        y = ops.layernorm(x, a, a)
+    assert gc.isenabled()
+    g.replay(); torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError):
+        with Fn.capture_graph(g2):
+            ops.layernorm(x, a, a)
+            raise RuntimeError("inside the capture")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with Fn.capture_graph(torch.cuda.CUDAGraph()):      # a caller that had the collector off keeps it off
+            ops.layernorm(x, a, a)
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
