@@ -416,13 +416,18 @@ def stage_inputs(jobs) -> None:
         check(lib.bist_stage_inputs(arr, len(part), _stream()), "bist_stage_inputs")
 
 
+def _children_signature(mods) -> int:
+    return sum(id(c) for m in mods for c in m._modules.values()) + len(mods)
+
+
 def _module_list(root):
-    """The modules under `root`, cached on it; rebuilt when any of them gained or lost a child."""
+    """The modules under `root`, cached on it; rebuilt when any of them gained, lost or REPLACED a child (the sum of the children's
+    identities moves)."""
     hit = root.__dict__.get("_bist_module_list")
-    if hit is not None and sum(len(m._modules) for m in hit[0]) == hit[1]:
+    if hit is not None and _children_signature(hit[0]) == hit[1]:
         return hit[0]
     mods = list(root.modules())
-    root.__dict__["_bist_module_list"] = (mods, sum(len(m._modules) for m in mods))
+    root.__dict__["_bist_module_list"] = (mods, _children_signature(mods))
     return mods
 
 

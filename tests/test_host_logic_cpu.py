@@ -26,6 +26,8 @@ def test_module_parameters_are_the_current_parameter_objects():
     assert set(map(id, ops.module_parameters(net))) == set(map(id, net.parameters()))
     del net[1][0]                                         # ... or lost one
     assert set(map(id, ops.module_parameters(net))) == set(map(id, net.parameters()))
+    net[0] = nn.Linear(4, 4)                              # ... or had one replaced (same count)
+    assert set(map(id, ops.module_parameters(net))) == set(map(id, net.parameters()))
 
 
 def test_length_buckets_widen_tokens_and_masks_only():
