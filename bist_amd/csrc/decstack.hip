@@ -345,12 +345,11 @@ __device__ __forceinline__ void core_unit(const bf16_t* Q, const bf16_t* K, cons
   if (row < R) st8(ctx + (long)row * D + head * 64 + 16 * w + 4 * kg, make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3])), wt);
 }
 
-// The same unit over a LONG memory (a dialogue history of 65 .. 256 tokens: LkP = 128 or 256) in NC = LkP / 64 chunks of four key tiles
+// The same unit over a LONG memory (a dialogue history of 65 .. 512 tokens: LkP = 128, 256 or 512) in NC = LkP / 64 chunks of four key tiles
 // with a running maximum / denominator (the chunk's probabilities go into the P.V product unnormalised, the context is rescaled when the
 // maximum moves and divided once at the end): the register footprint of the short form, a few more dependent round trips -- the short
 // form stays as it is for LkP <= 64.  MASK_FILL is finite, so the running maximum is finite after the first chunk and a chunk that lies
 // wholly behind Lk contributes exp(-inf) = 0.
-template <int NC>
 __device__ __forceinline__ void core_unit_long(const bf16_t* Q, const bf16_t* K, const bf16_t* VT, const unsigned char* mask, int Lk, int LkP,
                                                bf16_t* ctx, int R, int head, int mt, int w, int x, int kg, bool wt) {
   const int row = 16 * mt + x, rowc = min(row, R - 1);
@@ -360,6 +359,7 @@ __device__ __forceinline__ void core_unit_long(const bf16_t* Q, const bf16_t* K,
   const bf16_t* vrow = VT + (long)(head * 64 + 16 * w + x) * LkP + 4 * kg;
   float m = -INFINITY, den = 0.f;
   f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int NC = LkP >> 6;
 #pragma unroll 1
   for (int c = 0; c < NC; ++c) {
     uint4 kf[2][4];
@@ -423,8 +423,7 @@ __device__ __forceinline__ void core_memory(const bf16_t* Q, const bf16_t* K, co
     core_unit<false>(Q, K, VT, mask, 0, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
   } else {
     if (LkP <= 64) core_unit<false>(Q, K, VT, mask, 0, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
-    else if (LkP <= 128) core_unit_long<2>(Q, K, VT, mask, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
-    else core_unit_long<4>(Q, K, VT, mask, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
+    else core_unit_long(Q, K, VT, mask, Lk, LkP, ctx, R, head, mt, w, x, kg, wt);
   }
 }
 
@@ -863,9 +862,9 @@ extern "C" int bist_decoder_cache_fill(const BistKvFill* jobs, int32_t n_jobs, i
   int maxp = 0;
   for (int j = 0; j < n_jobs; ++j) {
     const BistKvFill& b = jobs[j];
-    BIST_REQUIRE(b.src && b.K && b.VT && b.Lk >= 1 && b.Lk <= b.LkP && (b.LkP == 32 || b.LkP == 64 || b.LkP == 128 || b.LkP == 256) && b.ld >= 1024 && b.ld % 8 == 0 &&
+    BIST_REQUIRE(b.src && b.K && b.VT && b.Lk >= 1 && b.Lk <= b.LkP && (b.LkP == 32 || b.LkP == 64 || b.LkP == 128 || b.LkP == 256 || b.LkP == 512) && b.ld >= 1024 && b.ld % 8 == 0 &&
                  (((uintptr_t)b.src | (uintptr_t)b.K | (uintptr_t)b.VT) & 15) == 0,
-                 "bist_decoder_cache_fill: job %d: 1 <= Lk <= LkP in {32, 64, 128, 256}, rows of [k | v] 16-byte aligned", j);
+                 "bist_decoder_cache_fill: job %d: 1 <= Lk <= LkP in {32, 64, 128, 256, 512}, rows of [k | v] 16-byte aligned", j);
     a.j[j] = KvFillK{(const bf16_t*)b.src, (bf16_t*)b.K, (bf16_t*)b.VT, b.Lk, b.LkP, (long)b.ld};
     maxp = b.LkP > maxp ? b.LkP : maxp;
   }
@@ -875,7 +874,7 @@ extern "C" int bist_decoder_cache_fill(const BistKvFill* jobs, int32_t n_jobs, i
 }
 
 extern "C" int bist_decoder_stack_ok(int32_t R, int32_t d, int32_t h, int32_t Lk_max, int32_t dtype) {
-  return dtype == BIST_BF16 && d == D && h == H && R >= 1 && R <= 64 && Lk_max >= 1 && Lk_max <= 256 && bist_decoder_stack_device_ok();
+  return dtype == BIST_BF16 && d == D && h == H && R >= 1 && R <= 64 && Lk_max >= 1 && Lk_max <= 512 && bist_decoder_stack_device_ok();
 }
 
 extern "C" int64_t bist_decoder_layer_desc_bytes(void) { return (int64_t)sizeof(DecLayerDev); }
@@ -886,8 +885,8 @@ extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, 
   BIST_REQUIRE(layers_dev && x_in && xbuf0 && xbuf1 && qbuf && kcache && vcache && hbuf && self_mask && sync, "bist_decoder_stack_fwd: null pointer");
   BIST_REQUIRE(dtype == BIST_BF16 && n_layers >= 1 && R >= 1 && R <= 64 && slot0 >= 0 && slot0 + R <= 64 && LkS >= slot0 + R && LkS <= 64 && LkS % 32 == 0,
                "bist_decoder_stack_fwd: bf16, 1..64 rows, slots slot0 .. slot0 + R - 1 inside the LkS (32 or 64) key slots");
-  BIST_REQUIRE(lk_pad_max == 32 || lk_pad_max == 64 || lk_pad_max == 128 || lk_pad_max == 256,
-               "bist_decoder_stack_fwd: lk_pad_max = the largest padded memory length of the layer descriptors (32, 64, 128 or 256)");
+  BIST_REQUIRE(lk_pad_max == 32 || lk_pad_max == 64 || lk_pad_max == 128 || lk_pad_max == 256 || lk_pad_max == 512,
+               "bist_decoder_stack_fwd: lk_pad_max = the largest padded memory length of the layer descriptors (32, 64, 128, 256 or 512)");
   const bool lng = lk_pad_max > 64;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   BIST_REQUIRE(bist_decoder_stack_device_ok(), "bist_decoder_stack_fwd: this device cannot keep the kernel's %d workgroups resident on one XCD", NWG);

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void pointer_attn_bwd_kernel(const T* __restri
 //   sw_logits = W_sw,x x + W_sw,tgt tgt + b + sum_j p_j E_j.
 // One workgroup per row does the n masked softmaxes (generator.py:106-110, single head, fill -1e9), the switch and the mixture of
 // pointer_mix_kernel -- a step's pointer heads are ONE launch after the vocabulary product instead of eighteen (2 x {2 mask ops, 2
-// projections, attention core, text vector}, 4 switch products, mixture).  d <= 1024, L_j <= 256.
+// projections, attention core, text vector}, 4 switch products, mixture).  d <= 1024, L_j <= 512.
 struct PtrDecSrcK { const float* M; const float* c; const unsigned char* mask; const float* E; const long* text; float* p_out; int L; };
 struct PtrDecArgs { PtrDecSrcK s[3]; int n; };
 
@@ -432,9 +432,9 @@ template <typename T, bool LDSROW>
 __global__ __launch_bounds__(256) void pointer_decode_mix_kernel(const T* __restrict__ x, const T* __restrict__ tgt, const float* __restrict__ logits,
                                                                  PtrDecArgs a, const T* __restrict__ Wsw, long ldw, const T* __restrict__ bsw,
                                                                  float scale, float* __restrict__ out, int d, int V) {
-  __shared__ float xs[1024], ts[1024], pr[3][256], swl[4], red[4];
+  __shared__ float xs[1024], ts[1024], pr[3][512], swl[4], red[4];
   __shared__ float orow[LDSROW ? 4096 : 1];
-  __shared__ int tx[3][256];                  // the sources' token ids (the scatter walks them L^2 / 2 times: out of LDS, not global memory)
+  __shared__ int tx[3][512];                  // the sources' token ids (the scatter walks them L^2 / 2 times: out of LDS, not global memory)
   const long row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int k = tid; k < d; k += 256) { xs[k] = to_f(x[row * d + k]); ts[k] = to_f(tgt[row * d + k]); }
@@ -783,8 +783,8 @@ extern "C" int bist_pointer_decode_mix_fwd(const void* x, const void* tgt, const
   for (int j = 0; j < 3; ++j) a.s[j] = PtrDecSrcK{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   for (int j = 0; j < n_ptr; ++j) {
     const BistPtrDecSrc& sj = src[j];
-    BIST_REQUIRE(sj.M && sj.c && sj.mask && sj.E && sj.text && sj.L >= 1 && sj.L <= 256 && ((uintptr_t)sj.M & 15) == 0,
-                 "bist_pointer_decode_mix_fwd: bad pointer source %d (1..256 positions, M 16-byte aligned)", j);
+    BIST_REQUIRE(sj.M && sj.c && sj.mask && sj.E && sj.text && sj.L >= 1 && sj.L <= 512 && ((uintptr_t)sj.M & 15) == 0,
+                 "bist_pointer_decode_mix_fwd: bad pointer source %d (1..512 positions, M 16-byte aligned)", j);
     a.s[j] = PtrDecSrcK{sj.M, sj.c, sj.mask, sj.E, (const long*)sj.text, sj.p_out, sj.L};
   }
   hipStream_t st = (hipStream_t)stream;

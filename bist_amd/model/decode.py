@@ -264,10 +264,10 @@ def _staged_shape(f, v, bucket):
     L = shp[-1]
     if bucket == "class":
         # the lengths the decoder kernel's caches and the pointer heads come in anyway (their padded lengths): a query goes to 32 (64, 96, ..),
-        # a history to 32 / 64 / 128 / 256 (then multiples of 64), a caption -- it only shapes the first-step graph -- to a multiple of 8
+        # a history to 32 / 64 / 128 / 256 / 512 (then multiples of 64), a caption -- it only shapes the first-step graph -- to a multiple of 8
         if f.startswith("his"):
             P = 32
-            while P < L and P < 256:
+            while P < L and P < 512:
                 P *= 2
             P = P if L <= P else -(-L // 64) * 64
         elif f.startswith("query"):

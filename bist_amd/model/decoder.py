@@ -197,7 +197,7 @@ class MultimodalDecoder8(nn.Module):
         mems = lambda l: (ft["encoded_his"][0], ft["encoded_query"][0], cache[l]["encoded_ft"][0])
         masks = (b.his_mask[0].reshape(-1), b.query_mask[0].reshape(-1), b.query_mask[0].reshape(-1))
         Lks = [m.shape[0] for m in mems(0)]
-        LkPs = [32 if k <= 32 else 64 if k <= 64 else 128 if k <= 128 else 256 for k in Lks]     # (histories of 65 .. 256 tokens: the kernel's long core)
+        LkPs = [32 if k <= 32 else 64 if k <= 64 else 128 if k <= 128 else 256 if k <= 256 else 512 for k in Lks]     # (histories of 65 .. 512 tokens: the kernel's long core)
         # one set of cache buffers per dialogue geometry, kept for the decoder's lifetime: captured step graphs of that geometry hold
         # their addresses (and the descriptor's), so they are never freed or re-used for another geometry
         kvs = st.setdefault("kv_by_len", {})

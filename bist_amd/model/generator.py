@@ -179,7 +179,7 @@ class MultiPointerGenerator(nn.Module):
         tgt = ft.get("encoded_tgt")
         names = args.ptr_ft.split(",")
         if tc is None or not self.DECODE_FAST or torch.is_grad_enabled() or not x.is_cuda or tgt is None or tgt.shape != x.shape or x.shape[-1] > 1024 \
-                or x.shape[-1] % 8 or len(names) > 3 or any(ft.get("encoded_" + n) is None or ft["encoded_" + n].shape[1] > 256 for n in names):
+                or x.shape[-1] % 8 or len(names) > 3 or any(ft.get("encoded_" + n) is None or ft["encoded_" + n].shape[1] > 512 for n in names):
             return None
         dec, kv = tc
         B, Lt, d = x.shape

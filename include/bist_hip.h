@@ -297,7 +297,7 @@ int bist_beam_step(const float* logp, float* lp, int64_t* tok, uint8_t* mask64, 
  * across it; hand-offs are write-through stores + sc1 loads, no cache fences.
  *   layers_dev  device array of n_layers BistDecLayer (below): LayerNorm gains/offsets, nn.Linear weights [out][in] and biases,
  *               and per memory c = 0 (history), 1 (query), 2 (fused modalities) the keys K = mem W_k^T + b_k as [LkP][512] and
- *               the values TRANSPOSED, V^T [512][LkP] (LkP = Lk rounded up to 32, 64, 128 or 256, padding zero), computed once per turn
+ *               the values TRANSPOSED, V^T [512][LkP] (LkP = Lk rounded up to 32, 64, 128, 256 or 512, padding zero), computed once per turn
  *               (they do not depend on the prefix), with the key mask [LkP] (uint8, 1 = attend; -1e9 REPLACES a masked score)
  *   x_in [R][512] the embedded rows of this call; xbuf0 / xbuf1 [64][512], qbuf [64][512], hbuf [64][2048]: caller-owned scratch, ZERO
  *   when first handed over.  kcache / vcache [n_layers][64][512]: the self-attention keys / values (row-major) of every row the
@@ -311,8 +311,8 @@ int bist_beam_step(const float* logp, float* lp, int64_t* tok, uint8_t* mask64, 
  *   sync: 32 bytes = 8 words the caller zeroes ONCE: words 0, 1
  *   the barrier's arrival / exit counters (the kernel leaves them zero for the next call -- no memset node per call), word 4 a STICKY
  *   error flag to read after a turn: non-zero = a barrier timed out (the 32 workgroups were not co-resident), the results of that call are invalid.
- *   lk_pad_max: the largest LkP among the descriptors' memories (32, 64, 128 or 256); above 64 the launch is the instance whose attention core
- *   walks a memory in 64-key chunks (dialogue histories of 65 .. 256 tokens).
+ *   lk_pad_max: the largest LkP among the descriptors' memories (32, 64, 128, 256 or 512); above 64 the launch is the instance whose attention core
+ *   walks a memory in 64-key chunks (dialogue histories of 65 .. 512 tokens).
  * Result: the rows of xbuf[(5 * n_layers - 1) % 2] (the residual stream ping-pongs between the two buffers, five writes per layer).  Returns BIST_EINVAL outside the envelope (bist_decoder_stack_ok).
  * ------------------------------------------------------------------------------------------ */
 typedef struct BistDecLayer {

@@ -45,7 +45,7 @@ def test_length_buckets_widen_tokens_and_masks_only():
     assert set(D._BUCKETED_FIELDS) <= set(D._TURN_FIELDS)
     # "class": the padded lengths of the decoder kernel's caches
     for f, L, P in (("query", 5, 32), ("query", 32, 32), ("query", 33, 64), ("his", 2, 32), ("his", 33, 64), ("his", 64, 64), ("his", 65, 128),
-                    ("his", 129, 256), ("his", 256, 256), ("his", 257, 320), ("cap", 9, 16), ("cap_mask", 25, 32), ("his_mask", 70, 128),
+                    ("his", 129, 256), ("his", 256, 256), ("his", 257, 512), ("his", 512, 512), ("his", 513, 576), ("cap", 9, 16), ("cap_mask", 25, 32), ("his_mask", 70, 128),
                     ("query_mask2", 20, 32)):
         assert D._staged_shape(f, torch.zeros(1, 1, L), "class") == (1, 1, P), (f, L)
     assert D._staged_shape("fts", torch.zeros(1, 3, 4), "class") == (1, 3, 4)

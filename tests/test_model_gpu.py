@@ -257,12 +257,12 @@ def test_full_size_fp32_matches_reference_digests(hip, golden_dir, tag):
 
 
 @pytest.mark.parametrize("n,Lt,Lh", [(1, 1, 30), (3, 5, 30), (5, 12, 30), (2, 7, 30), (5, 1, 65), (3, 5, 100), (5, 12, 128), (2, 7, 129), (5, 3, 200),
-                                     (1, 1, 256)])
+                                     (1, 1, 256), (4, 2, 257), (5, 1, 512)])
 def test_fused_decoder_stack_matches_the_layer_by_layer_path(hip, n, Lt, Lh):
     """bist_decoder_stack_fwd (one persistent launch for all decoder layers of a decode step) against the same layers run one
     launch per operation, bf16, d_model=512, h=8, on the replicated turn of a beam-search step (n hypotheses x Lt prefix tokens).
     Lh: tokens of the dialogue history -- up to 64 the attention core holds a memory's scores in registers at once, from 65 to 256 it
-    walks 64-key chunks with a running maximum (decstack.hip core_unit_long)."""
+    walks 64-key chunks with a running maximum (decstack.hip core_unit_long, memories of up to 512 keys)."""
     from bist_amd import _lib, functional as Fn
     from bist_amd.data.batch import subsequent_mask
     from bist_amd.model.decode import _turn_for_rows
@@ -559,7 +559,7 @@ def test_head_local_decoder_kernel_equals_the_column_split_kernel(hip):
         dec.check_decode_errors()
 
 
-@pytest.mark.parametrize("Ls", [(20, 61), (23, 256), (129,)])
+@pytest.mark.parametrize("Ls", [(20, 61), (23, 256), (129,), (512, 300)])
 def test_pointer_decode_launch_matches_its_formulas(hip, Ls):
     """bist_pointer_decode_mix_fwd (the pointer heads of a decode step in one launch: folded keys M = K W_q, c = K b_q, switch blocks
     E = enc W_sw^T) against the same formulas in torch f64 on random f32 operands: scores -> masked softmax -> switch -> log mixture

@@ -634,8 +634,8 @@ def test_new_entry_points_refuse_calls_outside_their_envelope():
     assert stack(5, 64, 60) != 0 and b"slot" in lib.bist_last_error()          # slots 60..64 leave the pool
     assert stack(5, 48, 0) != 0                                                  # LkS must be 32 or 64
     assert stack(40, 32, 0) != 0                                                 # more rows than key slots
-    assert stack(5, 32, 0, lk_pad_max=96) != 0 and b"lk_pad_max" in lib.bist_last_error()      # padded memory lengths are 32, 64, 128 or 256
-    assert stack(5, 32, 0, lk_pad_max=512) != 0
+    assert stack(5, 32, 0, lk_pad_max=96) != 0 and b"lk_pad_max" in lib.bist_last_error()      # padded memory lengths are 32, 64, 128, 256 or 512
+    assert stack(5, 32, 0, lk_pad_max=1024) != 0
     # LayerNorm prologue with K != 512
     x, w, y = z(64, 256), z(512, 256), z(64, 512)
     g = ops.gemm_desc(x, w, y, M=64, N=512, K=256, a_rs=256, b_rs=256, ldc=512)
