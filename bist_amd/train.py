@@ -169,7 +169,10 @@ class Trainer:
         self._skip_head_clear = False
         self.pending = torch.zeros(1, device=dev, dtype=torch.int64)     # deferred optimiser: the step whose update is still to be applied (0: none)
         self.deferred = self.deferred and dev.type == "cuda"
-        self._adam_stream = torch.cuda.Stream(device=dev) if self.deferred else None
+        # (the deferred optimiser's launches go to the caption / decoder stream, idle at the head of a step: a FOURTH stream in the captured
+        # step made replays of small models crash now and then inside hipGraphLaunch -- three times on the last day of round 3, always with
+        # a fourth stream in the graph, never with three)
+        self._adam_stream = None
         if self.deferred:
             object.__setattr__(model, "_bist_trainer", weakref.ref(self))     # model.eval() / state_dict() flush the pending update
 
@@ -250,12 +253,12 @@ class Trainer:
         ops.WEIGHTS_EPOCH += 1
 
     def _backward_deferred(self, batch):
-        """One replayed step with the deferred optimiser.  Head: the scalars of the pending step, then -- on the optimiser's own
-        stream -- Adam piece by piece (each also clears its gradients), an event after each piece; the forward pass waits for a
+        """One replayed step with the deferred optimiser.  Head: the scalars of the pending step, then -- on the caption / decoder
+        stream, idle until the first caption layer -- Adam piece by piece (each also clears its gradients), an event after each piece; the forward pass waits for a
         piece just before it first reads it (Fn.param_gate, called by the model on the main stream).  Tail: backward, closing
         reductions, pending <- this step."""
         self._pending_hyper()
-        main, ad = torch.cuda.current_stream(), self._adam_stream
+        main, ad = torch.cuda.current_stream(), Fn.side_stream(1)
         ad.wait_stream(main)
         events = []
         with torch.cuda.stream(ad):
@@ -480,16 +483,17 @@ class Trainer:
             # the big pieces' updates on a side stream, each behind its own all-reduce: beside the closing reductions (as in the one-rank
             # step) instead of after them -- with a fast exchange (few ranks) the step no longer pays Adam's 0.8 ms in line
             main, side = torch.cuda.current_stream(), Fn.side_stream(0)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                for (lo, hi), wk in zip(big, works):
-                    wk.wait()                # (orders the CURRENT stream behind the collective; the host does not block)
-                    adam(lo, hi, 1.0)
+            side.wait_stream(main)           # (the fork: before the closing reductions are queued on the main stream)
         if self.use_graph:
             self._graph2.replay()
         else:
             self._backward_close()
         prefix = parallel.exchange_gradients_async(self.flat_grad, [(0, self.n32)], self.pg)
+        if side is not None:
+            with torch.cuda.stream(side):
+                for (lo, hi), wk in zip(big, works):
+                    wk.wait()                # (RCCL: orders the CURRENT stream behind the collective, the host does not block; gloo blocks the host)
+                    adam(lo, hi, 1.0)
         if side is None:
             for (lo, hi), wk in zip(big, works):
                 wk.wait()
