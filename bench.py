@@ -25,6 +25,12 @@ cpu_baseline= the CPU oracle (oracle/bist_oracle.py, a port of the reference ver
               at B=16 in target tokens/s, 2 warm-up + 5 timed, median; `rows` adds the eval forwards and a decode turn.
 """
 import argparse
+import os
+
+# HIP runtime switches the split-graph executor needs (bist_amd/__init__.py), set before anything can initialise the runtime
+os.environ.setdefault("DEBUG_HIP_DYNAMIC_QUEUES", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "1")
 import json
 import os
 import subprocess
@@ -287,7 +293,7 @@ def main():
                 for _ in range(2):
                     run()
             torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
+            g = Fn.Graph()
             with Fn.capture_graph(g):
                 run()
             for _ in range(3):
@@ -327,34 +333,45 @@ def main():
                 "kernels": kernels}
 
     def decode_turn_ms():
-        """BASELINE configs[4]: one dialogue turn of beam_search_decode (B=1, beam 5, maxlen 12) with and without the
-        per-turn reuse of the target-independent reasoning."""
-        from bist_amd.model.decode import beam_search_decode
+        """BASELINE configs[4]: dialogue turns of beam_search_decode (B=1, beam 5, maxlen 12).  Two turns that may capture hipGraphs, then
+        20 replayed turns, each bracketed by a device synchronisation: median, p90 and the per-turn list; what the turns did
+        (bist_amd.model.decode.STATS: decided on the device / handed back to the host loop and run twice / captures) and the host's
+        garbage collections during them are reported beside the times, so an outlier can be read.  Then the same without the per-turn
+        reuse of the target-independent reasoning and late in a dialogue (200 history tokens)."""
+        import gc
+        from bist_amd.model import decode as D
         from bist_amd.model.decoder import MultimodalDecoder8
         b1 = make_batch(1, c["T"], 99)
-        res = {}
-        with torch.no_grad():
-            for name, flag in (("cached", True), ("recompute", False)):
-                MultimodalDecoder8.REASONING_CACHE = flag
-                try:
-                    ts = []
-                    for _ in range(3):
-                        torch.cuda.synchronize(); t0 = time.perf_counter()
-                        beam_search_decode(model, b1, 12, 2, 0, 3, 1, beam=5, penalty=1.0, nbest=5, train_args=args)
-                        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-                    res[name] = min(ts)
-                finally:
-                    MultimodalDecoder8.REASONING_CACHE = True
-            # the same turn late in a dialogue: 200 history tokens instead of configs[4]'s 60 (the decoder kernel's chunked attention core)
-            b200 = make_batch(1, c["T"], 99, Lh=200)
+
+        def turns(bt, capture, replay):
             ts = []
-            for _ in range(3):
+            for _ in range(capture):
+                D.beam_search_decode(model, bt, 12, 2, 0, 3, 1, beam=5, penalty=1.0, nbest=5, train_args=args)
+            before, gc0 = dict(D.STATS), sum(g_["collections"] for g_ in gc.get_stats())
+            for _ in range(replay):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-                beam_search_decode(model, b200, 12, 2, 0, 3, 1, beam=5, penalty=1.0, nbest=5, train_args=args)
+                D.beam_search_decode(model, bt, 12, 2, 0, 3, 1, beam=5, penalty=1.0, nbest=5, train_args=args)
                 torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-            res["history200"] = min(ts)
-        return {"what": "beam_search_decode turn, B=1 beam=5 maxlen=12 (BASELINE configs[4]), one decode step at a time through the persistent decoder kernel, one hipGraph replay per (rows, position)", "ms_per_turn": res["cached"],
-                "ms_per_turn_reasoning_recomputed": res["recompute"], "ms_per_turn_history_200_tokens": res["history200"]}
+            did = {k: D.STATS[k] - before[k] for k in before}
+            did["gc_collections"] = sum(g_["collections"] for g_ in gc.get_stats()) - gc0
+            srt = sorted(ts)
+            return {"median": srt[len(srt) // 2], "p90": srt[min(len(srt) - 1, int(0.9 * len(srt)))], "min": srt[0], "max": srt[-1],
+                    "turns_ms": [round(t, 3) for t in ts], "did": did}
+        with torch.no_grad():
+            cached = turns(b1, 2, 20)
+            MultimodalDecoder8.REASONING_CACHE = False
+            try:
+                recompute = turns(b1, 1, 2)
+            finally:
+                MultimodalDecoder8.REASONING_CACHE = True
+            # the same turn late in a dialogue: 200 history tokens instead of configs[4]'s 60 (the decoder kernel's chunked attention core)
+            h200 = turns(make_batch(1, c["T"], 99, Lh=200), 2, 10)
+        return {"what": "beam_search_decode turn, B=1 beam=5 maxlen=12 (BASELINE configs[4]), one decode step at a time through the persistent decoder kernel, one hipGraph replay per (rows, position); "
+                        "median of 20 replayed turns after 2 turns that capture",
+                "ms_per_turn": cached["median"], "ms_per_turn_p90": cached["p90"], "ms_per_turn_min": cached["min"], "ms_per_turn_max": cached["max"],
+                "turns_ms": cached["turns_ms"], "turns_did": cached["did"],
+                "ms_per_turn_reasoning_recomputed": recompute["median"],
+                "ms_per_turn_history_200_tokens": h200["median"], "history_200_tokens": {k: h200[k] for k in ("p90", "min", "max", "did")}}
 
     decode = decode_turn_ms() if (rank == 0 and not a.no_decode) else None
     attn = region_report(c["B"], c["T"], batch)

@@ -90,6 +90,7 @@ SIGNATURES = {
     "bist_launch_count": (C.c_int64, [_I32]),
     "bist_launch_count_reset": (None, []),
     "bist_dev_set_stamps": (C.c_int, [_I32, _P]),
+    "bist_dev_timestamp": (C.c_int, [_P, _P]),
     "bist_gemm": (C.c_int, [C.POINTER(BistGemm), _P]),
     "bist_gemm_pair": (C.c_int, [C.POINTER(BistGemm), C.POINTER(BistGemm), _P]),
     "bist_gemm_is_fast": (C.c_int, [C.POINTER(BistGemm)]),
@@ -165,6 +166,19 @@ SIGNATURES = {
     "bist_noam_hyper_pending": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "bist_adam_apply_dev": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _P]),
     "bist_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _P]),
+    "bist_graph_capture_tail": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "bist_graph_nodes": (C.c_int, [_P, C.POINTER(C.c_void_p), _I32, C.POINTER(C.c_int32)]),
+    "bist_graph_split_plan": (C.c_int64, [_I32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I32, C.POINTER(C.c_int32), _I32, _I32, C.POINTER(C.c_int32), _I64]),
+    "bist_graph_split_create": (C.c_int, [_P, C.POINTER(C.c_int32), _I32, _I32, _I32, C.POINTER(C.c_void_p)]),
+    "bist_graph_split_sync_words": (C.c_int64, [_P]),
+    "bist_graph_split_sync_items": (C.c_int64, [_P, C.POINTER(C.c_int32), _I64]),
+    "bist_graph_split_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "bist_graph_split_build": (C.c_int, [_P, _P, _P, _I64]),
+    "bist_graph_split_launch": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "bist_graph_split_launch_chain": (C.c_int, [_P, _I32, _P]),
+    "bist_graph_split_destroy": (None, [_P]),
+    "bist_graph_queues_distinct": (C.c_int, [_P, _P, _P, _I64]),
+    "bist_dev_idle_wave": (C.c_int, [_P, _I64, _I32, _P]),
 }
 
 
@@ -187,6 +201,11 @@ class BistError(RuntimeError):
     pass
 
 
+AFTER_LAUNCH = None      # bist_amd.graphsplit.Labels: called after every checked library call while a capture is being labelled
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise BistError(f"{what} failed (rc={rc}): {lib.bist_last_error().decode()}")
+    if AFTER_LAUNCH is not None:
+        AFTER_LAUNCH()

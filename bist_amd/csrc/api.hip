@@ -39,6 +39,15 @@ extern "C" int bist_dev_set_stamps(int32_t which, void* device_buffer) {
   return BIST_OK;
 }
 
+// Development hook: one thread writes the device's constant-rate wall clock (100 MHz) to *slot, as a launch of its own on `stream` --
+// captured into a hipGraph it timestamps that point of that stream in every replay (bist_amd/stamps.py, scripts/stamp_step.py).
+namespace { __global__ void timestamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); } }
+extern "C" int bist_dev_timestamp(void* slot, void* stream) {
+  BIST_REQUIRE(slot != nullptr, "bist_dev_timestamp: null slot");
+  timestamp_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(reinterpret_cast<unsigned long long*>(slot));
+  return BIST_OK;
+}
+
 extern "C" int bist_version(void) { return 101; }   // 0.1.1
 
 extern "C" const char* bist_last_error(void) { return g_err; }

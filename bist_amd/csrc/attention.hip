@@ -285,7 +285,8 @@ extern "C" int bist_st_stage1_pv_fwd(const void* scores, const void* V, const ui
   BIST_REQUIRE(direction == 0 || direction == 1, "bist_st_stage1_pv_fwd: direction must be 0 (t2s) or 1 (s2t)");
   BIST_REQUIRE(sc_dtype == BIST_F32 || sc_dtype == dtype, "bist_st_stage1_pv_fwd: scores must be f32 or the value dtype");
   BIST_REQUIRE(ldv >= (int64_t)h * dk, "bist_st_stage1_pv_fwd: ldv too small");
-  if (dtype == BIST_BF16 && !getenv("BIST_ST1_VALU")) {          // matrix-core path (attention_mfma.hip)
+  static const bool valu_st1 = getenv("BIST_ST1_VALU") != nullptr;      // tuning aid, read once
+  if (dtype == BIST_BF16 && !valu_st1) {          // matrix-core path (attention_mfma.hip)
     const int r = bist_st1_mfma(scores, sc_dtype == BIST_F32, V, tmask, O, nullptr, nullptr, 0, nullptr, B, T, S, Lq, h, dk, ldv, 0,
                                 direction, 0, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
@@ -321,7 +322,8 @@ extern "C" int bist_st_stage2_fwd(const void* q2f, const void* Y, const uint8_t*
   BIST_REQUIRE(dr.p == 0.f || rowsum, "bist_st_stage2_fwd: dropout needs the rowsum output (the value bias is scaled by it)");
   BIST_REQUIRE(B > 0 && G > 0 && Lq > 0 && h > 0 && d > 0, "bist_st_stage2_fwd: bad shape");
   BIST_REQUIRE(h <= ST2_MAXH, "bist_st_stage2_fwd: at most %d heads", ST2_MAXH);
-  if (dtype == BIST_BF16 && !getenv("BIST_ST2_VALU")) {          // matrix-core path (attention_mfma.hip)
+  static const bool valu_st2 = getenv("BIST_ST2_VALU") != nullptr;      // tuning aid, read once
+  if (dtype == BIST_BF16 && !valu_st2) {          // matrix-core path (attention_mfma.hip)
     const int r = bist_st2_mfma(q2f, Y, gmask, PY, nullptr, nullptr, nullptr, rowsum, nullptr, B, G, Lq, h, d, 0, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
     if (r < 0) return BIST_ELAUNCH;      // (the matrix-core launcher left the reason in bist_last_error)

@@ -329,7 +329,8 @@ extern "C" int bist_mha_core_bwd(const void* Q, const void* K, const void* V, co
   BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_mha_core_bwd: drop p out of range");
   const DropArg dr = make_drop(drop);
   BIST_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && h > 0 && dk > 0, "bist_mha_core_bwd: bad shape");
-  if (dtype == BIST_BF16 && !getenv("BIST_MHA_VALU")) {          // matrix-core path (attention_mfma.hip)
+  static const bool valu_mha = getenv("BIST_MHA_VALU") != nullptr;      // tuning aid, read once
+  if (dtype == BIST_BF16 && !valu_mha) {          // matrix-core path (attention_mfma.hip)
     const int r = bist_mha_bwd_mfma(Q, K, V, mask, dO, dP_ext, dQ, dK, dV, N, Lq, Lk, h, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs,
                                     lddq, lddk, lddv, dq_bs, dk_bs, dv_bs, mask_bs, mask_qs, scale, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
@@ -361,7 +362,8 @@ extern "C" int bist_st_stage1_pv_bwd(const float* scores, const void* V, const u
   BIST_REQUIRE(direction == 0 || direction == 1, "bist_st_stage1_pv_bwd: bad direction");
   BIST_REQUIRE(dscores_dtype == BIST_F32 || dscores_dtype == BIST_BF16, "bist_st_stage1_pv_bwd: bad dscores dtype %d", (int)dscores_dtype);
   const int dsc_bf16 = dscores_dtype == BIST_BF16;
-  if (dtype == BIST_BF16 && !getenv("BIST_ST1_VALU")) {          // matrix-core path (attention_mfma.hip)
+  static const bool valu_st1 = getenv("BIST_ST1_VALU") != nullptr;      // tuning aid, read once
+  if (dtype == BIST_BF16 && !valu_st1) {          // matrix-core path (attention_mfma.hip)
     const int r = bist_st1_mfma(scores, 1, V, tmask, nullptr, dO, dscores, dsc_bf16, dV, B, T, S, Lq, h, dk, ldv, lddv, direction, 1, dr,
                                 (hipStream_t)stream);
     if (r == 1) return BIST_OK;
@@ -408,7 +410,8 @@ extern "C" int bist_st_stage2_bwd(const void* q2f, const void* Y, const uint8_t*
   BIST_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "bist_st_stage2_bwd: drop p out of range");
   const DropArg dr = make_drop(drop);
   BIST_REQUIRE(B > 0 && G > 0 && Lq > 0 && h > 0 && h <= ST2_MAXH && d > 0, "bist_st_stage2_bwd: bad shape");
-  if (dtype == BIST_BF16 && !getenv("BIST_ST2_VALU")) {          // matrix-core path (attention_mfma.hip)
+  static const bool valu_st2 = getenv("BIST_ST2_VALU") != nullptr;      // tuning aid, read once
+  if (dtype == BIST_BF16 && !valu_st2) {          // matrix-core path (attention_mfma.hip)
     const int r = bist_st2_mfma(q2f, Y, gmask, nullptr, dPY, dq2f, dY, nullptr, d_rowsum, B, G, Lq, h, d, 1, dr, (hipStream_t)stream);
     if (r == 1) return BIST_OK;
     if (r < 0) return BIST_ELAUNCH;      // (the matrix-core launcher left the reason in bist_last_error)

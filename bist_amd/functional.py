@@ -358,9 +358,13 @@ def side_stream(i: int):
     key = (torch.cuda.current_device(), i)
     st = _SIDE.get(key)
     if st is None:
-        st = torch.cuda.Stream()
-        _SIDE[key] = st
+        if not _streams_ready() or key not in _SIDE:      # (the split executor's stream set, else a stream of the framework's pool)
+            _SIDE[key] = torch.cuda.Stream()
+        st = _SIDE[key]
     return st
+
+
+
 
 
 BRANCH_V = os.environ.get("BIST_BRANCH_V", "0") != "0"      # tuning aid: value projection of a direction inside its branch (training); measured slower (14.5 vs 13.0 ms)
@@ -380,35 +384,136 @@ def param_gate(k: int) -> None:
         PARAM_GATE(k)
 
 
+# Streams a captured graph may span when it is replayed by the RUNTIME's graph executor (the capturing stream included).  Every replay
+# crash seen so far (host-side segmentation fault inside hipGraphLaunch, round 3) was in a graph captured over FOUR streams -- an optimiser
+# stream of its own beside the three of a training step, the four-stream first step of a decode turn -- and none in tens of thousands of
+# replays of three-stream graphs; tests/test_soak_gpu.py holds the three-stream forms to that.  A capture for the runtime's executor that
+# ends with more streams joined is refused.  (A ``Graph`` replayed by the split executor -- one single-queue graph per stream,
+# bist_amd/graphsplit.py -- never hands a multi-branch graph to the runtime and is not limited.)
+MAX_CAPTURE_STREAMS = 3
+
+
+def _streams_ready() -> bool:
+    """The package's streams on hardware queues of their own (split executor usable): [capturing stream, side 0, side 1, side 2, leaf]."""
+    from . import graphsplit as GS
+    dev = torch.cuda.current_device()
+    if (dev, "cap") in _SIDE:
+        return True
+    if torch.cuda.is_current_stream_capturing() or not GS.usable():
+        return False
+    torch.cuda.synchronize()
+    st = GS.distinct_streams(5)
+    _SIDE[(dev, "cap")] = st[0]
+    for i in range(3):
+        _SIDE[(dev, i)] = st[1 + i]
+    _SIDE[(dev, "leaf")] = st[4]
+    return True
+
+
+def leaf_stream():
+    """The stream of the backward pass's leaf products (weight gradients and video-tensor gradients of the frame-grid products: nothing
+    on a direction's chain reads them), or None when the step is replayed by the runtime's executor (a fourth stream there: see
+    MAX_CAPTURE_STREAMS)."""
+    return _SIDE.get((torch.cuda.current_device(), "leaf"))
+
+
+class Graph:
+    """A captured launch sequence and its replay.  ``with capture_graph(g): ...`` then ``g.replay()``.  When the split executor is usable
+    (bist_amd/graphsplit.py: its self-test passes in this process) the capture is labelled per stream and -- if it spans more than one --
+    replayed as one single-queue hipGraph per stream tied by device flags; otherwise, and for one-stream captures, by the runtime."""
+
+    def __init__(self, split: Optional[bool] = None):
+        self.want_split = SPLIT_GRAPHS if split is None else bool(split)
+        self.cuda_graph = None
+        self.split = None
+        self.streams = 0
+
+    def replay(self) -> None:
+        if self.split is not None:
+            self.split.launch()
+        else:
+            self.cuda_graph.replay()
+
+    def errors(self) -> int:
+        return self.split.errors() if self.split is not None else 0
+
+
+SPLIT_GRAPHS = os.environ.get("BIST_SPLIT_GRAPH", "1") != "0"      # tuning aid: 0 = every graph through the runtime's executor
+
+
 class capture_graph:
     """``with capture_graph(graph):`` = torch.cuda.graph(graph, capture_error_mode="thread_local") with Python's cyclic collector paused.
     Cyclic garbage may own hipGraphs and device buffers of EARLIER captures (a model that decoded, a trainer: nn.Module trees are cycles, so
     they die whenever the collector happens to run); destroying those is a runtime call a stream capture does not allow, and the process
     aborts.  torch.cuda.graph stopped collecting before a capture (2.10: only with torch.compiler.config.force_cudagraph_gc), so the
     collector is simply not allowed to run between capture begin and end.  (thread_local: other threads -- the RCCL watchdog -- may touch
-    the runtime during a capture.)"""
+    the runtime during a capture.)  ``graph``: a ``Graph`` (split executor when usable) or a plain torch.cuda.CUDAGraph (runtime's
+    executor: on exit the streams that joined the capture are counted, MAX_CAPTURE_STREAMS, RuntimeError beyond)."""
+
+    LAST_STREAMS = 0          # streams of the most recent capture (tests)
 
     def __init__(self, graph, **kw):
-        self.ctx = torch.cuda.graph(graph, capture_error_mode="thread_local", **kw)
+        self.kw = {k: v for k, v in kw.items() if v is not None}
+        self.g = graph if isinstance(graph, Graph) else None
+        self.raw = None if self.g is not None else graph
+        self.lab = None
 
     def __enter__(self):
         import gc
+        from . import graphsplit as GS
+        split = False
+        if self.g is not None:
+            split = self.g.want_split and CONCURRENT and _streams_ready()
+            self.g.cuda_graph = torch.cuda.CUDAGraph(keep_graph=True) if split else torch.cuda.CUDAGraph()
+            self.raw = self.g.cuda_graph
+            if split:
+                self.kw.setdefault("stream", _SIDE[(torch.cuda.current_device(), "cap")])
+                self.lab = GS.Labels()
+        self.split = split
+        self.ctx = torch.cuda.graph(self.raw, capture_error_mode="thread_local", **self.kw)
         self.was = gc.isenabled()
         gc.disable()
         try:
-            return self.ctx.__enter__()
+            if self.lab is not None:
+                self.lab.__enter__()
+            res = self.ctx.__enter__()
+            self.origin = torch.cuda.current_stream().cuda_stream
+            return res
         except BaseException:
+            if self.lab is not None:
+                self.lab.__exit__(None, None, None)
             if self.was:
                 gc.enable()
             raise
 
     def __exit__(self, *exc):
         import gc
+        from . import graphsplit as GS
+        n = 0
         try:
-            return self.ctx.__exit__(*exc)
+            if exc[0] is None:
+                try:
+                    n = 1 + len(live_side_streams()) if torch.cuda.is_current_stream_capturing() else 0
+                except Exception:
+                    n = 0
+            res = self.ctx.__exit__(*exc)
         finally:
+            if self.lab is not None:
+                self.lab.__exit__(None, None, None)
             if self.was:
                 gc.enable()
+        capture_graph.LAST_STREAMS = n
+        if self.g is not None:
+            self.g.streams = n
+        if exc[0] is None and self.split:
+            sp = GS.SplitGraph(self.raw, self.lab, self.origin)
+            if sp.n_chains > 1:
+                self.g.split = sp
+            # (a one-stream capture: the runtime replays it on its single-queue path as it is)
+        elif exc[0] is None and n > MAX_CAPTURE_STREAMS:
+            raise RuntimeError(f"bist_amd: a hipGraph capture spanning {n} streams for the runtime's graph executor (at most "
+                               f"{MAX_CAPTURE_STREAMS}: replays of wider graphs have crashed inside hipGraphLaunch); it must not be replayed")
+        return res
 
 
 VALUES_AHEAD = os.environ.get("BIST_VALUES_AHEAD", "1") != "0"      # tuning aid: value projections of layer l+1 on the caption stream
@@ -431,9 +536,11 @@ def live_side_streams():
     being captured into a hipGraph -- those that have joined the capture (a wait on a stream outside it would leave the graph)."""
     cap = torch.cuda.is_current_stream_capturing()
     out = []
+    seen = set()
     for (dev, _), st in _SIDE.items():
-        if dev != torch.cuda.current_device():
+        if dev != torch.cuda.current_device() or st.cuda_stream in seen or st.cuda_stream == torch.cuda.current_stream().cuda_stream:
             continue
+        seen.add(st.cuda_stream)
         if cap:
             with torch.cuda.stream(st):
                 if not torch.cuda.is_current_stream_capturing():
@@ -446,9 +553,8 @@ def join_side_streams() -> None:
     """Order the current stream after everything queued on the side streams (end of a backward pass: the weight-gradient
     GEMMs of a side branch write the flat gradient directly, which autograd's own leaf-stream join does not see)."""
     cur = torch.cuda.current_stream()
-    for (dev, _), st in _SIDE.items():
-        if dev == torch.cuda.current_device():
-            cur.wait_stream(st)
+    for st in live_side_streams():       # (during a capture: only the streams that joined it)
+        cur.wait_stream(st)
 
 
 def column_block(w: Tensor, j: int, d: int) -> Tensor:

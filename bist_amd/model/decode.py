@@ -181,9 +181,10 @@ def _graph_step(model, bn, fn, trg, train_args):
         with torch.cuda.stream(side):
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
+        graph = Fn.Graph()
         with Fn.capture_graph(graph):   # other threads (RCCL watchdog) may touch the runtime during capture
             out = run()
+        STATS["captures"] += 1
         g = store[(Lt,) + geom] = (graph, strg, tb.b.trg_mask, out)
     graph, strg, _, out = g
     strg.copy_(trg)
@@ -237,9 +238,10 @@ def _graph_step_incr(model, bn, fn, new_tokens, pos, slot0, mask_np, train_args,
         with torch.cuda.stream(side):
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
+        graph = Fn.Graph()
         with Fn.capture_graph(graph):
             out = run()
+        STATS["captures"] += 1
         g = store[key] = (graph, strg, smask, out, bool(flags.get("self_contained")))
     graph, strg, smask, out, _ = g
     if shared is None:
@@ -337,9 +339,10 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True, pad_sym
         with torch.cuda.stream(side):
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
+        graph = Fn.Graph()
         with Fn.capture_graph(graph):   # other threads (RCCL watchdog) may touch the runtime during capture
             f2, out = run()
+        STATS["captures"] += 1
         fused = "_bist_fused_first" in f2
         g = store[("first",) + geom] = (graph, sb, f2, out, fused)
     graph, sb, f2, out, _ = g
@@ -358,6 +361,11 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True, pad_sym
         # True: the replayed first step ran the decoder layers through the persistent kernel (position 0 sits in slot 0 of its pools)
         ft["_bist_pool_ready"] = bool(g[4]) and dec.select_decode_cache(ft, ft["_bist_turn"])
     return ft, (out.cpu().numpy() if host else out), seen
+
+
+# What the turns of this process did (bench.py reports it next to the turn times): turns decided on the device, turns the device handed back
+# to the host loop (ties / NaN / too few candidates: the turn is then run TWICE), turns on the host loop from the start, hipGraph captures.
+STATS = {"turns": 0, "device": 0, "host_redo": 0, "host": 0, "captures": 0}
 
 
 DEVICE_BEAM = os.environ.get("BIST_DEVICE_BEAM", "1") != "0"      # tuning aid: 0 = the beam update of every step on the host (one D2H + sync per step, like the reference)
@@ -466,6 +474,7 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
     use_graphs = (STEP_GRAPHS and BATCH_HYPOTHESES and batch.query.is_cuda and not torch.is_grad_enabled() and not model.training
                   and getattr(type(model.mutlimodal_decoder), "REASONING_CACHE", False))
     lp_first = None
+    STATS["turns"] += 1
     if use_graphs:
         dec0 = getattr(model, "mutlimodal_decoder", None)
         want_dev = (DEVICE_BEAM and INCREMENTAL and max_len * beam <= 64 and beam + 2 <= 16 and dec0 is not None
@@ -476,10 +485,14 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
             res = _device_beam_turn(model, batch, ft, out0, max_len, unk_symbol, end_symbol, beam, penalty, nbest, min_len, train_args, dec_eos)
             if res is not None:
                 dec0.check_decode_errors()
+                STATS["device"] += 1
                 return res
+            STATS["host_redo"] += 1
             # (ties / NaN / too few candidates: decided on the host exactly like the reference, from the same first step)
         lp_first = out0.cpu().numpy() if want_dev else out0
+        STATS["host"] += 0 if want_dev else 1
     else:
+        STATS["host"] += 1
         ft = model.encode(batch)
     # the hypotheses' token prefixes live on the HOST (the reference keeps them as device tensors and pays two tiny device
     # launches per candidate: decode.py:88-99); one [n, Lt] copy per step carries them to the device

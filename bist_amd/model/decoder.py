@@ -12,6 +12,7 @@ import ctypes as C
 
 from .. import functional as Fn
 from .. import ops
+from .. import stamps as STM
 from .. import zbatch as Z
 from .._lib import BistDecLayer, BistKvFill, check, lib
 from .encoder import _cross_attention, _feed_forward, _self_attention
@@ -421,6 +422,9 @@ class MultimodalDecoder8(nn.Module):
                 # of all layers go to fragment order in ONE launch, into buffers that keep their addresses (hipGraph replays re-run it).
                 ft["_bist_fused_train"] = True
                 ft["_bist_vft_fan"] = Fn.Fan(vft_, 4 * L, FAN_JOIN)
+                # deferred optimiser: the pack reads the value / output weights of EVERY reasoning layer, so the pending update of all
+                # layer pieces must have landed (the per-layer gates below come too late for this launch)
+                Fn.param_gate(len(self.layers))
                 ws, outs = [], []
                 for vl in self.v_layers[:L]:
                     for ai in (1, 4):
@@ -453,6 +457,7 @@ class MultimodalDecoder8(nn.Module):
             both_v = Z.ENABLED                                    # lock-step layer: its stage-1 node consumes both on the main stream
             vb = ft["_bist_vft_fan"].take() if both_v else None
             with torch.cuda.stream(side_):
+                STM.mark("L%d values ahead" % l) if STM.ENABLED else None
                 v1 = self.v_layers[l].train_value(va, 1)          # two-chain layer: t2s only -- its consumer (and its gradient) live on the main
                 v4 = self.v_layers[l].train_value(vb, 4) if both_v else None      # stream; an edge between two side streams crashes hipGraph capture
                 ev = torch.cuda.Event()
@@ -464,19 +469,25 @@ class MultimodalDecoder8(nn.Module):
             issue_values(0)
         conc_keep = Fn.CONCURRENT and x.is_cuda
         for l, layer in enumerate(self.layers):
+            STM.LAYER = l
             Fn.param_gate(1 + min(l + 1, len(self.layers) - 1))      # layer l + 1: its value projection is issued during layer l
             fork_cap = self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda
             if fork_cap:                     # the caption reasoning layer is independent of the visual one
                 main, side = torch.cuda.current_stream(), Fn.side_stream(1)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
+                    in_ft["cap"] = STM.through(in_ft["cap"], "cap in", True)
                     in_ft = self.c_layers[l](in_ft, ft, b)
+                    in_ft["cap"] = STM.through(in_ft["cap"], "cap out", True)
                     ft["cap_ft"], in_ft["cap"] = Fn.layernorm_res(in_ft["cap"], self.cap_out_norm.a_2, self.cap_out_norm.b_2, self.cap_out_norm.eps)                           # decoder.py:132
             if self.v_N > 0:
                 if torch.is_grad_enabled():
                     ft["_bist_out_norms"] = (self.spatial_out_norm, self.temporal_out_norm)
+                if fork_cap:
+                    ft["_bist_cap_fork"] = True
                 in_ft = self.v_layers[l](in_ft, ft, b)
                 ft.pop("_bist_out_norms", None)
+                ft.pop("_bist_cap_fork", None)
                 if in_ft.pop("_norms_done", False):
                     pass                              # the layer applied the two output norms at the end of its direction chains (encoder.py)
                 elif "_z" in in_ft:
@@ -510,7 +521,10 @@ class MultimodalDecoder8(nn.Module):
                 # the last layer's outputs also feed the auto-encoder heads (optimize.py:66-82): an alias per consumer, one-pass gradient sum
                 for k_ in ("cap_ft", "spatial_ft", "temporal_ft"):
                     Fn.fan_set(ft, k_, 2)
+            STM.lmark("main joined")
             self._fuse(ft)
+            if STM.ENABLED:
+                ft["encoded_ft"] = STM.through(ft["encoded_ft"], "fused", True)
             if cache is not None:
                 cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})
             if values_ahead and l + 1 < len(self.layers):
@@ -524,7 +538,7 @@ class MultimodalDecoder8(nn.Module):
                 side.wait_stream(main)
                 Fn._keep_taken(x); Fn._keep_taken(ft.get("encoded_ft"))
                 with torch.cuda.stream(side):
-                    x = layer(b, ft, x)                                                      # :182
+                    x = STM.through(layer(b, ft, STM.through(x, "dec in", True)), "dec out", True)                                                      # :182
                 dec_pending = side
             else:
                 x = layer(b, ft, x)                                                          # :182
@@ -542,7 +556,7 @@ class MultimodalDecoder8(nn.Module):
         ft.pop("_bist_pre_vid", None)
         if cache is not None:
             ft["_bist_reasoning"] = cache
-        ft["decoded_text"] = self.norm(x)                                                    # :185
+        ft["decoded_text"] = STM.through(self.norm(x), "decoded_text")                        # :185
         if torch.is_grad_enabled():
             Fn.fan_set(ft, "decoded_text", 5)          # vocabulary logits, switch logits, one query projection per pointer attention
         return ft

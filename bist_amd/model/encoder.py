@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .. import ops
+from .. import stamps as STM
 from .. import zbatch as Z
 from .modules import LayerNorm, MultiHeadedAttention, PositionwiseFeedForward, SublayerConnection, clones
 
@@ -173,6 +174,7 @@ class VidEncoderLayer4(nn.Module):
             v_event = self.__dict__.get("_v_event")
             if v is not None and v_event is not None:
                 torch.cuda.current_stream().wait_event(v_event)
+            STM.lmark("dir%d pre-st1 (Qf ready, V awaited)" % direction)
             y, xnext = Fn.st_stage1_fused_train(qf, xr, vft, train_fused if v is None else None, tmask, attn, self.frag_train(ai), h=h, direction=direction,
                                                 attn_drop=adrop, sub_drop=(kw["drop_p"], kw["drop_seed"]) if kw else None, v=v,
                                                 offload=direction == 0 and bool(self.__dict__.get("_offload_main")))
@@ -469,36 +471,46 @@ class VidEncoderLayer4(nn.Module):
         out_norms = ft.get("_bist_out_norms") if (torch.is_grad_enabled() and t2s_on and s2t_on) else None
 
         def t2s_branch(ai, si, fi):
-            x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["t2s"], b.query_mask)     # A0
+            x = _self_attention(self.sublayer[si], self.attn[ai], STM.through(in_ft["t2s"], "t2s in", True), b.query_mask)     # A0
+            x = STM.through(x, "t2s A0", True)
             y = self._stage1(ai + 1, si + 1, x, vft_t2s, branch_v(ai + 1) if per_branch_v else v_t2s, b.temporal_mask, 0,
                              permuted=permuted, train_fused=(take() if own_v else True) if train_fused else None)     # A1
             x = self.__dict__.pop("_x_next", x)
+            y = STM.through(y, "t2s st1", True)
             z = self._stage2(ai + 2, si + 2, x, y, None)                                          # A2
-            in_ft["t2s"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F0
+            z = STM.through(z, "t2s st2", True)
+            in_ft["t2s"] = STM.through(_feed_forward(self.sublayer[si + 3], self.ff[fi], z), "t2s ff", True)                   # F0
             if trace is not None:
                 trace.update(t2s_self=x, t2s_stage1=y, t2s_stage2=z, t2s_ff=in_ft["t2s"])
             if out_norms is not None:       # the layer loop's output norm of this stream, here on ITS stream; the stream goes on through the norm's node
                 ft["spatial_ft"], in_ft["t2s"] = Fn.layernorm_res(in_ft["t2s"], out_norms[0].a_2, out_norms[0].b_2, out_norms[0].eps)
 
         def s2t_branch(ai, si, fi):
-            x = _self_attention(self.sublayer[si], self.attn[ai], in_ft["s2t"], b.query_mask)     # A3
+            x = _self_attention(self.sublayer[si], self.attn[ai], STM.through(in_ft["s2t"], "s2t in", True), b.query_mask)     # A3
+            x = STM.through(x, "s2t A3", True)
             y = self._stage1(ai + 1, si + 1, x, vft_s2t, branch_v(ai + 1) if per_branch_v else v_s2t, None, 1,
                              train_fused=(take() if own_v_s2t else True) if train_fused else None)    # A4
             x = self.__dict__.pop("_x_next", x)
+            y = STM.through(y, "s2t st1", True)
             z = self._stage2(ai + 2, si + 2, x, y, b.temporal_mask)                               # A5
-            in_ft["s2t"] = _feed_forward(self.sublayer[si + 3], self.ff[fi], z)                   # F1
+            z = STM.through(z, "s2t st2", True)
+            in_ft["s2t"] = STM.through(_feed_forward(self.sublayer[si + 3], self.ff[fi], z), "s2t ff", True)                   # F1
             if trace is not None:
                 trace.update(s2t_self=x, s2t_stage1=y, s2t_stage2=z, s2t_ff=in_ft["s2t"])
             if out_norms is not None:
                 ft["temporal_ft"], in_ft["s2t"] = Fn.layernorm_res(in_ft["s2t"], out_norms[1].a_2, out_norms[1].b_2, out_norms[1].eps)
 
+        # stream schedule of the fused inference layer; beside a caption layer forked onto its own stream (decoder.py) schedule 1 would make
+        # the capture span four streams, which the runtime's graph executor is not trusted with (Fn.MAX_CAPTURE_STREAMS): schedule 0 there,
+        # unless the graph is replayed by the split executor
+        sched = 0 if (ft.get("_bist_cap_fork") and Fn.leaf_stream() is None and Fn.EVAL_SCHED == 1) else Fn.EVAL_SCHED
         pre_vid = ft.pop("_bist_pre_vid", None)
-        if pre_vid is not None and not (concurrent and fused and Fn.EVAL_SCHED in (1, 2)):
+        if pre_vid is not None and not (concurrent and fused and sched in (1, 2)):
             torch.cuda.current_stream().wait_event(pre_vid)      # no schedule below waits on it: consume it here (see VidEncoder8.forward)
         if trace is not None and fused:
             fused = False                                # the traced form keeps every stage's output: separate launches
             v_t2s, v_s2t = self.value_projection(take())
-        if concurrent and fused and Fn.EVAL_SCHED == 1:
+        if concurrent and fused and sched == 1:
             # both directions as whole chains on two side streams, forked ahead of the input projection when this is the first layer
             side, side2 = Fn.side_stream(0), Fn.side_stream(2)
             for st_ in (side, side2):
@@ -519,7 +531,7 @@ class VidEncoderLayer4(nn.Module):
                 ys = self._stage1_fused(4, xs, qfs, vft_s2t, None, 1)
                 in_ft["s2t"] = _feed_forward(self.sublayer[7], self.ff[1], self._stage2(5, 6, xs, ys, b.temporal_mask))
             main.wait_stream(side2); main.wait_stream(side)
-        elif concurrent and fused and Fn.EVAL_SCHED == 2:
+        elif concurrent and fused and sched == 2:
             # Inference at the production width.  Main stream: the two fused stage-1 launches (each fills the chip), back to back;
             # side stream: the query-side chains of BOTH directions ahead of them (self-attention, LayerNorm, query projection,
             # fold: small launches that depend on the encoded query only -- in the first layer they are forked from BEFORE the

@@ -21,6 +21,7 @@ from .modules import (Embeddings, MultiHeadedAttention, PositionalEncoding, Posi
                       embed_with_position)
 
 from .. import functional as Fn
+from .. import stamps as STM
 
 TGT_EMBED_ON_DECODER_STREAM = os.environ.get("BIST_TGT_EMBED_SIDE", "1") != "0"      # tuning aid, see MTN.multimodal_decode_text
 
@@ -83,11 +84,14 @@ class MTN(nn.Module):
         q, c, h = self.text_encoder(embed_with_position(e, b.query),
                                     embed_with_position(e, b.cap) if b.cap is not None else None,
                                     embed_with_position(e, b.his))
-        ft["encoded_query"], ft["encoded_cap"], ft["encoded_his"] = q, c, h
+        ft["encoded_query"], ft["encoded_cap"], ft["encoded_his"] = STM.through(q, "text enc"), c, h
         return ft
 
     def encode_vid(self, b, ft):
-        return self.vid_encoder(b, ft)
+        ft = self.vid_encoder(b, ft)
+        if STM.ENABLED and "spatiotemporal_ft" in ft:
+            ft["spatiotemporal_ft"] = STM.through(ft["spatiotemporal_ft"], "P0")
+        return ft
 
     def decode(self, b, ft, pos0: int = 0):
         """pos0 (beam search, one decode step at a time): ``b.trg`` holds only the tokens at positions pos0 .. of the prefixes."""

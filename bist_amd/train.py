@@ -36,6 +36,8 @@ from .model.label_smoothing import LabelSmoothing
 from .model.modules import MultiHeadedAttention
 from .model.optimize import SimpleLossCompute
 from . import functional as Fn
+from . import graphsplit as GS
+from . import stamps as STM
 from . import ops, parallel
 from .ops import _stream, dtype_code
 
@@ -45,6 +47,9 @@ ALIGN = 64      # elements; keeps every parameter view 16-byte aligned for the L
 ADAM_CLEARS = os.environ.get("BIST_ADAM_CLEARS", "0") != "0"      # tuning aid: 1 = Adam on 4 elements per thread that also clears the gradients it consumed, no memset of the gradient
                                                                   # buffer at the head of a replayed step (measured 11.83-11.91 vs 11.72-11.79 ms per step: not adopted)
 ALWAYS_COPY_INPUTS = os.environ.get("BIST_ALWAYS_COPY_INPUTS", "0") != "0"      # 1 = every step copies the batch into the graph's static buffers (see Trainer.invalidate_inputs)
+# The captured step replayed as one linear hipGraph per stream, tied by device-side flags (bist_amd/graphsplit.py) instead of through the
+# runtime's multi-branch graph executor, which serialises independent branches.  0 = torch's CUDAGraph.replay().
+SPLIT_GRAPH = os.environ.get("BIST_SPLIT_GRAPH", "1") != "0"
 EXCHANGE_CHUNKS = int(os.environ.get("BIST_EXCHANGE_CHUNKS", "4"))        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
 
 
@@ -60,6 +65,7 @@ class Trainer:
         self.model, self.args = model, args
         self.use_graph = use_graph
         self._graph = self._graph2 = self._graph_key = self._static_batch = self._static_terms = None
+        self._split = self._split2 = None
         self._static_src = {}
         self.compute_dtype = compute_dtype
         self.warmup, self.factor, self.betas, self.eps = warmup, factor, betas, eps
@@ -291,7 +297,9 @@ class Trainer:
         if clear:
             self.flat_grad.zero_()
         self.acc32.zero_()
+        STM.mark("step head")
         loss, terms = self.forward_loss(batch)
+        loss = STM.through(loss, "loss")
         if after_forward is not None:
             after_forward()
         ops.COLSUM_QUEUE = []                 # bias gradients: queued by LinearFn.backward, summed in a few launches by _backward_close
@@ -300,8 +308,10 @@ class Trainer:
         ops.WGRAD_STREAM = wg                 # weight-gradient GEMMs: off the critical path, on their own stream
         try:
             loss.backward()
+            STM.mark("backward issued (main)")
             if loss.is_cuda:
                 Fn.join_side_streams()
+            STM.mark("streams joined")
             if wg is not None:
                 torch.cuda.current_stream().wait_stream(wg)
             for p in self.params:                # anything autograd still produced itself (views, fallbacks)
@@ -347,10 +357,13 @@ class Trainer:
             with torch.cuda.stream(side):
                 (self._adam_apply if ADAM_CLEARS else self._adam_dev)(self.n32, self.numel)
         self._backward_close()
+        STM.mark("closing reductions done")
         if optimizer:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
+                STM.mark("adam (big) done")
                 (self._adam_apply if ADAM_CLEARS else self._adam_dev)(0, self.n32)
+                STM.mark("step end")
             else:
                 self._adam_dev(0, self.numel)
         else:
@@ -370,17 +383,22 @@ class Trainer:
         static inputs).  Warm-up runs on a side stream first, as graph capture requires.  Several ranks: TWO graphs, the
         cut where the big matrices' gradients are final, so that their all-reduce starts under the closing reductions."""
         batch = self._own_copy(batch)             # the graphs read trainer-owned buffers, never the caller's (a feeder slot is rewritten in flight)
+        graph = Fn.Graph(split=SPLIT_GRAPH and self.flat_grad.is_cuda)
+        if graph.want_split and Fn._streams_ready():
+            # the weight-gradient stream (BIST_WGRAD_STREAM=1) on a hardware queue of its own as well
+            if self.wgrad_side_stream:
+                self._wgrad_stream = GS.distinct_streams(6)[5]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
                 self.backward(batch)              # warm-up passes leave the weights alone
         torch.cuda.current_stream().wait_stream(side)
-        graph, graph2 = torch.cuda.CUDAGraph(), None
+        graph2 = None
         if self.exchanging:
             with Fn.capture_graph(graph):   # other threads (RCCL watchdog) may touch the runtime during capture
                 terms = self._backward_open(batch)
-            graph2 = torch.cuda.CUDAGraph()
+            graph2 = Fn.Graph(split=False)
             with Fn.capture_graph(graph2):
                 self._backward_close()
         else:
@@ -390,6 +408,7 @@ class Trainer:
                     terms = self.backward(batch, optimizer=self.adam_in_step)
             finally:
                 self._skip_head_clear = False
+        self._split = graph.split
         self._graph, self._graph2, self._graph_key, self._static_batch, self._static_terms = graph, graph2, key, batch, terms
         self._static_src = {}
 

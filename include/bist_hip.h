@@ -65,6 +65,9 @@ void bist_launch_count_reset(void);
  * buffer for its in-kernel s_memtime stamps (8 / 128 uint64 per workgroup; see scripts/stamp_*.py), or NULL to switch them off.
  * Production never calls it; nothing is read from the environment.                                                           */
 int bist_dev_set_stamps(int32_t which, void* device_buffer);
+/* Development hook: a one-thread launch on `stream` that writes the device's 100 MHz wall clock to *slot (uint64, device memory).
+ * Captured into a hipGraph it timestamps that point of that stream on every replay (bist_amd/stamps.py).  Production never calls it. */
+int bist_dev_timestamp(void* slot, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM  C[z] = epilogue( alpha * A[z] . B[z]^T )            (fp32 accumulate on the MFMA units)
@@ -624,6 +627,51 @@ typedef struct BistStageJob {
   const void* src; void* dst; int64_t rows; int64_t src_row_bytes; int64_t dst_row_bytes; uint64_t pad; int32_t pad_bytes; int32_t reserved_;
 } BistStageJob;
 int bist_stage_inputs(const BistStageJob* jobs, int32_t n_jobs, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Replay of a captured multi-stream hipGraph as ONE LINEAR GRAPH PER STREAM (csrc/graphsplit.hip).
+ *
+ * The reference runs its step as eager PyTorch launches on one stream (train.py:29-37; there is no graph or executor in the
+ * reference to cite); this build captures the step over three streams (bist_amd/train.py) and, instead of handing the multi-branch
+ * graph to the runtime's executor -- which serialises independent branches -- splits it: per capture stream a
+ * clone that keeps that stream's nodes in capture order, with every cross-stream dependency replaced by a SIGNAL launch after the
+ * producer and a WAIT launch before the consumer on a device flag word (step-numbered, so nothing is reset between replays; waits
+ * implied by earlier waits are dropped; waits are bounded by a time-out that counts into an error word instead of hanging a queue).
+ *
+ *   bist_graph_capture_tail   during a capture: the node the capturing `stream` would depend on next (its last node), or NULL --
+ *                             the caller records "this node was captured on this stream" after each of its launches
+ *   bist_graph_nodes          the node handles of a hipGraph_t in the order the labels are given in
+ *   bist_graph_split_plan     the planner alone on index arrays (host only, no device): tests check it against random DAGs
+ *   bist_graph_split_create   plan for `graph`: labels[i] = chain (0..n_chains-1) of node i, -1 = unknown (joins a predecessor's chain);
+ *                             main_chain = the chain that is launched into the caller's stream
+ *   bist_graph_split_sync_words   uint64 words of DEVICE memory the caller provides, zeroed: [n_chains epochs][1 error count][flags][2 stamps per sync launch]
+ *   bist_graph_split_build    clones, prunes, inserts the sync launches, instantiates; timeout_ticks of the 100 MHz device clock per wait
+ *   bist_graph_split_launch   one hipGraphLaunch per chain; streams[c] must sit on pairwise different hardware queues
+ *   bist_graph_queues_distinct    probe for that: scratch = 4 zeroed uint64 (device); after both streams drained scratch[1] == 0 iff
+ *                             a launch on stream_b could run while stream_a held a wait for it AND a further launch behind that wait
+ * The library allocates no device memory; the BistGraphSplit object is host memory released by bist_graph_split_destroy.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct BistGraphSplit BistGraphSplit;
+int bist_graph_capture_tail(void* stream, void** node_out);
+int bist_graph_nodes(void* hip_graph, void** nodes_out, int32_t cap, int32_t* n_out);
+int64_t bist_graph_split_plan(int32_t n_nodes, const int32_t* edge_from, const int32_t* edge_to, int32_t n_edges, const int32_t* labels,
+                              int32_t n_chains, int32_t main_chain, int32_t* out, int64_t cap);
+int bist_graph_split_create(void* hip_graph, const int32_t* labels, int32_t n_labels, int32_t n_chains, int32_t main_chain, BistGraphSplit** out);
+int64_t bist_graph_split_sync_words(const BistGraphSplit* split);
+/* The sync launches in the order of their stamp words (the caller's words end with two uint64 per sync launch: device clock at its begin
+ * and end): 8 int32 each -- chain, kind (1 epoch bump, 2 signal, 3 wait), index of the captured node a signal follows / a wait precedes
+ * (-1: none), flag ids (signal: one; wait: up to four, -1 unused), 0.  Returns the number of int32 (also when cap is too small). */
+int64_t bist_graph_split_sync_items(const BistGraphSplit* split, int32_t* out, int64_t cap);
+int bist_graph_split_info(const BistGraphSplit* split, int32_t* out5, int32_t* nodes_per_chain);
+int bist_graph_split_build(BistGraphSplit* split, void* hip_graph, void* sync_words, int64_t timeout_ticks);
+int bist_graph_split_launch(BistGraphSplit* split, void* const* streams);
+int bist_graph_split_launch_chain(BistGraphSplit* split, int32_t chain, void* stream);      /* development aid: one chain's launch alone */
+void bist_graph_split_destroy(BistGraphSplit* split);
+int bist_graph_queues_distinct(void* stream_a, void* stream_b, void* scratch, int64_t timeout_ticks);
+/* Development aid: a one-wave launch that stays resident on `stream` for `ticks` of the 100 MHz clock (mode 0: sleeps and reads the clock;
+ * 1: also polls word[0] with relaxed loads; 2: with acquire loads; 3: `ticks` rounds of s_sleep, no memory, no clock) -- measures what a
+ * resident wave on another queue costs the launches of a step (scripts/probe_idle_wave.py).  word: 2 uint64 of device memory. */
+int bist_dev_idle_wave(void* stream, int64_t ticks, int32_t mode, void* word);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,121 @@
+"""The split-graph executor on the device (bist_amd/graphsplit.py, csrc/graphsplit.hip): a graph captured over three streams replayed as
+three linear graphs tied by device flags must compute what the captured graph computes, on every replay, with changing inputs, and
+report no timed-out wait; the hardware-queue probe must tell one stream from another; the trainer's split step must train exactly
+like its eager step."""
+import argparse
+import copy
+
+import pytest
+import torch
+
+from oracle import bist_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    from bist_amd import functional as Fn, graphsplit as GS, ops
+    return Fn, GS, ops
+
+
+def _issue(ops, x, streams, rounds):
+    """A little DAG with forks, joins and chains on three streams; returns the result tensor."""
+    main = torch.cuda.current_stream()
+    s1, s2 = streams
+    a = ops.add(x, x)                                   # main
+    acc = a
+    for r in range(rounds):
+        s1.wait_stream(main)
+        with torch.cuda.stream(s1):
+            b = ops.add(acc, a)
+            for _ in range(3):
+                b = ops.add(b, a)                       # a chain on s1
+        s2.wait_stream(main)
+        with torch.cuda.stream(s2):
+            c = ops.add(acc, acc)
+            c = ops.add(c, a)
+        d = ops.add(acc, x)                             # main goes on meanwhile
+        main.wait_stream(s1)
+        main.wait_stream(s2)
+        acc = ops.add_n([b, c, d])                      # join
+    return acc
+
+
+def test_three_stream_graph_split_equals_the_captured_graph(env):
+    Fn, GS, ops = env
+    torch.manual_seed(0)
+    x = torch.randn(1 << 14, device="cuda") * 0.01
+    s0, *streams = GS.distinct_streams(3)               # every chain replays on the stream it was captured on: three hardware queues
+    ref = _issue(ops, x, streams, 6)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _issue(ops, x, streams, 6)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with GS.Labels() as lab, torch.cuda.graph(g, stream=s0, capture_error_mode="thread_local"):
+        origin = torch.cuda.current_stream().cuda_stream
+        out = _issue(ops, x, streams, 6)
+    sp = GS.SplitGraph(g, lab, origin)
+    assert sp.info["chains"] == 3 and sp.info["nodes"] == 1 + 6 * 8 and sp.info["labelled"] == sp.info["nodes"], sp.info
+    assert 0 < sp.info["waits"] <= 4 * 6 + 3 and min(sp.info["nodes_per_chain"]) >= 12, sp.info
+    for i in range(5):
+        x.mul_(1.5 if i else 1.0)                       # the graphs read x in place
+        want = _issue(ops, x, streams, 6)
+        sp.launch()
+        assert sp.errors() == 0
+        assert torch.equal(out, want), i
+    for _ in range(200):                                # back to back: epochs, not resets, keep the flags apart
+        sp.launch()
+    assert sp.errors() == 0 and torch.equal(out, want)
+
+
+def test_queue_probe_tells_a_stream_from_itself(env):
+    Fn, GS, ops = env
+    s = torch.cuda.Stream()
+    scratch = torch.zeros(4, dtype=torch.int64, device="cuda")
+    assert not GS._distinct(s.cuda_stream, s.cuda_stream, scratch)         # a wait ahead of its own signal can only time out
+    three = GS.distinct_streams(3)
+    assert len(three) == 3 and all(t.cuda_stream != 0 for t in three)
+    assert all(GS._distinct(a.cuda_stream, b.cuda_stream, scratch) for a in three for b in three if a is not b)
+
+
+def _args(cfg):
+    return argparse.Namespace(**{**cfg.__dict__, "d_ff": 4 * cfg.d_model})
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_trainer_split_step_trains_like_the_runtime_replay(env, dtype, monkeypatch):
+    """Six optimiser steps: the split executor against torch's replay of the same capture and against the eager step."""
+    Fn, GS, ops = env
+    assert GS.usable(), GS.WHY_NOT
+    import bist_amd.model as M
+    from bist_amd import train as T
+    from bist_amd.data.synthetic import synthetic_batch
+    cfg = O.Cfg(d_model=64, att_h=4, nb_blocks=3, nb_venc_blocks=3, nb_cenc_blocks=3)
+    args = _args(cfg)
+    torch.manual_seed(0)
+    m0 = M.make_model(80, 80, args, ft_sizes=[64]).cuda().eval()
+    bs = [synthetic_batch(4, T=6, S=9, C=64, Lq=7, Lh=9, Lc=6, Lt=6, vocab=80, seed=s_, dtype=dtype) for s_ in (1, 2)]
+    res, losses = {}, {}
+    for tag, split, graph in (("eager", False, False), ("replay", False, True), ("split", True, True)):
+        monkeypatch.setattr(T, "SPLIT_GRAPH", split)
+        m = copy.deepcopy(m0)
+        t = T.Trainer(m, args, 80, compute_dtype=dtype, warmup=20, factor=2.0, use_graph=graph)
+        losses[tag] = [t.step(bs[i % 2])["out"].item() for i in range(6)]
+        if split:
+            assert t._split is not None and t._split.info["chains"] == 3 and t._split.errors() == 0, t._split.info
+        m.eval()
+        torch.cuda.synchronize()
+        res[tag] = {k: v.detach().float().clone() for k, v in m.named_parameters()}
+    keys = [k for k in res["eager"] if not k.endswith("linears.1.bias")]      # (exactly-zero gradients: see test_train_gpu.py)
+    scale = max(res["eager"][k].abs().max().item() for k in keys)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    for other in ("replay", "split"):
+        worst, key = max(((res["eager"][k] - res[other][k]).abs().max().item(), k) for k in keys)
+        assert worst <= tol * scale, (other, worst, key)
+        assert all(abs(a - b) <= (1e-3 if dtype == torch.float32 else 5e-2) * abs(a) for a, b in zip(losses["eager"], losses[other])), (other, losses)
