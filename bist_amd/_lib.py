@@ -169,6 +169,8 @@ SIGNATURES = {
     "bist_graph_capture_tail": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "bist_graph_nodes": (C.c_int, [_P, C.POINTER(C.c_void_p), _I32, C.POINTER(C.c_int32)]),
     "bist_graph_split_plan": (C.c_int64, [_I32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I32, C.POINTER(C.c_int32), _I32, _I32, C.POINTER(C.c_int32), _I64]),
+    "bist_graph_edges": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I32, C.POINTER(C.c_int32)]),
+    "bist_graph_split_dump": (C.c_int64, [_P, C.POINTER(C.c_int32), _I64]),
     "bist_graph_split_create": (C.c_int, [_P, C.POINTER(C.c_int32), _I32, _I32, _I32, C.POINTER(C.c_void_p)]),
     "bist_graph_split_sync_words": (C.c_int64, [_P]),
     "bist_graph_split_sync_items": (C.c_int64, [_P, C.POINTER(C.c_int32), _I64]),
@@ -179,6 +181,7 @@ SIGNATURES = {
     "bist_graph_split_destroy": (None, [_P]),
     "bist_graph_queues_distinct": (C.c_int, [_P, _P, _P, _I64]),
     "bist_dev_idle_wave": (C.c_int, [_P, _I64, _I32, _P]),
+    "bist_graph_queue_pace": (C.c_int, [_P, _I32, _P, _I64, _P, C.POINTER(C.c_float)]),
 }
 
 

@@ -59,6 +59,43 @@ class _WeightGradStream:
         return False
 
 
+class _Leaf:
+    """Products of a backward node that nothing on its chain of dependent launches reads -- weight gradients (they accumulate into the
+    trainer's flat gradient) and the video tensor's gradients of the frame-grid products (summed once, at the end, by FanOutFn) -- leave
+    the chain: on ``ops.LEAF_STREAM`` (set by the trainer around a backward pass whose step is replayed by the split executor; a chain
+    of its own there) after a fork from the current stream.  Operands are kept alive in ``ops.WGRAD_KEEP`` until the trainer has joined
+    the streams; a tensor that escapes to another autograd node takes ``ready()`` -- the event its consumer waits on -- as its
+    ``_bist_ready`` attribute (FanOutFn honours it).  Without a leaf stream the body runs in line."""
+
+    def __init__(self, *keep, on: bool = True):
+        self.keep = keep
+        self.cm = None
+        self.st = None
+        self.on = on
+
+    def __enter__(self):
+        st = ops.LEAF_STREAM if self.on else None
+        if st is not None and st != torch.cuda.current_stream():
+            st.wait_stream(torch.cuda.current_stream())
+            ops.WGRAD_KEEP.append(self.keep)
+            self.st = st
+            self.cm = torch.cuda.stream(st)
+            self.cm.__enter__()
+        return self
+
+    def ready(self):
+        if self.st is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.st)
+        return ev
+
+    def __exit__(self, *exc):
+        if self.cm is not None:
+            self.cm.__exit__(*exc)
+        return False
+
+
 def _mask_u8(mask: Optional[Tensor]):
     if mask is None:
         return None
@@ -87,7 +124,8 @@ class LinearFn(Function):
     """y = drop(act(alpha * x.W^T + bias)) + residual[row map]   (GEMM epilogue, include/bist_hip.h)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, act, res_map, alpha, drop_p, drop_seed, out_dtype, out_shape=None):
+    def forward(ctx, x, w, bias, residual, act, res_map, alpha, drop_p, drop_seed, out_dtype, out_shape=None, leaf=False):
+        ctx.leaf = bool(leaf)
         K = x.shape[-1]
         ln = getattr(x, "_bist_ln", None)              # x is a pending LayerNorm output: this product normalises the rows itself and fills x
         if ln is not None:
@@ -153,6 +191,19 @@ class LinearFn(Function):
                                         _ptr(ops.DROP_CTR) if drop_p > 0 else None, dtype_code(dz.dtype), _stream()),
                   "bist_epilogue_bwd")
             dz = dz2
+        if ctx.leaf and ctx.gate is None and ops.LEAF_STREAM is not None and (ops.LEAF_MASK & 1):
+            # a projection of the video tensor (the stage-1 values): both backward products are leaves -- dX is one of the video tensor's
+            # gradients (FanOutFn sums them at the end), dW accumulates into the flat gradient
+            with _Leaf(x2, w, dz) as lf:
+                dx, dw, db = _linear_grads(x2, w, dz, alpha, ctx.w_dst, ctx.b_dst, bias_dtype if has_bias else None,
+                                           ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
+                ev = lf.ready()
+            if dx is not None:
+                dx = dx.view(x_shape)
+                if ev is not None:
+                    dx._bist_ready = ev
+                    ops.WGRAD_KEEP.append((dx,))
+            return dx, dw, db, dres, None, None, None, None, None, None, None, None
         dx, dw, db = _linear_grads(x2, w, dz, alpha, ctx.w_dst, ctx.b_dst, bias_dtype if has_bias else None,
                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2], gate=ctx.gate)
         if dx is not None:
@@ -161,7 +212,7 @@ class LinearFn(Function):
                 dx._bist_dz = (dx, ctx.gate[0], ctx.gate[1], "gate")      # survives only if autograd hands THIS tensor to the producer
                 if isinstance(ctx.gate, GateTag):
                     ctx.gate.gated += 1
-        return dx, dw, db, dres, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
 def _linear_grads(x2, w, dz, alpha, w_dst, b_dst, bias_dtype, need_dx, need_dw, need_db, gate=None):
@@ -244,7 +295,8 @@ GATE_HANDOFF = os.environ.get("BIST_GATE_HANDOFF", "1") != "0"      # tuning aid
 
 
 def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, res_map=(0, 0), alpha=1.0, out=None, out_dtype=None,
-           accumulate=False, drop_p=0.0, drop_seed=0, out_shape=None):
+           accumulate=False, drop_p=0.0, drop_seed=0, out_shape=None, leaf=False):
+    """leaf: both backward products of this projection are leaves of the backward pass (see _Leaf): x is the video tensor."""
     if not torch.is_grad_enabled():
         y = ops.linear(x, w, bias, act=act, residual=residual, res_map=res_map, alpha=alpha, out=out, out_dtype=out_dtype,
                        accumulate=accumulate, drop_p=drop_p, drop_seed=drop_seed)
@@ -254,7 +306,7 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, res_map=(0, 0), alph
     if residual is not None and residual.dim() != 2:
         residual = residual.reshape(-1, residual.shape[-1])
     y = LinearFn.apply(x, w, bias, residual, act, tuple(res_map), alpha, drop_p, drop_seed, out_dtype,
-                       tuple(out_shape) if out_shape is not None else None)
+                       tuple(out_shape) if out_shape is not None else None, bool(leaf))
     if drop_p > 0 and act == ACT_NONE and res_map == (0, 0):
         # y = drop(z) + res: a LayerNorm that consumes y can hand the masked gradient of z back (see _ln_backward)
         y._bist_drop = (float(drop_p), int(drop_seed), w.shape[0])
@@ -596,10 +648,21 @@ class FuseDynFn(Function):
             wd = gw if gw is not None else torch.empty(W.shape, device=W.device, dtype=W.dtype)
             want_b = bdt is not None
             bd = (ctx.b_dst if ctx.b_dst is not None else torch.empty((n,), device=W.device, dtype=torch.float32)) if want_b else None
-            check(lib.bist_switch_logits_bwd(arr, n_, W.data_ptr(), W.stride(0), dscore.data_ptr(), dtype_code(dscore.dtype), darr, rarr,
-                                            wd.data_ptr(), wd.stride(0), dtype_code(wd.dtype), 1 if gw is not None else 0,
-                                            _ptr(bd), 1 if (want_b and ctx.b_dst is not None) else 0, M, d, n, dtype_code(W.dtype), _stream()),
-                  "bist_switch_logits_bwd")
+            if ops.LEAF_STREAM is not None and (ops.LEAF_MASK & 2) and gw is not None and (not want_b or ctx.b_dst is not None):
+                # the parts' gradients on this chain; the weight / bias gradient (one slow launch on few workgroups: a leaf) off it
+                check(lib.bist_switch_logits_bwd(arr, n_, W.data_ptr(), W.stride(0), dscore.data_ptr(), dtype_code(dscore.dtype), darr, rarr,
+                                                None, 0, dtype_code(wd.dtype), 0, None, 0, M, d, n, dtype_code(W.dtype), _stream()),
+                      "bist_switch_logits_bwd")
+                with _Leaf(dscore, *p2):
+                    check(lib.bist_switch_logits_bwd(arr, n_, W.data_ptr(), W.stride(0), dscore.data_ptr(), dtype_code(dscore.dtype), None, None,
+                                                    wd.data_ptr(), wd.stride(0), dtype_code(wd.dtype), 1,
+                                                    _ptr(bd), 1 if want_b else 0, M, d, n, dtype_code(W.dtype), _stream()),
+                          "bist_switch_logits_bwd")
+            else:
+                check(lib.bist_switch_logits_bwd(arr, n_, W.data_ptr(), W.stride(0), dscore.data_ptr(), dtype_code(dscore.dtype), darr, rarr,
+                                                wd.data_ptr(), wd.stride(0), dtype_code(wd.dtype), 1 if gw is not None else 0,
+                                                _ptr(bd), 1 if (want_b and ctx.b_dst is not None) else 0, M, d, n, dtype_code(W.dtype), _stream()),
+                      "bist_switch_logits_bwd")
             db = None
             if want_b and ctx.b_dst is None:
                 db = _to_dtype_from_f32(bd, bdt)
@@ -877,7 +940,9 @@ class St1FusedTrainFn(Function):
         # direction's chain -- they go to the caption / decoder stream; the video gradient carries the event its consumer (the one-pass sum of
         # the video tensor's gradients, FanOutFn) waits on, the weight gradient is joined with every side stream at the end of the backward pass.
         side = None
-        if offload and ctx.w_dst[1] is not None and ctx.b_dst[1] is not None and dev.type == "cuda":
+        if ops.LEAF_STREAM is not None and (ops.LEAF_MASK & 1) and ctx.w_dst[1] is not None and ctx.b_dst[1] is not None and dev.type == "cuda":
+            side = ops.LEAF_STREAM              # split executor: a chain of its own for the leaves of BOTH directions
+        elif offload and ctx.w_dst[1] is not None and ctx.b_dst[1] is not None and dev.type == "cuda":
             from . import functional as Fn_
             if Fn_.CONCURRENT:
                 side = Fn_.side_stream(1)
@@ -905,6 +970,7 @@ class St1FusedTrainFn(Function):
         else:
             cur = torch.cuda.current_stream()
             side.wait_stream(cur)
+            ops.WGRAD_KEEP.append((dz, o2, dsc, q3, dvft_a))
             for t_ in (dz, o2, dsc, q3, dvft_a):
                 t_.record_stream(side)              # read / written by the side stream after this call has released them
             with torch.cuda.stream(side):
@@ -918,9 +984,15 @@ class St1FusedTrainFn(Function):
             gva._bist_ready = dvft_a._bist_ready
         if not ctx.own_v:            # the value projection is a product of its own (another stream): its backward takes dV from here
             return (dqf.view(qf_shape), dres.view(x_shape), gva, None, dv, None, None, None, dwo, dbo, None, None, None)
-        dvft_b, dwv, dbv = _linear_grads(vft.view(B * TS, d), wv, dv.view(B * TS, d), 1.0, ctx.w_dst[0], ctx.b_dst[0], bdt, True,
-                                         ctx.needs_input_grad[6], ctx.needs_input_grad[7])
-        return (dqf.view(qf_shape), dres.view(x_shape), gva, dvft_b.view(vft.shape), None, None, dwv, dbv, dwo, dbo, None, None, None)
+        with _Leaf(vft, wv, dv, on=bool(ops.LEAF_MASK & 1)) as lf:        # the launch projected the values itself: the projection's two backward products are leaves too
+            dvft_b, dwv, dbv = _linear_grads(vft.view(B * TS, d), wv, dv.view(B * TS, d), 1.0, ctx.w_dst[0], ctx.b_dst[0], bdt, True,
+                                             ctx.needs_input_grad[6], ctx.needs_input_grad[7])
+            ev_b = lf.ready()
+        gvb = dvft_b.view(vft.shape)
+        if ev_b is not None:
+            gvb._bist_ready = ev_b
+            ops.WGRAD_KEEP.append((dvft_b,))
+        return (dqf.view(qf_shape), dres.view(x_shape), gva, gvb, None, None, dwv, dbv, dwo, dbo, None, None, None)
 
 
 class StStage2Fn(Function):

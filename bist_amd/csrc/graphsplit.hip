@@ -262,6 +262,41 @@ extern "C" int bist_graph_nodes(void* graph, void** nodes_out, int32_t cap, int3
   return BIST_OK;
 }
 
+// The edges of a hipGraph as index pairs into bist_graph_nodes' order (analysis aid: scripts/critical_path.py)
+extern "C" int bist_graph_edges(void* graph, int32_t* from_out, int32_t* to_out, int32_t cap, int32_t* n_out) {
+  BIST_REQUIRE(graph && n_out, "bist_graph_edges: null argument");
+  hipGraph_t g = static_cast<hipGraph_t>(graph);
+  size_t n = 0, ne = 0;
+  GS_HIP(hipGraphGetNodes(g, nullptr, &n), "hipGraphGetNodes");
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n) GS_HIP(hipGraphGetNodes(g, nodes.data(), &n), "hipGraphGetNodes");
+  GS_HIP(hipGraphGetEdges(g, nullptr, nullptr, &ne), "hipGraphGetEdges");
+  *n_out = (int32_t)ne;
+  if (!from_out || !to_out || cap < (int32_t)ne || !ne) return BIST_OK;
+  std::vector<hipGraphNode_t> ef(ne), et(ne);
+  GS_HIP(hipGraphGetEdges(g, ef.data(), et.data(), &ne), "hipGraphGetEdges");
+  std::vector<std::pair<hipGraphNode_t, int>> idx(n);
+  for (size_t i = 0; i < n; ++i) idx[i] = {nodes[i], (int)i};
+  std::sort(idx.begin(), idx.end());
+  auto find = [&](hipGraphNode_t p) { auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(p, -1)); return (it != idx.end() && it->first == p) ? it->second : -1; };
+  for (size_t e = 0; e < ne; ++e) { from_out[e] = find(ef[e]); to_out[e] = find(et[e]); }
+  return BIST_OK;
+}
+
+// The whole plan in the flat form of bist_graph_split_plan (analysis aid)
+extern "C" int64_t bist_graph_split_dump(const BistGraphSplit* S, int32_t* out, int64_t cap) {
+  if (!S) return -1;
+  const Plan& P = S->plan;
+  int64_t k = 0;
+  auto put = [&](int v) { if (out && k < cap) out[k] = v; ++k; };
+  for (int c = 0; c < P.C; ++c) {
+    put(-1); put(c);
+    for (const Item& it : P.seq[c]) { put(it.kind); put(it.node); for (int j = 0; j < MAXW; ++j) put(it.flags[j]); }
+  }
+  put(-2); put(P.n_flags);
+  return k;
+}
+
 extern "C" int bist_graph_split_create(void* graph, const int32_t* labels, int32_t n_labels, int32_t n_chains, int32_t main_chain,
                                        BistGraphSplit** out) {
   BIST_REQUIRE(graph && out, "bist_graph_split_create: null argument");
@@ -444,4 +479,51 @@ extern "C" int bist_dev_idle_wave(void* stream, int64_t ticks, int32_t mode, voi
   gs_idle_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>((unsigned long long)ticks, mode, w, w + 1);
   BIST_LAUNCH_CHECK("bist_dev_idle_wave");
   return BIST_OK;
+}
+
+// Do two hardware queues get in each other's way?  A linear graph of n one-thread launches replayed into `stream`, timed with events:
+// alone (resident_stream null) or while one wave stays resident on `resident_stream` for resident_ticks of the 100 MHz clock.  Measured
+// on MI355X (profiles/r04_queue_pairs.txt): with eight hardware queues the queues come in PAIRS that share a dispatch pipe -- a
+// resident wave on one triples the launch-to-launch time on its partner (2.1 -> 6.2 us) and leaves the other six alone; a chain of a
+// split graph spends much of its life resident in a wait, so chains must sit on different pipes.  word: 2 uint64 of device memory.
+// Synchronises both streams.  us_per_launch_out: the measured microseconds per launch.
+extern "C" int bist_graph_queue_pace(void* stream, int32_t n, void* resident_stream, int64_t resident_ticks, void* word, float* us_per_launch_out) {
+  BIST_REQUIRE(stream && n >= 8 && n <= 4096 && word && us_per_launch_out, "bist_graph_queue_pace: bad argument (a non-null stream, 8..4096 launches)");
+  unsigned long long* w = static_cast<unsigned long long*>(word);
+  hipGraph_t g = nullptr;
+  GS_HIP(hipGraphCreate(&g, 0), "hipGraphCreate");
+  hipGraphNode_t prev = nullptr;
+  unsigned long long* e = w;
+  unsigned long long* nostamp = nullptr;
+  for (int i = 0; i < n; ++i) {
+    void* args[] = {&e, &nostamp};
+    hipGraphNode_t node = nullptr;
+    int rc = add_kernel_node(g, prev, reinterpret_cast<void*>(gs_bump_kernel), args, &node);
+    if (rc != BIST_OK) { (void)hipGraphDestroy(g); return rc; }
+    prev = node;
+  }
+  hipGraphExec_t ex = nullptr;
+  hipError_t er = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (er != hipSuccess) { (void)hipGraphDestroy(g); bist_set_error("bist_graph_queue_pace: hipGraphInstantiate: %s", hipGetErrorString(er)); return BIST_ELAUNCH; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = BIST_OK;
+  float ms = 0.f;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = BIST_ELAUNCH; bist_set_error("bist_graph_queue_pace: hipEventCreate failed"); }
+  if (rc == BIST_OK && hipGraphLaunch(ex, st) != hipSuccess) rc = BIST_ELAUNCH;          // warm-up
+  if (rc == BIST_OK) (void)hipStreamSynchronize(st);
+  if (rc == BIST_OK && resident_stream) {
+    gs_idle_kernel<<<1, 1, 0, static_cast<hipStream_t>(resident_stream)>>>((unsigned long long)resident_ticks, 0, w, w + 1);
+    if (hipGetLastError() != hipSuccess) rc = BIST_ELAUNCH;
+  }
+  if (rc == BIST_OK && (hipEventRecord(e0, st) != hipSuccess || hipGraphLaunch(ex, st) != hipSuccess || hipEventRecord(e1, st) != hipSuccess)) rc = BIST_ELAUNCH;
+  if (rc == BIST_OK && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)) rc = BIST_ELAUNCH;
+  if (resident_stream) (void)hipStreamSynchronize(static_cast<hipStream_t>(resident_stream));
+  if (rc != BIST_OK && !*bist_last_error()) bist_set_error("bist_graph_queue_pace: a runtime call failed");
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipGraphExecDestroy(ex);
+  (void)hipGraphDestroy(g);
+  *us_per_launch_out = ms * 1e3f / (float)n;
+  return rc;
 }

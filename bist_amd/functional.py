@@ -394,7 +394,9 @@ MAX_CAPTURE_STREAMS = 3
 
 
 def _streams_ready() -> bool:
-    """The package's streams on hardware queues of their own (split executor usable): [capturing stream, side 0, side 1, side 2, leaf]."""
+    """The package's streams on hardware queues AND dispatch pipes of their own (split executor usable).  The device has four pipes
+    (graphsplit.distinct_streams): [capturing stream, side 0, side 1, side 2 = leaf] -- side 2 is an inference stream (the third chain of
+    the fused reasoning layer), the leaf stream a training one (backward leaves); no step uses both."""
     from . import graphsplit as GS
     dev = torch.cuda.current_device()
     if (dev, "cap") in _SIDE:
@@ -402,11 +404,11 @@ def _streams_ready() -> bool:
     if torch.cuda.is_current_stream_capturing() or not GS.usable():
         return False
     torch.cuda.synchronize()
-    st = GS.distinct_streams(5)
+    st = GS.distinct_streams(4)
     _SIDE[(dev, "cap")] = st[0]
     for i in range(3):
         _SIDE[(dev, i)] = st[1 + i]
-    _SIDE[(dev, "leaf")] = st[4]
+    _SIDE[(dev, "leaf")] = st[3]
     return True
 
 

@@ -72,9 +72,26 @@ def _distinct(a: int, b: int, scratch: torch.Tensor) -> bool:
     return int(scratch[1].item()) == 0
 
 
+def _pace(a: int, b: Optional[int], scratch: torch.Tensor) -> float:
+    """us per launch of a 200-launch single-queue graph on stream a, alone or beside a wave resident on stream b."""
+    out = C.c_float()
+    torch.cuda.synchronize()
+    check(lib.bist_graph_queue_pace(a, 200, b, int(2e-3 * 1e8), scratch.data_ptr(), C.byref(out)), "bist_graph_queue_pace")
+    return float(out.value)
+
+
+def _independent(a: int, b: int, scratch: torch.Tensor) -> bool:
+    """Different hardware queues AND different dispatch pipes: a wave resident on one does not slow the other's launches."""
+    if not (_distinct(a, b, scratch) and _distinct(b, a, scratch)):
+        return False
+    alone = min(_pace(a, None, scratch), _pace(a, None, scratch))
+    return _pace(a, b, scratch) < 1.6 * alone and _pace(b, a, scratch) < 1.6 * min(_pace(b, None, scratch), _pace(b, None, scratch))
+
+
 def distinct_streams(n: int) -> List[torch.cuda.Stream]:
-    """n streams (none of them the NULL stream) on pairwise different hardware queues: probed, kept per device, the same set for every
-    caller.  Must not be called during a capture (the probe synchronises)."""
+    """n streams (none of them the NULL stream) on pairwise different hardware queues that do not share a dispatch pipe: probed (a wait
+    ahead of its signal must see it; a resident wave on one must not slow the launches of the other), kept per device, the same set
+    for every caller.  MI355X has four such pipes.  Must not be called during a capture (the probe synchronises)."""
     dev = torch.cuda.current_device()
     keep = _EXEC_STREAMS.setdefault(dev, [])
     if len(keep) >= n:
@@ -89,7 +106,7 @@ def distinct_streams(n: int) -> List[torch.cuda.Stream]:
         s = torch.cuda.Stream()
         if any(s.cuda_stream == o.cuda_stream for o in keep):
             continue
-        if all(_distinct(o.cuda_stream, s.cuda_stream, scratch) and _distinct(s.cuda_stream, o.cuda_stream, scratch) for o in keep):
+        if all(_independent(o.cuda_stream, s.cuda_stream, scratch) for o in keep):
             keep.append(s)
     return keep[:n]
 
@@ -211,6 +228,20 @@ class SplitGraph:
         self._exec_main.wait_stream(cur)
         check(lib.bist_graph_split_launch(self._h, self._arr), "bist_graph_split_launch")
         cur.wait_stream(self._exec_main)
+
+    def dump(self, path: str) -> None:
+        """The plan (chain sequences) and the captured graph's edges as JSON (analysis aid: scripts/critical_path.py)."""
+        import json
+        n = lib.bist_graph_split_dump(self._h, None, 0)
+        arr = (C.c_int32 * n)()
+        lib.bist_graph_split_dump(self._h, arr, n)
+        raw = self.graph.raw_cuda_graph()
+        ne = C.c_int32()
+        check(lib.bist_graph_edges(raw, None, None, 0, C.byref(ne)), "bist_graph_edges")
+        ef, et = (C.c_int32 * max(1, ne.value))(), (C.c_int32 * max(1, ne.value))()
+        check(lib.bist_graph_edges(raw, ef, et, ne.value, C.byref(ne)), "bist_graph_edges")
+        with open(path, "w") as f:
+            json.dump({"plan": list(arr), "edges": [[ef[i], et[i]] for i in range(ne.value)], "info": self.info}, f)
 
     def launch_order(self, order, times=None) -> None:
         """Development aid: the chains launched one by one in `order` (host seconds per call appended to `times`)."""

@@ -277,7 +277,7 @@ class VidEncoderLayer4(nn.Module):
     def train_value(self, vft_a: Tensor, ai: int):
         B, T, S, d = vft_a.shape
         a = self.attn[ai]
-        return Fn.linear(vft_a.view(B * T * S, d), a.linears[2].weight, a.linears[2].bias).view(B, T, S, d)
+        return Fn.linear(vft_a.view(B * T * S, d), a.linears[2].weight, a.linears[2].bias, leaf=True).view(B, T, S, d)
 
     def train_values(self, vft_a: Tensor, vft_b: Tensor):
         """Training: one value GEMM per direction (each dV is a whole tensor) -> (v_t2s, v_s2t)."""

@@ -127,6 +127,8 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> Tensor:
 
 WGRAD_STREAM = None       # trainer: side stream of the weight-gradient GEMMs (autograd._WeightGradStream); None = in line
 WGRAD_KEEP = []           # their operands, kept alive until the trainer joins that stream
+LEAF_STREAM = None        # trainer: the stream of the backward pass's leaf products (autograd._Leaf); None = in line
+LEAF_MASK = 0             # which leaves go there (bist_amd/train.py: LEAF_MASK)
 def gemm_pair(ga: BistGemm, gb: BistGemm) -> None:
     """Two independent products (descriptors from gemm_desc) in one call; one launch when they are the small dX / dW
     pair of a linear layer's backward (bist_gemm_pair)."""

@@ -50,6 +50,14 @@ ALWAYS_COPY_INPUTS = os.environ.get("BIST_ALWAYS_COPY_INPUTS", "0") != "0"      
 # The captured step replayed as one linear hipGraph per stream, tied by device-side flags (bist_amd/graphsplit.py) instead of through the
 # runtime's multi-branch graph executor, which serialises independent branches.  0 = torch's CUDAGraph.replay().
 SPLIT_GRAPH = os.environ.get("BIST_SPLIT_GRAPH", "1") != "0"
+# tuning aid: which leaves of the backward pass go to the leaf chain (bit mask; ops.LEAF_MASK): 1 = the frame-grid products (output
+# projection dW + video gradient of stage 1, value projection dX / dW), 2 = the fusion logits' weight gradient, 4 = the closing
+# reductions in per-layer batches.  Chip-filling products beside the direction chains cost those chains more than they save (measured
+# 10.0 vs 8.9 ms per step with mask 1); moving only the fusion logits' weight gradient (mask 2: seven 58 us launches on four workgroups) gains
+# nothing measurable either (8.93-8.99 vs 8.90-8.96) although a critical-path model of the step puts them on the path -- the step has many
+# near-critical paths (scripts/critical_path.py).  Default 0: three chains.
+LEAF_MASK = int(os.environ.get("BIST_LEAF_MASK", "0"))
+LEAF_OFFLOAD = LEAF_MASK != 0
 EXCHANGE_CHUNKS = int(os.environ.get("BIST_EXCHANGE_CHUNKS", "4"))        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
 
 
@@ -306,6 +314,10 @@ class Trainer:
         ops.LNGRAD_QUEUE = []                 # LayerNorm gain/offset gradients: likewise
         wg = self._wgrad_stream if (self.wgrad_side_stream and loss.is_cuda) else None
         ops.WGRAD_STREAM = wg                 # weight-gradient GEMMs: off the critical path, on their own stream
+        # the leaves of the backward pass (frame-grid weight / video gradients) on a chain of their own: only when the step is replayed by
+        # the split executor (a fourth stream in a graph for the runtime's executor is not trusted: Fn.MAX_CAPTURE_STREAMS)
+        ops.LEAF_STREAM = Fn.leaf_stream() if (LEAF_OFFLOAD and self.use_graph and SPLIT_GRAPH and loss.is_cuda and Fn.CONCURRENT) else None
+        ops.LEAF_MASK = LEAF_MASK
         try:
             loss.backward()
             STM.mark("backward issued (main)")
@@ -323,6 +335,7 @@ class Trainer:
             raise
         finally:
             ops.WGRAD_STREAM = None
+            ops.LEAF_STREAM = None
             ops.WGRAD_KEEP.clear()
             Fn.release_taken()
         return terms
@@ -387,7 +400,7 @@ class Trainer:
         if graph.want_split and Fn._streams_ready():
             # the weight-gradient stream (BIST_WGRAD_STREAM=1) on a hardware queue of its own as well
             if self.wgrad_side_stream:
-                self._wgrad_stream = GS.distinct_streams(6)[5]
+                self._wgrad_stream = Fn.leaf_stream()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -656,6 +656,8 @@ int bist_graph_capture_tail(void* stream, void** node_out);
 int bist_graph_nodes(void* hip_graph, void** nodes_out, int32_t cap, int32_t* n_out);
 int64_t bist_graph_split_plan(int32_t n_nodes, const int32_t* edge_from, const int32_t* edge_to, int32_t n_edges, const int32_t* labels,
                               int32_t n_chains, int32_t main_chain, int32_t* out, int64_t cap);
+int bist_graph_edges(void* hip_graph, int32_t* from_out, int32_t* to_out, int32_t cap, int32_t* n_out);      /* analysis aid: edges as index pairs */
+int64_t bist_graph_split_dump(const BistGraphSplit* split, int32_t* out, int64_t cap);                        /* analysis aid: the plan, flat form of _plan */
 int bist_graph_split_create(void* hip_graph, const int32_t* labels, int32_t n_labels, int32_t n_chains, int32_t main_chain, BistGraphSplit** out);
 int64_t bist_graph_split_sync_words(const BistGraphSplit* split);
 /* The sync launches in the order of their stamp words (the caller's words end with two uint64 per sync launch: device clock at its begin
@@ -668,6 +670,10 @@ int bist_graph_split_launch(BistGraphSplit* split, void* const* streams);
 int bist_graph_split_launch_chain(BistGraphSplit* split, int32_t chain, void* stream);      /* development aid: one chain's launch alone */
 void bist_graph_split_destroy(BistGraphSplit* split);
 int bist_graph_queues_distinct(void* stream_a, void* stream_b, void* scratch, int64_t timeout_ticks);
+/* Launch-to-launch time (us) of a linear graph of n one-thread launches replayed into `stream`, alone (resident_stream NULL) or while one
+ * wave stays resident on `resident_stream` for resident_ticks of the 100 MHz clock: hardware queues that share a dispatch pipe slow each
+ * other down threefold (csrc/graphsplit.hip), and the chains of a split graph must not.  word: 2 uint64 of device memory.  Synchronises. */
+int bist_graph_queue_pace(void* stream, int32_t n, void* resident_stream, int64_t resident_ticks, void* word, float* us_per_launch_out);
 /* Development aid: a one-wave launch that stays resident on `stream` for `ticks` of the 100 MHz clock (mode 0: sleeps and reads the clock;
  * 1: also polls word[0] with relaxed loads; 2: with acquire loads; 3: `ticks` rounds of s_sleep, no memory, no clock) -- measures what a
  * resident wave on another queue costs the launches of a step (scripts/probe_idle_wave.py).  word: 2 uint64 of device memory. */

@@ -51,6 +51,8 @@ from bist_amd import graphsplit as GS
 print("usable:", GS._USABLE, "|", GS.WHY_NOT, flush=True)
 print(f"T={c['T']} split={'on ' + str(sp.info) if sp is not None else 'off'}: ms/step {[round(r, 3) for r in res]}; loss {float(terms['out']):.4f}; "
       f"timed-out waits {sp.errors() if sp is not None else '-'}", flush=True)
+if sp is not None and os.environ.get("DUMP"):
+    sp.dump(os.environ["DUMP"])
 if sp is not None and os.environ.get("TIMELINE"):
     tr.step(b)
     rows = sp.timeline()

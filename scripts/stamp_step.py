@@ -42,6 +42,8 @@ if os.environ.get("IDLE"):
     wq = torch.zeros(4, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     CK(L.bist_dev_idle_wave(extra.cuda_stream, int(150e-3 * 1e8), 0, wq.data_ptr()), "idle")
+    for _ in range(int(os.environ.get("IDLE_PENDING", "0"))):      # launches queued BEHIND the resident wave on its queue
+        CK(L.bist_dev_idle_wave(extra.cuda_stream, 10, 0, wq.data_ptr()), "idle")
 if os.environ.get("STEADY", "1") != "0":
     for _ in range(8):        # the stamps of the LAST of several back-to-back replays: the steady state the bench measures
         tr.step(b)
