@@ -15,7 +15,7 @@ import os as _os
 
 import torch as _torch
 
-if not _torch.cuda.is_initialized():
+if not _torch.cuda.is_initialized() and _os.environ.get("BIST_SPLIT_GRAPH", "1") != "0":
     _os.environ.setdefault("DEBUG_HIP_DYNAMIC_QUEUES", "0")
     _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     _os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "1")      # every graph the runtime replays is a single-queue graph: its fast path

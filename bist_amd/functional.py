@@ -391,6 +391,7 @@ def param_gate(k: int) -> None:
 # ends with more streams joined is refused.  (A ``Graph`` replayed by the split executor -- one single-queue graph per stream,
 # bist_amd/graphsplit.py -- never hands a multi-branch graph to the runtime and is not limited.)
 MAX_CAPTURE_STREAMS = 3
+SPLIT_GRAPHS = os.environ.get("BIST_SPLIT_GRAPH", "1") != "0"      # tuning aid: 0 = every graph through the runtime's executor
 
 
 def _streams_ready() -> bool:
@@ -398,6 +399,8 @@ def _streams_ready() -> bool:
     (graphsplit.distinct_streams): [capturing stream, side 0, side 1, side 2 = leaf] -- side 2 is an inference stream (the third chain of
     the fused reasoning layer), the leaf stream a training one (backward leaves); no step uses both."""
     from . import graphsplit as GS
+    if not SPLIT_GRAPHS:
+        return False
     dev = torch.cuda.current_device()
     if (dev, "cap") in _SIDE:
         return True
@@ -438,9 +441,6 @@ class Graph:
 
     def errors(self) -> int:
         return self.split.errors() if self.split is not None else 0
-
-
-SPLIT_GRAPHS = os.environ.get("BIST_SPLIT_GRAPH", "1") != "0"      # tuning aid: 0 = every graph through the runtime's executor
 
 
 class capture_graph:
@@ -514,7 +514,8 @@ class capture_graph:
             # (a one-stream capture: the runtime replays it on its single-queue path as it is)
         elif exc[0] is None and n > MAX_CAPTURE_STREAMS:
             raise RuntimeError(f"bist_amd: a hipGraph capture spanning {n} streams for the runtime's graph executor (at most "
-                               f"{MAX_CAPTURE_STREAMS}: replays of wider graphs have crashed inside hipGraphLaunch); it must not be replayed")
+                               f"{MAX_CAPTURE_STREAMS}: replays of wider graphs have crashed inside hipGraphLaunch); it must not be replayed"
+                               f" [streams of this package: {sorted((str(k[1]), hex(v.cuda_stream)) for k, v in _SIDE.items())}]")
         return res
 
 

@@ -334,14 +334,24 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True, pad_sym
             step["decoded_text"] = f2["decoded_text"][:, -1:].contiguous()
             step["encoded_tgt"] = f2["encoded_tgt"][:, -1:].contiguous()
             return f2, model.generator(step, sb, train_args).float()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            run()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph = Fn.Graph()
-        with Fn.capture_graph(graph):   # other threads (RCCL watchdog) may touch the runtime during capture
-            f2, out = run()
+        # At B = 1 every launch of the first step is a few microseconds: several chains buy little and every cross-chain edge costs two
+        # sync launches under the split executor (measured 7.85 ms per turn with four chains, 7.15 ms through the runtime's executor --
+        # whose replays of this very graph have crashed).  FIRST_STEP_STREAMS = 1 captures it on ONE stream: the
+        # runtime's single-queue path, 0.3 us of host time per node.
+        conc = Fn.CONCURRENT
+        if FIRST_STEP_STREAMS == 1:
+            Fn.CONCURRENT = False
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                run()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = Fn.Graph()
+            with Fn.capture_graph(graph):   # other threads (RCCL watchdog) may touch the runtime during capture
+                f2, out = run()
+        finally:
+            Fn.CONCURRENT = conc
         STATS["captures"] += 1
         fused = "_bist_fused_first" in f2
         g = store[("first",) + geom] = (graph, sb, f2, out, fused)
@@ -366,6 +376,9 @@ def _graph_first_step(model, batch, start_symbol, train_args, host=True, pad_sym
 # What the turns of this process did (bench.py reports it next to the turn times): turns decided on the device, turns the device handed back
 # to the host loop (ties / NaN / too few candidates: the turn is then run TWICE), turns on the host loop from the start, hipGraph captures.
 STATS = {"turns": 0, "device": 0, "host_redo": 0, "host": 0, "captures": 0}
+
+
+FIRST_STEP_STREAMS = int(os.environ.get("BIST_DECODE_FIRST_STREAMS", "0"))      # tuning aid: 1 = the turn's first step captured on one stream; 0 = the model's streams
 
 
 DEVICE_BEAM = os.environ.get("BIST_DEVICE_BEAM", "1") != "0"      # tuning aid: 0 = the beam update of every step on the host (one D2H + sync per step, like the reference)

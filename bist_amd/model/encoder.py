@@ -450,9 +450,10 @@ class VidEncoderLayer4(nn.Module):
         elif torch.is_grad_enabled() and t2s_on and s2t_on:
             v_t2s = self.train_value(take_t2s(), 1)
             v_s2t = None if own_v_s2t else self.train_value(take(), 4)
-        elif concurrent:
+        elif concurrent and not (ft.get("_bist_cap_fork") and Fn.leaf_stream() is None):
             # (inference only: under autograd a third forked stream makes hipGraph capture of the training step crash in
-            # the HIP runtime -- also with every side stream joined explicitly after backward)
+            # the HIP runtime -- also with every side stream joined explicitly after backward; beside a forked caption layer it would be
+            # the capture's FOURTH stream, which only the split executor's graphs may have: Fn.MAX_CAPTURE_STREAMS)
             # The value projections are the layer's big GEMMs and depend on the video tensor only: they run on
             # their own stream, under the query-side chains (self-attention, LayerNorm, Q projection, fold) of the
             # two directions, and are awaited just before the stage-1 cores.

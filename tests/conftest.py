@@ -1,9 +1,10 @@
 import os
 
 # HIP runtime switches the split-graph executor needs (bist_amd/__init__.py), set before anything can initialise the runtime
-os.environ.setdefault("DEBUG_HIP_DYNAMIC_QUEUES", "0")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "1")
+if os.environ.get("BIST_SPLIT_GRAPH", "1") != "0":
+    os.environ.setdefault("DEBUG_HIP_DYNAMIC_QUEUES", "0")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "1")
 import sys
 
 import pytest
