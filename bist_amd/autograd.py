@@ -153,6 +153,10 @@ class LinearFn(Function):
         M, K = x2.shape
         N = w.shape[0]
         pre = getattr(dy, "_bist_dz", None)            # (masked gradient, p, seed) left by _ln_backward on this very tensor
+        if pre is None and getattr(ctx, "_bist_expect_dz", False):
+            raise RuntimeError("bist_amd: the fused loss hands this projection its gradient as an attribute of an UNINITIALISED placeholder "
+                               "tensor, and the attribute did not arrive (a hook, retain_grad or a view on the logits re-wrapped it): using "
+                               "the placeholder would feed garbage into the shared embedding's gradient -- set BIST_AE_GROUPED=0 for such graphs")
         dy = dy.reshape(M, N)
         if not dy.is_contiguous():
             dy = dy.contiguous()

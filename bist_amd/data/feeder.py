@@ -108,16 +108,21 @@ class DeviceFeeder:
         self._last_slot = slot
         return out, ready
 
-    def host_buffers_reusable(self, batches_ago: int = 2) -> None:
-        """Block the host until the copies of the batch staged `batches_ago` (1 = the latest, 2 = the one before) calls ago have read their
-        host buffers.  Producers that hand over their OWN pinned tensors and reuse them must call this before overwriting them; pageable
-        producers need nothing (their staging copy is guarded inside the feeder).  Two slots alternate, so the batch staged k calls ago
-        sits in the latest slot for odd k and in the other one for even k; only that slot's copy event is waited for."""
-        if batches_ago < 1:
-            raise ValueError("batches_ago counts back from the latest staged batch: 1, 2, ...")
+    def host_buffers_reusable(self, batches_ago: Optional[int] = None) -> None:
+        """Block the host until staged copies have read their host buffers.  Producers that hand over their OWN pinned tensors and reuse
+        them must call this before overwriting them; pageable producers need nothing (their staging copy is guarded inside the feeder).
+        Default (None): BOTH slots' copies -- safe whichever buffers the producer is about to rewrite.  batches_ago = k (1 = the latest
+        staged batch, 2 = the one before, ...): only that batch's slot (two slots alternate: odd k is the latest slot, even k the other)."""
         last = getattr(self, "_last_slot", None)
         if last is None:
             return                                   # nothing staged yet
+        if batches_ago is None:
+            for ev in self._copied:
+                if ev is not None:
+                    ev.synchronize()
+            return
+        if batches_ago < 1:
+            raise ValueError("batches_ago counts back from the latest staged batch: 1, 2, ...")
         ev = self._copied[last if batches_ago % 2 == 1 else last ^ 1]
         if ev is not None:
             ev.synchronize()

@@ -155,7 +155,7 @@ def attn_drop(module):
     """(p, seed) for the dropout of attention probabilities held by a MultiHeadedAttention (modules.py:79,95)."""
     p = float(getattr(getattr(module, "dropout", None), "p", 0.0))
     if module.training and p > 0.0:
-        return (p, next_seed())
+        return (p, next_seed("attn", module))
     return None
 
 
@@ -274,6 +274,10 @@ def stack_rows(xs) -> Tensor:
 def xent_smooth_losses(logits: Tensor, target: Tensor, denom, smoothing: float, pad: int, G: int, grad_dtype):
     """G device scalars [1]: label-smoothed KL of softmax(logits) per group of rows / denom (autograd.XentSmoothLossFn)."""
     if _grad():
+        if grad_dtype != torch.float32 and type(getattr(logits, "grad_fn", None)).__name__ == "LinearFnBackward":
+            # the logits' gradient will travel as an attribute of a never-initialised placeholder (autograd.XentSmoothLossFn): the producing
+            # projection must refuse the placeholder if the attribute got lost on the way (hook, retain_grad, a re-wrapping view)
+            logits.grad_fn._bist_expect_dz = True
         return ag.XentSmoothLossFn.apply(logits, target, denom, smoothing, pad, G, grad_dtype)
     return ag.XentSmoothLossFn.forward(_NoCtx(), logits, target, denom, smoothing, pad, G, grad_dtype)
 
@@ -334,16 +338,22 @@ def manual_seed(seed: int) -> None:
     _SEED[0], _SEED[1] = int(seed) & 0xFFFFFFFF, 0
 
 
-def next_seed() -> int:
+SEED_LOG = None           # tests: a list that receives (kind, module, seed) for every dropout site a training-mode forward pass draws
+
+
+def next_seed(kind: Optional[str] = None, module=None) -> int:
     _SEED[1] += 1
-    return ((_SEED[0] << 32) ^ (_SEED[1] * 0x9E3779B1)) & 0x7FFFFFFFFFFFFFFF
+    seed = ((_SEED[0] << 32) ^ (_SEED[1] * 0x9E3779B1)) & 0x7FFFFFFFFFFFFFFF
+    if SEED_LOG is not None:
+        SEED_LOG.append((kind, module, seed))
+    return seed
 
 
 def drop_args(module) -> dict:
     """kwargs for linear(): the dropout of a SublayerConnection / nn.Dropout holder in training mode."""
     p = float(getattr(module, "p", 0.0))
     if module.training and p > 0.0:
-        return {"drop_p": p, "drop_seed": next_seed()}
+        return {"drop_p": p, "drop_seed": next_seed("sub", module)}
     return {}
 
 

@@ -127,6 +127,13 @@ class VidEncoderLayer4(nn.Module):
     directions on, attn 0..5 = A0,A1,A2,A3,A4,A5; sublayer 0..7 = A0,A1,A2,F0,A3,A4,A5,F1; ff 0,1.
     """
 
+    _RUNTIME_ATTRS = ("_frag_train", "_frag_cache", "_vpack", "_v_ready", "_v_event", "_offload_main", "_x_next")
+
+    def __getstate__(self):
+        """torch.save / copy.deepcopy: derived device buffers (fragment-ordered weights, packed projections) and per-call stream state
+        stay behind -- they are rebuilt on demand (the same filter as MTN / MultimodalDecoder8 apply to their _bist_* attributes)."""
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_bist_") and k not in self._RUNTIME_ATTRS}
+
     def __init__(self, size, attn, nb_attn, ff, nb_ff, dropout, args):
         super().__init__()
         self.size = size
@@ -134,6 +141,7 @@ class VidEncoderLayer4(nn.Module):
         self.ff = clones(ff, nb_ff)
         self.sublayer = clones(SublayerConnection(size, dropout), nb_attn + nb_ff)
         self.args = args
+        self._v_ready = self._v_event = None
         if args.enc_st_combine in ("early_sum", "early_dyn"):
             raise NotImplementedError("enc_st_combine=%s cannot run for more than one layer in the reference "
                                       "(decoder.py:123-124 overwrites the video tensor)" % args.enc_st_combine)
@@ -390,7 +398,7 @@ class VidEncoderLayer4(nn.Module):
         xn3, xr3 = Z.layernorm_res(x2, sub[3].norm, sub[7].norm)
         inner = {}
         if ff[0].training and ff[0].dropout.p > 0:          # dropout(relu(w_1 x)), modules.py:113
-            inner = {"drop_p": float(ff[0].dropout.p), "drop_seed": Fn.next_seed()}
+            inner = {"drop_p": float(ff[0].dropout.p), "drop_seed": Fn.next_seed("ffn", ff[0])}
         hdn = Z.linear(xn3, (ff[0].w_1.weight, ff[0].w_1.bias), (ff[1].w_1.weight, ff[1].w_1.bias), act=Fn.ACT_RELU, **inner)
         out = Z.linear(hdn, (ff[0].w_2.weight, ff[0].w_2.bias), (ff[1].w_2.weight, ff[1].w_2.bias), residual=xr3, out_shape=(2, B, Lq, d),
                        **Fn.drop_args(sub[3]))

@@ -64,7 +64,7 @@ class SublayerConnection(nn.Module):
     def forward(self, x: Tensor, sublayer) -> Tensor:
         y = sublayer(self.norm(x))
         if self.training and self.p > 0:
-            return Fn.add_dropout(x, y, (self.p, Fn.next_seed()), 0)
+            return Fn.add_dropout(x, y, (self.p, Fn.next_seed("sub", self)), 0)
         return Fn.add(x, y)
 
 
@@ -162,7 +162,7 @@ class PositionwiseFeedForward(nn.Module):
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, out_drop: Optional[dict] = None) -> Tensor:
         inner = {}
         if self.training and self.dropout.p > 0:          # dropout(relu(w_1 x)), modules.py:113
-            inner = {"drop_p": float(self.dropout.p), "drop_seed": Fn.next_seed()}
+            inner = {"drop_p": float(self.dropout.p), "drop_seed": Fn.next_seed("ffn", self)}
         hdn = Fn.linear(x, self.w_1.weight, self.w_1.bias, act=Fn.ACT_RELU, **inner)
         return Fn.linear(hdn, self.w_2.weight, self.w_2.bias, residual=residual, out_shape=(*x.shape[:-1], self.w_2.weight.shape[0]),
                          **(out_drop or {}))
@@ -220,7 +220,7 @@ class PositionalEncoding(nn.Module):
         L = x.shape[1]
         pe = self.table()[:L].to(x.dtype).contiguous()
         if self.training and self.dropout.p > 0:
-            return Fn.add_dropout(x, pe, (float(self.dropout.p), Fn.next_seed()), 1)
+            return Fn.add_dropout(x, pe, (float(self.dropout.p), Fn.next_seed("pe", self)), 1)
         return Fn.add(x, pe)
 
 
@@ -229,5 +229,5 @@ def embed_with_position(seq: nn.Sequential, ids: Tensor, pos0: int = 0) -> Tenso
     emb, pos = seq[0], seq[1]
     drop = None
     if pos.training and pos.dropout.p > 0:                 # dropout after the position is added (modules.py:144)
-        drop = (float(pos.dropout.p), Fn.next_seed())
+        drop = (float(pos.dropout.p), Fn.next_seed("pe", pos))
     return Fn.embed_pe(ids, emb.lut.weight, pos.table()[pos0:] if pos0 else pos.table(), drop)

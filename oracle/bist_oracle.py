@@ -114,6 +114,19 @@ def make_std_mask(trg: Tensor, pad: int) -> Tensor:
 # ----------------------------------------------------------------------------
 # primitives (model/modules.py)
 # ----------------------------------------------------------------------------
+# Training-mode dropout (tests only): the reference drops at four kinds of site -- the sum of position encoding and embedding
+# (modules.py:144, kind "pe"), the attention probabilities after the softmax (modules.py:62-63, "attn"), the feed-forward block's
+# hidden layer (modules.py:113, "ffn") and every sublayer's output before the residual (modules.py:44, "sub").  With DROP_HOOK set
+# -- callable(kind, site name, tensor) -> tensor with that site's mask and 1/(1-p) applied -- the oracle passes the tensor of every
+# such site through it (site name: the module's state_dict path; None for "pe", whose sites come in the order query, caption,
+# history, target).  tests/test_dropout_parity_gpu.py feeds it the masks the HIP kernels drew.  None (default): evaluation mode.
+DROP_HOOK = None
+
+
+def _drop(kind: str, name: Optional[str], x: Tensor) -> Tensor:
+    return x if DROP_HOOK is None else DROP_HOOK(kind, name, x)
+
+
 def layer_norm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
     """modules.py:28-31.  NOT F.layer_norm: unbiased std, eps added to the std."""
     mean = x.mean(-1, keepdim=True)
@@ -149,14 +162,14 @@ def mha(sd: SD, p: str, h: int, query: Tensor, key: Tensor, value: Tensor,
     scores = q @ k.transpose(-2, -1) / math.sqrt(dk)
     if mask is not None:
         scores = scores.masked_fill(mask.unsqueeze(1) == 0, -1e9)
-    p_attn = torch.softmax(scores, dim=-1)
+    p_attn = _drop("attn", p, torch.softmax(scores, dim=-1))                   # modules.py:62-63
     ctx = (p_attn @ v).transpose(1, 2).reshape(n, lq, d)
     return _lin(sd, p + ".linears.3", ctx), p_attn
 
 
 def ffn(sd: SD, p: str, x: Tensor) -> Tensor:
     """modules.py:112-113."""
-    return _lin(sd, p + ".w_2", torch.relu(_lin(sd, p + ".w_1", x)))
+    return _lin(sd, p + ".w_2", _drop("ffn", p, torch.relu(_lin(sd, p + ".w_1", x))))
 
 
 def pos_encoding(length: int, d: int) -> Tensor:
@@ -172,7 +185,7 @@ def pos_encoding(length: int, d: int) -> Tensor:
 def embed(sd: SD, ids: Tensor, d: int) -> Tensor:
     """modules.py:121-123 + 141-144: lut[ids]*sqrt(d) + PE (dropout off)."""
     lut = sd["query_embed.0.lut.weight"]        # == tgt_embed.0.lut.weight (mtn.py:82)
-    return lut[ids] * math.sqrt(d) + pos_encoding(ids.size(1), d).to(lut.dtype)
+    return _drop("pe", None, lut[ids] * math.sqrt(d) + pos_encoding(ids.size(1), d).to(lut.dtype))
 
 
 # ----------------------------------------------------------------------------
@@ -210,7 +223,7 @@ def st_stage1(sd: SD, lp: str, h: int, a: int, s: int, x: Tensor, kv: Tensor,
     if mask is not None:
         m = mask.unsqueeze(1).expand(B, G, 1, K).reshape(B * G, 1, K)
     out, _ = mha(sd, f"{lp}.attn.{a}", h, _ln(sd, f"{lp}.sublayer.{s}.norm", xe), kvf, kvf, m)
-    return (xe + out).reshape(B, G, Lq, d)
+    return (xe + _drop("sub", f"{lp}.sublayer.{s}", out)).reshape(B, G, Lq, d)
 
 
 def st_stage2(sd: SD, lp: str, h: int, a: int, s: int, x: Tensor, y: Tensor,
@@ -228,7 +241,7 @@ def st_stage2(sd: SD, lp: str, h: int, a: int, s: int, x: Tensor, y: Tensor,
     if mask is not None:
         m = mask.unsqueeze(1).expand(B, Lq, 1, G).reshape(B * Lq, 1, G)
     out, _ = mha(sd, f"{lp}.attn.{a}", h, _ln(sd, f"{lp}.sublayer.{s}.norm", q), keys, keys, m)
-    return (q + out).reshape(B, Lq, d)
+    return (q + _drop("sub", f"{lp}.sublayer.{s}", out)).reshape(B, Lq, d)
 
 
 def vid_layer(sd: SD, cfg: Cfg, lp: str, in_ft: Dict[str, Tensor], vft: Tensor,
@@ -246,13 +259,14 @@ def vid_layer(sd: SD, cfg: Cfg, lp: str, in_ft: Dict[str, Tensor], vft: Tensor,
         nonlocal ai, si
         n = _ln(sd, f"{lp}.sublayer.{si}.norm", x)
         o, _ = mha(sd, f"{lp}.attn.{ai}", h, n, n, n, b.query_mask)
+        o = _drop("sub", f"{lp}.sublayer.{si}", o)
         ai += 1
         si += 1
         return x + o
 
     def ff_block(x):
         nonlocal si, fi
-        o = ffn(sd, f"{lp}.ff.{fi}", _ln(sd, f"{lp}.sublayer.{si}.norm", x))
+        o = _drop("sub", f"{lp}.sublayer.{si}", ffn(sd, f"{lp}.ff.{fi}", _ln(sd, f"{lp}.sublayer.{si}.norm", x)))
         si += 1
         fi += 1
         return x + o
@@ -283,9 +297,9 @@ def cap_layer(sd: SD, cfg: Cfg, lp: str, c: Tensor, enc_cap: Tensor, b: OBatch) 
     """CapEncoderLayer.forward encoder.py:211-218."""
     h = cfg.att_h
     n = _ln(sd, f"{lp}.sublayer.0.norm", c)
-    c = c + mha(sd, f"{lp}.attn.0", h, n, n, n, b.query_mask)[0]
-    c = c + mha(sd, f"{lp}.attn.1", h, _ln(sd, f"{lp}.sublayer.1.norm", c), enc_cap, enc_cap, b.cap_mask)[0]
-    return c + ffn(sd, f"{lp}.ff", _ln(sd, f"{lp}.sublayer.2.norm", c))
+    c = c + _drop("sub", f"{lp}.sublayer.0", mha(sd, f"{lp}.attn.0", h, n, n, n, b.query_mask)[0])
+    c = c + _drop("sub", f"{lp}.sublayer.1", mha(sd, f"{lp}.attn.1", h, _ln(sd, f"{lp}.sublayer.1.norm", c), enc_cap, enc_cap, b.cap_mask)[0])
+    return c + _drop("sub", f"{lp}.sublayer.2", ffn(sd, f"{lp}.ff", _ln(sd, f"{lp}.sublayer.2.norm", c)))
 
 
 # ----------------------------------------------------------------------------
@@ -296,10 +310,10 @@ def dec_layer(sd: SD, cfg: Cfg, lp: str, b: OBatch, ft: Dict[str, Tensor], x: Te
     h = cfg.att_h
 
     def cross(i, x, mem, mask):
-        return x + mha(sd, f"{lp}.attn.{i}", h, _ln(sd, f"{lp}.sublayer.{i}.norm", x), mem, mem, mask)[0]
+        return x + _drop("sub", f"{lp}.sublayer.{i}", mha(sd, f"{lp}.attn.{i}", h, _ln(sd, f"{lp}.sublayer.{i}.norm", x), mem, mem, mask)[0])
 
     n = _ln(sd, f"{lp}.sublayer.0.norm", x)
-    x = x + mha(sd, f"{lp}.attn.0", h, n, n, n, b.trg_mask)[0]            # decoder.py:21
+    x = x + _drop("sub", f"{lp}.sublayer.0", mha(sd, f"{lp}.attn.0", h, n, n, n, b.trg_mask)[0])            # decoder.py:21
     x = cross(1, x, ft["encoded_his"], b.his_mask)                         # :22
     x = cross(2, x, ft["encoded_query"], b.query_mask)                     # :23
     cnt = 3
@@ -322,7 +336,7 @@ def dec_layer(sd: SD, cfg: Cfg, lp: str, b: OBatch, ft: Dict[str, Tensor], x: Te
                 tx = cross(cnt, x, ft["temporal_ft"], b.query_mask); cnt += 1
                 sx = cross(cnt, x, ft["spatial_ft"], b.query_mask); cnt += 1
                 x = tx + sx
-    return x + ffn(sd, f"{lp}.ff", _ln(sd, f"{lp}.sublayer.{cnt}.norm", x))   # :58
+    return x + _drop("sub", f"{lp}.sublayer.{cnt}", ffn(sd, f"{lp}.ff", _ln(sd, f"{lp}.sublayer.{cnt}.norm", x)))   # :58
 
 
 def fuse_modalities(sd: SD, cfg: Cfg, ft: Dict[str, Tensor]) -> Optional[Tensor]:
