@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the beam-search turn timing (BASELINE configs[4])")
     ap.add_argument("--no-t128", action="store_true", help="skip the T=128 (BASELINE configs[3]) step / forward timing")
     ap.add_argument("--no-f32", action="store_true", help="skip the float32 side line (the same step in the parity dtype)")
+    ap.add_argument("--no-fed", action="store_true", help="skip the PCIe-inclusive side line (features from host memory every step)")
     ap.add_argument("--no-graph", action="store_true", help="launch the kernels of a step eagerly instead of replaying a hipGraph")
     a = ap.parse_args()
 
@@ -238,6 +239,12 @@ def main():
     from bist_amd.data.synthetic import synthetic_batch
     from bist_amd.train import Trainer
 
+    # Everything below runs on the package's main stream instead of the NULL stream: the split-graph executor replays a graph's main chain
+    # there, so a replay needs no event hop to and from the caller's stream -- hops that, from the NULL stream, each cost the runtime a walk
+    # over all streams of the process (measured: the 0.75 ms region graph replays at 1.06 ms from the NULL stream once the process holds
+    # the training and decode graphs' streams).  None: graphs go to the runtime's executor (BIST_SPLIT_GRAPH=0 / self-test failed).
+    if not a.no_graph and Fn.main_stream() is not None:
+        torch.cuda.set_stream(Fn.main_stream())
     c = dict(CFG, B=a.batch, T=a.T)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     args = model_args(c["L"], c["d"], c["h"], a.dropout)
@@ -269,6 +276,17 @@ def main():
         return time.perf_counter() - t0
 
     dt = timed_steps(trainer, batch, a.warmup, a.steps)
+    # what replayed the step: the split-graph executor (one single-queue hipGraph per stream, device-flag syncs) or the runtime's
+    sp = getattr(trainer, "_split", None)
+    executor = {"kind": "split" if sp is not None else ("runtime" if trainer.use_graph else "eager")}
+    if sp is not None:
+        executor.update({k: sp.info[k] for k in ("chains", "nodes", "waits", "signals", "nodes_per_chain")})
+        executor["timed_out_waits"] = sp.errors()
+    hs = []
+    for _ in range(10):                           # host time of one step() call with the device idle (hipGraphLaunch and the loop around it)
+        torch.cuda.synchronize(); h0 = time.perf_counter(); trainer.step(batch); hs.append((time.perf_counter() - h0) * 1e3)
+    torch.cuda.synchronize()
+    executor["host_ms_per_step"] = sorted(hs)[len(hs) // 2]
     tot = torch.tensor([dt, float(ntok)], device="cuda", dtype=torch.float64)
     if world > 1:
         tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -412,6 +430,35 @@ def main():
                "ms_per_step": dt32 / 4 * 1e3, "tokens_per_s": float(b32.ntokens.item()) * 4 / dt32}
         del tr32, b32
 
+    # PCIe-inclusive side line: the same step with the features handed over as HOST fp32 tensors every step through DeviceFeeder
+    # (pinned double buffer, H2D on a copy stream, cast on the device).  Never `value`.
+    fed = None
+    if rank == 0 and world == 1 and not a.no_fed and a.dtype == "bf16":
+        from bist_amd.data.feeder import DeviceFeeder, HostBatch
+        model.train()
+        trf = Trainer(model, args, c["V"], compute_dtype=dtype, use_graph=not a.no_graph)
+        host = []
+        for i in range(2):
+            hb = synthetic_batch(c["B"], T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=c["Lh"], Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"], seed=1234 + i,
+                                 dtype=torch.float32, device="cpu")
+            pf = DeviceFeeder.pinned_like(hb.fts.shape, hb.fts.dtype); pf.copy_(hb.fts)
+            host.append(HostBatch(hb.query, hb.his, pf, hb.cap, hb.trg, hb.trg_y))
+        tok = [int((h_.trg_y != 1).sum()) for h_ in host]          # non-pad target tokens per batch (pad id 1, dataset.py:98)
+        nf = 20
+        it = iter(DeviceFeeder([host[i % 2] for i in range(nf + 4)], feature_dtype=dtype))
+        for _ in range(4):
+            trf.step(next(it))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ntf, k = 0.0, 0
+        for fb in it:
+            trf.step(fb); ntf += tok[k % 2]; k += 1
+        torch.cuda.synchronize(); dtf = time.perf_counter() - t0
+        model.eval()
+        fed = {"what": "the same training step with the features handed over as host fp32 tensors EVERY step (pinned producer buffers, DeviceFeeder: H2D on a copy "
+                       "stream, cast to bf16 on the device, temporal mask derived on the device); PCIe-inclusive, not the headline",
+               "ms_per_step": dtf / k * 1e3, "tokens_per_s": ntf / dtf, "h2d_bytes_per_step": int(host[0].fts.numel() * 4), "steps": k}
+        del trf, it, host
+
     out = {
         "metric": "training-step tokens/sec (BiST hot path: fwd + pointer-generator losses + bwd + Adam)",
         "value": ntok_all * a.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -428,9 +475,11 @@ def main():
                                f"B={roof['B']}, T={roof['T']}, 7x7, C=2048, one hipGraph replay",
                      "gflop_alg": roof["gflop_alg"], "avg_launch_ms": roof["ms"], "kernel": dom["kernel"], "kernels": roof["kernels"]},
         "attn_fwd": {"what": "the same region on the bench batch", **attn, "at_B64": attn64},
+        "executor": executor,
         "decode": decode,
         "t128": t128,
         "f32": f32,
+        "fed": fed,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_rows, a.cpu_threads)

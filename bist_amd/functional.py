@@ -425,6 +425,14 @@ def _streams_ready() -> bool:
     return True
 
 
+def main_stream():
+    """The stream the package captures its graphs on -- and the split executor replays their main chain on -- or None when graphs go to the
+    runtime's executor.  A caller that makes it the CURRENT stream (``torch.cuda.set_stream``; bench.py does) spares every replay the
+    two event hops between its own stream and this one; from the NULL stream each of those also costs the runtime a walk over all
+    streams of the process."""
+    return _SIDE.get((torch.cuda.current_device(), "cap")) if _streams_ready() else None
+
+
 def leaf_stream():
     """The stream of the backward pass's leaf products (weight gradients and video-tensor gradients of the frame-grid products: nothing
     on a direction's chain reads them), or None when the step is replayed by the runtime's executor (a fourth stream there: see

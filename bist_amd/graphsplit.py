@@ -225,9 +225,12 @@ class SplitGraph:
             self._exec_main, self._side = ext[0], ext[1:]
             for i, s in enumerate(ext):
                 self._arr[i] = s.cuda_stream
-        self._exec_main.wait_stream(cur)
+        same = cur.cuda_stream == self._exec_main.cuda_stream
+        if not same:
+            self._exec_main.wait_stream(cur)
         check(lib.bist_graph_split_launch(self._h, self._arr), "bist_graph_split_launch")
-        cur.wait_stream(self._exec_main)
+        if not same:
+            cur.wait_stream(self._exec_main)
 
     def dump(self, path: str) -> None:
         """The plan (chain sequences) and the captured graph's edges as JSON (analysis aid: scripts/critical_path.py)."""
