@@ -48,7 +48,7 @@ CFG = dict(L=6, d=512, h=8, B=16, T=32, S=49, C=2048, Lq=20, Lh=60, Lc=25, Lt=20
 
 
 REGION_SOURCES = ("common.hpp", "gemm.hip", "rowops.hip", "attention.hip", "attention_mfma.hip", "st1_fused.hip")
-REGION_PMC = "r03_attn_fwd_B64_pmc.json"
+REGION_PMC = "r04_attn_fwd_B64_pmc.json"
 
 
 def region_sources_sha():
@@ -76,7 +76,7 @@ def region_traffic(B, T):
     if t.get("B") != B or t.get("T") != T:
         return None, "the committed counter passes are of B=%s T=%s" % (t.get("B"), t.get("T"))
     if t.get("region_sources_sha256") != region_sources_sha():
-        return None, "the region's kernel sources changed since the committed counter passes (re-run scripts/prof_round_r03.sh)"
+        return None, "the region's kernel sources changed since the committed counter passes (re-run scripts/prof_round_r04.sh)"
     return t, None
 
 

@@ -48,6 +48,7 @@ struct DecArgs {
   unsigned* sync;                // 8 words, zero before the first call: [0] barrier arrivals, [1] exits (both zero again when a call ends),
                                  // [4] STICKY error flag (a barrier timed out)
   int dbg;                       // BIST_DECSTACK_DBG (development): 1 = agent-scope acquire after every barrier
+  int spread;                    // BIST_DECSTACK_XCDS: the 32 workers on 1 (default), 2 or 4 XCDs (8 * spread consecutive blocks hold `spread` workers)
   unsigned long long* stamps;    // BIST_DECSTACK_STAMPS (development): s_memtime stamps of workgroup 0 in layer 0, or null
   float* pbuf;                   // head-local form: per-head partial output projections, f32 [2][8 heads][16 rows][512]
 };
@@ -438,8 +439,11 @@ __global__ __launch_bounds__(NT, 1) void decstack_kernel(const DecArgs a) {
   // HW_REG_XCC_ID before the first barrier); until then, and for good if the ids differ, payload stores are write-through (wt).
   if ((a.dbg & 8) && threadIdx.x == 0)      // development: the XCC ids of ALL 256 blocks, or-ed into sync[6] (8 XCDs -> 0xff)
     __hip_atomic_fetch_or((gu32*)a.sync + 6, 1u << (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (blockIdx.x & 7) return;
-  const int wg = blockIdx.x >> 3, R = a.R, RP = (R + 15) & ~15, MTR = RP >> 4;
+  // spread s (1 / 2 / 4): of every 8 s consecutive blocks the first s work -- blocks b, b + 1, .. of a group of eight sit on XCDs b % 8, so
+  // the workers cover s XCDs (s times the fabric bandwidth for the weight stream; hand-offs then write through, see wt)
+  const int sp = a.spread;
+  if ((int)(blockIdx.x % (8 * sp)) >= sp) return;
+  const int wg = (blockIdx.x / (8 * sp)) * sp + blockIdx.x % (8 * sp), R = a.R, RP = (R + 15) & ~15, MTR = RP >> 4;
   bool wt = true;
   __shared__ unsigned same_xcd;
   if (tid == 0) {
@@ -891,8 +895,9 @@ extern "C" int bist_decoder_stack_fwd(const void* layers_dev, int32_t n_layers, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   BIST_REQUIRE(bist_decoder_stack_device_ok(), "bist_decoder_stack_fwd: this device cannot keep the kernel's %d workgroups resident on one XCD", NWG);
   DecArgs a{(const DecLayerDev*)layers_dev, n_layers, (const bf16_t*)x_in, {(bf16_t*)xbuf0, (bf16_t*)xbuf1}, (bf16_t*)qbuf, (bf16_t*)kcache,
-            (bf16_t*)vcache, slot0, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, nullptr, pbuf};
+            (bf16_t*)vcache, slot0, (bf16_t*)hbuf, self_mask, R, LkS, (unsigned*)sync, 0, 1, nullptr, pbuf};
   a.dbg = bist_dev_dbg(1);
+  { static const int xcds = [] { const char* e = getenv("BIST_DECSTACK_XCDS"); int v = e ? atoi(e) : 1; return (v == 2 || v == 4) ? v : 1; }(); a.spread = xcds; }
   a.stamps = bist_dev_stamps(1);
   // a partial buffer and one 16-row tile select the head-local form (6 grid barriers per layer instead of 14).  Measured on the beam-5
   // turn of BASELINE configs[4] it is the SLOWER one (431 vs ~380 us per six-layer step; profiles/README.md, round 3): a head's chain of

@@ -52,11 +52,11 @@ class DeviceFeeder:
         if not torch.cuda.is_available():
             raise RuntimeError("bist_amd.data.DeviceFeeder needs the MI355X (there is no CPU path)")
         self.source, self.device, self.feature_dtype, self.pad = source, torch.device(device), feature_dtype, pad
-        # The copy stream must not share a hardware queue (or dispatch pipe) with a chain of the split-graph executor: its cast launch sits
-        # behind a 4 ms host-to-device copy, and a chain queued behind THAT stands still for as long (measured: 17.5 instead of 12.7 ms per
-        # fed step).  The package's fourth stream -- the inference / leaf stream, idle in a training step -- is on a pipe of its own.
+        # The copy stream must not share a hardware QUEUE with a chain of the split-graph executor: its cast launch sits behind a 4 ms
+        # host-to-device copy, and a chain queued behind THAT stands still for as long (measured: 17.5 ms per fed step from a pool stream,
+        # 11.6 ms sharing the caption chain's queue, against 8.4 ms resident).
         from .. import functional as _Fn
-        self.copy_stream = (_Fn.leaf_stream() if _Fn.main_stream() is not None else None) or torch.cuda.Stream(device=self.device)
+        self.copy_stream = _Fn.copy_stream() or torch.cuda.Stream(device=self.device)
         self._pinned = [{}, {}]
         self._dev = [{}, {}]
         self._free = [None, None]          # event: the slot's previous consumer is done (recorded when its Batch is replaced)

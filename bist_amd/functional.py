@@ -401,6 +401,7 @@ def param_gate(k: int) -> None:
 # ends with more streams joined is refused.  (A ``Graph`` replayed by the split executor -- one single-queue graph per stream,
 # bist_amd/graphsplit.py -- never hands a multi-branch graph to the runtime and is not limited.)
 MAX_CAPTURE_STREAMS = 3
+CAPTURE_FOR_RUNTIME = False      # True while a capture for the runtime's executor is being recorded: model code then keeps to three streams
 SPLIT_GRAPHS = os.environ.get("BIST_SPLIT_GRAPH", "1") != "0"      # tuning aid: 0 = every graph through the runtime's executor
 
 
@@ -431,6 +432,31 @@ def main_stream():
     two event hops between its own stream and this one; from the NULL stream each of those also costs the runtime a walk over all
     streams of the process."""
     return _SIDE.get((torch.cuda.current_device(), "cap")) if _streams_ready() else None
+
+
+def copy_stream():
+    """A stream for host-to-device copies (bist_amd/data/feeder.py) that shares its hardware queue with none of the package's four streams --
+    a copy and the cast ordered behind it hold their queue for milliseconds -- or None when the split executor is not in use."""
+    if not _streams_ready():
+        return None
+    dev = torch.cuda.current_device()
+    st = _COPY.get(dev)
+    if st is None and not torch.cuda.is_current_stream_capturing():
+        from . import graphsplit as GS
+        torch.cuda.synchronize()
+        st = GS.queue_distinct_stream([_SIDE[(dev, k)] for k in ("cap", 0, 1, 2)])
+        _COPY[dev] = st
+        return st
+    return _COPY.get(dev)
+
+
+_COPY = {}
+
+
+def fourth_stream():
+    """The package's fourth stream for work that may have a chain of its own -- or None while a capture for the runtime's graph executor is
+    being recorded (MAX_CAPTURE_STREAMS) and when the split executor is not in use."""
+    return None if CAPTURE_FOR_RUNTIME else leaf_stream()
 
 
 def leaf_stream():
@@ -490,6 +516,8 @@ class capture_graph:
                 self.kw.setdefault("stream", _SIDE[(torch.cuda.current_device(), "cap")])
                 self.lab = GS.Labels()
         self.split = split
+        global CAPTURE_FOR_RUNTIME
+        self._prev_cfr, CAPTURE_FOR_RUNTIME = CAPTURE_FOR_RUNTIME, not split
         self.ctx = torch.cuda.graph(self.raw, capture_error_mode="thread_local", **self.kw)
         self.was = gc.isenabled()
         gc.disable()
@@ -500,6 +528,7 @@ class capture_graph:
             self.origin = torch.cuda.current_stream().cuda_stream
             return res
         except BaseException:
+            CAPTURE_FOR_RUNTIME = self._prev_cfr
             if self.lab is not None:
                 self.lab.__exit__(None, None, None)
             if self.was:
@@ -509,6 +538,8 @@ class capture_graph:
     def __exit__(self, *exc):
         import gc
         from . import graphsplit as GS
+        global CAPTURE_FOR_RUNTIME
+        CAPTURE_FOR_RUNTIME = self._prev_cfr
         n = 0
         try:
             if exc[0] is None:

@@ -111,6 +111,20 @@ def distinct_streams(n: int) -> List[torch.cuda.Stream]:
     return keep[:n]
 
 
+def queue_distinct_stream(avoid: List[torch.cuda.Stream]) -> torch.cuda.Stream:
+    """A stream on a hardware QUEUE none of `avoid` uses (it may share a dispatch pipe with one of them): for work that must never sit
+    in a chain's queue -- a host-to-device copy and what is ordered behind it hold their queue for milliseconds -- when all four
+    independent pipes are taken.  Not during a capture (the probe synchronises)."""
+    scratch = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for _ in range(96):
+        s = torch.cuda.Stream()
+        if any(s.cuda_stream == o.cuda_stream for o in avoid):
+            continue
+        if all(_distinct(o.cuda_stream, s.cuda_stream, scratch) and _distinct(s.cuda_stream, o.cuda_stream, scratch) for o in avoid):
+            return s
+    raise RuntimeError("bist_amd.graphsplit: no stream on a hardware queue of its own beside the chains' (GPU_MAX_HW_QUEUES >= 8 before the first HIP call)")
+
+
 _USABLE: Dict[int, bool] = {}
 WHY_NOT = ""            # why usable() said no (diagnostics)
 

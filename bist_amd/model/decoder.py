@@ -24,6 +24,7 @@ def ag_fuse_one() -> bool:
     return ag.FUSE_ONE_LAUNCH
 
 
+CAP_OWN_CHAIN = os.environ.get("BIST_CAP_CHAIN", "1") != "0"      # tuning aid: 0 = the caption layers of a training step on the decoder layers' stream
 FAN_JOIN = os.environ.get("BIST_FAN_JOIN", "1") != "0"      # 0 = the gradient sums of the multi-stream fans rely on the engine's ordering alone
 
 
@@ -474,8 +475,12 @@ class MultimodalDecoder8(nn.Module):
             fork_cap = self.c_N > 0 and self.v_N > 0 and Fn.CONCURRENT and x.is_cuda
             if fork_cap:                     # the caption reasoning layer is independent of the visual one
                 main, side = torch.cuda.current_stream(), Fn.side_stream(1)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
+                # Training under the split-graph executor: the caption layers on the FOURTH chain (the inference / leaf stream, idle in a
+                # training step) instead of ahead of the decoder layer on its stream -- that stream carried 455 us per layer forward (value
+                # projection 30, decoder layer 285, caption layer 100) against 270 on each direction's chain and bounded the forward pass.
+                cside = Fn.fourth_stream() if (CAP_OWN_CHAIN and torch.is_grad_enabled() and Fn.fourth_stream() is not None) else side
+                cside.wait_stream(main)
+                with torch.cuda.stream(cside):
                     in_ft["cap"] = STM.through(in_ft["cap"], "cap in", True)
                     in_ft = self.c_layers[l](in_ft, ft, b)
                     in_ft["cap"] = STM.through(in_ft["cap"], "cap out", True)
@@ -509,7 +514,7 @@ class MultimodalDecoder8(nn.Module):
                         n_ = self.spatial_out_norm
                         ft["spatial_ft"], in_ft["t2s"] = Fn.layernorm_res(in_ft["t2s"], n_.a_2, n_.b_2, n_.eps)      # :129
             if fork_cap:
-                main.wait_stream(side)
+                main.wait_stream(cside)
             elif self.c_N > 0:
                 in_ft = self.c_layers[l](in_ft, ft, b)
                 ft["cap_ft"], in_ft["cap"] = Fn.layernorm_res(in_ft["cap"], self.cap_out_norm.a_2, self.cap_out_norm.b_2, self.cap_out_norm.eps)                               # :132

@@ -458,7 +458,7 @@ class VidEncoderLayer4(nn.Module):
         elif torch.is_grad_enabled() and t2s_on and s2t_on:
             v_t2s = self.train_value(take_t2s(), 1)
             v_s2t = None if own_v_s2t else self.train_value(take(), 4)
-        elif concurrent and not (ft.get("_bist_cap_fork") and Fn.leaf_stream() is None):
+        elif concurrent and not (ft.get("_bist_cap_fork") and Fn.fourth_stream() is None):
             # (inference only: under autograd a third forked stream makes hipGraph capture of the training step crash in
             # the HIP runtime -- also with every side stream joined explicitly after backward; beside a forked caption layer it would be
             # the capture's FOURTH stream, which only the split executor's graphs may have: Fn.MAX_CAPTURE_STREAMS)
@@ -512,7 +512,7 @@ class VidEncoderLayer4(nn.Module):
         # stream schedule of the fused inference layer; beside a caption layer forked onto its own stream (decoder.py) schedule 1 would make
         # the capture span four streams, which the runtime's graph executor is not trusted with (Fn.MAX_CAPTURE_STREAMS): schedule 0 there,
         # unless the graph is replayed by the split executor
-        sched = 0 if (ft.get("_bist_cap_fork") and Fn.leaf_stream() is None and Fn.EVAL_SCHED == 1) else Fn.EVAL_SCHED
+        sched = 0 if (ft.get("_bist_cap_fork") and Fn.fourth_stream() is None and Fn.EVAL_SCHED == 1) else Fn.EVAL_SCHED
         pre_vid = ft.pop("_bist_pre_vid", None)
         if pre_vid is not None and not (concurrent and fused and sched in (1, 2)):
             torch.cuda.current_stream().wait_event(pre_vid)      # no schedule below waits on it: consume it here (see VidEncoder8.forward)

@@ -11,6 +11,8 @@ from bist_amd.model import decode as D
 c = dict(bench.CFG)
 args = bench.model_args(c["L"], c["d"], c["h"], 0.1)
 torch.manual_seed(1)
+if Fn.main_stream() is not None and os.environ.get("NULLSTREAM") != "1":
+    torch.cuda.set_stream(Fn.main_stream())
 model = M.make_model(c["V"], c["V"], args, ft_sizes=[c["C"]]).cuda().to(torch.bfloat16).eval()
 for Lh in (60, 200):
     b1 = synthetic_batch(1, T=c["T"], S=c["S"], C=c["C"], Lq=c["Lq"], Lh=Lh, Lc=c["Lc"], Lt=c["Lt"], vocab=c["V"], seed=99, dtype=torch.bfloat16)

@@ -11,6 +11,9 @@ from bist_amd.train import Trainer
 c = dict(bench.CFG)
 if len(sys.argv) > 1:
     c["T"] = int(sys.argv[1])
+from bist_amd import functional as Fn
+if Fn.main_stream() is not None and os.environ.get("NULLSTREAM") != "1":
+    torch.cuda.set_stream(Fn.main_stream())
 args = bench.model_args(c["L"], c["d"], c["h"], 0.1)
 torch.manual_seed(1)
 model = M.make_model(c["V"], c["V"], args, ft_sizes=[c["C"]]).cuda(); model.train()

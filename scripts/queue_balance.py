@@ -3,11 +3,15 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 # the last occurrence of adam_kernel marks step ends; take the window between the last two adam launches of the replayed steps
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+adam = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]          # adam_kernel / adam4_kernel / adam_apply4: every optimiser launch
+if not adam:
+    sys.exit("no optimiser launch in the trace: cannot cut it into steps")
 if len({int(rows[i]["Grid_Size_X"]) for i in adam}) > 1:          # two Adam launches per step: the small (prefix) one ends it
     gmin = min(int(rows[i]["Grid_Size_X"]) for i in adam)
     adam = [i for i in adam if int(rows[i]["Grid_Size_X"]) == gmin]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+if len(adam) < 2:
+    sys.exit("fewer than two steps in the trace")
+k = min(int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) - 1, len(adam) - 1)          # the k-th step (default: the last whole one)
 lo, hi = adam[k - 1] + 1, adam[k] + 1
 win = rows[lo:hi]
 t0 = min(int(r["Start_Timestamp"]) for r in win); t1 = max(int(r["End_Timestamp"]) for r in win)

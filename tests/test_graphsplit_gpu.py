@@ -108,7 +108,7 @@ def test_trainer_split_step_trains_like_the_runtime_replay(env, dtype, monkeypat
         t = T.Trainer(m, args, 80, compute_dtype=dtype, warmup=20, factor=2.0, use_graph=graph)
         losses[tag] = [t.step(bs[i % 2])["out"].item() for i in range(6)]
         if split:
-            assert t._split is not None and t._split.info["chains"] == 3 and t._split.errors() == 0, t._split.info
+            assert t._split is not None and t._split.info["chains"] in (3, 4) and t._split.errors() == 0, t._split.info      # (4: the caption layers on a chain of their own)
         m.eval()
         torch.cuda.synchronize()
         res[tag] = {k: v.detach().float().clone() for k, v in m.named_parameters()}
