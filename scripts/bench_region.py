@@ -19,9 +19,9 @@ with torch.no_grad():
     vl = model.mutlimodal_decoder.v_layers[0]
 
     def run():
-        f = model.vid_encoder(bt, {})
+        f = model.vid_encoder(bt, {"_bist_layers_follow": True} if os.environ.get("FOLLOW", "1") == "1" else {})
         vl({"t2s": q, "s2t": q}, f, bt)
-    for sched in (1, 0, 2):
+    for sched in [int(v) for v in os.environ.get("SCHEDS", "1,0,2").split(",")]:
         Fn.EVAL_SCHED = sched
         side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
