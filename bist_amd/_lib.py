@@ -107,7 +107,6 @@ SIGNATURES = {
     "bist_pack_frag_rows_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I32, _I32, _I32, _I32, _P]),
     "bist_st_stage1_fused_ok": (C.c_int, [_I32] * 7),
     "bist_st_stage1_fused_fwd": (C.c_int, [_P] * 9 + [_I32] * 8 + [_P]),
-    "bist_st_stage1_fused_raw_fwd": (C.c_int, [_P] * 10 + [_I32] * 8 + [C.c_float, _P]),
     "bist_st_stage1_fused_train_ok": (C.c_int, [_I32] * 7),
     "bist_st_stage1_fused_train_fwd": (C.c_int, [_P] * 12 + [C.POINTER(BistDrop), C.POINTER(BistDrop)] + [_I32] * 8 + [_P]),
     "bist_st_stage1_pv_bwd_p": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I32, _P] + [_I32] * 6 + [_I64, _I64, _I32, C.POINTER(BistDrop), _I32, _P]),

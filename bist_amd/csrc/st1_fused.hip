@@ -46,10 +46,6 @@ struct St1F {
   int KP;
   DropArg adrop;                 // attention-probability dropout, element index ((((b G + g) h + hh) Lq + i) K + key
   DropArg sdrop;                 // sublayer-output dropout, element index (row of Y) * d + column
-  // RAW form (bist_st_stage1_fused_raw_fwd, inference): vft holds the UN-normalised rows x of the input projection and the LayerNorm
-  // between it and this attention (encoder.py:80) is applied algebraically -- see chunk_body
-  const float* wbar;             // [d] f32: row sums of the gain-scaled value weights
-  float ln_eps;
 };
 
 __device__ uint4 g_zero_line;      // 16 zero bytes: DMA source of every padding row
@@ -154,22 +150,8 @@ struct Chunk { int b, g0, ng, w, lane; };
 
 // The work of one chunk with MTA active key tiles (NGA = MTA / KT groups) and MT4A row tiles in the output projection.  The full
 // chunk is <KT, 8, MT4>; the last chunk of a clip (G % NG groups) runs the smallest instantiation that holds it.
-// RAW (inference): the video rows arrive UN-normalised.  With LayerNorm LN(x) = a (x - mu) r + beta, r = 1 / (std_unbiased + eps)
-// (modules.py:28-31), the two products of a key row x_t are affine in x_t:
-//   scores   Qf_i . LN(x_t) = r_t (Qf'_i . x_t - mu_t c_i) + e_i     Qf' = Qf * a (the caller scales W_k's columns), c_i = sum_k Qf'_ik,
-//                                                                    e_i = Qf_i . beta: constant along the softmax axis, it cancels;
-//   values   LN(x_t) W_v^T + b_v = r_t (x_t W'^T - mu_t wbar) + b'   W' = W_v * a (the caller packs it), wbar_c = sum_k W'_ck,
-//                                                                    b' = beta W_v^T + b_v (passed as the bias);
-//   context  sum_t P_it V_t = sum_t (P_it r_t) (x_t W'^T) - (sum_t P_it r_t mu_t) wbar + b'      (rows of P sum to one).
-// So steps 1 and 2 run on the raw rows, the scores are corrected per key before the softmax, the probabilities are scaled by r_t on their
-// way into step 3 and the context gets a rank-one correction.  mu_t, r_t: each wave computes them for the rows it staged, from the
-// LDS image (v_dot2_f32_bf16 sums, one 16-lane reduction per 4 rows), before the first barrier; c_i: one extra MFMA per k-step with
-// an all-ones A operand.  The 45 us LayerNorm pass over [B T S, d] leaves the critical path (the normalised tensor is still produced,
-// for the API, beside this kernel).
-template <int KT, int MTA, int MT4A, bool TRAIN = false, bool RAW = false>
-__device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* smem, float* st_mu = nullptr, float* st_ri = nullptr,
-                                           const float* st_wb = nullptr) {
-  static_assert(!(TRAIN && RAW), "the raw form is an inference form");
+template <int KT, int MTA, int MT4A, bool TRAIN = false>
+__device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* smem) {
   constexpr int NGA = MTA / KT;
   const int w = c.w, lane = c.lane, b = c.b, g0 = c.g0, ng = c.ng;
   const int x = lane & 15, kg = lane >> 4;
@@ -207,36 +189,6 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("" ::: "memory");
-  if (RAW && !(a.dbg & 32)) {
-    // mean and 1 / (unbiased std + eps) of the rows THIS wave staged (they have landed: vmcnt(0) above), four rows at a time: lane
-    // (q = lane >> 4, cq = lane & 15) sums chunks cq, cq + 16, cq + 32, cq + 48 of row 4 j + q (any chunk order: it is a whole-row sum)
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-    const unsigned ones2 = 0x3f803f80u;
-#pragma unroll
-    for (int j4 = 0; j4 < NDMA / 4; ++j4) {
-      const int r = w * NDMA + 4 * j4 + kg;
-      float sx = 0.f, sxx = 0.f;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const uint4 q = *reinterpret_cast<const uint4*>(smem + r * 1024 + (x + 16 * cc) * 16);
-        const unsigned u[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sx = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, u[e]), __builtin_bit_cast(bf2, ones2), sx, false);
-          sxx = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, u[e]), __builtin_bit_cast(bf2, u[e]), sxx, false);
-        }
-      }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 16); sxx += __shfl_xor(sxx, o, 16); }
-      if (x == 0) {
-        const float mu = sx * (1.f / D);
-        const float var = fmaxf(sxx - sx * mu, 0.f) * (1.f / (D - 1));
-        st_mu[r] = mu;
-        st_ri[r] = 1.f / (sqrtf(var) + a.ln_eps);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (visible to every wave behind the barrier of step 1)
-  }
   // fragment g (parity e = g / NM, tile mt = g % NM) of pair kp in a swizzled [rows][1024 B] image: lane (x, kg) reads row
   // 16*mt + x, logical 16-byte chunk 8*kp + 2*kg + e, stored at chunk ^ x
   const unsigned img0 = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)x * 1024u;
@@ -284,9 +236,7 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
   STAMP(2);
   // ---- 2. S_hh^T = X . Qf_hh^T -----------------------------------------------------------------------------
   f32x4 sacc[MTA][2];
-  f32x4 cacc[RAW ? 2 : 1];                       // RAW: c_i = sum_k Qf'[i][k] of this lane's query rows i = 16 it + x (every register the same)
   {
-    if constexpr (RAW) { cacc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; cacc[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int mt = 0; mt < MTA; ++mt)
 #pragma unroll
@@ -306,11 +256,6 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
 #pragma unroll
                               for (int it = 0; it < 2; ++it) sacc[mt][it] = mfma16(ax, u4(bq[e][it]), sacc[mt][it]);
                               if constexpr (mt == MTA - 1) {
-                                if (RAW && !(a.dbg & 64)) {           // an all-ones "key row": the row sums of this k-step's Qf' slice
-                                  const uint4 one = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-#pragma unroll
-                                  for (int it = 0; it < 2; ++it) cacc[it] = mfma16(one, u4(bq[e][it]), cacc[it]);
-                                }
                                 if (!(a.dbg & 2)) load_q2(bq[e], q0, q1, min(kp + 1, 7), e);
                               }
                             });
@@ -327,7 +272,6 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
   // finish steps 1-2 together, and this vector work of the first runs under the matrix work of the second
   uint4 pf[NGA][2][KT / 2];
   float rsum[TRAIN ? NGA : 1][2];                // TRAIN: sum of the KEPT (dropped-out, rescaled) probabilities of this lane's query rows
-  float msum[RAW ? NGA : 1][2];                  // RAW: sum_t P_it r_t mu_t of this lane's query rows (the context's rank-one correction)
   if (!(a.dbg & 16)) {
     const bool plain = repl == 0;            // per lane; uniform in the common case (no padding keys, nothing masked)
     const unsigned long long akey = (TRAIN && a.adrop.p > 0.f) ? a.adrop.key() : 0ULL;
@@ -339,25 +283,14 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
         float sv[KT][4];
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          float4 mu4 = {0.f, 0.f, 0.f, 0.f}, ri4 = {1.f, 1.f, 1.f, 1.f};
-          if (RAW && !(a.dbg & 128)) {           // this lane's keys 16 (gl KT + kt) + 4 kg + r of the chunk image
-            mu4 = *reinterpret_cast<const float4*>(st_mu + 16 * (gl * KT + kt) + 4 * kg);
-            ri4 = *reinterpret_cast<const float4*>(st_ri + 16 * (gl * KT + kt) + 4 * kg);
-          }
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = sacc[gl * KT + kt][it][r];
-            if constexpr (RAW) {
-              const float mu_r = r == 0 ? mu4.x : r == 1 ? mu4.y : r == 2 ? mu4.z : mu4.w;
-              const float ri_r = r == 0 ? ri4.x : r == 1 ? ri4.y : r == 2 ? ri4.z : ri4.w;
-              v = ri_r * (v - mu_r * cacc[it][0]);
-            }
             if (!plain) v = (repl >> (kt * 4 + r) & 1u) ? ((padb >> (kt * 4 + r) & 1u) ? -INFINITY : MASK_FILL) : v;
             sv[kt][r] = v;
             mx = fmaxf(mx, v);
           }
-        }
         mx = rows_max(mx);
         float den = 0.f;
 #pragma unroll
@@ -385,23 +318,6 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
             for (int r = 0; r < 4; ++r) kept += sv[kt][r];
           }
           rsum[gl][it] = rows_sum(kept);
-#pragma unroll
-          for (int k2 = 0; k2 < KT / 2; ++k2)
-            pf[gl][it][k2] = make_uint4(pack2(sv[2 * k2][0], sv[2 * k2][1]), pack2(sv[2 * k2][2], sv[2 * k2][3]),
-                                        pack2(sv[2 * k2 + 1][0], sv[2 * k2 + 1][1]), pack2(sv[2 * k2 + 1][2], sv[2 * k2 + 1][3]));
-        } else if constexpr (RAW) {
-          float m = 0.f;
-#pragma unroll
-          for (int kt = 0; kt < KT; ++kt) {       // P' = P r (the operand of step 3), m = sum P' mu
-            float4 mu4 = {0.f, 0.f, 0.f, 0.f}, ri4 = {1.f, 1.f, 1.f, 1.f};
-            if (!(a.dbg & 128)) {
-              mu4 = *reinterpret_cast<const float4*>(st_mu + 16 * (gl * KT + kt) + 4 * kg);
-              ri4 = *reinterpret_cast<const float4*>(st_ri + 16 * (gl * KT + kt) + 4 * kg);
-            }
-            sv[kt][0] *= inv * ri4.x; sv[kt][1] *= inv * ri4.y; sv[kt][2] *= inv * ri4.z; sv[kt][3] *= inv * ri4.w;
-            m += sv[kt][0] * mu4.x + sv[kt][1] * mu4.y + sv[kt][2] * mu4.z + sv[kt][3] * mu4.w;
-          }
-          msum[gl][it] = rows_sum(m);
 #pragma unroll
           for (int k2 = 0; k2 < KT / 2; ++k2)
             pf[gl][it][k2] = make_uint4(pack2(sv[2 * k2][0], sv[2 * k2][1]), pack2(sv[2 * k2][2], sv[2 * k2][3]),
@@ -460,8 +376,6 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int c0 = w * 64 + nt * 16 + kg * 4;                    // this lane's 4 consecutive output channels
-      float4 wb = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (RAW) wb = *reinterpret_cast<const float4*>(st_wb + c0);
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -471,10 +385,6 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
         if (i < Lq) {
           const int row = gl * Lq + i;
           const float bs = TRAIN ? rsum[TRAIN ? gl : 0][it] : 1.f;      // dropped probabilities do not sum to one: P'(V + b) = P'V + rowsum(P') b
-          if constexpr (RAW) {
-            const float m = msum[RAW ? gl : 0][it];
-            o[0] -= m * wb.x; o[1] -= m * wb.y; o[2] -= m * wb.z; o[3] -= m * wb.w;
-          }
           char* dst = smem + row * 1024 + ((((c0 >> 3)) ^ (row & 15)) << 4) + (kg & 1) * 8;
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(o[0] + bs * bvf[nt][0], o[1] + bs * bvf[nt][1]), pack2(o[2] + bs * bvf[nt][2], o[3] + bs * bvf[nt][3]));
         }
@@ -584,14 +494,11 @@ __device__ __forceinline__ void chunk_body(const St1F& a, const Chunk c, char* s
   STAMP(7);
 }
 
-template <int KT, int MT4, bool TRAIN = false, bool RAW = false>
+template <int KT, int MT4, bool TRAIN = false>
 __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
   constexpr int NG = MT / KT;
   constexpr int LQC = MT4 * 16 / NG;                    // the query-length class of this instantiation (20 or 32 rows per group)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  __shared__ __attribute__((aligned(16))) float st_mu[RAW ? MT * 16 : 4], st_ri[RAW ? MT * 16 : 4];      // RAW: per key row of the chunk image
-  __shared__ __attribute__((aligned(16))) float st_wb[RAW ? D : 4];                                       // RAW: wbar (visible behind step 1's barrier)
-  if constexpr (RAW) st_wb[threadIdx.x] = a.wbar[threadIdx.x];
   const int G = a.dir == 0 ? a.S : a.T;
   // Block order: the B * (G / NG) full chunks first, in XCD-contiguous order (blocks b, b+8, ... share an XCD and its L2: each XCD
   // walks a contiguous range of chunks, so the Qf rows of the few clips it works on stay in that L2), then the B short chunks
@@ -608,12 +515,12 @@ __global__ __launch_bounds__(512, 2) void st1_fused_kernel(const St1F a) {
   }
   c.lane = threadIdx.x & 63; c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if constexpr (KT == 2) {
-    if (c.ng == 1) { chunk_body<2, 2, (LQC + 15) / 16, TRAIN, RAW>(a, c, smem, st_mu, st_ri, st_wb); return; }
-    if (c.ng == 2) { chunk_body<2, 4, (2 * LQC + 15) / 16, TRAIN, RAW>(a, c, smem, st_mu, st_ri, st_wb); return; }
+    if (c.ng == 1) { chunk_body<2, 2, (LQC + 15) / 16, TRAIN>(a, c, smem); return; }
+    if (c.ng == 2) { chunk_body<2, 4, (2 * LQC + 15) / 16, TRAIN>(a, c, smem); return; }
   } else if constexpr (KT == 4) {
-    if (c.ng == 1) { chunk_body<4, 4, (LQC + 15) / 16, TRAIN, RAW>(a, c, smem, st_mu, st_ri, st_wb); return; }
+    if (c.ng == 1) { chunk_body<4, 4, (LQC + 15) / 16, TRAIN>(a, c, smem); return; }
   }
-  chunk_body<KT, MT, MT4, TRAIN, RAW>(a, c, smem, st_mu, st_ri, st_wb);
+  chunk_body<KT, MT, MT4, TRAIN>(a, c, smem);
 }
 
 // W [rows][cols] row-major -> fragment order [rows/16][cols/64][2][64 lanes][8]: lane (x = lane & 15, kg = lane >> 4) of block
@@ -645,10 +552,10 @@ __global__ void pack_frag_rows_multi_kernel(const PackSets sets, int rows, int c
   reinterpret_cast<uint4*>(out)[piece] = *reinterpret_cast<const uint4*>(src);
 }
 
-template <int KT, int MT4, bool TRAIN = false, bool RAW = false>
+template <int KT, int MT4, bool TRAIN = false>
 int launch(const St1F& a, hipStream_t st) {
-  BIST_LDS_OPTIN((&st1_fused_kernel<KT, MT4, TRAIN, RAW>), MT * 16 * 1024, "bist_st_stage1_fused_fwd", BIST_ELAUNCH);
-  hipLaunchKernelGGL((st1_fused_kernel<KT, MT4, TRAIN, RAW>), dim3((unsigned)(a.B * a.cpc)), dim3(512), MT * 16 * 1024, st, a);
+  BIST_LDS_OPTIN((&st1_fused_kernel<KT, MT4, TRAIN>), MT * 16 * 1024, "bist_st_stage1_fused_fwd", BIST_ELAUNCH);
+  hipLaunchKernelGGL((st1_fused_kernel<KT, MT4, TRAIN>), dim3((unsigned)(a.B * a.cpc)), dim3(512), MT * 16 * 1024, st, a);
   BIST_LAUNCH_CHECK("bist_st_stage1_fused_fwd");
   bist_count_launch(TRAIN ? BIST_K_ST1_FUSED_TRAIN : BIST_K_ST1_FUSED);
   return BIST_OK;
@@ -691,9 +598,8 @@ extern "C" int bist_st_stage1_fused_ok(int32_t T, int32_t S, int32_t Lq, int32_t
 namespace {
 int fused_common(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv, const void* Wo, const void* bo,
                  const void* xres, void* Y, int32_t B, int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype,
-                 void* Vout, float* Pout, void* Oout, const BistDrop* attn_drop, const BistDrop* sub_drop, bool train, void* stream,
-                 const float* wbar = nullptr, float ln_eps = 0.f) {
-  const char* who = train ? "bist_st_stage1_fused_train_fwd" : wbar ? "bist_st_stage1_fused_raw_fwd" : "bist_st_stage1_fused_fwd";
+                 void* Vout, float* Pout, void* Oout, const BistDrop* attn_drop, const BistDrop* sub_drop, bool train, void* stream) {
+  const char* who = train ? "bist_st_stage1_fused_train_fwd" : "bist_st_stage1_fused_fwd";
   BIST_REQUIRE(qf && vft && Wv && bv && Wo && bo && xres && Y && B > 0, "%s: null pointer or empty batch", who);
   BIST_REQUIRE(bist_st_stage1_fused_ok(T, S, Lq, d, h, direction, dtype), "%s: shape outside the kernel's envelope (bf16, d=512, h=8, Lq<=32, keys<=128)", who);
   const void* ptrs[] = {qf, vft, Wv, bv, Wo, bo, xres, Y, Vout, Pout, Oout};
@@ -702,7 +608,7 @@ int fused_common(const void* qf, const void* vft, const uint8_t* kmask, const vo
   const int KT = K <= 32 ? 2 : K <= 64 ? 4 : 8, NG = MT / KT;
   St1F a{(const bf16_t*)qf, (const bf16_t*)vft, kmask, (const bf16_t*)Wv, (const bf16_t*)bv, (const bf16_t*)Wo, (const bf16_t*)bo,
          (const bf16_t*)xres, (bf16_t*)Y, B, T, S, Lq, direction, (G + NG - 1) / NG, nullptr, 0,
-         (bf16_t*)Vout, Pout, (bf16_t*)Oout, (K + 3) / 4 * 4, make_drop(attn_drop), make_drop(sub_drop), wbar, ln_eps};
+         (bf16_t*)Vout, Pout, (bf16_t*)Oout, (K + 3) / 4 * 4, make_drop(attn_drop), make_drop(sub_drop)};
   a.stamps = bist_dev_stamps(0);
   a.dbg = bist_dev_dbg(0);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -714,12 +620,6 @@ int fused_common(const void* qf, const void* vft, const uint8_t* kmask, const vo
     if (KT == 2) return need <= 5 ? launch<2, 5, true>(a, st) : launch<2, 8, true>(a, st);
     if (KT == 4) return need <= 3 ? launch<4, 3, true>(a, st) : launch<4, 4, true>(a, st);
     return launch<8, 2, true>(a, st);
-  }
-  if (wbar) {
-    BIST_REQUIRE((reinterpret_cast<uintptr_t>(wbar) & 15) == 0 && ln_eps > 0.f, "%s: wbar 16-byte aligned, eps > 0", who);
-    if (KT == 2) return need <= 5 ? launch<2, 5, false, true>(a, st) : launch<2, 8, false, true>(a, st);
-    if (KT == 4) return need <= 3 ? launch<4, 3, false, true>(a, st) : launch<4, 4, false, true>(a, st);
-    return launch<8, 2, false, true>(a, st);
   }
   if (KT == 2) return need <= 5 ? launch<2, 5>(a, st) : launch<2, 8>(a, st);
   if (KT == 4) return need <= 3 ? launch<4, 3>(a, st) : launch<4, 4>(a, st);
@@ -745,16 +645,4 @@ extern "C" int bist_st_stage1_fused_train_fwd(const void* qf, const void* vft, c
                                               const BistDrop* attn_drop, const BistDrop* sub_drop, int32_t B, int32_t T, int32_t S,
                                               int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream) {
   return fused_common(qf, vft, kmask, Wv, bv, Wo, bo, xres, Y, B, T, S, Lq, d, h, direction, dtype, Vout, Pout, Oout, attn_drop, sub_drop, true, stream);
-}
-
-// The same launch on the UN-normalised rows of the input projection (inference): x_raw [B,T,S,d] = ReLU(W fts + b) of encoder.py:75, the
-// LayerNorm of encoder.py:80 folded into the products (see chunk_body).  qf_scaled: the folded query through W_k with its columns
-// scaled by the LayerNorm gain; Wv_scaled: W_v with its columns scaled by the gain, fragment order; bv_folded [d] = beta W_v^T + b_v;
-// wbar [d] f32 = row sums of the scaled W_v.  Same result as bist_st_stage1_fused_fwd on LN(x_raw) up to bf16 rounding of LN(x_raw).
-extern "C" int bist_st_stage1_fused_raw_fwd(const void* qf_scaled, const void* x_raw, const uint8_t* kmask, const void* Wv_scaled, const void* bv_folded,
-                                            const float* wbar, const void* Wo, const void* bo, const void* xres, void* Y, int32_t B, int32_t T,
-                                            int32_t S, int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, float ln_eps, void* stream) {
-  BIST_REQUIRE(wbar != nullptr, "bist_st_stage1_fused_raw_fwd: null wbar");
-  return fused_common(qf_scaled, x_raw, kmask, Wv_scaled, bv_folded, Wo, bo, xres, Y, B, T, S, Lq, d, h, direction, dtype, nullptr, nullptr, nullptr, nullptr,
-                      nullptr, false, stream, wbar, ln_eps);
 }

@@ -580,10 +580,6 @@ FUSED_ST1 = os.environ.get("BIST_FUSED_ST1", "1") != "0"      # tuning aid: 0 = 
 FUSED_DECODE = os.environ.get("BIST_FUSED_DECODE", "1") != "0"      # tuning aid: 0 = the decoder layers of a decode step as separate launches
 
 
-# LayerNorm of the video rows folded into the fused stage-1 launches of the inference layer (bist_st_stage1_fused_raw_fwd): the
-# normalising pass over [B T S, d] then runs BESIDE them (main stream) instead of ahead of them.  0 = the pass first, the launches on its output.
-RAW_ST1 = os.environ.get("BIST_ST1_RAW", "1") != "0"
-RAW_LN_LATE = os.environ.get("BIST_RAW_LN_LATE", "1") != "0"   # ... and behind them (under the chains' tails) when the caller announces the layer
 EVAL_SCHED = int(os.environ.get("BIST_EVAL_SCHED", "1"))      # tuning aid: stream schedule of the fused inference layer (0: one fork after the input projection, 1: two chains forked ahead of it, 2: stage-1 launches on the main stream)
 
 

@@ -88,25 +88,7 @@ class VidEncoder8(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record()
                 ft["_bist_pre_vid"] = ev
-            n = self.in_norm
-            if (not torch.is_grad_enabled() and fts.is_cuda and "_bist_pre_vid" in ft and Fn.RAW_ST1 and Fn.FUSED_ST1 and Fn.EVAL_SCHED == 1
-                    and not ops.LN_EPILOGUE and fts.dtype == torch.bfloat16 and self.W.weight.shape[0] == 512):
-                # inference, fused reasoning layers: they read the UN-normalised rows and apply this LayerNorm inside their stage-1
-                # launches (bist_st_stage1_fused_raw_fwd), so the normalising pass over [B T S, d] is off their path: it runs here, on
-                # the main stream, beside them, for the readers of ft['spatiotemporal_ft'] (the API's tensor; decoder layers do not
-                # read it).  The event is consumed by the first reasoning layer (a captured record nobody waits on: see above).
-                act = ops.linear(fts.reshape(B * T * S, C), self.W.weight, self.W.bias, act=Fn.ACT_RELU)
-                ev = torch.cuda.Event()
-                ev.record()
-                ft["_bist_vft_raw"] = raw = {"x": act.view(B, T, S, -1), "norm": n, "event": ev}
-                if ft.get("_bist_layers_follow") and Fn.RAW_LN_LATE:
-                    # the caller runs a reasoning layer next (MTN.encode): the pass is launched BY that layer, behind its stage-1 launches
-                    out = torch.empty_like(act)
-                    raw["finish"] = lambda: ops.layernorm(act, n.a_2, n.b_2, n.eps, out=out)
-                    ft["spatiotemporal_ft"] = out.view(B, T, S, -1)
-                else:
-                    ft["spatiotemporal_ft"] = ops.layernorm(act, n.a_2, n.b_2, n.eps).view(B, T, S, -1)
-            elif not torch.is_grad_enabled() and fts.is_cuda:
+            if not torch.is_grad_enabled() and fts.is_cuda:
                 # inference: LayerNorm(ReLU(W fts + b)) as ONE launch where the product's LayerNorm epilogue covers the shape (no
                 # separate pass over the [B*T*S, 512] activations); training keeps both tensors for the backward pass
                 n = self.in_norm
@@ -145,7 +127,7 @@ class VidEncoderLayer4(nn.Module):
     directions on, attn 0..5 = A0,A1,A2,A3,A4,A5; sublayer 0..7 = A0,A1,A2,F0,A3,A4,A5,F1; ff 0,1.
     """
 
-    _RUNTIME_ATTRS = ("_frag_train", "_frag_cache", "_raw_cache", "_vpack", "_v_ready", "_v_event", "_offload_main", "_x_next")
+    _RUNTIME_ATTRS = ("_frag_train", "_frag_cache", "_vpack", "_v_ready", "_v_event", "_offload_main", "_x_next")
 
     def __getstate__(self):
         """torch.save / copy.deepcopy: derived device buffers (fragment-ordered weights, packed projections) and per-call stream state
@@ -221,51 +203,20 @@ class VidEncoderLayer4(nn.Module):
         y = Fn.linear(o, attn.linears[3].weight, attn.linears[3].bias, residual=xr, res_map=(G * Lq, Lq), **Fn.drop_args(sub))
         return y.view(B, G, Lq, d)
 
-    def _stage1_query(self, ai: int, si: int, x_in: Tensor, query_mask, raw=None):
+    def _stage1_query(self, ai: int, si: int, x_in: Tensor, query_mask):
         """Query side of one direction up to the fused stage-1 launch: self-attention sublayer (A0 / A3), then LayerNorm, query
-        projection and the fold through W_k of the stage-1 attention -> (x, Qf [B, Lq*h, d]).  raw: the fold goes through W_k with its
-        columns scaled by the video LayerNorm's gain (_raw_weights)."""
+        projection and the fold through W_k of the stage-1 attention -> (x, Qf [B, Lq*h, d])."""
         x = _self_attention(self.sublayer[si], self.attn[ai], x_in, query_mask)
         attn, sub = self.attn[ai + 1], self.sublayer[si + 1]
         B, Lq, d = x.shape
         xn, _ = sub.norm.with_residual(x, lazy=True)
         q = Fn.linear(xn, attn.linears[0].weight, attn.linears[0].bias)
-        wk = attn.linears[1].weight if raw is None else self._raw_weights(ai + 1, raw["norm"])[0]
-        return x, Fn.head_fold(q, wk, attn.h, 1.0 / math.sqrt(attn.d_k)).view(B, Lq * attn.h, d)
+        return x, Fn.head_fold(q, attn.linears[1].weight, attn.h, 1.0 / math.sqrt(attn.d_k)).view(B, Lq * attn.h, d)
 
-    def _stage1_fused(self, ai: int, x: Tensor, qf: Tensor, vft: Tensor, kmask, direction: int, raw=None) -> Tensor:
+    def _stage1_fused(self, ai: int, x: Tensor, qf: Tensor, vft: Tensor, kmask, direction: int) -> Tensor:
         attn = self.attn[ai]
         wv, wo = self._frag_weights(ai)
-        if raw is not None:
-            _, wv_s, bv_f, wbar = self._raw_weights(ai, raw["norm"])
-            return ops.st_stage1_fused(qf, raw["x"], kmask, wv_s, bv_f, wo, attn.linears[3].bias, x, h=attn.h, direction=direction,
-                                       raw=(wbar, raw["norm"].eps))
         return ops.st_stage1_fused(qf, vft, kmask, wv, attn.linears[2].bias, wo, attn.linears[3].bias, x, h=attn.h, direction=direction)
-
-    def _raw_weights(self, ai: int, norm):
-        """Operands of the LayerNorm-folded stage-1 launch of attention `ai` (bist_st_stage1_fused_raw_fwd), with a = norm.a_2, beta = norm.b_2:
-        (W_k * a [d,d], fragment-ordered W_v * a, beta W_v^T + b_v [d], row sums of the scaled W_v [d] f32).  Cached like _frag_weights:
-        refreshed INTO THE SAME BUFFERS when a parameter changes."""
-        attn = self.attn[ai]
-        wk, wv, bv = attn.linears[1].weight, attn.linears[2].weight, attn.linears[2].bias
-        key = ops.weights_key(wk, wv, bv, norm.a_2, norm.b_2)
-        cache = self.__dict__.setdefault("_raw_cache", {})
-        hit = cache.get(ai)
-        if hit is None or hit[0] != key or hit[1][0].device != wv.device or hit[1][0].dtype != wv.dtype:
-            with torch.no_grad():
-                d = wv.shape[0]
-                bufs = hit[1] if hit is not None and hit[1][0].device == wv.device and hit[1][0].dtype == wv.dtype else (
-                    torch.empty_like(wk), torch.empty_like(wv), torch.empty(d, device=wv.device, dtype=wv.dtype),
-                    torch.empty(d, device=wv.device, dtype=torch.float32), torch.empty_like(wv))
-                wk_s, wv_frag, bv_f, wbar, wv_s = bufs
-                torch.mul(wk.detach(), norm.a_2.detach()[None, :], out=wk_s)
-                torch.mul(wv.detach(), norm.a_2.detach()[None, :], out=wv_s)
-                ops.pack_frag_rows(wv_s, wv_frag)
-                ops.linear(norm.b_2.detach()[None, :], wv.detach(), bv.detach(), out=bv_f.view(1, d))
-                ops.linear(torch.ones(1, d, device=wv.device, dtype=wv.dtype), wv_s, None, out=wbar.view(1, d))
-            hit = cache[ai] = (key, bufs)
-        wk_s, wv_frag, bv_f, wbar, _ = hit[1]
-        return wk_s, wv_frag, bv_f, wbar
 
     def _frag_weights(self, ai: int):
         """W_v and W_o of attention `ai` in MFMA-fragment order (ops.pack_frag_rows), re-packed INTO THE SAME BUFFERS whenever the
@@ -565,17 +516,6 @@ class VidEncoderLayer4(nn.Module):
         pre_vid = ft.pop("_bist_pre_vid", None)
         if pre_vid is not None and not (concurrent and fused and sched in (1, 2)):
             torch.cuda.current_stream().wait_event(pre_vid)      # no schedule below waits on it: consume it here (see VidEncoder8.forward)
-        # un-normalised video rows + their LayerNorm (VidEncoder8.forward): read by the fused launches of schedule 1
-        raw = ft.get("_bist_vft_raw")
-        raw_ev = raw.pop("event", None) if raw is not None else None
-        raw_finish = raw.pop("finish", None) if raw is not None else None
-        if not (concurrent and fused and sched == 1 and trace is None):
-            raw = None
-            if raw_ev is not None:
-                torch.cuda.current_stream().wait_event(raw_ev)   # (consumed, like pre_vid)
-            if raw_finish is not None:
-                raw_finish()                                     # this layer reads the normalised tensor: the pass runs now
-                raw_finish = None
         if trace is not None and fused:
             fused = False                                # the traced form keeps every stage's output: separate launches
             v_t2s, v_s2t = self.value_projection(take())
@@ -587,28 +527,18 @@ class VidEncoderLayer4(nn.Module):
                     st_.wait_event(pre_vid)
                 else:
                     st_.wait_stream(main)
-            if raw_ev is not None:
-                ev = raw_ev                              # the rows are ready BEFORE the main stream's normalising pass
-            else:
-                ev = torch.cuda.Event()
-                ev.record(main)
+            ev = torch.cuda.Event()
+            ev.record(main)
             with torch.cuda.stream(side2):
-                xt, qft = self._stage1_query(0, 0, in_ft["t2s"], b.query_mask, raw)
+                xt, qft = self._stage1_query(0, 0, in_ft["t2s"], b.query_mask)
                 side2.wait_event(ev)
-                yt = self._stage1_fused(1, xt, qft, vft_t2s, b.temporal_mask, 0, raw)
-                if raw_finish is not None:
-                    ev_t = torch.cuda.Event(); ev_t.record(side2)
+                yt = self._stage1_fused(1, xt, qft, vft_t2s, b.temporal_mask, 0)
                 in_ft["t2s"] = _feed_forward(self.sublayer[3], self.ff[0], self._stage2(2, 2, xt, yt, None))
             with torch.cuda.stream(side):
-                xs, qfs = self._stage1_query(3, 4, in_ft["s2t"], b.query_mask, raw)
+                xs, qfs = self._stage1_query(3, 4, in_ft["s2t"], b.query_mask)
                 side.wait_event(ev)
-                ys = self._stage1_fused(4, xs, qfs, vft_s2t, None, 1, raw)
-                if raw_finish is not None:
-                    ev_s = torch.cuda.Event(); ev_s.record(side)
+                ys = self._stage1_fused(4, xs, qfs, vft_s2t, None, 1)
                 in_ft["s2t"] = _feed_forward(self.sublayer[7], self.ff[1], self._stage2(5, 6, xs, ys, b.temporal_mask))
-            if raw_finish is not None:       # the normalising pass for ft['spatiotemporal_ft']: under the two chains' stage 2 / feed-forward tails
-                main.wait_event(ev_t); main.wait_event(ev_s)
-                raw_finish()
             main.wait_stream(side2); main.wait_stream(side)
         elif concurrent and fused and sched == 2:
             # Inference at the production width.  Main stream: the two fused stage-1 launches (each fills the chip), back to back;

@@ -496,11 +496,9 @@ def st_stage1_fused_train(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: 
 
 
 def st_stage1_fused(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: Tensor, bv: Tensor, wo: Tensor, bo: Tensor,
-                    xres: Tensor, *, h: int, direction: int, out: Optional[Tensor] = None, raw=None) -> Tensor:
+                    xres: Tensor, *, h: int, direction: int, out: Optional[Tensor] = None) -> Tensor:
     """Stage 1 of one direction in one launch (inference form): qf [B, Lq*h, d] folded query, vft [B,T,S,d], kmask [B,K] or
-    None, wv / wo in fragment order (pack_frag_rows), xres [B,Lq,d] -> Y [B,G,Lq,d]; see include/bist_hip.h.
-    ``raw`` = (wbar [d] f32, eps): bist_st_stage1_fused_raw_fwd -- vft holds the UN-normalised rows of the input projection, qf / wv /
-    bv are the LayerNorm-folded operands (gain-scaled fold, gain-scaled W_v, beta W_v^T + b_v)."""
+    None, wv / wo in fragment order (pack_frag_rows), xres [B,Lq,d] -> Y [B,G,Lq,d]; see include/bist_hip.h."""
     _dev(qf, vft, kmask, wv, bv, wo, bo, xres)
     B, T, S, d = vft.shape
     Lq = xres.shape[1]
@@ -522,18 +520,9 @@ def st_stage1_fused(qf: Tensor, vft: Tensor, kmask: Optional[Tensor], wv: Tensor
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda._sleep(200_000)
         e0.record()
-    if raw is not None:
-        wbar, eps = raw
-        _dev(wbar)
-        if wbar.dtype != torch.float32 or wbar.shape != (d,) or not wbar.is_contiguous():
-            raise ValueError("bist_amd.st_stage1_fused: wbar must be a contiguous f32 [d] vector")
-        check(lib.bist_st_stage1_fused_raw_fwd(qf.data_ptr(), vft.data_ptr(), mptr, wv.data_ptr(), bv.data_ptr(), wbar.data_ptr(), wo.data_ptr(),
-                                               bo.data_ptr(), xres.data_ptr(), out.data_ptr(), B, T, S, Lq, d, h, direction,
-                                               dtype_code(vft.dtype), float(eps), _stream()), "bist_st_stage1_fused_raw_fwd")
-    else:
-        check(lib.bist_st_stage1_fused_fwd(qf.data_ptr(), vft.data_ptr(), mptr, wv.data_ptr(), bv.data_ptr(), wo.data_ptr(),
-                                           bo.data_ptr(), xres.data_ptr(), out.data_ptr(), B, T, S, Lq, d, h, direction,
-                                           dtype_code(vft.dtype), _stream()), "bist_st_stage1_fused_fwd")
+    check(lib.bist_st_stage1_fused_fwd(qf.data_ptr(), vft.data_ptr(), mptr, wv.data_ptr(), bv.data_ptr(), wo.data_ptr(),
+                                       bo.data_ptr(), xres.data_ptr(), out.data_ptr(), B, T, S, Lq, d, h, direction,
+                                       dtype_code(vft.dtype), _stream()), "bist_st_stage1_fused_fwd")
     if timed:
         e1.record()
         ST1F_TIMING.append(((B, T, S, Lq, direction), e0, e1))

@@ -252,16 +252,6 @@ int bist_st_stage1_fused_ok(int32_t T, int32_t S, int32_t Lq, int32_t d, int32_t
 int bist_st_stage1_fused_fwd(const void* qf, const void* vft, const uint8_t* kmask, const void* Wv, const void* bv,
                              const void* Wo, const void* bo, const void* xres, void* Y, int32_t B, int32_t T, int32_t S,
                              int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, void* stream);
-/* bist_st_stage1_fused_raw_fwd: bist_st_stage1_fused_fwd on the UN-normalised rows x_raw = ReLU(W fts + b) of the input projection
- * (reference encoder.py:75); the LayerNorm between the projection and this attention (encoder.py:80, modules.py:28-31) is applied
- * inside the launch: per-row mean and 1 / (unbiased std + eps) from the staged rows, scores corrected per key before the softmax,
- * probabilities scaled per key, rank-one correction of the context.  qf_scaled: the folded query with W_k's columns scaled by the
- * LayerNorm gain; Wv_scaled: W_v with its columns scaled by the gain, fragment order; bv_folded [d] = offset W_v^T + b_v;
- * wbar [d] f32: row sums of the scaled W_v.  Result: that of bist_st_stage1_fused_fwd on LN(x_raw), up to the bf16 rounding of LN(x_raw). */
-int bist_st_stage1_fused_raw_fwd(const void* qf_scaled, const void* x_raw, const uint8_t* kmask, const void* Wv_scaled, const void* bv_folded,
-                                 const float* wbar, const void* Wo, const void* bo, const void* xres, void* Y, int32_t B, int32_t T, int32_t S,
-                                 int32_t Lq, int32_t d, int32_t h, int32_t direction, int32_t dtype, float ln_eps, void* stream);
-
 /* The TRAINING form of the same launch: the sublayer's two dropouts are applied in the kernel -- attn_drop on the probabilities
  * (modules.py:62-63; mask index ((((b*G + g)*h + hh)*Lq + i)*K + key, as bist_st_stage1_pv_fwd; the value bias is then scaled by the
  * kept probabilities' row sum) and sub_drop on W_o ctx + b_o before the residual (modules.py:44; mask index (row of Y)*d + column,

@@ -19,9 +19,9 @@ with torch.no_grad():
     vl = model.mutlimodal_decoder.v_layers[0]
 
     def run():
-        f = model.vid_encoder(bt, {"_bist_layers_follow": True} if os.environ.get("FOLLOW", "1") == "1" else {})
+        f = model.vid_encoder(bt, {})
         vl({"t2s": q, "s2t": q}, f, bt)
-    for sched in [int(v) for v in os.environ.get("SCHEDS", "1,0,2").split(",")]:
+    for sched in (1, 0, 2):
         Fn.EVAL_SCHED = sched
         side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
