@@ -21,7 +21,7 @@ with torch.no_grad():
     def run():
         f = model.vid_encoder(bt, {})
         vl({"t2s": q, "s2t": q}, f, bt)
-    for sched in (1, 0, 2):
+    for sched in [int(v) for v in os.environ.get("SCHEDS", "1,0,2").split(",")]:
         Fn.EVAL_SCHED = sched
         side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
