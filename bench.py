@@ -282,11 +282,21 @@ def main():
     if sp is not None:
         executor.update({k: sp.info[k] for k in ("chains", "nodes", "waits", "signals", "nodes_per_chain")})
         executor["timed_out_waits"] = sp.errors()
-    hs = []
+    hs, ready, whole = [], [], []
     for _ in range(10):                           # host time of one step() call with the device idle (hipGraphLaunch and the loop around it)
         torch.cuda.synchronize(); h0 = time.perf_counter(); trainer.step(batch); hs.append((time.perf_counter() - h0) * 1e3)
-    torch.cuda.synchronize()
+        ready.append(list(getattr(trainer, "exchange_ready_s", [])))
+        torch.cuda.synchronize(); whole.append((time.perf_counter() - h0) * 1e3)
     executor["host_ms_per_step"] = sorted(hs)[len(hs) // 2]
+    if getattr(trainer, "overlap", False):
+        # several ranks (or the one-rank rehearsal): the buckets exchanged DURING the backward pass -- their sizes and when, after the
+        # step's launch, the step's streams had signalled each as final (the host then issues its all-reduce); one isolated step
+        es = trainer.flat_grad.element_size()
+        executor["exchange"] = {"bucket_MB": [round((hi - lo) * es / 1e6, 1) for _, lo, hi in trainer.buckets],
+                                "after_backward_MB": round((trainer._bucket_end - trainer.n32) * es / 1e6, 1),
+                                "bucket_ready_ms": [round(sorted(r[j] for r in ready)[len(ready) // 2] * 1e3, 2) for j in range(len(trainer.buckets))],
+                                "isolated_step_ms": round(sorted(whole)[len(whole) // 2], 2)}
+        executor["host_ms_per_step"] = None       # (the host polls the buckets' flags inside step(): not a launch cost)
     tot = torch.tensor([dt, float(ntok)], device="cuda", dtype=torch.float64)
     if world > 1:
         tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -181,6 +181,7 @@ SIGNATURES = {
     "bist_graph_split_destroy": (None, [_P]),
     "bist_graph_queues_distinct": (C.c_int, [_P, _P, _P, _I64]),
     "bist_dev_idle_wave": (C.c_int, [_P, _I64, _I32, _P]),
+    "bist_flag_signal": (C.c_int, [_P, _P, _P]),
     "bist_graph_queue_pace": (C.c_int, [_P, _I32, _P, _I64, _P, C.POINTER(C.c_float)]),
 }
 

@@ -707,6 +707,20 @@ class AddFn(Function):
         return dy, dy
 
 
+class BucketMarkFn(Function):
+    """Identity whose backward tells the trainer that the backward pass of everything recorded AFTER this node has been issued (the
+    engine runs nodes in decreasing sequence number, i.e. in reverse program order): Fn.bucket_mark, the overlapped gradient exchange."""
+    @staticmethod
+    def forward(ctx, x, k, notify):
+        ctx.k, ctx.notify = k, notify
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ctx.notify(ctx.k)
+        return dy, None, None
+
+
 class AddDropoutFn(Function):
     """mode 0: a + dropout(b) (SublayerConnection.forward, modules.py:44); mode 1: dropout(a + b) with b a constant table
     (PositionalEncoding.forward, modules.py:144).  The backward regenerates the mask (bist_epilogue_bwd)."""

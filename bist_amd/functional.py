@@ -394,6 +394,18 @@ def param_gate(k: int) -> None:
         PARAM_GATE(k)
 
 
+# Overlapped gradient exchange (bist_amd/train.py): the layer loop marks the point in the forward pass behind which every launch belongs
+# to layers >= k (their ahead-issued value projections included); when the backward pass has issued everything behind the mark, the
+# trainer's callback signals "the gradients of layers >= k are final" on every stream of the step.
+BUCKET_MARK = None               # (set of layer indices k that open a bucket, callback(k))
+
+
+def bucket_mark(x: Tensor, k: int) -> Tensor:
+    if BUCKET_MARK is None or not _grad() or k not in BUCKET_MARK[0] or not x.requires_grad:
+        return x
+    return ag.BucketMarkFn.apply(x, k, BUCKET_MARK[1])
+
+
 # Streams a captured graph may span when it is replayed by the RUNTIME's graph executor (the capturing stream included).  Every replay
 # crash seen so far (host-side segmentation fault inside hipGraphLaunch, round 3) was in a graph captured over FOUR streams -- an optimiser
 # stream of its own beside the three of a training step, the four-stream first step of a decode turn -- and none in tens of thousands of
@@ -591,6 +603,25 @@ def live_side_streams():
     seen = set()
     for (dev, _), st in _SIDE.items():
         if dev != torch.cuda.current_device() or st.cuda_stream in seen or st.cuda_stream == torch.cuda.current_stream().cuda_stream:
+            continue
+        seen.add(st.cuda_stream)
+        if cap:
+            with torch.cuda.stream(st):
+                if not torch.cuda.is_current_stream_capturing():
+                    continue
+        out.append(st)
+    return out
+
+
+def step_streams(main) -> list:
+    """`main` and every side stream of this device that carries (or may carry) launches of the running pass: all of them, or -- while
+    `main` is being captured -- those that have joined the capture.  Unlike live_side_streams() this does not depend on the calling
+    thread's current stream (the autograd thread's is whichever stream the node it runs was recorded on)."""
+    with torch.cuda.stream(main):
+        cap = torch.cuda.is_current_stream_capturing()
+    out, seen = [main], {main.cuda_stream}
+    for (dev, _), st in _SIDE.items():
+        if dev != torch.cuda.current_device() or st.cuda_stream in seen:
             continue
         seen.add(st.cuda_stream)
         if cap:

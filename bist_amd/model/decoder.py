@@ -532,6 +532,9 @@ class MultimodalDecoder8(nn.Module):
                 ft["encoded_ft"] = STM.through(ft["encoded_ft"], "fused", True)
             if cache is not None:
                 cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})
+            # (training, several ranks) everything recorded from here on -- the value projections of layer l + 1, decoder layer l, the
+            # iterations l + 1 .. -- is behind this mark: when its backward has run, the gradients of reasoning / caption layers >= l + 1 are final
+            x = Fn.bucket_mark(x, l + 1)
             if values_ahead and l + 1 < len(self.layers):
                 issue_values(l + 1)
             if fused_after:

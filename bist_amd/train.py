@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import copy
 import os
+import time
 import re
 import weakref
 from typing import Dict, List, Optional
@@ -58,6 +59,12 @@ SPLIT_GRAPH = os.environ.get("BIST_SPLIT_GRAPH", "1") != "0"
 # near-critical paths (scripts/critical_path.py).  Default 0: three chains.
 LEAF_MASK = int(os.environ.get("BIST_LEAF_MASK", "0"))
 LEAF_OFFLOAD = LEAF_MASK != 0
+# Several ranks: the matrices of the LAST layers (their backward runs first) are exchanged in this many buckets DURING the backward pass,
+# each as soon as the step's streams have signalled that its gradients are final (bist_flag_signal into pinned memory, polled by the
+# host); 0 = every all-reduce after the backward pass (the round-3 schedule).  The remaining matrices follow after the pass in
+# EXCHANGE_CHUNKS pieces.
+EXCHANGE_BUCKETS = int(os.environ.get("BIST_EXCHANGE_BUCKETS", "2"))
+EXCHANGE_TIMEOUT_S = float(os.environ.get("BIST_EXCHANGE_TIMEOUT_S", "20"))       # a bucket whose flags do not arrive within this raises
 EXCHANGE_CHUNKS = int(os.environ.get("BIST_EXCHANGE_CHUNKS", "4"))        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
 
 
@@ -158,6 +165,22 @@ class Trainer:
         assert not starts or starts[0] == self.n32
         # (lo, hi) of the fp32-accumulated prefix, then of every piece, in flat elements
         self.pieces = [(0, self.n32)] + [(lo, hi) for lo, hi in zip(starts, starts[1:] + [n]) if hi > lo]
+        # Overlapped exchange: bucket j = the matrices of layers >= cut_j (all three stacks), cuts descending -- final, in the backward
+        # pass, when everything recorded behind the layer loop's mark `cut_j` has run (decoder.py, Fn.bucket_mark); flat ranges, in the
+        # order they become final.  What is left (layers below the last cut, everything outside the stacks) is exchanged after the pass.
+        piece_lo = {pc: offs[id(q)] for pc, q in first_of_piece.items()}
+        n_layers = max(piece_lo) if piece_lo else 0
+        self.buckets: List[Tuple[int, int, int]] = []          # (cut layer, lo, hi)
+        nb = max(0, min(EXCHANGE_BUCKETS, n_layers - 1)) if self.exchanging else 0
+        hi_ = n
+        for j in range(nb):
+            cut = n_layers - (j + 1) * n_layers // (nb + 1)    # e.g. 6 layers, 2 buckets: cuts 4, 2
+            lo_ = piece_lo.get(cut + 1)
+            if lo_ is None or lo_ >= hi_ or cut < 1:
+                break
+            self.buckets.append((cut, lo_, hi_))
+            hi_ = lo_
+        self._bucket_end = hi_                                  # [n32, _bucket_end): exchanged after the backward pass
         for m in attns:                                   # a packed member must start 16-byte aligned
             for t in ("bias", "weight"):
                 o0 = offs[id(getattr(m.linears[0], t))]
@@ -217,6 +240,14 @@ class Trainer:
         self._wgrad_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.drop_ctr = torch.zeros(1, device=dev, dtype=torch.int64)
         ops.DROP_CTR = self.drop_ctr
+        # ready flags of the buckets, in pinned host memory: 4 per bucket (one per stream of the step)
+        self.overlap = bool(self.buckets) and dev.type == "cuda" and Fn.CONCURRENT
+        self._flags = torch.zeros(4 * max(1, len(self.buckets)), dtype=torch.int64).pin_memory() if self.overlap else None
+        self._flags_np = self._flags.numpy() if self.overlap else None
+        self._flag_streams = [0] * len(self.buckets)           # streams that signalled bucket j in the last recorded / eager pass
+        self.exchange_ready_s: List[float] = []                # last step: seconds from the step's launch to each bucket's flags (diagnostics)
+        self._comm_stream = None
+        self._main_stream = None
         self.criterion = LabelSmoothing(vocab_size, pad, smoothing)
         self.loss_compute = SimpleLossCompute(model.generator, model.ae_generator, self.criterion, opt=None, args=args)
 
@@ -299,6 +330,39 @@ class Trainer:
         self.pending.copy_(self.drop_ctr)
         return terms
 
+    def _bucket_ready(self, cut: int) -> None:
+        """Backward-pass callback of the layer loop's mark `cut` (autograd thread): every launch of the backward pass of layers >= cut
+        has been issued -- signal the bucket's flag on each stream of the step, behind those launches."""
+        j = next(i for i, b_ in enumerate(self.buckets) if b_[0] == cut)
+        streams = Fn.step_streams(self._main_stream)
+        with torch.cuda.stream(self._main_stream):
+            capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            # an eager pass: every side stream of the package may hold launches -- the main stream waits for them (free outside a
+            # graph) and signals alone
+            for st in streams[1:]:
+                self._main_stream.wait_stream(st)
+            streams = streams[:1]
+        if len(streams) > 4:
+            raise RuntimeError("bist_amd.Trainer: a captured step over more than four streams cannot signal its buckets (4 flags per wait)")
+        for c, st in enumerate(streams):
+            check(lib.bist_flag_signal(self._flags.data_ptr() + 8 * (4 * j + c), self.drop_ctr.data_ptr(), st.cuda_stream), "bist_flag_signal")     # (pinned: the host pointer is the device's)
+        self._flag_streams[j] = len(streams)
+
+    def _await_bucket(self, j: int) -> None:
+        """Host: until every stream of the queued step has written this step's number into bucket j's flags."""
+        n = self._flag_streams[j]
+        if n == 0:
+            raise RuntimeError("bist_amd.Trainer: bucket %d was never signalled (the model's layer loop does not call Fn.bucket_mark)" % j)
+        fl, want = self._flags_np[4 * j: 4 * j + n], self._step
+        t0 = time.monotonic()
+        while (fl < want).any():
+            if time.monotonic() - t0 > EXCHANGE_TIMEOUT_S:
+                raise RuntimeError("bist_amd.Trainer: the gradients of bucket %d were not signalled within %.0f s (flags %s, step %d)"
+                                   % (j, EXCHANGE_TIMEOUT_S, fl.tolist(), want))
+            time.sleep(0)                  # (yields the interpreter lock: the feeder's thread keeps running)
+        self.exchange_ready_s.append(time.monotonic() - self._launched_at)
+
     def _backward_open(self, batch, clear: bool = True, after_forward=None):
         """forward + backward up to the point where every gradient BEHIND the fp32-accumulated prefix (the big matrices, 98 %
         of the elements) is final; the bias / LayerNorm-parameter reductions stay queued for _backward_close()."""
@@ -306,7 +370,11 @@ class Trainer:
             self.flat_grad.zero_()
         self.acc32.zero_()
         STM.mark("step head")
-        loss, terms = self.forward_loss(batch)
+        Fn.BUCKET_MARK = ({b_[0] for b_ in self.buckets}, self._bucket_ready) if self.overlap else None
+        try:
+            loss, terms = self.forward_loss(batch)
+        finally:
+            Fn.BUCKET_MARK = None
         loss = STM.through(loss, "loss")
         if after_forward is not None:
             after_forward()
@@ -319,6 +387,9 @@ class Trainer:
         ops.LEAF_STREAM = Fn.leaf_stream() if (LEAF_OFFLOAD and self.use_graph and SPLIT_GRAPH and loss.is_cuda and Fn.CONCURRENT) else None
         ops.LEAF_MASK = LEAF_MASK
         try:
+            if self.overlap:
+                self._main_stream = torch.cuda.current_stream()
+                self._flag_streams = [0] * len(self.buckets)
             loss.backward()
             STM.mark("backward issued (main)")
             if loss.is_cuda:
@@ -479,6 +550,18 @@ class Trainer:
         self._graph.replay()
         return self._static_terms
 
+    def _exchange_stream(self):
+        """An idle stream to issue the early buckets' all-reduces from (RCCL makes its own stream wait for the issuing one: from the
+        stream the step runs on that would be the end of the step)."""
+        if self._comm_stream is None:
+            mine = {s_.cuda_stream for s_ in Fn.step_streams(torch.cuda.current_stream())}
+            for _ in range(64):
+                st = torch.cuda.Stream()
+                if st.cuda_stream not in mine:
+                    break
+            self._comm_stream = st
+        return self._comm_stream
+
     def step(self, batch) -> Dict[str, torch.Tensor]:
         """One optimiser step; returns the (detached, device-side) loss terms."""
         self._step += 1
@@ -507,9 +590,24 @@ class Trainer:
         # and Adam runs on a piece as soon as its own all-reduce has finished, i.e. under the next piece's (the compute
         # stream waits on the collective's event, never the host).
         batch = self._globally_normalised(batch)
+        self._launched_at = time.monotonic()
         terms = self._graph_open(batch) if self.use_graph else self._backward_open(batch)
-        big = [(self.n32 + lo, self.n32 + hi) for lo, hi in parallel.chunk_bounds(self.numel - self.n32, EXCHANGE_CHUNKS, ALIGN)]
-        works = parallel.exchange_gradients_async(self.flat_grad, big, self.pg)
+        big, works = [], []
+        if self.overlap:
+            # The step is queued (a replayed graph returns at once; an eager pass has issued its launches).  Per bucket: poll the flags
+            # the step's streams write when the bucket's gradients are final, then issue its all-reduce from an idle stream -- RCCL orders a
+            # collective behind the stream it is issued from, so it starts at once, under the rest of the backward pass.  The flags carry
+            # THIS step's number: the collective is behind this step's writes of its gradients, themselves behind the previous step's Adam.
+            self.exchange_ready_s = []
+            with torch.cuda.stream(self._exchange_stream()):
+                for j, (_cut, lo, hi) in enumerate(self.buckets):
+                    self._await_bucket(j)
+                    big.append((lo, hi))
+                    works += parallel.exchange_gradients_async(self.flat_grad, [(lo, hi)], self.pg)
+        rest = [(self.n32 + lo, self.n32 + hi) for lo, hi in parallel.chunk_bounds((self._bucket_end if self.overlap else self.numel) - self.n32,
+                                                                                      EXCHANGE_CHUNKS, ALIGN)]
+        big += rest
+        works += parallel.exchange_gradients_async(self.flat_grad, rest, self.pg)
         main = side = None
         if self.flat_grad.is_cuda and Fn.CONCURRENT:
             # the big pieces' updates on a side stream, each behind its own all-reduce: beside the closing reductions (as in the one-rank

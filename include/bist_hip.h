@@ -674,6 +674,11 @@ int bist_graph_queues_distinct(void* stream_a, void* stream_b, void* scratch, in
  * wave stays resident on `resident_stream` for resident_ticks of the 100 MHz clock: hardware queues that share a dispatch pipe slow each
  * other down threefold (csrc/graphsplit.hip), and the chains of a split graph must not.  word: 2 uint64 of device memory.  Synchronises. */
 int bist_graph_queue_pace(void* stream, int32_t n, void* resident_stream, int64_t resident_ticks, void* word, float* us_per_launch_out);
+/* Ready flag of the overlapped gradient exchange (the reference's DataParallel exchange, train.py:96-99, as a bucketed all-reduce that
+ * starts DURING the backward pass): *flag = *value_dev -- flag a 64-bit word in pinned (host-coherent) memory, value_dev a 64-bit word in
+ * device memory (the step counter) -- as a system-scope release store ordered behind the stream's earlier launches.  Capturable: the
+ * replayed step signals "this stream's share of bucket j is final", the host polls the word and issues the bucket's all-reduce. */
+int bist_flag_signal(void* flag, const void* value_dev, void* stream);
 /* Development aid: a one-wave launch that stays resident on `stream` for `ticks` of the 100 MHz clock (mode 0: sleeps and reads the clock;
  * 1: also polls word[0] with relaxed loads; 2: with acquire loads; 3: `ticks` rounds of s_sleep, no memory, no clock) -- measures what a
  * resident wave on another queue costs the launches of a step (scripts/probe_idle_wave.py).  word: 2 uint64 of device memory. */

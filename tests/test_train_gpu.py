@@ -781,9 +781,13 @@ def test_exchange_path_matches_single_rank_step(env):
     try:
         t2 = Trainer(m2, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=True)
         assert t2.exchanging and not t2.adam_in_step
+        # the last layer's matrices are exchanged DURING the backward pass, behind the ready flags the captured step writes
+        assert t2.overlap and [b_[0] for b_ in t2.buckets] == [1] and t2.buckets[0][2] == t2.numel and t2._bucket_end == t2.buckets[0][1]
         l1 = [t1.step(b)["out"].item() for _ in range(4)]
         l2 = [t2.step(b)["out"].item() for _ in range(4)]
         assert t2._graph2 is not None
+        assert t2._flag_streams[0] >= 2
+        assert t2._flags[:t2._flag_streams[0]].tolist() == [4] * t2._flag_streams[0]      # every stream of the step signalled step 4
     finally:
         os.environ.pop("BIST_FORCE_EXCHANGE", None)
         dist.destroy_process_group()
