@@ -13,7 +13,6 @@ import ctypes as C
 from .. import functional as Fn
 from .. import ops
 from .. import stamps as STM
-from .. import zbatch as Z
 from .._lib import BistDecLayer, BistKvFill, check, lib
 from .encoder import _cross_attention, _feed_forward, _self_attention
 from .modules import LayerNorm, SublayerConnection, clones
@@ -114,30 +113,25 @@ class MultimodalDecoder8(nn.Module):
             return
         if mode != "dyn":
             return
-        spare = ft.get("_bist_alias") or {}
-
-        def other(k):            # a second alias of ft[k] where the producer handed several out (one consumer each: no gradient accumulation pass)
-            lst = spare.get(k)
-            return lst.pop(0) if lst else Fn.fan_take(ft, k)
         parts = [Fn.fan_take(ft, "encoded_query")]
         if self.c_N > 0:
             parts.append(Fn.fan_take(ft, "cap_ft"))
         if args.t2s:
-            parts.append(other("spatial_ft"))
+            parts.append(Fn.fan_take(ft, "spatial_ft"))
         if args.s2t:
-            parts.append(other("temporal_ft"))
+            parts.append(Fn.fan_take(ft, "temporal_ft"))
         W, bias = self.vc_combine_W.weight, self.vc_combine_W.bias
         d = parts[0].shape[-1]
         if W.shape[1] != d * len(parts):
             raise ValueError("vc_combine_W does not match the enabled modalities")
-        if (torch.is_grad_enabled() and self.c_N > 0 and args.t2s and args.s2t and parts[0].is_cuda and not spare
+        if (torch.is_grad_enabled() and self.c_N > 0 and args.t2s and args.s2t and parts[0].is_cuda
                 and all(p.is_contiguous() for p in parts)):
             # training: the fusion logits and the weighted sum as ONE autograd node -- every modality tensor has one consumer here instead of
             # two (autograd.FuseDynFn); parts = [query, cap, spatial, temporal], score column j -> temporal, spatial, cap (decoder.py:156-159)
             ft["encoded_ft"] = Fn.fuse_dyn(W, bias, parts, (3, 2, 1))
             return
         if torch.is_grad_enabled() and ag_fuse_one() and Fn.switch_logits_ok(W, bias, parts):
-            # training without the one-node form (the lock-step layer hands out aliases): the same one-launch logits as autograd.FuseDynFn
+            # training without the one-node form (a direction or the caption stack switched off): the same one-launch logits as autograd.FuseDynFn
             score = Fn.switch_logits(W, bias, parts, out_dtype=parts[0].dtype)
         else:
             score = None
@@ -413,7 +407,7 @@ class MultimodalDecoder8(nn.Module):
             both = getattr(self.args, "t2s", 1) and getattr(self.args, "s2t", 1)
             vft_ = ft["spatiotemporal_ft"]
             a0 = self.v_layers[0].attn[0]
-            fused_train = bool(torch.is_grad_enabled() and both and Fn.FUSED_TRAIN and not Z.ENABLED and vft_.is_cuda and vft_.dim() == 4 and vft_.is_contiguous()
+            fused_train = bool(torch.is_grad_enabled() and both and Fn.FUSED_TRAIN and vft_.is_cuda and vft_.dim() == 4 and vft_.is_contiguous()
                                and q.dtype == vft_.dtype and len(self.v_layers[0].attn) == 6
                                and all(ops.st_stage1_fused_train_ok(vft_.shape[1], vft_.shape[2], q.shape[1], vft_.shape[3], a0.h, dr, vft_.dtype) for dr in (0, 1)))
             if fused_train:
@@ -455,12 +449,10 @@ class MultimodalDecoder8(nn.Module):
             fan = ft.get("_bist_vftp_fan") or ft["_bist_vft_fan"]
             va = fan.take()
             side_.wait_stream(main_)
-            both_v = Z.ENABLED                                    # lock-step layer: its stage-1 node consumes both on the main stream
-            vb = ft["_bist_vft_fan"].take() if both_v else None
             with torch.cuda.stream(side_):
                 STM.mark("L%d values ahead" % l) if STM.ENABLED else None
-                v1 = self.v_layers[l].train_value(va, 1)          # two-chain layer: t2s only -- its consumer (and its gradient) live on the main
-                v4 = self.v_layers[l].train_value(vb, 4) if both_v else None      # stream; an edge between two side streams crashes hipGraph capture
+                v1 = self.v_layers[l].train_value(va, 1)          # t2s only -- its consumer (and its gradient) live on the main stream; an
+                v4 = None                                         # edge between two side streams crashes hipGraph capture
                 ev = torch.cuda.Event()
                 ev.record(side_)
             Fn._keep_taken(v1); Fn._keep_taken(v4)               # allocated on this stream, consumed (and saved) on the main one
@@ -495,15 +487,6 @@ class MultimodalDecoder8(nn.Module):
                 ft.pop("_bist_cap_fork", None)
                 if in_ft.pop("_norms_done", False):
                     pass                              # the layer applied the two output norms at the end of its direction chains (encoder.py)
-                elif "_z" in in_ft:
-                    # both directions came back stacked (bist_amd/zbatch.py): the two output norms as ONE launch; the stacked tensor
-                    # goes on to the next reasoning layer through the LayerNorm node (one consumer each, no accumulation pass)
-                    normed, in_ft["_z"] = Z.layernorm_res(in_ft["_z"], self.spatial_out_norm, self.temporal_out_norm)   # decoder.py:127,129
-                    last = l + 1 == len(self.layers)
-                    n_use = 2 + (1 if (last and torch.is_grad_enabled()) else 0)      # fusion logits, fusion sum (, auto-encoder loss)
-                    sp, tp = Z.unstack(normed, n_use, n_use)
-                    ft["spatial_ft"], ft["temporal_ft"] = sp[0], tp[0]
-                    ft["_bist_alias"] = {"spatial_ft": sp[1:], "temporal_ft": tp[1:]}
                 else:
                     if self.args.s2t:
                         ft["temporal_ft"] = self.temporal_out_norm(in_ft["s2t"])             # decoder.py:127
@@ -522,7 +505,7 @@ class MultimodalDecoder8(nn.Module):
                 # every tensor handed from one stream's chain to another's at this layer boundary (see Fn._keep_taken)
                 for t_ in (*[v for v in in_ft.values() if torch.is_tensor(v)], ft.get("cap_ft"), ft.get("spatial_ft"), ft.get("temporal_ft")):
                     Fn._keep_taken(t_)
-            if torch.is_grad_enabled() and l + 1 == len(self.layers) and getattr(self.args, "auto_encoder", 0) and "_z" not in in_ft:
+            if torch.is_grad_enabled() and l + 1 == len(self.layers) and getattr(self.args, "auto_encoder", 0):
                 # the last layer's outputs also feed the auto-encoder heads (optimize.py:66-82): an alias per consumer, one-pass gradient sum
                 for k_ in ("cap_ft", "spatial_ft", "temporal_ft"):
                     Fn.fan_set(ft, k_, 2)

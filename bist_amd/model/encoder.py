@@ -26,7 +26,6 @@ import torch.nn as nn
 from .. import functional as Fn
 from .. import ops
 from .. import stamps as STM
-from .. import zbatch as Z
 from .modules import LayerNorm, MultiHeadedAttention, PositionwiseFeedForward, SublayerConnection, clones
 
 Tensor = torch.Tensor
@@ -80,7 +79,7 @@ class VidEncoder8(nn.Module):
             if fts.dtype != self.W.weight.dtype:
                 fts = Fn.cast(fts, self.W.weight.dtype)
             B, T, S, C = fts.shape
-            if fts.is_cuda and not torch.is_grad_enabled() and not Z.ENABLED and Fn.CONCURRENT:
+            if fts.is_cuda and not torch.is_grad_enabled() and Fn.CONCURRENT:
                 # inference: everything queued so far (the text encoders) is done at this point of the stream; the first reasoning
                 # layer forks its query-side chains from HERE, so that they run under the input projection instead of after it.
                 # (Recorded ONLY when a layer will wait on it: an event recorded during a hipGraph capture and never waited on stays in
@@ -294,126 +293,7 @@ class VidEncoderLayer4(nn.Module):
         return (Fn.linear(vft_a.view(B * T * S, d), a1.linears[2].weight, a1.linears[2].bias).view(B, T, S, d),
                 Fn.linear(vft_b.view(B * T * S, d), a4.linears[2].weight, a4.linears[2].bias).view(B, T, S, d))
 
-    # -- both directions as ONE sequence of launches (bist_amd/zbatch.py) -------------------------------------------------------
-    def _z_ok(self, in_ft, ft, b) -> bool:
-        a = self.args
-        vft = ft["spatiotemporal_ft"]
-        x = in_ft.get("_z", in_ft["t2s"])
-        return (Z.ENABLED and getattr(a, "t2s", 1) and getattr(a, "s2t", 1) and vft.is_cuda and vft.dim() == 4 and len(self.attn) == 6
-                and x.dtype == vft.dtype and (x.shape[-1] * x.element_size()) % 16 == 0 and (x.shape[-2] * x.shape[-1] * x.element_size()) % 16 == 0)
-
-    @staticmethod
-    def _mask2(b, ft, B: int):
-        """query_mask [B,1,Lq] repeated for the stacked batch of 2B sequences: the batch's own ``query_mask2`` field when it has one
-        (bist_amd.data.Batch builds it with the other masks, outside the step), else built once per forward pass (kept in ``ft``)."""
-        qm = b.query_mask
-        m2 = getattr(b, "query_mask2", None)
-        if m2 is not None and m2.shape[0] == 2 * B and m2.device == qm.device:
-            return m2
-        m2 = ft.get("_bist_qmask2")
-        if m2 is None or m2.shape[0] != 2 * B:
-            m2 = ft["_bist_qmask2"] = torch.cat([qm, qm], dim=0)
-        return m2
-
-    def _forward_z(self, in_ft: Dict[str, Tensor], ft: Dict[str, Tensor], b) -> Dict[str, Tensor]:
-        """encoder.py:172-188 with z = (t2s, s2t) stacked: A0|A3 -> A1|A4 -> A2|A5 -> F0|F1 on [2, B, Lq, d] tensors.  Sublayer /
-        attention / feed-forward index of direction z: sublayer 4z + j, attn 3z + j, ff z."""
-        vft = ft["spatiotemporal_ft"]
-        B, T, S, d = vft.shape
-        att, sub, ff = self.attn, self.sublayer, self.ff
-        h, dk = att[0].h, att[0].d_k
-        grad = torch.is_grad_enabled()
-        fan = ft.get("_bist_vft_fan")
-        take = fan.take if fan is not None else (lambda: vft)
-        fan_p = ft.get("_bist_vftp_fan")
-        permuted = fan_p is not None
-        take0 = fan_p.take if permuted else take
-        xz = in_ft.get("_z")
-        if xz is None:
-            xz = Z.stack2(in_ft["t2s"], in_ft["s2t"])
-        Lq = xz.shape[2]
-        M2 = 2 * B * Lq
-        trace = self.__dict__.get("_bist_trace")
-        # ---- A0 | A3: self-attention of the query streams -------------------------------------------------------------------
-        xn, xr = Z.layernorm_res(xz, sub[0].norm, sub[4].norm)
-        qkv = Z.linear(xn, att[0]._packed((0, 1, 2)), att[3]._packed((0, 1, 2)))
-        ctx, _ = Fn.mha_packed(qkv.view(2 * B, Lq, 3 * d), None, None, "qkv", self._mask2(b, ft, B), h, False, Fn.attn_drop(att[0]))
-        x1 = Z.linear(ctx, (att[0].linears[3].weight, att[0].linears[3].bias), (att[3].linears[3].weight, att[3].linears[3].bias),
-                      residual=xr, out_shape=(2, B, Lq, d), **Fn.drop_args(sub[0]))
-        # ---- A1 | A4: stage 1; the query side of stage 2 (A2 | A5: LayerNorm, projection, fold -- it depends on x1 only) goes to a side
-        # stream and runs under the stage-1 launches -----------------------------------------------------------------------------
-        xn1, xr1 = Z.layernorm_res(x1, sub[1].norm, sub[5].norm)
-        main = torch.cuda.current_stream()
-        side = Fn.side_stream(0) if (Fn.CONCURRENT and Z.DIR_STREAMS) else None
-
-        def stage2_query(xr_):
-            xn2_, xr2_ = Z.layernorm_res(xr_, sub[2].norm, sub[6].norm)
-            q2_ = Z.linear(xn2_, (att[2].linears[0].weight, att[2].linears[0].bias), (att[5].linears[0].weight, att[5].linears[0].bias))
-            return xr2_, Z.head_fold(q2_, att[2].linears[1].weight, att[5].linears[1].weight, h, 1.0 / math.sqrt(dk))
-        ev2 = None
-        if side is not None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                xr1b, q2f = stage2_query(xr1)
-                ev2 = torch.cuda.Event()
-                ev2.record(side)
-        else:
-            xr1b, q2f = stage2_query(xr1)
-        q = Z.linear(xn1, (att[1].linears[0].weight, att[1].linears[0].bias), (att[4].linears[0].weight, att[4].linears[0].bias))
-        qf = Z.head_fold(q, att[1].linears[1].weight, att[4].linears[1].weight, h, 1.0 / math.sqrt(dk)).view(2, B, Lq * h, d)
-        fused = (Fn.FUSED_ST1 and not grad and all(ops.st_stage1_fused_ok(T, S, Lq, d, h, dr, vft.dtype) for dr in (0, 1)))
-        if fused:
-            # inference at the production width: value projection, scores, softmax, P.V, output projection and residual of a
-            # direction in one launch (csrc/st1_fused.hip)
-            y0 = self._stage1_fused(1, x1[0], qf[0], take0(), b.temporal_mask, 0)
-            y1 = self._stage1_fused(4, x1[1], qf[1], take(), None, 1)
-            xr2 = xr1b
-        else:
-            pre = ft.pop("_bist_v_pre", None)            # (v_t2s, v_s2t or None, event): projected ahead by the layer loop (decoder.py)
-            vft0, vft1 = take0(), take()
-            if pre is not None:
-                v0, v1, ev = pre
-                main.wait_event(ev)
-                if v1 is None:
-                    v1 = self.train_value(take(), 4)
-            else:
-                v0, v1 = self.train_value(take0(), 1), self.train_value(take(), 4)
-            cfg = (B, T, S, Lq, h, dk, permuted, (Fn.attn_drop(att[1]), Fn.attn_drop(att[4])),
-                   tuple(((kw["drop_p"], kw["drop_seed"]) if kw else None) for kw in (Fn.drop_args(sub[1]), Fn.drop_args(sub[5]))))
-            y0, y1, xr2 = Z.ZStage1Fn.apply(qf, xr1b, vft0, vft1, v0, v1, b.temporal_mask, att[1].linears[3].weight, att[1].linears[3].bias,
-                                            att[4].linears[3].weight, att[4].linears[3].bias, cfg)
-        if ev2 is not None:
-            main.wait_event(ev2)
-        # ---- A2 | A5: stage 2 --------------------------------------------------------------------------------------------
-        py, rs = Z.ZStage2Fn.apply(q2f, y0, y1, b.temporal_mask, h, (Fn.attn_drop(att[2]), Fn.attn_drop(att[5])))
-        wv2, wv5, bv2, bv5 = att[2].linears[2].weight, att[5].linears[2].weight, att[2].linears[2].bias, att[5].linears[2].bias
-        if rs is None:
-            c2 = Z.head_unfold(py.view(M2, h * d), wv2, wv5, bv2, bv5, h)
-        else:       # dropped probabilities do not sum to one: P'(Y W^T + b) = (P'Y) W^T + rowsum(P') b
-            c2 = Z.head_unfold(py.view(M2, h * d), wv2, wv5, None, None, h)
-            c2 = Z.scaled_bias(c2, rs.view(M2, h), bv2, bv5, h)
-        x2 = Z.linear(c2, (att[2].linears[3].weight, att[2].linears[3].bias), (att[5].linears[3].weight, att[5].linears[3].bias),
-                      residual=xr2, out_shape=(2, B, Lq, d), **Fn.drop_args(sub[2]))
-        # ---- F0 | F1 -----------------------------------------------------------------------------------------------------
-        xn3, xr3 = Z.layernorm_res(x2, sub[3].norm, sub[7].norm)
-        inner = {}
-        if ff[0].training and ff[0].dropout.p > 0:          # dropout(relu(w_1 x)), modules.py:113
-            inner = {"drop_p": float(ff[0].dropout.p), "drop_seed": Fn.next_seed("ffn", ff[0])}
-        hdn = Z.linear(xn3, (ff[0].w_1.weight, ff[0].w_1.bias), (ff[1].w_1.weight, ff[1].w_1.bias), act=Fn.ACT_RELU, **inner)
-        out = Z.linear(hdn, (ff[0].w_2.weight, ff[0].w_2.bias), (ff[1].w_2.weight, ff[1].w_2.bias), residual=xr3, out_shape=(2, B, Lq, d),
-                       **Fn.drop_args(sub[3]))
-        if trace is not None:
-            trace.update(t2s_self=x1[0], t2s_stage1=y0, t2s_stage2=x2[0], t2s_ff=out[0], s2t_self=x1[1], s2t_stage1=y1, s2t_stage2=x2[1],
-                         s2t_ff=out[1])
-        new = dict(in_ft)
-        new["_z"] = out
-        new["t2s"], new["s2t"] = out[0], out[1]      # plain views for readers outside the lock-step path (the layer loop reads "_z")
-        return new
-
     def forward(self, in_ft: Dict[str, Tensor], ft: Dict[str, Tensor], b) -> Dict[str, Tensor]:
-        if self._z_ok(in_ft, ft, b):
-            return self._forward_z(in_ft, ft, b)
-        in_ft = {k: v for k, v in in_ft.items() if k != "_z"}
         vft = ft["spatiotemporal_ft"]
         fan = ft.get("_bist_vft_fan")                      # aliases whose gradients are summed in one pass (training)
         take = fan.take if fan is not None else (lambda: vft)

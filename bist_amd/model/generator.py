@@ -32,8 +32,7 @@ class Generator(nn.Module):
             self.shared_W = False
 
     def forward(self, ft, batch, args, ft_key="decoded_text"):
-        spare = (ft.get("_bist_alias") or {}).get(ft_key)        # an alias of ft[ft_key] set aside for this consumer (one-pass gradient sum)
-        x = spare.pop(0) if spare else Fn.fan_take(ft, ft_key)
+        x = Fn.fan_take(ft, ft_key)                              # an alias of ft[ft_key] set aside for this consumer (one-pass gradient sum)
         if self.shared_W:
             logits = Fn.linear(x, self.proj, None, out_dtype=torch.float32)
         else:

@@ -88,8 +88,7 @@ class SimpleLossCompute:
             return None
         xs = []
         for _, key in keys:
-            spare = (ft.get("_bist_alias") or {}).get(key)
-            xs.append(spare.pop(0) if spare else Fn.fan_take(ft, key))
+            xs.append(Fn.fan_take(ft, key))
         x0 = xs[0]
         if not (x0.is_cuda and all(x.shape == x0.shape and x.dtype == x0.dtype for x in xs) and 1 <= len(xs) <= 4
                 and x0.dtype in (torch.bfloat16, torch.float32) and (x0.numel() * x0.element_size()) % 16 == 0

@@ -524,6 +524,38 @@ def test_st_stage1_fused_matches_textbook_attention(ops, B, T, S, Lq, direction)
     _cmp(out, ref, 2e-2, f"st_stage1_fused dir{direction}")
 
 
+def test_multi_set_row_ops_equal_their_single_set_forms(ops):
+    """bist_layernorm_fwd_multi / bist_layernorm_bwd_multi / bist_scaled_bias_fwd_z (the C ABI's several-sets-per-launch row operations:
+    the two directions' instances of a sublayer norm, include/bist_hip.h) against the reference's LayerNorm (modules.py:28-31) and its
+    autograd gradients per set."""
+    from oracle import bist_oracle as O
+    rows, d, h = 40, 128, 8
+    xs = [_rand(rows, d, seed=70 + i).cuda() for i in range(2)]
+    ga = [(1 + 0.2 * _rand(d, seed=72 + i)).cuda() for i in range(2)]
+    gb = [(0.1 * _rand(d, seed=74 + i)).cuda() for i in range(2)]
+    outs = [torch.empty_like(x) for x in xs]
+    ops.layernorm_multi(xs, ga, gb, outs, 1e-6)
+    dys = [_rand(rows, d, seed=76 + i).cuda() for i in range(2)]
+    dxs = [torch.empty_like(x) for x in xs]
+    das, dbs = [torch.zeros(d, device="cuda") for _ in range(2)], [torch.zeros(d, device="cuda") for _ in range(2)]
+    ops.layernorm_bwd_multi([(dys[i], xs[i], ga[i], dxs[i], das[i], dbs[i], None, None, 0) for i in range(2)], rows, d, d, d, d, 1e-6, 0, None, torch.float32)
+    for i in range(2):
+        x, a, b = xs[i].double().cpu().requires_grad_(True), ga[i].double().cpu().requires_grad_(True), gb[i].double().cpu().requires_grad_(True)
+        y = O.layer_norm(x, a, b)
+        y.backward(dys[i].double().cpu())
+        _cmp(outs[i], y.detach(), 1e-5, f"layernorm_multi set {i}")
+        _cmp(dxs[i], x.grad, 1e-4, f"layernorm_bwd_multi dx set {i}")
+        _cmp(das[i], a.grad, 1e-4, f"layernorm_bwd_multi da set {i}")
+        _cmp(dbs[i], b.grad, 1e-4, f"layernorm_bwd_multi db set {i}")
+    # scaled bias over two stacked row blocks, each with its own bias (at bias0 + z * stride)
+    x = _rand(2 * rows, d, seed=80).cuda()
+    sc = torch.rand(2 * rows, h, device="cuda")
+    bias = _rand(2, d, seed=81).cuda()
+    got = ops.scaled_bias_z(x, sc, bias, d, h, 2)
+    want = torch.cat([ops.scaled_bias(x[z * rows:(z + 1) * rows].contiguous(), sc[z * rows:(z + 1) * rows].contiguous(), bias[z], h) for z in range(2)])
+    assert torch.equal(got, want)
+
+
 def test_pack_frag_rows_layout(ops):
     """bist_pack_frag_rows: block (tile nt, pair kp, parity e), lane (x, kg) holds W[16 nt + x][64 kp + 16 kg + 8 e .. +7]."""
     R, Ccols = 48, 192
