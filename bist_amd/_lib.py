@@ -165,6 +165,7 @@ SIGNATURES = {
     "bist_pointer_decode_mix_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _P, _I64, _P, _F, _P, _I64, _I32, _I32, _I32, _P]),
     "bist_noam_hyper_pending": (C.c_int, [_P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "bist_adam_apply_dev": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _P]),
+    "bist_adam_step_dev_bg": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _I32, _I32, _I32, _P]),
     "bist_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _P]),
     "bist_graph_capture_tail": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "bist_graph_nodes": (C.c_int, [_P, C.POINTER(C.c_void_p), _I32, C.POINTER(C.c_int32)]),

@@ -519,9 +519,10 @@ __global__ void adam_kernel(float* __restrict__ p, const TG* __restrict__ g, flo
 template <typename TG, typename TW>
 __global__ __launch_bounds__(256) void adam4_kernel(float* __restrict__ p, const TG* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     TW* __restrict__ work, long n4, float b1, float b2, float eps, const float* __restrict__ hyper) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
   const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gscale = hyper[3];
+  // grid-stride: one pass for the chip-filling launch; the BACKGROUND form (bist_adam_step_dev_bg) runs a few hundred workgroups that
+  // leave the CUs' wave slots to the step's small launches
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
   float gi[4];
   if constexpr (sizeof(TG) == 2) {
     const uint2 q = reinterpret_cast<const uint2*>(g)[i];
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(256) void adam4_kernel(float* __restrict__ p, const
     } else {
       reinterpret_cast<float4*>(work)[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
     }
+  }
   }
 }
 
@@ -996,14 +998,25 @@ extern "C" int bist_noam_hyper(const int64_t* step_ctr, float* hyper, float d_mo
   return BIST_OK;
 }
 
+extern "C" int bist_adam_step_dev_bg(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
+                                     float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, int32_t max_blocks, void* stream);
 extern "C" int bist_adam_step_dev(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
                                   float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream) {
-  BIST_REQUIRE(p && g && m && v && hyper && n > 0, "bist_adam_step_dev: bad argument");
+  return bist_adam_step_dev_bg(p, g, m, v, work, n, hyper, beta1, beta2, eps, grad_dtype, work_dtype, 0, stream);
+}
+// max_blocks > 0: at most that many workgroups walk the range (a background update beside latency-bound launches); 0: one element group per thread
+extern "C" int bist_adam_step_dev_bg(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
+                                     float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, int32_t max_blocks, void* stream) {
+  BIST_REQUIRE(p && g && m && v && hyper && n > 0 && max_blocks >= 0, "bist_adam_step_dev: bad argument");
   hipStream_t st = (hipStream_t)stream;
   // whole 16-byte groups: four elements per thread
   const bool vec = n % 4 == 0 && ((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) % 16 == 0 && (uintptr_t)g % (grad_dtype == BIST_BF16 ? 8 : 16) == 0 &&
                    (!work || (uintptr_t)work % (work_dtype == BIST_BF16 ? 8 : 16) == 0);
-  const unsigned grid = vec ? blocks_for(n / 4, 256) : blocks_for(n, 256);
+  unsigned grid = vec ? blocks_for(n / 4, 256) : blocks_for(n, 256);
+  if (max_blocks > 0) {
+    BIST_REQUIRE(vec, "bist_adam_step_dev_bg: the background form needs whole 16-byte groups (n %% 4 == 0, aligned pointers)");
+    if (grid > (unsigned)max_blocks) grid = (unsigned)max_blocks;
+  }
 #define ADAM(TG, TW)                                                                                                                                  \
   do {                                                                                                                                                \
     if (vec) hipLaunchKernelGGL((adam4_kernel<TG, TW>), dim3(grid), dim3(256), 0, st, p, (const TG*)g, m, v, (TW*)work, (long)(n / 4), beta1, beta2, eps, hyper); \

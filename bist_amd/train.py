@@ -64,6 +64,12 @@ LEAF_OFFLOAD = LEAF_MASK != 0
 # host); 0 = every all-reduce after the backward pass (the round-3 schedule).  The remaining matrices follow after the pass in
 # EXCHANGE_CHUNKS pieces.
 EXCHANGE_BUCKETS = int(os.environ.get("BIST_EXCHANGE_BUCKETS", "2"))
+# One rank, replayed by the split executor: the same buckets are UPDATED during the backward pass -- Adam on a bucket as a background
+# launch (ADAM_BG_BLOCKS workgroups) on the caption chain, which has the least backward work, once all chains have passed the bucket's
+# mark -- so that the step's tail is the update of the remaining matrices only.  0 = the whole update at the tail.
+ADAM_EARLY_BUCKETS = int(os.environ.get("BIST_ADAM_EARLY_BUCKETS", "2"))
+ADAM_BG_BLOCKS = int(os.environ.get("BIST_ADAM_BG_BLOCKS", "256"))
+EARLY_REDUCTIONS = os.environ.get("BIST_EARLY_REDUCTIONS", "1") != "0"      # ... and the bias / LayerNorm-parameter reductions queued up to each bucket's mark
 EXCHANGE_TIMEOUT_S = float(os.environ.get("BIST_EXCHANGE_TIMEOUT_S", "20"))       # a bucket whose flags do not arrive within this raises
 EXCHANGE_CHUNKS = int(os.environ.get("BIST_EXCHANGE_CHUNKS", "4"))        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
 
@@ -171,10 +177,13 @@ class Trainer:
         piece_lo = {pc: offs[id(q)] for pc, q in first_of_piece.items()}
         n_layers = max(piece_lo) if piece_lo else 0
         self.buckets: List[Tuple[int, int, int]] = []          # (cut layer, lo, hi)
-        nb = max(0, min(EXCHANGE_BUCKETS, n_layers - 1)) if self.exchanging else 0
+        self.early_adam = (self.adam_in_step and not self.deferred and use_graph and SPLIT_GRAPH and ADAM_EARLY_BUCKETS > 0 and not ADAM_CLEARS
+                           and dev.type == "cuda" and Fn.CONCURRENT)
+        nb = max(0, min(EXCHANGE_BUCKETS if self.exchanging else ADAM_EARLY_BUCKETS if self.early_adam else 0, n_layers - 1))
         hi_ = n
-        for j in range(nb):
-            cut = n_layers - (j + 1) * n_layers // (nb + 1)    # e.g. 6 layers, 2 buckets: cuts 4, 2
+        cuts_env = os.environ.get("BIST_BUCKET_CUTS")          # tuning aid: explicit cut layers, descending ("3,1")
+        cuts = [int(c) for c in cuts_env.split(",")] if (cuts_env and nb) else [n_layers - (j + 1) * n_layers // (nb + 1) for j in range(nb)]
+        for cut in cuts:                                       # default, e.g. 6 layers, 2 buckets: cuts 4, 2
             lo_ = piece_lo.get(cut + 1)
             if lo_ is None or lo_ >= hi_ or cut < 1:
                 break
@@ -241,7 +250,11 @@ class Trainer:
         self.drop_ctr = torch.zeros(1, device=dev, dtype=torch.int64)
         ops.DROP_CTR = self.drop_ctr
         # ready flags of the buckets, in pinned host memory: 4 per bucket (one per stream of the step)
-        self.overlap = bool(self.buckets) and dev.type == "cuda" and Fn.CONCURRENT
+        self.early_adam = self.early_adam and bool(self.buckets)
+        self._early_done = 0                                   # buckets updated inside the running backward pass
+        self._early_armed = False                              # (set by backward(optimizer=True) around its pass)
+        self._early_keep: list = []
+        self.overlap = self.exchanging and bool(self.buckets) and dev.type == "cuda" and Fn.CONCURRENT
         self._flags = torch.zeros(4 * max(1, len(self.buckets)), dtype=torch.int64).pin_memory() if self.overlap else None
         self._flags_np = self._flags.numpy() if self.overlap else None
         self._flag_streams = [0] * len(self.buckets)           # streams that signalled bucket j in the last recorded / eager pass
@@ -260,16 +273,17 @@ class Trainer:
         terms, logp = self.loss_compute.terms(ft, batch)
         return Fn.sum_terms(terms.values()), terms
 
-    def _adam_dev(self, lo: int, hi: int) -> None:
-        """Adam on flat elements [lo, hi) with this step's scalars read from ``self.hyper`` (device): capturable."""
+    def _adam_dev(self, lo: int, hi: int, max_blocks: int = 0) -> None:
+        """Adam on flat elements [lo, hi) with this step's scalars read from ``self.hyper`` (device): capturable.  max_blocks > 0: as a
+        background launch of that many workgroups (bist_adam_step_dev_bg)."""
         if hi <= lo:
             return
         work = None if self.compute_dtype == torch.float32 else self.flat_param
         gsz = self.flat_grad.element_size()
-        check(lib.bist_adam_step_dev(self.master.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + gsz * lo, self.m.data_ptr() + 4 * lo,
-                                     self.v.data_ptr() + 4 * lo, (work.data_ptr() + work.element_size() * lo) if work is not None else None,
-                                     hi - lo, self.hyper.data_ptr(), self.betas[0], self.betas[1], self.eps,
-                                     dtype_code(self.compute_dtype), dtype_code(self.compute_dtype), _stream()), "bist_adam_step_dev")
+        check(lib.bist_adam_step_dev_bg(self.master.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + gsz * lo, self.m.data_ptr() + 4 * lo,
+                                        self.v.data_ptr() + 4 * lo, (work.data_ptr() + work.element_size() * lo) if work is not None else None,
+                                        hi - lo, self.hyper.data_ptr(), self.betas[0], self.betas[1], self.eps,
+                                        dtype_code(self.compute_dtype), dtype_code(self.compute_dtype), max_blocks, _stream()), "bist_adam_step_dev")
 
     def _adam_apply(self, lo: int, hi: int) -> None:
         """bist_adam_apply_dev on flat elements [lo, hi): Adam with ``self.hyper`` (skipped when nothing is pending) + clear of the gradient."""
@@ -349,6 +363,28 @@ class Trainer:
             check(lib.bist_flag_signal(self._flags.data_ptr() + 8 * (4 * j + c), self.drop_ctr.data_ptr(), st.cuda_stream), "bist_flag_signal")     # (pinned: the host pointer is the device's)
         self._flag_streams[j] = len(streams)
 
+    def _bucket_adam(self, cut: int) -> None:
+        """One rank, captured step: backward-pass callback of the layer loop's mark `cut` (autograd thread).  Every launch of the backward
+        pass of layers >= cut has been issued: the caption chain -- the one with the least backward work -- waits for the other chains at
+        this point and updates the bucket as a background launch, beside the backward pass of the earlier layers (which reads none of the
+        bucket's parameters)."""
+        j = next(i for i, b_ in enumerate(self.buckets) if b_[0] == cut)
+        cap = Fn.fourth_stream()
+        for st in Fn.step_streams(self._main_stream):
+            if st.cuda_stream != cap.cuda_stream:
+                cap.wait_stream(st)
+        with torch.cuda.stream(cap):
+            STM.mark("early adam %d" % j) if STM.ENABLED else None
+            if EARLY_REDUCTIONS:
+                # the bias / LayerNorm-parameter reductions queued so far, here instead of at the tail (their operands were produced on
+                # the chains this one has just waited for; they stay referenced until the pass ends, so no chain recycles them meanwhile)
+                self._early_keep.extend(ops.COLSUM_QUEUE or [])
+                self._early_keep.extend(ops.LNGRAD_QUEUE or [])
+                ops.col_sum_flush()
+                ops.lngrad_flush()
+            self._adam_dev(self.buckets[j][1], self.buckets[j][2], ADAM_BG_BLOCKS)
+        self._early_done = j + 1
+
     def _await_bucket(self, j: int) -> None:
         """Host: until every stream of the queued step has written this step's number into bucket j's flags."""
         n = self._flag_streams[j]
@@ -370,7 +406,10 @@ class Trainer:
             self.flat_grad.zero_()
         self.acc32.zero_()
         STM.mark("step head")
-        Fn.BUCKET_MARK = ({b_[0] for b_ in self.buckets}, self._bucket_ready) if self.overlap else None
+        self._early_done = 0
+        early = self._early_armed and Fn.fourth_stream() is not None and torch.cuda.is_current_stream_capturing()
+        Fn.BUCKET_MARK = (({b_[0] for b_ in self.buckets}, self._bucket_ready) if self.overlap else
+                          ({b_[0] for b_ in self.buckets}, self._bucket_adam) if early else None)
         try:
             loss, terms = self.forward_loss(batch)
         finally:
@@ -387,8 +426,9 @@ class Trainer:
         ops.LEAF_STREAM = Fn.leaf_stream() if (LEAF_OFFLOAD and self.use_graph and SPLIT_GRAPH and loss.is_cuda and Fn.CONCURRENT) else None
         ops.LEAF_MASK = LEAF_MASK
         try:
-            if self.overlap:
+            if self.overlap or early:
                 self._main_stream = torch.cuda.current_stream()
+            if self.overlap:
                 self._flag_streams = [0] * len(self.buckets)
             loss.backward()
             STM.mark("backward issued (main)")
@@ -405,6 +445,7 @@ class Trainer:
             ops.COLSUM_QUEUE = ops.LNGRAD_QUEUE = None
             raise
         finally:
+            self._early_keep.clear()
             ops.WGRAD_STREAM = None
             ops.LEAF_STREAM = None
             ops.WGRAD_KEEP.clear()
@@ -433,13 +474,18 @@ class Trainer:
                                       float(self.warmup), self.betas[0], self.betas[1], 1.0, _stream()), "bist_noam_hyper")
         # one rank, optimiser in the step: Adam clears every gradient it consumes (bist_adam_apply_dev), so a REPLAYED step starts from a
         # clean buffer without a memset of its own (_graph_open clears it when something else left a gradient behind)
-        terms = self._backward_open(batch, clear=not (optimizer and self._skip_head_clear))
+        self._early_armed = bool(optimizer and self.early_adam)
+        try:
+            terms = self._backward_open(batch, clear=not (optimizer and self._skip_head_clear))
+        finally:
+            self._early_armed = False
+        big_end = self.buckets[self._early_done - 1][1] if self._early_done else self.numel      # (the buckets above were updated inside the pass)
         side = None
         if optimizer and self.flat_grad.is_cuda:
             main, side = torch.cuda.current_stream(), Fn.side_stream(0)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                (self._adam_apply if ADAM_CLEARS else self._adam_dev)(self.n32, self.numel)
+                (self._adam_apply if ADAM_CLEARS else self._adam_dev)(self.n32, big_end)
         self._backward_close()
         STM.mark("closing reductions done")
         if optimizer:

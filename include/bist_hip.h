@@ -602,6 +602,10 @@ int bist_noam_hyper(const int64_t* step_ctr, float* hyper, float d_model, float 
                     float grad_scale, void* stream);
 int bist_adam_step_dev(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
                        float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, void* stream);
+/* The same update as a BACKGROUND launch: at most max_blocks workgroups walk the range (0 = the chip-filling form above), so that it can
+ * run beside the latency-bound launches of a backward pass without taking the CUs' wave slots from them (n % 4 == 0, aligned pointers). */
+int bist_adam_step_dev_bg(float* p, const void* g, float* m, float* v, void* work, int64_t n, const float* hyper, float beta1,
+                          float beta2, float eps, int32_t grad_dtype, int32_t work_dtype, int32_t max_blocks, void* stream);
 /* Deferred form: the update of optimiser step t is applied at the HEAD of step t+1, beside its forward pass (the tail of a step is
  * then the backward pass alone).  bist_noam_hyper_pending reads t = pending[0] (device int64; 0 = nothing pending), writes
  * hyper[0..4] = {rate(t), 1 - beta1^t, 1 - beta2^t, grad_scale, apply = (t > 0)} and sets pending[0] = 0; the caller sets

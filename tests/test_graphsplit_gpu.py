@@ -109,6 +109,11 @@ def test_trainer_split_step_trains_like_the_runtime_replay(env, dtype, monkeypat
         losses[tag] = [t.step(bs[i % 2])["out"].item() for i in range(6)]
         if split:
             assert t._split is not None and t._split.info["chains"] in (3, 4) and t._split.errors() == 0, t._split.info      # (4: the caption layers on a chain of their own)
+            # the matrices of layers 2 and 1 were updated INSIDE the captured backward pass (background Adam on the caption chain, behind the
+            # reductions queued up to their marks); the eager and runtime-replayed trainers update everything at the tail
+            assert t.early_adam and [b_[0] for b_ in t.buckets] == [2, 1] and t._early_done == 2
+        else:
+            assert not t.early_adam
         m.eval()
         torch.cuda.synchronize()
         res[tag] = {k: v.detach().float().clone() for k, v in m.named_parameters()}
