@@ -498,6 +498,28 @@ class Graph:
     def errors(self) -> int:
         return self.split.errors() if self.split is not None else 0
 
+    def __del__(self):
+        # Destroying the EXECUTABLE of a multi-stream capture (hipGraphExecDestroy, the runtime's multi-branch executor) corrupts host memory:
+        # in the runtime-executor soak the size of a live tensor came back one less -- a reference count released in freed memory -- or the
+        # process died, in 7 runs of 10, always in the first capture after a graph had been dropped; also with the device drained first;
+        # never (6 of 6) when the dropped graphs were kept alive.  So such a graph is RETIRED, not destroyed: it stays referenced (with its
+        # memory pool) in a module list.  Only the fallback executor is affected -- a split graph never instantiates the capture, and
+        # destroying the captured hipGraph itself and single-stream executables is clean (300 captures in the split soak) -- and a graph
+        # dies only when a batch geometry changes or its trainer / decoder goes; beyond RETIRED_MAX the oldest is destroyed after all.
+        try:
+            if self.cuda_graph is not None and self.split is None and self.streams > 1:
+                _RETIRED.append(self.cuda_graph)
+                if len(_RETIRED) > RETIRED_MAX:
+                    if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                        torch.cuda.synchronize()
+                    del _RETIRED[0]
+        except Exception:
+            pass
+
+
+_RETIRED: list = []
+RETIRED_MAX = int(os.environ.get("BIST_RETIRED_GRAPHS_MAX", "64"))      # multi-stream runtime-executor graphs kept alive instead of destroyed (see Graph.__del__)
+
 
 class capture_graph:
     """``with capture_graph(graph):`` = torch.cuda.graph(graph, capture_error_mode="thread_local") with Python's cyclic collector paused.

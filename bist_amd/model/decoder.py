@@ -23,6 +23,7 @@ def ag_fuse_one() -> bool:
     return ag.FUSE_ONE_LAUNCH
 
 
+FUSE_ON_DEC = os.environ.get("BIST_FUSE_ON_DEC", "1") != "0"      # training: the modality fusion on the decoder layers' stream (0: on the main stream)
 CAP_OWN_CHAIN = os.environ.get("BIST_CAP_CHAIN", "1") != "0"      # tuning aid: 0 = the caption layers of a training step on the decoder layers' stream
 FAN_JOIN = os.environ.get("BIST_FAN_JOIN", "1") != "0"      # 0 = the gradient sums of the multi-stream fans rely on the engine's ordering alone
 
@@ -458,6 +459,7 @@ class MultimodalDecoder8(nn.Module):
             Fn._keep_taken(v1); Fn._keep_taken(v4)               # allocated on this stream, consumed (and saved) on the main one
             ft["_bist_v_pre"] = (v1, v4, ev)
         Fn.param_gate(1)                     # deferred optimiser: layer 0's parameters (and everything outside the layer stacks) are final
+        x = Fn.bucket_mark(x, 0)             # everything recorded from here on belongs to the layer stacks (see the mark inside the loop)
         if values_ahead:
             issue_values(0)
         conc_keep = Fn.CONCURRENT and x.is_cuda
@@ -510,9 +512,14 @@ class MultimodalDecoder8(nn.Module):
                 for k_ in ("cap_ft", "spatial_ft", "temporal_ft"):
                     Fn.fan_set(ft, k_, 2)
             STM.lmark("main joined")
-            self._fuse(ft)
-            if STM.ENABLED:
-                ft["encoded_ft"] = STM.through(ft["encoded_ft"], "fused", True)
+            # Training with the decoder layer pipelined onto the caption / decoder stream: the fusion of the modalities (decoder.py:140-165) goes
+            # there too, ahead of its only consumer -- its forward launches (3) and, above all, its backward ones (~10 per layer, 80-150 us:
+            # the fusion logits' weight gradient) then leave the main stream's chain, the one that bounds the step
+            fuse_on_dec = (FUSE_ON_DEC and torch.is_grad_enabled() and fork_cap and Fn.PIPELINE_DECODER and not fused_after and cache is None)
+            if not fuse_on_dec:
+                self._fuse(ft)
+                if STM.ENABLED:
+                    ft["encoded_ft"] = STM.through(ft["encoded_ft"], "fused", True)
             if cache is not None:
                 cache.append({k: ft[k] for k in self._REASONING_KEYS if k in ft})
             # (training, several ranks) everything recorded from here on -- the value projections of layer l + 1, decoder layer l, the
@@ -529,6 +536,10 @@ class MultimodalDecoder8(nn.Module):
                 side.wait_stream(main)
                 Fn._keep_taken(x); Fn._keep_taken(ft.get("encoded_ft"))
                 with torch.cuda.stream(side):
+                    if fuse_on_dec:
+                        self._fuse(ft)
+                        if STM.ENABLED:
+                            ft["encoded_ft"] = STM.through(ft["encoded_ft"], "fused", True)
                     x = STM.through(layer(b, ft, STM.through(x, "dec in", True)), "dec out", True)                                                      # :182
                 dec_pending = side
             else:

@@ -185,7 +185,7 @@ class Trainer:
         cuts = [int(c) for c in cuts_env.split(",")] if (cuts_env and nb) else [n_layers - (j + 1) * n_layers // (nb + 1) for j in range(nb)]
         for cut in cuts:                                       # default, e.g. 6 layers, 2 buckets: cuts 4, 2
             lo_ = piece_lo.get(cut + 1)
-            if lo_ is None or lo_ >= hi_ or cut < 1:
+            if lo_ is None or lo_ >= hi_ or cut < 0:
                 break
             self.buckets.append((cut, lo_, hi_))
             hi_ = lo_

@@ -31,10 +31,17 @@ torch.manual_seed(0)
 t0 = time.time()
 caps = reps = 0
 junk = []
+junk_graphs = []
 max_streams = 0
 
 
 def churn(i):
+    if os.environ.get("SOAK_NOCHURN"):
+        return
+    _churn(i)
+
+
+def _churn(i):
     """allocations of changing sizes + a collector run now and then: cyclic garbage owning graphs and buffers dies HERE, not inside a capture"""
     junk.append(torch.empty((1 + (i * 7919) % 4096, 33), device="cuda"))
     if len(junk) > 12:
@@ -45,6 +52,9 @@ def churn(i):
 
 kinds = [("default", dict(), torch.float32), ("default", dict(), torch.bfloat16), ("deferred", dict(deferred_adam=True), torch.float32),
          ("deferred", dict(deferred_adam=True), torch.bfloat16)]
+if os.environ.get("SOAK_KINDS"):          # development aid: restrict the trainer kinds ("default", "deferred") / dtypes ("f32", "bf16")
+    sel = os.environ["SOAK_KINDS"].split(",")
+    kinds = [k for k in kinds if k[0] in sel and (("f32" in sel) == (k[2] == torch.float32) or not ({"f32", "bf16"} & set(sel)))]
 batches = {dt: [synthetic_batch(3, T=5, S=9, C=64, Lq=6, Lh=8, Lc=5, Lt=5, vocab=80, seed=s_, dtype=dt) for s_ in (1, 2)] for dt in (torch.float32, torch.bfloat16)}
 batches2 = {dt: [synthetic_batch(2, T=4, S=9, C=64, Lq=5, Lh=7, Lc=4, Lt=6, vocab=80, seed=s_, dtype=dt) for s_ in (3, 4)] for dt in (torch.float32, torch.bfloat16)}
 per_trainer_caps = 4
@@ -57,8 +67,14 @@ for r in range(rounds):
         tr = Trainer(model, args, 80, compute_dtype=dt, warmup=20, factor=2.0, use_graph=True, **kw)
         for c in range(per_trainer_caps):           # a new batch geometry forces a new capture
             bs = (batches if c % 2 == 0 else batches2)[dt]
+            if os.environ.get("SOAK_LEAK"):          # development aid: retire the old graphs instead of destroying them
+                junk_graphs.append((tr._graph, tr._graph2))
+            if os.environ.get("SOAK_SYNC"):
+                torch.cuda.synchronize()
             tr._graph = None
             for k in range(replays_each):
+                if os.environ.get("SOAK_TRACE"):
+                    print("step", r, tag, dt, c, k, file=sys.stderr, flush=True)
                 out = tr.step(bs[k % 2])
                 reps += 1
                 churn(reps)
@@ -80,6 +96,10 @@ for r in range(max(1, rounds // 2)):
         tr = Trainer(model, args, 80, compute_dtype=dt, warmup=20, factor=2.0, use_graph=True)
         assert tr.exchanging
         for c in range(2):
+            if os.environ.get("SOAK_LEAK"):          # development aid: retire the old graphs instead of destroying them
+                junk_graphs.append((tr._graph, tr._graph2))
+            if os.environ.get("SOAK_SYNC"):
+                torch.cuda.synchronize()
             tr._graph = None
             for k in range(replays_each):
                 tr.step((batches if c % 2 == 0 else batches2)[dt][k % 2]); reps += 1; churn(reps)
