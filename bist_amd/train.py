@@ -69,6 +69,7 @@ EXCHANGE_BUCKETS = int(os.environ.get("BIST_EXCHANGE_BUCKETS", "2"))
 # mark -- so that the step's tail is the update of the remaining matrices only.  0 = the whole update at the tail.
 ADAM_EARLY_BUCKETS = int(os.environ.get("BIST_ADAM_EARLY_BUCKETS", "2"))
 ADAM_BG_BLOCKS = int(os.environ.get("BIST_ADAM_BG_BLOCKS", "256"))
+FLUSH_AT_0 = os.environ.get("BIST_FLUSH_AT_0", "1") != "0"      # ... and, reductions only, at the end of the layer stacks' backward
 EARLY_REDUCTIONS = os.environ.get("BIST_EARLY_REDUCTIONS", "1") != "0"      # ... and the bias / LayerNorm-parameter reductions queued up to each bucket's mark
 EXCHANGE_TIMEOUT_S = float(os.environ.get("BIST_EXCHANGE_TIMEOUT_S", "20"))       # a bucket whose flags do not arrive within this raises
 EXCHANGE_CHUNKS = int(os.environ.get("BIST_EXCHANGE_CHUNKS", "4"))        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
@@ -368,11 +369,20 @@ class Trainer:
         pass of layers >= cut has been issued: the caption chain -- the one with the least backward work -- waits for the other chains at
         this point and updates the bucket as a background launch, beside the backward pass of the earlier layers (which reads none of the
         bucket's parameters)."""
-        j = next(i for i, b_ in enumerate(self.buckets) if b_[0] == cut)
+        j = next((i for i, b_ in enumerate(self.buckets) if b_[0] == cut), None)
         cap = Fn.fourth_stream()
         for st in Fn.step_streams(self._main_stream):
             if st.cuda_stream != cap.cuda_stream:
                 cap.wait_stream(st)
+        if j is None:
+            # mark 0 (FLUSH_AT_0): the layer stacks' backward is over -- what is left runs on the main stream (the video gradient's sum, the input
+            # projection's and the text encoders' backward): the reductions queued so far leave the tail, the matrices stay with the tail's update
+            with torch.cuda.stream(cap):
+                self._early_keep.extend(ops.COLSUM_QUEUE or [])
+                self._early_keep.extend(ops.LNGRAD_QUEUE or [])
+                ops.col_sum_flush()
+                ops.lngrad_flush()
+            return
         with torch.cuda.stream(cap):
             STM.mark("early adam %d" % j) if STM.ENABLED else None
             if EARLY_REDUCTIONS:
@@ -409,7 +419,7 @@ class Trainer:
         self._early_done = 0
         early = self._early_armed and Fn.fourth_stream() is not None and torch.cuda.is_current_stream_capturing()
         Fn.BUCKET_MARK = (({b_[0] for b_ in self.buckets}, self._bucket_ready) if self.overlap else
-                          ({b_[0] for b_ in self.buckets}, self._bucket_adam) if early else None)
+                          ({b_[0] for b_ in self.buckets} | ({0} if (FLUSH_AT_0 and EARLY_REDUCTIONS) else set()), self._bucket_adam) if early else None)
         try:
             loss, terms = self.forward_loss(batch)
         finally:
