@@ -345,6 +345,19 @@ class Trainer:
         self.pending.copy_(self.drop_ctr)
         return terms
 
+    def _flush_on_caption_chain(self) -> None:
+        """The bias / LayerNorm-parameter reductions queued so far, on the caption chain behind a wait for the other chains (captured split
+        step only): their operands were produced on those chains and stay referenced until the pass ends, so none is recycled meanwhile."""
+        cap = Fn.fourth_stream()
+        for st in Fn.step_streams(self._main_stream):
+            if st.cuda_stream != cap.cuda_stream:
+                cap.wait_stream(st)
+        with torch.cuda.stream(cap):
+            self._early_keep.extend(ops.COLSUM_QUEUE or [])
+            self._early_keep.extend(ops.LNGRAD_QUEUE or [])
+            ops.col_sum_flush()
+            ops.lngrad_flush()
+
     def _bucket_ready(self, cut: int) -> None:
         """Backward-pass callback of the layer loop's mark `cut` (autograd thread): every launch of the backward pass of layers >= cut
         has been issued -- signal the bucket's flag on each stream of the step, behind those launches."""
@@ -371,27 +384,18 @@ class Trainer:
         bucket's parameters)."""
         j = next((i for i, b_ in enumerate(self.buckets) if b_[0] == cut), None)
         cap = Fn.fourth_stream()
-        for st in Fn.step_streams(self._main_stream):
-            if st.cuda_stream != cap.cuda_stream:
-                cap.wait_stream(st)
+        if EARLY_REDUCTIONS or j is None:
+            # (mark 0, FLUSH_AT_0: the layer stacks' backward is over -- what is left runs on the main stream: the video gradient's sum, the
+            # input projection's and the text encoders' backward; the reductions queued so far leave the tail, the matrices stay with its update)
+            self._flush_on_caption_chain()
+        else:
+            for st in Fn.step_streams(self._main_stream):
+                if st.cuda_stream != cap.cuda_stream:
+                    cap.wait_stream(st)
         if j is None:
-            # mark 0 (FLUSH_AT_0): the layer stacks' backward is over -- what is left runs on the main stream (the video gradient's sum, the input
-            # projection's and the text encoders' backward): the reductions queued so far leave the tail, the matrices stay with the tail's update
-            with torch.cuda.stream(cap):
-                self._early_keep.extend(ops.COLSUM_QUEUE or [])
-                self._early_keep.extend(ops.LNGRAD_QUEUE or [])
-                ops.col_sum_flush()
-                ops.lngrad_flush()
             return
         with torch.cuda.stream(cap):
             STM.mark("early adam %d" % j) if STM.ENABLED else None
-            if EARLY_REDUCTIONS:
-                # the bias / LayerNorm-parameter reductions queued so far, here instead of at the tail (their operands were produced on
-                # the chains this one has just waited for; they stay referenced until the pass ends, so no chain recycles them meanwhile)
-                self._early_keep.extend(ops.COLSUM_QUEUE or [])
-                self._early_keep.extend(ops.LNGRAD_QUEUE or [])
-                ops.col_sum_flush()
-                ops.lngrad_flush()
             self._adam_dev(self.buckets[j][1], self.buckets[j][2], ADAM_BG_BLOCKS)
         self._early_done = j + 1
 
@@ -418,8 +422,9 @@ class Trainer:
         STM.mark("step head")
         self._early_done = 0
         early = self._early_armed and Fn.fourth_stream() is not None and torch.cuda.is_current_stream_capturing()
+        flush0 = {0} if (FLUSH_AT_0 and EARLY_REDUCTIONS) else set()
         Fn.BUCKET_MARK = (({b_[0] for b_ in self.buckets}, self._bucket_ready) if self.overlap else
-                          ({b_[0] for b_ in self.buckets} | ({0} if (FLUSH_AT_0 and EARLY_REDUCTIONS) else set()), self._bucket_adam) if early else None)
+                          ({b_[0] for b_ in self.buckets} | flush0, self._bucket_adam) if early else None)
         try:
             loss, terms = self.forward_loss(batch)
         finally:
