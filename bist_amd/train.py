@@ -56,7 +56,7 @@ SPLIT_GRAPH = os.environ.get("BIST_SPLIT_GRAPH", "1") != "0"
 # reductions in per-layer batches.  Chip-filling products beside the direction chains cost those chains more than they save (measured
 # 10.0 vs 8.9 ms per step with mask 1); moving only the fusion logits' weight gradient (mask 2: seven 58 us launches on four workgroups) gains
 # nothing measurable either (8.93-8.99 vs 8.90-8.96) although a critical-path model of the step puts them on the path -- the step has many
-# near-critical paths (scripts/critical_path.py).  Default 0: three chains.
+# near-critical paths (scripts/critical_path.py).  Default 0.
 LEAF_MASK = int(os.environ.get("BIST_LEAF_MASK", "0"))
 LEAF_OFFLOAD = LEAF_MASK != 0
 # Several ranks: the matrices of the LAST layers (their backward runs first) are exchanged in this many buckets DURING the backward pass,
@@ -69,8 +69,8 @@ EXCHANGE_BUCKETS = int(os.environ.get("BIST_EXCHANGE_BUCKETS", "2"))
 # mark -- so that the step's tail is the update of the remaining matrices only.  0 = the whole update at the tail.
 ADAM_EARLY_BUCKETS = int(os.environ.get("BIST_ADAM_EARLY_BUCKETS", "2"))
 ADAM_BG_BLOCKS = int(os.environ.get("BIST_ADAM_BG_BLOCKS", "256"))
-FLUSH_AT_0 = os.environ.get("BIST_FLUSH_AT_0", "1") != "0"      # ... and, reductions only, at the end of the layer stacks' backward
-EARLY_REDUCTIONS = os.environ.get("BIST_EARLY_REDUCTIONS", "1") != "0"      # ... and the bias / LayerNorm-parameter reductions queued up to each bucket's mark
+EARLY_REDUCTIONS = os.environ.get("BIST_EARLY_REDUCTIONS", "1") != "0"      # ... together with the bias / LayerNorm-parameter reductions queued up to each bucket's mark
+FLUSH_AT_0 = os.environ.get("BIST_FLUSH_AT_0", "1") != "0"      # ... and, reductions only, once more at the end of the layer stacks' backward (mark 0)
 EXCHANGE_TIMEOUT_S = float(os.environ.get("BIST_EXCHANGE_TIMEOUT_S", "20"))       # a bucket whose flags do not arrive within this raises
 EXCHANGE_CHUNKS = int(os.environ.get("BIST_EXCHANGE_CHUNKS", "4"))        # pieces of the flat gradient per step (multi-rank): all-reduce k+1 runs under Adam k
 
