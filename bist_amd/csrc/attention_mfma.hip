@@ -558,10 +558,13 @@ __device__ __forceinline__ uint4 k16_only(uint4 v, int lane) {
   return v;
 }
 
-template <bool BWD, int GB>                       // GB = 64-key blocks: G <= 64 GB (GB = 2: T = 128, BASELINE configs[3])
+// HALF (forward, G <= 32: the s2t direction at T = 32): 32-row images -- 42 KiB of LDS instead of 74, THREE workgroups per CU instead of
+// two (the B = 64 launch of 1 280 workgroups then takes two rounds of shorter workgroups instead of three), half the staging.
+template <bool BWD, int GB, bool HALF = false>    // GB = 64-key blocks: G <= 64 GB (GB = 2: T = 128, BASELINE configs[3])
 __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
+  static_assert(!HALF || (!BWD && GB == 1), "the 32-key form is a forward form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int GP = 64 * GB;                                      // padded key count = pitch of the score / probability images
+  constexpr int GP = HALF ? 32 : 64 * GB;                          // padded key count = pitch of the score / probability images
   const int G = a.G, Lq = a.Lq, h = a.h, d = a.d;
   const int i = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -596,6 +599,7 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
   // ---- scores (and dP): wave w owns keys g = 64 kb + 16w .. +15 of every key block kb --------------------------
 #pragma unroll
   for (int kb = 0; kb < GB; ++kb) {
+    if (HALF && w >= 2) break;                                     // (32 keys: waves 0 and 1 hold them all)
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acd = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < d / 32; ++ks) {
       const uint4 bfr = sfrag_rows(yimg, d, 64 * kb + 16 * w + x, ks * 32, lane);
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
       float s[GB], e[GB], m[GB];
       float mx = -INFINITY;
 #pragma unroll
-      for (int kb = 0; kb < GB; ++kb) { s[kb] = scf[hh * GP + 64 * kb + lane]; mx = fmaxf(mx, s[kb]); }
+      for (int kb = 0; kb < GB; ++kb) { s[kb] = (64 * kb + lane < GP) ? scf[hh * GP + 64 * kb + lane] : -INFINITY; mx = fmaxf(mx, s[kb]); }
       mx = wave_max(mx);
       float den = 0.f;
 #pragma unroll
@@ -635,6 +639,7 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
         const int g = 64 * kb + lane;
         const float p = e[kb] * inv;
         e[kb] = p;
+        if (g >= GP) continue;                                // (HALF: lanes 32-63 hold no key)
         scf[hh * GP + g] = p;
         // dropout of the probabilities (modules.py:62-63): P' = mask * P / (1-p) feeds the weighted sums
         m[kb] = 1.f;
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(256) void st2_mfma_kernel(const St2Args a) {
       const int col0 = (w * nf + f) * 16;
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2 * GB; ++ks)
+      for (int ks = 0; ks < GP / 32; ++ks)
         acc = mfma_bf16(frag_rows(pimg, GP, 0, ks * 32, lane & ~8), sfrag_cols(yimg, d, col0, ks * 32, lane), acc);
       if (lg < 2) {
 #pragma unroll
@@ -945,7 +950,9 @@ int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, vo
                   float* rowsum, const float* d_rowsum, int B, int G, int Lq, int h, int d, int bwd, const DropArg& drop, hipStream_t st) {
   if (G > 128 || h > 8 || d > 512 || (d % 128) != 0) return 0;
   if (((uintptr_t)q2f | (uintptr_t)Y | (uintptr_t)(bwd ? dPY : q2f)) % 16) return 0;
-  const int gb = G > 64 ? 2 : 1, gp = 64 * gb;
+  static const int no_half = [] { const char* e = getenv("BIST_ST2_NO_HALF"); return e ? atoi(e) : 0; }();      // tuning aid
+  const bool half = !bwd && G <= 32 && !no_half;
+  const int gb = G > 64 ? 2 : 1, gp = half ? 32 : 64 * gb;
   const size_t lds = (size_t)gp * d * 2 + (size_t)(bwd ? 16 : 8) * d * 2 + (size_t)(bwd ? 2 : 1) * 8 * gp * 4 + 16 * gp * 2;
   St2Args a{(const bf16_t*)q2f, (const bf16_t*)Y, gmask, (bf16_t*)PY, (const bf16_t*)dPY, (bf16_t*)dq2f, (bf16_t*)dY, G, Lq, h, d,
             rowsum, d_rowsum, drop};
@@ -956,7 +963,10 @@ int bist_st2_mfma(const void* q2f, const void* Y, const unsigned char* gmask, vo
     hipLaunchKernelGGL((st2_mfma_kernel<BWD_, GB_>), grid, dim3(256), lds, st, a);                                         \
   } while (0)
   if (bwd) { if (gb == 2) ST2_GO(true, 2); else ST2_GO(true, 1); }
-  else { if (gb == 2) ST2_GO(false, 2); else ST2_GO(false, 1); }
+  else if (half) {
+    BIST_LDS_OPTIN((&st2_mfma_kernel<false, 1, true>), 160 * 1024, "bist_st_stage2 (matrix-core kernel)", -1);
+    hipLaunchKernelGGL((st2_mfma_kernel<false, 1, true>), grid, dim3(256), lds, st, a);
+  } else { if (gb == 2) ST2_GO(false, 2); else ST2_GO(false, 1); }
 #undef ST2_GO
   bist_count_launch(bwd ? BIST_K_ST2_MFMA_BWD : BIST_K_ST2_MFMA_FWD);
   return launched("st2_mfma_kernel");
