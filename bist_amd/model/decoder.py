@@ -515,7 +515,9 @@ class MultimodalDecoder8(nn.Module):
             # Training with the decoder layer pipelined onto the caption / decoder stream: the fusion of the modalities (decoder.py:140-165) goes
             # there too, ahead of its only consumer -- its forward launches (3) and, above all, its backward ones (~10 per layer, 80-150 us:
             # the fusion logits' weight gradient) then leave the main stream's chain, the one that bounds the step
-            fuse_on_dec = (FUSE_ON_DEC and torch.is_grad_enabled() and fork_cap and Fn.PIPELINE_DECODER and not fused_after and cache is None)
+            # (only where the caption layers have a chain of their own: otherwise that stream already carries them and bounds the forward pass)
+            fuse_on_dec = (FUSE_ON_DEC and torch.is_grad_enabled() and fork_cap and Fn.PIPELINE_DECODER and not fused_after and cache is None
+                           and cside is not side)
             if not fuse_on_dec:
                 self._fuse(ft)
                 if STM.ENABLED:
