@@ -758,10 +758,12 @@ def test_fan_out_sums_consumer_gradients_in_one_pass(env):
     assert torch.allclose(out, ws[0].float() + ws[1].float() + ws[2].float())
 
 
-def test_exchange_path_matches_single_rank_step(env):
+@pytest.mark.parametrize("graphs", [True, False], ids=["two_graphs", "eager"])
+def test_exchange_path_matches_single_rank_step(env, graphs):
     """The several-rank form of the step -- two hipGraphs with the big matrices' all-reduce issued between them, Adam per
     exchanged piece -- run with a ONE-rank RCCL group (the all-reduce is then the identity): same losses, step for step,
-    as the one-rank form with the optimiser inside the captured step."""
+    as the one-rank form with the optimiser inside the captured step.  Also as eager launches (bench.py --no-graph at N > 1): the
+    bucket is then signalled by the main stream alone, behind a wait for the side streams."""
     import copy, os, socket
     import torch.distributed as dist
     import bist_amd.model as M
@@ -779,14 +781,14 @@ def test_exchange_path_matches_single_rank_step(env):
     dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}", device_id=torch.device("cuda", 0))
     os.environ["BIST_FORCE_EXCHANGE"] = "1"
     try:
-        t2 = Trainer(m2, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=True)
+        t2 = Trainer(m2, args, 80, compute_dtype=torch.float32, warmup=20, factor=2.0, use_graph=graphs)
         assert t2.exchanging and not t2.adam_in_step
         # the last layer's matrices are exchanged DURING the backward pass, behind the ready flags the captured step writes
         assert t2.overlap and [b_[0] for b_ in t2.buckets] == [1] and t2.buckets[0][2] == t2.numel and t2._bucket_end == t2.buckets[0][1]
         l1 = [t1.step(b)["out"].item() for _ in range(4)]
         l2 = [t2.step(b)["out"].item() for _ in range(4)]
-        assert t2._graph2 is not None
-        assert t2._flag_streams[0] >= 2
+        assert (t2._graph2 is not None) == graphs
+        assert t2._flag_streams[0] >= 2 if graphs else t2._flag_streams[0] == 1
         assert t2._flags[:t2._flag_streams[0]].tolist() == [4] * t2._flag_streams[0]      # every stream of the step signalled step 4
     finally:
         os.environ.pop("BIST_FORCE_EXCHANGE", None)
