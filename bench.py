@@ -464,8 +464,9 @@ def main():
             trf.step(fb); ntf += tok[k % 2]; k += 1
         torch.cuda.synchronize(); dtf = time.perf_counter() - t0
         model.eval()
-        fed = {"what": "the same training step with the features handed over as host fp32 tensors EVERY step (pinned producer buffers, DeviceFeeder: H2D on a copy "
-                       "stream, cast to bf16 on the device, temporal mask derived on the device); PCIe-inclusive, not the headline",
+        fed = {"what": "the same training step with the features handed over as host fp32 tensors EVERY step (pinned producer buffers, DeviceFeeder: H2D a step "
+                       "ahead on a copy stream that carries nothing but copies, cast to bf16 at the head of the step, temporal mask derived on the device); "
+                       "PCIe-inclusive, not the headline",
                "ms_per_step": dtf / k * 1e3, "tokens_per_s": ntf / dtf, "h2d_bytes_per_step": int(host[0].fts.numel() * 4), "steps": k}
         del trf, it, host
 

@@ -40,11 +40,14 @@ class HostBatch:
         self.query, self.his, self.fts, self.cap, self.trg, self.trg_y = query, his, fts, cap, trg, trg_y
 
 
+SLOTS = max(2, int(__import__("os").environ.get("BIST_FEEDER_SLOTS", "3")))      # device / pinned staging slots (2: the round-3 double buffer)
+
+
 class DeviceFeeder:
     """Iterate device-resident ``Batch`` objects over an iterable of ``HostBatch``.
 
     feature_dtype: dtype of the features in HBM (bf16 for the throughput path, fp32 for the parity path).
-    The Batch yielded for step i is valid until the next one is requested (its slot is then refilled with step i+2,
+    The Batch yielded for step i is valid until the next one is requested (its slot is refilled with step i+3 -- three slots --
     after the work queued on the consumer stream up to that point has finished).
     """
 
@@ -57,10 +60,15 @@ class DeviceFeeder:
         # 11.6 ms sharing the caption chain's queue, against 8.4 ms resident).
         from .. import functional as _Fn
         self.copy_stream = _Fn.copy_stream() or torch.cuda.Stream(device=self.device)
-        self._pinned = [{}, {}]
-        self._dev = [{}, {}]
-        self._free = [None, None]          # event: the slot's previous consumer is done (recorded when its Batch is replaced)
-        self._copied = [None, None]        # event: the slot's last H2D copies have finished READING their host buffers
+        # THREE slots: the slot refilled for step i+1 was read by step i-2, which is over when the host gets here (it runs at most one step
+        # ahead: it waits for that step below).  With two slots the copy stream stood in a wait for step i-1 -- a packet resident on its
+        # queue for the whole step, and the chain that shares the queue's dispatch pipe paid the threefold launch gap for as long: the
+        # fed step took 10.7 ms where the copy itself (3.6 ms, a step ahead) costs 0.1.
+        self.slots = SLOTS
+        self._pinned = [{} for _ in range(self.slots)]
+        self._dev = [{} for _ in range(self.slots)]
+        self._free = [None] * self.slots          # event: the slot's previous consumer is done (recorded when its Batch is replaced)
+        self._in_flight = False                   # the batch staged last may still be crossing PCIe
 
     # -- staging ---------------------------------------------------------------------------------
     def _slot(self, table, name, like: torch.Tensor, dtype, pinned: bool):
@@ -77,16 +85,17 @@ class DeviceFeeder:
         return torch.empty(shape, dtype=dtype, pin_memory=True)
 
     def _stage(self, hb: HostBatch, slot: int):
-        """host tensors -> (pinned staging) -> device slot -> compute dtype, all on the copy stream;
-        returns (device tensors, ready event)."""
+        """host tensors -> (pinned staging) -> device slot, on the copy stream: COPIES ONLY.  Nothing is queued behind them -- an event or
+        a kernel behind a 3.6 ms host-to-device copy is a packet that sits on the copy stream's hardware queue for as long, and the chain of
+        the replayed step that shares that queue's dispatch pipe pays the threefold launch gap meanwhile (1.1-1.4 ms per step, measured:
+        scripts/probe_h2d_interference.py); _finish() completes the batch one step later.  Returns the device tensors (features as copied)."""
         pin, dev = self._pinned[slot], self._dev[slot]
         out = {}
-        if self._copied[slot] is not None:
-            # The H2D copies of batch i-2 read this slot's pinned staging buffers asynchronously (they may still be queued behind
-            # the consumer's work when the host runs ahead): the HOST must not rewrite those buffers before they are done.
-            self._copied[slot].synchronize()
         if self._free[slot] is not None:
-            self.copy_stream.wait_event(self._free[slot])          # the device slot is still being read by step i-2
+            # the device slot was read by the step before the last (three slots): the HOST waits for it -- normally over already -- so the
+            # copy stream never holds a wait either; this is also what keeps the host from running more than a step ahead.  (The slot's
+            # pinned staging buffers were read by copies that _finish() has waited for.)
+            self._free[slot].synchronize()
         with torch.cuda.stream(self.copy_stream):
             for name in _FIELDS + ("fts",):
                 t = getattr(hb, name)
@@ -99,40 +108,41 @@ class DeviceFeeder:
                     t = p
                 d = self._slot(dev, name, t, t.dtype, False)
                 d.copy_(t, non_blocking=True)
-                if name == "fts" and t.dtype != self.feature_dtype:
-                    c = self._slot(dev, "fts_cast", t, self.feature_dtype, False)
-                    check(lib.bist_cast(d.data_ptr(), c.data_ptr(), d.numel(), dtype_code(d.dtype), dtype_code(self.feature_dtype),
-                                        self.copy_stream.cuda_stream), "bist_cast")
-                    d = c
-                d._bist_generation = getattr(d, "_bist_generation", 0) + 1      # the slot tensor is reused: tell consumers that cache by identity
                 out[name] = d
-            ready = torch.cuda.Event()
-            ready.record(self.copy_stream)
-        self._copied[slot] = ready
+        self._in_flight = True
         self._last_slot = slot
-        return out, ready
+        return out, slot
+
+    def _finish(self, tensors, slot: int):
+        """The staged batch becomes a device batch: the HOST waits for the copy stream (its copies were queued a step ago: normally
+        over) -- no event, the consumer's stream has nothing to wait for -- and the features are cast to the compute dtype ON THE CONSUMER'S
+        stream, i.e. at the head of the step that reads them (behind the copy, on the copy stream, the cast measured 0.6 ms per step more)."""
+        self.copy_stream.synchronize()
+        self._in_flight = False
+        dev = self._dev[slot]
+        d = tensors["fts"]
+        if d is not None and d.dtype != self.feature_dtype:
+            c = self._slot(dev, "fts_cast", d, self.feature_dtype, False)
+            check(lib.bist_cast(d.data_ptr(), c.data_ptr(), d.numel(), dtype_code(d.dtype), dtype_code(self.feature_dtype),
+                                torch.cuda.current_stream(self.device).cuda_stream), "bist_cast")
+            tensors["fts"] = c
+        for t in tensors.values():
+            if t is not None:
+                t._bist_generation = getattr(t, "_bist_generation", 0) + 1      # the slot tensors are reused: tell consumers that cache by identity
+        return (tensors,)
 
     def host_buffers_reusable(self, batches_ago: Optional[int] = None) -> None:
         """Block the host until staged copies have read their host buffers.  Producers that hand over their OWN pinned tensors and reuse
         them must call this before overwriting them; pageable producers need nothing (their staging copy is guarded inside the feeder).
-        Default (None): BOTH slots' copies -- safe whichever buffers the producer is about to rewrite.  batches_ago = k (1 = the latest
-        staged batch, 2 = the one before, ...): only that batch's slot (two slots alternate: odd k is the latest slot, even k the other)."""
-        last = getattr(self, "_last_slot", None)
-        if last is None:
-            return                                   # nothing staged yet
-        if batches_ago is None:
-            for ev in self._copied:
-                if ev is not None:
-                    ev.synchronize()
-            return
-        if batches_ago < 1:
+        Only the batch staged last can still be crossing PCIe (the feeder waits for every earlier one before it yields it), so whatever
+        ``batches_ago`` names, the host waits for the copy stream -- where nothing but copies is ever queued ahead of it."""
+        if batches_ago is not None and batches_ago < 1:
             raise ValueError("batches_ago counts back from the latest staged batch: 1, 2, ...")
-        ev = self._copied[last if batches_ago % 2 == 1 else last ^ 1]
-        if ev is not None:
-            ev.synchronize()
+        if getattr(self, "_in_flight", False):
+            self.copy_stream.synchronize()
+            self._in_flight = False
 
-    def _batch(self, tensors, ready) -> Batch:
-        torch.cuda.current_stream(self.device).wait_event(ready)
+    def _batch(self, tensors) -> Batch:
         return Batch(tensors["query"], tensors["his"], tensors["fts"], tensors["cap"], tensors["trg"], tensors["trg_y"], pad=self.pad)
 
     # -- iteration -------------------------------------------------------------------------------
@@ -145,13 +155,14 @@ class DeviceFeeder:
             return
         while pending is not None:
             cur, cur_slot = pending, slot
-            slot ^= 1
+            slot = (slot + 1) % self.slots
             try:
                 nxt = next(it)
             except StopIteration:
                 nxt = None
+            fin = self._finish(*cur)                                           # batch i has crossed (host wait), cast, event
             pending = self._stage(nxt, slot) if nxt is not None else None      # batch i+1 starts crossing PCIe now
-            b = self._batch(*cur)
+            b = self._batch(*fin)
             yield b
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(self.device))              # consumer of batch i is done with slot cur_slot

@@ -456,13 +456,17 @@ def copy_stream():
     if st is None and not torch.cuda.is_current_stream_capturing():
         from . import graphsplit as GS
         torch.cuda.synchronize()
-        st = GS.queue_distinct_stream([_SIDE[(dev, k)] for k in ("cap", 0, 1, 2)])
+        # (on the dispatch pipe of the fourth stream: in a training step that is the caption chain, the one with slack)
+        chains = [_SIDE[(dev, k)] for k in ("cap", 0, 1, 2)]
+        st = GS.queue_distinct_stream(chains, pipe_with=chains[COPY_PIPE] if 0 <= COPY_PIPE < 4 else None)
         _COPY[dev] = st
         return st
     return _COPY.get(dev)
 
 
 _COPY = {}
+# whose dispatch pipe the feeder's copy queue shares (index into [capture stream, side 0, side 1, side 2]; -1: the first free queue)
+COPY_PIPE = int(os.environ.get("BIST_COPY_PIPE", "2"))
 
 
 def fourth_stream():

@@ -111,17 +111,33 @@ def distinct_streams(n: int) -> List[torch.cuda.Stream]:
     return keep[:n]
 
 
-def queue_distinct_stream(avoid: List[torch.cuda.Stream]) -> torch.cuda.Stream:
-    """A stream on a hardware QUEUE none of `avoid` uses (it may share a dispatch pipe with one of them): for work that must never sit
-    in a chain's queue -- a host-to-device copy and what is ordered behind it hold their queue for milliseconds -- when all four
-    independent pipes are taken.  Not during a capture (the probe synchronises)."""
+def queue_distinct_stream(avoid: List[torch.cuda.Stream], pipe_with: Optional[torch.cuda.Stream] = None) -> torch.cuda.Stream:
+    """A stream on a hardware QUEUE none of `avoid` uses (it shares a dispatch pipe with one of them: all four carry a chain): for work that
+    must never sit in a chain's queue -- a host-to-device copy and what is ordered behind it hold their queue for milliseconds.
+    pipe_with: the stream whose pipe the new stream should share -- while the copy is in flight that stream's launches pay the threefold
+    gap, so the caller names the chain with slack (a training step's caption chain: 170 of 1 165 launches); first choice, not a condition.
+    Not during a capture (the probe synchronises)."""
     scratch = torch.zeros(4, dtype=torch.int64, device="cuda")
+    alone = {o.cuda_stream: min(_pace(o.cuda_stream, None, scratch) for _ in range(3)) for o in avoid} if pipe_with is not None else {}
+    fallback = None
     for _ in range(96):
         s = torch.cuda.Stream()
-        if any(s.cuda_stream == o.cuda_stream for o in avoid):
+        if any(s.cuda_stream == o.cuda_stream for o in avoid) or (fallback is not None and s.cuda_stream == fallback.cuda_stream):
             continue
-        if all(_distinct(o.cuda_stream, s.cuda_stream, scratch) and _distinct(s.cuda_stream, o.cuda_stream, scratch) for o in avoid):
+        if not all(_distinct(o.cuda_stream, s.cuda_stream, scratch) and _distinct(s.cuda_stream, o.cuda_stream, scratch) for o in avoid):
+            continue
+        if pipe_with is None:
             return s
+        # whose launches does a wave resident on s slow down?  (each of the remaining queues is the pipe partner of exactly one chain)
+        ratio = {o.cuda_stream: min(_pace(o.cuda_stream, s.cuda_stream, scratch) for _ in range(3)) / alone[o.cuda_stream] for o in avoid}
+        slowed = [k for k, r in ratio.items() if r >= 1.5]
+        if os.environ.get("BIST_GS_DEBUG"):
+            print("graphsplit.queue_distinct_stream: candidate %#x slows %s" % (s.cuda_stream, {hex(k): round(r, 2) for k, r in ratio.items()}), flush=True)
+        if slowed == [pipe_with.cuda_stream]:
+            return s
+        fallback = fallback or s
+    if fallback is not None:
+        return fallback
     raise RuntimeError("bist_amd.graphsplit: no stream on a hardware queue of its own beside the chains' (GPU_MAX_HW_QUEUES >= 8 before the first HIP call)")
 
 

@@ -47,7 +47,77 @@ def h2d(stream, pieces=1, cast=False):
     return f
 
 
+from bist_amd._lib import lib, check
+from bist_amd.ops import dtype_code
+
+
+def cast_only(stream):
+    def f():
+        check(lib.bist_cast(dev.data_ptr(), dev16.data_ptr(), n, dtype_code(torch.float32), dtype_code(torch.bfloat16), stream.cuda_stream), "bist_cast")
+    return f
+
+
+def h2d_cast(stream):
+    g, cst = h2d(stream), cast_only(stream)
+    def f():
+        g(); cst()
+    return f
+
+
+gen = [0]
+def new_fts():
+    gen[0] += 1
+    b.fts._bist_generation = gen[0]          # the trainer copies the field into the graph's static buffer again (as for a fed batch)
+
+
+def h2d_event_wait(stream, with_cast):
+    g = h2d_cast(stream) if with_cast else h2d(stream)
+    def f():
+        g()
+        ev = torch.cuda.Event(); ev.record(stream)
+        torch.cuda.current_stream().wait_event(ev)      # (the NEXT step waits for this copy: not a step ahead -- the worst case)
+    return f
+
+
+def h2d_ahead(stream, with_cast, new=False):
+    """the copy for step i+1 is queued before step i and awaited (event) before step i+1, as the feeder does"""
+    g = h2d_cast(stream) if with_cast else h2d(stream)
+    pend = [None]
+    def f():
+        if pend[0] is not None:
+            torch.cuda.current_stream().wait_event(pend[0])
+        if new:
+            new_fts()
+        g()
+        ev = torch.cuda.Event(); ev.record(stream); pend[0] = ev
+    return f
+
+
+def h2d_ahead_hostsync(stream, then_cast):
+    """the copy for step i+1 is queued before step i; before step i+1 the HOST waits for the copy stream (no event behind the copy), then
+    (optionally) queues the cast + an event that the step waits for"""
+    g, cst = h2d(stream), cast_only(stream)
+    started = [False]
+    def f():
+        if started[0]:
+            stream.synchronize()
+            if then_cast:
+                cst()
+                ev = torch.cuda.Event(); ev.record(stream)
+                torch.cuda.current_stream().wait_event(ev)
+        g(); started[0] = True
+    return f
+
+
 run("no copy", lambda: None)
+run("H2D a step ahead, the HOST waits for the copy stream", h2d_ahead_hostsync(copy, False))
+run("H2D a step ahead, host wait, then cast + event", h2d_ahead_hostsync(copy, True))
+run("H2D a step ahead + event wait", h2d_ahead(copy, False))
+run("H2D a step ahead + event wait + the trainer's copy of a new tensor", h2d_ahead(copy, False, True))
+run("H2D + bist_cast a step ahead + event wait", h2d_ahead(copy, True))
+run("the feature tensor counted as new every step (the trainer's 103 MB device-to-device copy)", new_fts)
+run("bist_cast 205 -> 103 MB per step on the copy stream, no H2D", cast_only(copy))
+run("H2D + bist_cast on the copy stream", h2d_cast(copy))
 run("205 MB H2D per step on the feeder's copy stream", h2d(copy))
 run("... in 8 pieces", h2d(copy, 8))
 run("... on a pool stream", h2d(pool))
