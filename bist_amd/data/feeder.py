@@ -8,17 +8,21 @@ The reference collates a batch on the host (zero-padded fp32 features ``[B,T,S,C
 ``DeviceFeeder`` keeps that contract (it yields ``bist_amd.data.Batch`` objects on the device) and changes how the
 bytes move:
 
-  * two pinned staging slots and two device slots per field, filled by a copy stream, so that the transfer of batch
-    i+1 overlaps the compute of batch i; the consumer stream waits on an event, never on the host.  A producer that
-    writes its collated batch straight into ``pinned_like()`` buffers skips the staging copy;
+  * three pinned staging slots and three device slots per field, filled by a copy stream, so that the transfer of batch
+    i+1 overlaps the compute of batch i.  The copy stream carries NOTHING BUT COPIES: no wait ahead of them (the host
+    waits for the slot's previous reader, two steps back), no event or kernel behind them (the host waits for the copy
+    stream before it yields the batch: the copy was queued a step earlier) -- a packet that sits on the copy stream's
+    hardware queue while a 3.6 ms copy runs makes the chain of the replayed step that shares that queue's dispatch pipe
+    pay a threefold launch gap for as long (the PCIe-inclusive step went from 10.7 to 8.2 ms, 7.97
+    resident).  A producer that writes its collated batch straight into ``pinned_like()`` buffers skips the staging copy;
   * features cross PCIe in the dtype the producer has (the reference's fp32 ``.npy`` data, or bf16 if stored so) and
-    are cast to the compute dtype on the device by ``bist_cast`` on the copy stream -- a host-side cast of 51 M
-    elements per step would cost more than the whole training step;
+    are cast to the compute dtype on the device by ``bist_cast`` on the CONSUMER's stream, at the head of the step that
+    reads them -- a host-side cast of 51 M elements per step would cost more than the whole training step;
   * ``temporal_mask`` is derived on the device from the features that just landed (``bist_temporal_mask``,
     bit-identical to dataset.py:79), so the host never reduces the feature tensor.
 
-Nothing here is on the timed path of ``bench.py`` (features resident in HBM, as the metric prescribes);
-``scripts/bench_feed.py`` measures the PCIe-inclusive rate quoted in DESIGN.md.
+Nothing here is on the timed path of ``bench.py``'s ``value`` (features resident in HBM, as the metric prescribes); its ``fed``
+side line is the PCIe-inclusive rate through this class.
 """
 from __future__ import annotations
 
